@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI library ``libgeeco_hip.so`` (declared in include/geeco_hip.h).
+
+The library is the product's only compute path.  There is deliberately no CPU/PyTorch
+fallback: if the shared object is missing or a symbol does not resolve, importing the ops
+raises ``GeecoNativeError`` (the build recipe is ``geeco_amd/csrc/build.sh``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgeeco_hip.so')
+
+
+class GeecoNativeError(RuntimeError):
+  pass
+
+
+_P = c_void_p          # device (or host) pointer
+_PP = POINTER(c_void_p)
+_I, _L, _F = c_int, c_int64, c_float
+
+# symbol -> (restype, argtypes); mirrors include/geeco_hip.h one to one
+SIGNATURES = {
+    'geeco_abi_version': (_I, []),
+    'geeco_last_error': (c_char_p, []),
+    'geeco_dynimg_alpha': (None, [_I, _P]),
+    'geeco_dynimg_ws_bytes': (_L, [_I, _L]),
+    'geeco_dynimg_fwd': (_I, [_P, _P, _L, _L, _P, _I, _I, _L, _I, _I, _P, _P, _P]),
+    'geeco_pack_pixels': (_I, [_P, _L, _P, _L, _I, _L, _I, _I, _I, _P, _P]),
+    'geeco_conv3x3_fwd': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'geeco_conv3x3_dgrad': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
+    'geeco_conv3x3_wgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
+    'geeco_conv3x3_wgrad': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'geeco_transpose_hwio': (_I, [_P, _P, _I, _L, _L, _I, _I, _P]),
+    'geeco_pad_mid': (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    'geeco_state_concat_fwd': (_I, [_PP, POINTER(_I), _I, _I, _P, _L, _I, _P, _I, _I, _P, _L, _P]),
+    'geeco_state_concat_bwd': (_I, [_P, _L, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _I, _I, _P]),
+    'geeco_gemm_ws_bytes': (_L, [_I, _I, _I]),
+    'geeco_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _P]),
+    'geeco_lstm_gates_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'geeco_lstm_gates_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'geeco_colsum': (_I, [_P, _L, _I, _I, _P, _I, _P]),
+    'geeco_heads_ws_bytes': (_L, [_I, _I, _I]),
+    'geeco_heads_loss_fwd_bwd': (_I, [_P, _P, _P, _PP, _PP, _P, _P, _L, _P, _L, _F, _F, _I, _I, _I, _P, _P, _I,
+                                      _P, _P, _P, _PP, _PP, _P, _P]),
+    'geeco_adam_prepare': (_I, [_P, _F, _F, _F, _P, _P]),
+    'geeco_adam_tf': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
+    'geeco_sumsq': (_I, [_P, _L, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+  """Loads the shared library once and types every declared symbol. Raises if anything is missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise GeecoNativeError(
+        "HIP library not built: %s is missing. Run geeco_amd/csrc/build.sh (hipcc, gfx950). "
+        "geeco_amd has no CPU fallback." % LIB_PATH)
+  try:
+    lib = ctypes.CDLL(LIB_PATH)
+  except OSError as e:
+    raise GeecoNativeError("cannot load %s: %s" % (LIB_PATH, e))
+  for name, (res, args) in SIGNATURES.items():
+    try:
+      fn = getattr(lib, name)
+    except AttributeError:
+      raise GeecoNativeError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+    fn.restype = res
+    fn.argtypes = args
+  if lib.geeco_abi_version() != 1:
+    raise GeecoNativeError("ABI version mismatch: library %d, binding 1" % lib.geeco_abi_version())
+  _lib = lib
+  return lib
+
+
+def check(rc: int, what: str):
+  if rc != 0:
+    msg = load().geeco_last_error()
+    raise GeecoNativeError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ''))

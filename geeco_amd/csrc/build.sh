@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds the C-ABI shared library for gfx950 in-tree (geeco_amd/libgeeco_hip.so).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libgeeco_hip.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
+mkdir -p build
+pids=()
+for f in conv_gemm conv_wgrad dynimg decoder misc; do
+  $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+  pids+=($!)
+done
+$HIPCC $FLAGS -x hip -c errors.cpp -o build/errors.o &
+pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
+echo "built $(realpath $OUT)"

@@ -1,0 +1,269 @@
+// 3x3 convolution filter/bias gradient (Conv2DBackpropFilter + BiasAddGrad) on f32 MFMA.
+//
+// Autodiff of reference src/models/e2evmc/graph.py:76-115 taken by
+// tf.train.AdamOptimizer.minimize (src/models/e2evmc/estimator.py:243-244).
+//
+//   dw[(tap, ci)][co] = sum_m x[pix(m, tap)][ci] * dz[m][co]        db[co] = sum_m dz[m][co]
+//
+// GEMM view: rows = (tap, ci) ("k-rows", 9*Cin of them), cols = co, reduction over output
+// pixels m.  A block owns a BR x BC tile of dw for one slice of m (split-K); it streams MK = 16
+// pixels per stage through LDS (x rows gathered per tap, dz rows dense), and finally writes its
+// partial tile to a slab; wgrad_reduce sums the slabs in a fixed order (bitwise reproducible).
+//
+// MFMA roles (16x16x4): "row" i = co (operand from sB), "col" j = k-row (operand from sA), the
+// 4-deep k of one MFMA = 4 consecutive pixels.  Each lane then owns 4 consecutive co of one
+// k-row => one 16-byte store.  Both LDS images are [pixel][channels + pad] read with
+// ds_read_b32; the row pitch is 16 (mod 32) dwords so the two pixels of a 32-lane half use
+// different bank halves.
+#include "geeco_common.h"
+
+struct WgradParams {
+  const float* x;
+  const float* dz;
+  float* part;   // [G][S][Krows*Cout + Cout]
+  long long gs_x, gs_dz;
+  int N, H, W, Cin, Ho, Wo, Cout, stride, pt, pl;
+  long long M;          // N*Ho*Wo
+  long long m_per_split;
+  int S;
+  int Krows;            // 9*Cin
+  int row_tiles, col_tiles;
+};
+
+template <int BR, int BC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int MK = 16;
+  constexpr int LDA = (BR % 32 == 16) ? BR : BR + 16;
+  constexpr int LDBZ = (BC % 32 == 16) ? BC : BC + 16;
+  constexpr int BR4 = BR / 4, BC4 = BC / 4;
+  constexpr int NA4 = MK * BR4, NB4 = MK * BC4;
+  constexpr int PAS = (NA4 + 255) / 256, PBS = (NB4 + 255) / 256;
+  constexpr int TI = BC / 16;   // co tiles per wave (each wave: 16 k-rows x BC)
+  static_assert(BR == 64, "one 16-row strip per wave");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * MK * (LDA + LDBZ)];
+  float* sA = smem;
+  float* sB = smem + 2 * MK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = blockIdx.z;
+  const int rt = blockIdx.y / p.col_tiles;
+  const int ct = blockIdx.y - rt * p.col_tiles;
+  const int split = blockIdx.x;
+  const float* __restrict__ xg = p.x + (long long)g * p.gs_x;
+  const float* __restrict__ zg = p.dz + (long long)g * p.gs_dz;
+  const int Cin = p.Cin, C4 = Cin >> 2, Cout = p.Cout;
+  const long long mbeg = (long long)split * p.m_per_split;
+  long long mend = mbeg + p.m_per_split;
+  if (mend > p.M) mend = p.M;
+
+  // ---- staging state: A (x gather) -------------------------------------------------------------
+  int a_ky[PAS], a_kx[PAS], a_coff[PAS], a_mrow[PAS], a_slot[PAS];
+  bool a_ok[PAS];
+  int a_n[PAS], a_oy[PAS], a_ox[PAS];
+  const long long HoWo = (long long)p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < PAS; ++i) {
+    int idx = tid + i * 256;
+    a_mrow[i] = idx / BR4;
+    a_slot[i] = idx - a_mrow[i] * BR4;
+    int sg = rt * BR4 + a_slot[i];
+    int tap = sg / C4;
+    a_ok[i] = (idx < NA4) && (tap < 9);
+    if (tap > 8) tap = 8;
+    a_ky[i] = tap / 3 - p.pt;
+    a_kx[i] = tap % 3 - p.pl;
+    a_coff[i] = (sg - (sg / C4) * C4) * 4;
+    long long m = mbeg + a_mrow[i];
+    long long n = m / HoWo;
+    int rem = (int)(m - n * HoWo);
+    a_n[i] = (int)n;
+    a_oy[i] = rem / p.Wo;
+    a_ox[i] = rem - a_oy[i] * p.Wo;
+  }
+  // ---- staging state: B (dz rows) --------------------------------------------------------------
+  int b_mrow[PBS], b_c4[PBS];
+#pragma unroll
+  for (int i = 0; i < PBS; ++i) {
+    int idx = tid + i * 256;
+    b_mrow[i] = idx / BC4;
+    b_c4[i] = idx - b_mrow[i] * BC4;
+  }
+  const int co0 = ct * BC;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[PAS], rz[PBS];
+  f32x4 dbsum[PBS];
+#pragma unroll
+  for (int i = 0; i < PBS; ++i) dbsum[i] = zero4;
+
+  auto load_tiles = [&](long long mb) {
+#pragma unroll
+    for (int i = 0; i < PAS; ++i) {
+      int iy = a_oy[i] * p.stride + a_ky[i];
+      int ix = a_ox[i] * p.stride + a_kx[i];
+      bool v = a_ok[i] && (mb + a_mrow[i] < mend) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      ra[i] = v ? *reinterpret_cast<const f32x4*>(xg + (((long long)a_n[i] * p.H + iy) * p.W + ix) * Cin + a_coff[i])
+                : zero4;
+      // advance this thread's pixel by MK for the next stage
+      a_ox[i] += MK;
+      while (a_ox[i] >= p.Wo) {
+        a_ox[i] -= p.Wo;
+        if (++a_oy[i] >= p.Ho) {
+          a_oy[i] = 0;
+          ++a_n[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PBS; ++i) {
+      long long m = mb + b_mrow[i];
+      bool v = (tid + i * 256 < NB4) && (m < mend) && (co0 + b_c4[i] * 4 < Cout);
+      rz[i] = v ? *reinterpret_cast<const f32x4*>(zg + m * Cout + co0 + b_c4[i] * 4) : zero4;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* a = sA + buf * MK * LDA;
+    float* b = sB + buf * MK * LDBZ;
+#pragma unroll
+    for (int i = 0; i < PAS; ++i)
+      if (tid + i * 256 < NA4) *reinterpret_cast<f32x4*>(a + a_mrow[i] * LDA + a_slot[i] * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PBS; ++i)
+      if (tid + i * 256 < NB4) {
+        *reinterpret_cast<f32x4*>(b + b_mrow[i] * LDBZ + b_c4[i] * 4) = rz[i];
+        dbsum[i] += rz[i];
+      }
+  };
+
+  f32x4 acc[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) acc[i] = zero4;
+  const int r = lane & 15, q = lane >> 4;
+
+  const long long nchunk = (mend > mbeg) ? (mend - mbeg + MK - 1) / MK : 0;
+  if (nchunk > 0) {
+    load_tiles(mbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (long long c = 0; c < nchunk; ++c) {
+    const int buf = (int)(c & 1);
+    const bool more = c + 1 < nchunk;
+    if (more) load_tiles(mbeg + (c + 1) * MK);
+    const float* a = sA + buf * MK * LDA;
+    const float* b = sB + buf * MK * LDBZ;
+#pragma unroll
+    for (int blk = 0; blk < MK / 4; ++blk) {
+      float xv = a[(blk * 4 + q) * LDA + wid * 16 + r];
+      float zv[TI];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) zv[i] = b[(blk * 4 + q) * LDBZ + i * 16 + r];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[i], xv, acc[i], 0, 0, 0);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns k-row (lane & 15) of its wave's strip, co = 16 i + 4 q .. +3 ---------
+  const long long slab = (long long)p.Krows * Cout + Cout;
+  float* __restrict__ part = p.part + ((long long)g * p.S + split) * slab;
+  const int krow = rt * BR + wid * 16 + r;
+  if (krow < p.Krows) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      int co = co0 + i * 16 + 4 * q;
+      if (co < Cout) *reinterpret_cast<f32x4*>(part + (long long)krow * Cout + co) = acc[i];
+    }
+  }
+  if (rt == 0) {
+    // bias gradient: per-thread dz sums -> LDS [pixel row][BC] -> fixed-order column sums
+    // (the main loop ended with a barrier, so sB is free to reuse)
+    float* sT = sB;
+#pragma unroll
+    for (int i = 0; i < PBS; ++i)
+      if (tid + i * 256 < NB4) *reinterpret_cast<f32x4*>(sT + b_mrow[i] * LDBZ + b_c4[i] * 4) = dbsum[i];
+    __syncthreads();
+    if (tid < BC && co0 + tid < Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < MK; ++m) s += sT[m * LDBZ + tid];
+      part[(long long)p.Krows * Cout + co0 + tid] = s;
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                    long long gs_dw, long long gs_db, int S, long long KC, int Cout) {
+  const int g = blockIdx.y;
+  const long long slab = KC + Cout;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slab) return;
+  const float* src = part + (long long)g * S * slab + i;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += src[(long long)k * slab];
+  if (i < KC)
+    dw[(long long)g * gs_dw + i] = s;
+  else if (db)
+    db[(long long)g * gs_db + (i - KC)] = s;
+}
+
+static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride, WgradParams* p, int* bc) {
+  int Ho, Wo, pt, pl;
+  same_pad(H, 3, stride, &Ho, &pt);
+  same_pad(W, 3, stride, &Wo, &pl);
+  p->N = N; p->H = H; p->W = W; p->Cin = Cin; p->Ho = Ho; p->Wo = Wo; p->Cout = Cout;
+  p->stride = stride; p->pt = pt; p->pl = pl;
+  p->M = (long long)N * Ho * Wo;
+  p->Krows = 9 * Cin;
+  int BC = (Cout % 64 == 0) ? 64 : (Cout % 48 == 0) ? 48 : (Cout % 32 == 0) ? 32 : 16;
+  *bc = BC;
+  p->row_tiles = cdiv(p->Krows, 64);
+  p->col_tiles = cdiv(Cout, BC);
+  long long tiles = (long long)groups * p->row_tiles * p->col_tiles;
+  long long S = 1536 / tiles;
+  if (S < 1) S = 1;
+  long long maxS = p->M / 256;          // at least 256 pixels per slice
+  if (maxS < 1) maxS = 1;
+  if (S > maxS) S = maxS;
+  long long mps = cdiv64(p->M, S);
+  mps = cdiv64(mps, 16) * 16;
+  S = cdiv64(p->M, mps);
+  p->S = (int)S;
+  p->m_per_split = mps;
+}
+
+extern "C" int64_t geeco_conv3x3_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
+  WgradParams p = {};
+  int bc;
+  wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &bc);
+  return (int64_t)groups * p.S * ((int64_t)p.Krows * Cout + Cout) * 4;
+}
+
+extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, int groups,
+                                   int64_t gs_x, int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H,
+                                   int W, int Cin, int Cout, int stride, void* ws, void* stream) {
+  GEECO_CHECK_ARG(x && dz && dw && ws, "conv3x3_wgrad: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_wgrad: bad dims");
+  GEECO_CHECK_ARG(Cin % 4 == 0 && Cin >= 4, "conv3x3_wgrad: Cin=%d must be a multiple of 4", Cin);
+  GEECO_CHECK_ARG(Cout % 16 == 0, "conv3x3_wgrad: Cout=%d must be a multiple of 16", Cout);
+  WgradParams p = {};
+  int BC;
+  wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &BC);
+  p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)p.S, (unsigned)(p.row_tiles * p.col_tiles), (unsigned)groups);
+  switch (BC) {
+    case 64: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, p); break;
+    case 48: hipLaunchKernelGGL((conv_wgrad_kernel<64, 48>), grid, dim3(256), 0, s, p); break;
+    case 32: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32>), grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((conv_wgrad_kernel<64, 16>), grid, dim3(256), 0, s, p); break;
+  }
+  GEECO_LAUNCH_CHECK();
+  const long long KC = (long long)p.Krows * Cout;
+  dim3 rgrid((unsigned)cdiv64(KC + Cout, 256), (unsigned)groups);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, s, (const float*)ws, dw, db, (long long)gs_dw,
+                     (long long)gs_db, p.S, KC, Cout);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,508 @@
+// Policy head: state concat, LSTM cell (MFMA gate GEMM + fused gate math), fc1 + heads + losses.
+//
+// Replaces reference src/models/e2evmc/graph.py:123-192 (concats), :198-260 (lstm_decoder),
+// :452-500 (losses) and the loss composition of src/models/e2evmc/estimator.py:206-239.
+#include "geeco_common.h"
+
+// =====================================================================================================
+// state concat (graph.py:138-141, 162-165, 187-190)
+// =====================================================================================================
+struct ConcatParams {
+  const float* feats[3];
+  float* dfeats[3];
+  int ch[3];
+  int off[3];       // channel offset of feature i inside a cell
+  int nfeat, jnt_off, J, Ctot;
+  const float* jnt;
+  long long jnt_stride;
+  const float* sub_from;
+  int N, cells;
+  float* state;
+  long long state_stride;
+  int accumulate;
+};
+
+__global__ __launch_bounds__(256) void concat_fwd_kernel(const ConcatParams p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)p.cells * p.Ctot;
+  if (i >= per * p.N) return;
+  const int n = (int)(i / per);
+  const int rem = (int)(i - (long long)n * per);
+  const int cell = rem / p.Ctot, c = rem - cell * p.Ctot;
+  float v;
+  if (c >= p.jnt_off && c < p.jnt_off + p.J) {
+    v = p.jnt[(long long)n * p.jnt_stride + (c - p.jnt_off)];
+  } else {
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k)
+      if (k < p.nfeat && c >= p.off[k]) f = k;
+    const int cc = c - p.off[f];
+    const long long idx = ((long long)n * p.cells + cell) * p.ch[f] + cc;
+    v = p.feats[f][idx];
+    if (f == 0 && p.sub_from) v = p.sub_from[idx] - v;
+  }
+  p.state[(long long)n * p.state_stride + rem] = v;
+}
+
+__global__ __launch_bounds__(256) void concat_bwd_kernel(const ConcatParams p, int f) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)p.cells * p.ch[f];
+  if (i >= per * p.N) return;
+  const int n = (int)(i / per);
+  const int rem = (int)(i - (long long)n * per);
+  const int cell = rem / p.ch[f], c = rem - cell * p.ch[f];
+  float d = p.state[(long long)n * p.state_stride + cell * p.Ctot + p.off[f] + c];
+  d = p.feats[f][i] > 0.f ? d : 0.f;      // ReluGrad of the encoder's last layer
+  p.dfeats[f][i] = p.accumulate ? p.dfeats[f][i] + d : d;
+}
+
+static int fill_concat(ConcatParams* p, const int* feat_ch, int nfeat, int jnt_pos, int J) {
+  int off = 0;
+  for (int i = 0; i < nfeat; ++i) {
+    if (i == jnt_pos) {
+      p->jnt_off = off;
+      off += J;
+    }
+    p->ch[i] = feat_ch[i];
+    p->off[i] = off;
+    off += feat_ch[i];
+  }
+  if (jnt_pos >= nfeat) {
+    p->jnt_off = off;
+    off += J;
+  }
+  p->Ctot = off;
+  p->nfeat = nfeat;
+  p->J = J;
+  return off;
+}
+
+extern "C" int geeco_state_concat_fwd(const float* const* feats, const int* feat_ch, int nfeat, int jnt_pos,
+                                      const float* jnt, int64_t jnt_stride, int J, const float* sub_from, int N,
+                                      int cells, float* state, int64_t state_stride, void* stream) {
+  GEECO_CHECK_ARG(feats && feat_ch && jnt && state, "state_concat_fwd: null pointer");
+  GEECO_CHECK_ARG(nfeat >= 1 && nfeat <= 3 && jnt_pos >= 0 && jnt_pos <= nfeat, "state_concat_fwd: nfeat/jnt_pos");
+  ConcatParams p = {};
+  fill_concat(&p, feat_ch, nfeat, jnt_pos, J);
+  for (int i = 0; i < nfeat; ++i) p.feats[i] = feats[i];
+  p.jnt = jnt; p.jnt_stride = jnt_stride; p.sub_from = sub_from; p.N = N; p.cells = cells;
+  p.state = state; p.state_stride = state_stride;
+  GEECO_CHECK_ARG(state_stride >= (int64_t)cells * p.Ctot, "state_concat_fwd: state_stride too small");
+  const long long total = (long long)N * cells * p.Ctot;
+  hipLaunchKernelGGL(concat_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int geeco_state_concat_bwd(const float* dstate, int64_t dstate_stride, const float* const* feats_fwd,
+                                      float* const* dfeats, const int* feat_ch, int nfeat, int jnt_pos, int J, int N,
+                                      int cells, int accumulate, void* stream) {
+  GEECO_CHECK_ARG(dstate && feats_fwd && dfeats && feat_ch, "state_concat_bwd: null pointer");
+  GEECO_CHECK_ARG(nfeat >= 1 && nfeat <= 3 && jnt_pos >= 0 && jnt_pos <= nfeat, "state_concat_bwd: nfeat/jnt_pos");
+  ConcatParams p = {};
+  fill_concat(&p, feat_ch, nfeat, jnt_pos, J);
+  p.state = const_cast<float*>(dstate); p.state_stride = dstate_stride; p.N = N; p.cells = cells;
+  p.accumulate = accumulate;
+  for (int i = 0; i < nfeat; ++i) {
+    p.feats[i] = feats_fwd[i];
+    p.dfeats[i] = dfeats[i];
+  }
+  for (int f = 0; f < nfeat; ++f) {
+    if (!dfeats[f]) continue;
+    GEECO_CHECK_ARG(feats_fwd[f], "state_concat_bwd: feats_fwd[%d] is null", f);
+    const long long total = (long long)N * cells * p.ch[f];
+    hipLaunchKernelGGL(concat_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, p, f);
+    GEECO_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// =====================================================================================================
+// dense f32 GEMM on MFMA 16x16x4 with split-K slabs (LSTM gate matmul and its backward)
+// =====================================================================================================
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  float* part;
+  long long lda, ldb, ldc;
+  int M, N, K, ta, tb, accumulate, S, k_per_split;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+  constexpr int BMg = 64, BNg = 64, BKg = 16, LD = 80;   // LD = 16 (mod 32): conflict-free ds_read_b32
+  __shared__ float sA[2][BKg * LD];
+  __shared__ float sB[2][BKg * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m0 = blockIdx.y * BMg, n0 = blockIdx.x * BNg;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  if (kend > p.K) kend = p.K;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = (wid & 1) * 32, wn = (wid >> 1) * 32;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float ra[4], rb[4];
+  // element e = tid + 256*i of a 16 x 64 tile.  For row-major-in-k sources (A not transposed, B
+  // transposed) consecutive threads walk k; otherwise they walk m/n, which keeps loads coalesced.
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + 256 * i;
+      int kk, mm;
+      if (!p.ta) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      int gk = k0 + kk, gm = m0 + mm;
+      bool v = gk < kend && gm < p.M;
+      ra[i] = v ? (p.ta ? p.A[(long long)gk * p.lda + gm] : p.A[(long long)gm * p.lda + gk]) : 0.f;
+      int kb, nn;
+      if (p.tb) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
+      int gkb = k0 + kb, gn = n0 + nn;
+      bool vb = gkb < kend && gn < p.N;
+      rb[i] = vb ? (p.tb ? p.B[(long long)gn * p.ldb + gkb] : p.B[(long long)gkb * p.ldb + gn]) : 0.f;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + 256 * i;
+      int kk, mm;
+      if (!p.ta) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      sA[buf][kk * LD + mm] = ra[i];
+      int kb, nn;
+      if (p.tb) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
+      sB[buf][kb * LD + nn] = rb[i];
+    }
+  };
+
+  const int nk = kend > kbeg ? (kend - kbeg + BKg - 1) / BKg : 0;
+  if (nk > 0) {
+    load_tiles(kbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    const bool more = ks + 1 < nk;
+    if (more) load_tiles(kbeg + (ks + 1) * BKg);
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = sA[buf][(blk * 4 + q) * LD + wm + i * 16 + r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = sB[buf][(blk * 4 + q) * LD + wn + j * 16 + r];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+  // D[i = m][j = n]: lane holds n = lane & 15, m = 4 (lane >> 4) + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = n0 + wn + j * 16 + r;
+      if (gn >= p.N) continue;
+      const float e[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int gm = m0 + wm + i * 16 + 4 * q + k;
+        if (gm >= p.M) continue;
+        if (p.S == 1) {
+          float* c = p.C + (long long)gm * p.ldc + gn;
+          *c = p.accumulate ? *c + e[k] : e[k];
+        } else {
+          p.part[((long long)blockIdx.z * p.M + gm) * p.N + gn] = e[k];
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmParams p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long MN = (long long)p.M * p.N;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int k = 0; k < p.S; ++k) s += p.part[(long long)k * MN + i];
+  const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+  float* c = p.C + (long long)m * p.ldc + n;
+  *c = p.accumulate ? *c + s : s;
+}
+
+static void gemm_plan(int M, int N, int K, int* S, int* kps) {
+  long long tiles = (long long)cdiv(M, 64) * cdiv(N, 64);
+  long long s = 512 / tiles;
+  if (s < 1) s = 1;
+  long long maxs = K / 64;
+  if (maxs < 1) maxs = 1;
+  if (s > maxs) s = maxs;
+  int k = cdiv(cdiv(K, (int)s), 16) * 16;
+  *kps = k;
+  *S = cdiv(K, k);
+}
+
+extern "C" int64_t geeco_gemm_ws_bytes(int M, int N, int K) {
+  int S, kps;
+  gemm_plan(M, N, K, &S, &kps);
+  return S > 1 ? (int64_t)S * M * N * 4 : 16;
+}
+
+extern "C" int geeco_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C,
+                              int64_t ldc, int M, int N, int K, int accumulate, void* ws, void* stream) {
+  GEECO_CHECK_ARG(A && B && C, "gemm_f32: null pointer");
+  GEECO_CHECK_ARG(M >= 1 && N >= 1 && K >= 1, "gemm_f32: bad dims");
+  GemmParams p = {};
+  p.A = A; p.B = B; p.C = C; p.part = (float*)ws; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.ta = ta; p.tb = tb; p.accumulate = accumulate;
+  gemm_plan(M, N, K, &p.S, &p.k_per_split);
+  GEECO_CHECK_ARG(p.S == 1 || ws, "gemm_f32: workspace required for split-K");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)p.S);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+  GEECO_LAUNCH_CHECK();
+  if (p.S > 1) {
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)cdiv64((long long)M * N, 256)), dim3(256), 0, s, p);
+    GEECO_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// =====================================================================================================
+// LSTM gate math (tf.nn.rnn_cell.LSTMCell, gate order i, j, f, o; forget_bias = 1)
+// =====================================================================================================
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                             const float* __restrict__ c_prev, float* __restrict__ c,
+                                                             float* __restrict__ h, float* __restrict__ gates, int N,
+                                                             int H) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int n = i / H, u = i - n * H;
+  const float* zr = z + (long long)n * 4 * H;
+  const float zi = zr[u] + bias[u], zj = zr[H + u] + bias[H + u];
+  const float zf = zr[2 * H + u] + bias[2 * H + u], zo = zr[3 * H + u] + bias[3 * H + u];
+  const float si = sigmoidf_(zi), tj = tanhf(zj), sf = sigmoidf_(zf + 1.0f), so = sigmoidf_(zo);
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float cn = sf * cp + si * tj;
+  c[i] = cn;
+  h[i] = so * tanhf(cn);
+  float* gr = gates + (long long)n * 4 * H;
+  gr[u] = si; gr[H + u] = tj; gr[2 * H + u] = sf; gr[3 * H + u] = so;
+}
+
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ gates,
+                                                             const float* __restrict__ c_prev, const float* __restrict__ c,
+                                                             const float* __restrict__ dh, const float* __restrict__ dc,
+                                                             float* __restrict__ dz, float* __restrict__ dc_prev, int N,
+                                                             int H) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int n = i / H, u = i - n * H;
+  const float* gr = gates + (long long)n * 4 * H;
+  const float si = gr[u], tj = gr[H + u], sf = gr[2 * H + u], so = gr[3 * H + u];
+  const float tc = tanhf(c[i]);
+  const float dhv = dh ? dh[i] : 0.f;
+  const float dct = (dc ? dc[i] : 0.f) + dhv * so * (1.f - tc * tc);
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  float* dr = dz + (long long)n * 4 * H;
+  dr[u] = dct * tj * si * (1.f - si);
+  dr[H + u] = dct * si * (1.f - tj * tj);
+  dr[2 * H + u] = dct * cp * sf * (1.f - sf);
+  dr[3 * H + u] = dhv * tc * so * (1.f - so);
+  if (dc_prev) dc_prev[i] = dct * sf;
+}
+
+extern "C" int geeco_lstm_gates_fwd(const float* z, const float* bias, const float* c_prev, float* c, float* h,
+                                    float* gates, int N, int H, void* stream) {
+  GEECO_CHECK_ARG(z && bias && c && h && gates && N >= 1 && H >= 1, "lstm_gates_fwd: bad arguments");
+  hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3((unsigned)cdiv(N * H, 256)), dim3(256), 0, (hipStream_t)stream, z,
+                     bias, c_prev, c, h, gates, N, H);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh,
+                                    const float* dc, float* dz, float* dc_prev, int N, int H, void* stream) {
+  GEECO_CHECK_ARG(gates && c && dz && N >= 1 && H >= 1, "lstm_gates_bwd: bad arguments");
+  hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3((unsigned)cdiv(N * H, 256)), dim3(256), 0, (hipStream_t)stream,
+                     gates, c_prev, c, dh, dc, dz, dc_prev, N, H);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// =====================================================================================================
+// fc1 + heads + losses, forward and backward, one workgroup (everything is tiny: N x 128)
+// =====================================================================================================
+struct HeadsParams {
+  const float* h;
+  const float* fc1_w;
+  const float* fc1_b;
+  const float* hw[4];
+  const float* hb[4];
+  const float* cmd;
+  const float* ee;
+  const float* obj;
+  long long ee_stride, obj_stride;
+  float lambda_aux, loss_scale;
+  int N, H, Hfc, backward;
+  float* preds;
+  float* losses;
+  float* dh;
+  float* d_fc1_w;
+  float* d_fc1_b;
+  float* dhw[4];
+  float* dhb[4];
+  float* a1;    // ws: [N][Hfc]
+  float* da1;   // ws: [N][Hfc]
+  float* dpred; // ws: [N][12]
+};
+
+__global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
+  const int tid = threadIdx.x, NT = 1024;
+  const int N = p.N, H = p.H, F = p.Hfc;
+  __shared__ float s_red[16][4];
+  // P1: a1 = relu(h W1 + b1)                                   graph.py:229-230
+  for (int i = tid; i < N * F; i += NT) {
+    const int n = i / F, j = i - n * F;
+    float s = p.fc1_b[j];
+    for (int k = 0; k < H; ++k) s = fmaf(p.h[n * H + k], p.fc1_w[k * F + j], s);
+    p.a1[i] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  // P2: preds[n][4 heads x 3]                                  graph.py:233-259
+  for (int i = tid; i < N * 12; i += NT) {
+    const int n = i / 12, o = i - n * 12, hd = o / 3, c = o - hd * 3;
+    float s = p.hb[hd][c];
+    for (int j = 0; j < F; ++j) s = fmaf(p.a1[n * F + j], p.hw[hd][j * 3 + c], s);
+    p.preds[i] = s;
+  }
+  __syncthreads();
+  // P3: losses and d(loss)/d(pred)                              graph.py:452-500, estimator.py:206-239
+  float l_ee = 0.f, l_grp = 0.f, l_pe = 0.f, l_po = 0.f;
+  const float inv3n = 1.f / (3.f * N), invn = 1.f / N;
+  for (int n = tid; n < N; n += NT) {
+    const float* pr = p.preds + n * 12;
+    float* dp = p.dpred + n * 12;
+    const float* cm = p.cmd + n * 4;
+    const float* ee = p.ee + (long long)n * p.ee_stride;
+    const float* ob = p.obj + (long long)n * p.obj_stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float d = pr[c] - cm[c];
+      l_ee += d * d;
+      dp[c] = 2.f * d * inv3n * p.loss_scale;
+      float d2 = pr[6 + c] - ee[c];
+      l_pe += d2 * d2;
+      dp[6 + c] = 2.f * d2 * inv3n * p.lambda_aux * p.loss_scale;
+      float d3 = pr[9 + c] - ob[c];
+      l_po += d3 * d3;
+      dp[9 + c] = 2.f * d3 * inv3n * p.lambda_aux * p.loss_scale;
+    }
+    const int label = (int)rintf(cm[3]) + 1;                  // estimator.py:213-215
+    const float l0 = pr[3], l1 = pr[4], l2 = pr[5];
+    const float mx = fmaxf(l0, fmaxf(l1, l2));
+    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
+    const float se = e0 + e1 + e2;
+    const float lse = mx + logf(se);
+    const float picked = label == 0 ? l0 : (label == 1 ? l1 : (label == 2 ? l2 : 0.f));
+    l_grp += (label >= 0 && label < 3) ? (lse - picked) : lse * 0.f;   // one_hot of an out-of-range label is all-zero
+    dp[3] = (e0 / se - (label == 0 ? 1.f : 0.f)) * invn * p.loss_scale;
+    dp[4] = (e1 / se - (label == 1 ? 1.f : 0.f)) * invn * p.loss_scale;
+    dp[5] = (e2 / se - (label == 2 ? 1.f : 0.f)) * invn * p.loss_scale;
+    if (label < 0 || label > 2) { dp[3] = dp[4] = dp[5] = 0.f; }
+  }
+  l_ee = wave_reduce_sum(l_ee); l_grp = wave_reduce_sum(l_grp);
+  l_pe = wave_reduce_sum(l_pe); l_po = wave_reduce_sum(l_po);
+  if ((tid & 63) == 0) {
+    s_red[tid >> 6][0] = l_ee; s_red[tid >> 6][1] = l_grp; s_red[tid >> 6][2] = l_pe; s_red[tid >> 6][3] = l_po;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    for (int w = 0; w < 16; ++w) { a += s_red[w][0]; b += s_red[w][1]; c += s_red[w][2]; d += s_red[w][3]; }
+    a *= inv3n; b *= invn; c *= inv3n; d *= inv3n;
+    p.losses[1] = a; p.losses[2] = b; p.losses[3] = c; p.losses[4] = d;
+    p.losses[0] = (a + b) + p.lambda_aux * (c + d);             // estimator.py:224-225
+  }
+  if (!p.backward) return;
+  __syncthreads();
+  // P4: head gradients and d(a1) with fc1's ReluGrad
+  for (int i = tid; i < F * 12; i += NT) {
+    const int j = i / 12, o = i - j * 12, hd = o / 3, c = o - hd * 3;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(p.a1[n * F + j], p.dpred[n * 12 + o], s);
+    p.dhw[hd][j * 3 + c] = s;
+  }
+  for (int o = tid; o < 12; o += NT) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += p.dpred[n * 12 + o];
+    p.dhb[o / 3][o % 3] = s;
+  }
+  for (int i = tid; i < N * F; i += NT) {
+    const int n = i / F, j = i - n * F;
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < 12; ++o) s = fmaf(p.dpred[n * 12 + o], p.hw[o / 3][j * 3 + (o % 3)], s);
+    p.da1[i] = p.a1[i] > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  // P5: fc1 gradients and d(h)
+  for (int i = tid; i < H * F; i += NT) {
+    const int k = i / F, j = i - k * F;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(p.h[n * H + k], p.da1[n * F + j], s);
+    p.d_fc1_w[i] = s;
+  }
+  for (int j = tid; j < F; j += NT) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += p.da1[n * F + j];
+    p.d_fc1_b[j] = s;
+  }
+  for (int i = tid; i < N * H; i += NT) {
+    const int n = i / H, k = i - n * H;
+    float s = 0.f;
+    for (int j = 0; j < F; ++j) s = fmaf(p.da1[n * F + j], p.fc1_w[k * F + j], s);
+    p.dh[i] = s;
+  }
+}
+
+extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {
+  (void)H;
+  return ((int64_t)2 * N * Hfc + (int64_t)N * 12) * 4;
+}
+
+extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b,
+                                        const float* const* heads_w, const float* const* heads_b, const float* cmd,
+                                        const float* ee_tgt, int64_t ee_stride, const float* obj_tgt,
+                                        int64_t obj_stride, float lambda_aux, float loss_scale, int N, int H, int Hfc,
+                                        float* preds, float* losses, int backward, float* dh, float* d_fc1_w,
+                                        float* d_fc1_b, float* const* d_heads_w, float* const* d_heads_b, float* ws,
+                                        void* stream) {
+  GEECO_CHECK_ARG(h && fc1_w && fc1_b && heads_w && heads_b && cmd && ee_tgt && obj_tgt && preds && losses && ws,
+                  "heads_loss: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && N <= 4096 && H >= 1 && Hfc >= 1, "heads_loss: bad dims");
+  GEECO_CHECK_ARG(!backward || (dh && d_fc1_w && d_fc1_b && d_heads_w && d_heads_b), "heads_loss: null gradient pointer");
+  HeadsParams p = {};
+  p.h = h; p.fc1_w = fc1_w; p.fc1_b = fc1_b; p.cmd = cmd; p.ee = ee_tgt; p.obj = obj_tgt;
+  p.ee_stride = ee_stride; p.obj_stride = obj_stride; p.lambda_aux = lambda_aux; p.loss_scale = loss_scale;
+  p.N = N; p.H = H; p.Hfc = Hfc; p.backward = backward; p.preds = preds; p.losses = losses;
+  p.dh = dh; p.d_fc1_w = d_fc1_w; p.d_fc1_b = d_fc1_b;
+  for (int i = 0; i < 4; ++i) {
+    p.hw[i] = heads_w[i]; p.hb[i] = heads_b[i];
+    if (backward) { p.dhw[i] = d_heads_w[i]; p.dhb[i] = d_heads_b[i]; }
+  }
+  p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
+  hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,246 @@
+// Dynamic image (temporal rank pooling) + per-sample min/max normalisation, HBM-bound streaming.
+//
+// Replaces reference src/models/e2evmc/graph.py:30-55 (dynimg) with coefficients from :17-28:
+//   D[n] = sum_t alpha_t X[n][t];  out[n] = (D[n] - min D[n]) / (max D[n] - min D[n] + 1e-6)
+// Pass 1 streams the K frames once (16 B per lane), writes D (channel-padded) and per-block
+// min/max partials; pass 2 folds the partials (one wave reduce) and normalises in place.
+// Algorithmic bytes: N*K*HW*C*4 read + N*HW*Cpad*4 written (+ one extra read/write of D).
+#include "geeco_common.h"
+
+#define DYN_MAXK 64
+
+struct DynParams {
+  const float* frames;
+  const float* frames2;
+  long long sample_stride, frame_stride;
+  int N, K;
+  long long HW;
+  int C, Cpad;
+  float* out;
+  float* part;   // [N][nblk][2]
+  int nblk;
+  float alpha[DYN_MAXK];
+};
+
+__device__ __forceinline__ const float* dyn_frame_ptr(const DynParams& p, int n, int t) {
+  if (p.frames2 && t == 1) return p.frames2 + (long long)n * p.HW * p.C;
+  return p.frames + (long long)n * p.sample_stride + (long long)t * p.frame_stride;
+}
+
+__device__ __forceinline__ void block_minmax_store(float mn, float mx, float* dst) {
+  __shared__ float smn[4], smx[4];
+  mn = wave_reduce_min(mn);
+  mx = wave_reduce_max(mx);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    smn[wid] = mn;
+    smx[wid] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dst[0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    dst[1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+
+// C == 3, Cpad == 4, HW % 4 == 0: one thread = 4 pixels = 3 float4 in, 4 float4 out.
+__global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
+  const int n = blockIdx.y;
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;   // 4-pixel unit
+  const long long U = p.HW >> 2;
+  float mn = INFINITY, mx = -INFINITY;
+  if (u < U) {
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;
+#pragma unroll 4
+    for (int t = 0; t < p.K; ++t) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t)) + u * 3;
+      const float w = p.alpha[t];
+      f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
+      a0 += w * v0;
+      a1 += w * v1;
+      a2 += w * v2;
+    }
+    float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      mn = fminf(mn, e[i]);
+      mx = fmaxf(mx, e[i]);
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(p.out + ((long long)n * p.HW + u * 4) * 4);
+    dst[0] = f32x4{e[0], e[1], e[2], 0.f};
+    dst[1] = f32x4{e[3], e[4], e[5], 0.f};
+    dst[2] = f32x4{e[6], e[7], e[8], 0.f};
+    dst[3] = f32x4{e[9], e[10], e[11], 0.f};
+  }
+  block_minmax_store(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2);
+}
+
+// Generic: one thread = one pixel, C <= Cpad <= 8 channels (C == 4: one float4 per frame).
+__global__ __launch_bounds__(256) void dynimg_wsum_generic_kernel(const DynParams p) {
+  const int n = blockIdx.y;
+  const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+  float mn = INFINITY, mx = -INFINITY;
+  if (px < p.HW) {
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    if (p.C == 4) {
+#pragma unroll 4
+      for (int t = 0; t < p.K; ++t) {
+        f32x4 v = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t))[px];
+        const float w = p.alpha[t];
+        acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w;
+      }
+    } else {
+      for (int t = 0; t < p.K; ++t) {
+        const float* src = dyn_frame_ptr(p, n, t) + px * p.C;
+        const float w = p.alpha[t];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < p.C) acc[c] += w * src[c];
+      }
+    }
+    float* dst = p.out + ((long long)n * p.HW + px) * p.Cpad;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < p.C) {
+        mn = fminf(mn, acc[c]);
+        mx = fmaxf(mx, acc[c]);
+      }
+      if (c < p.Cpad) dst[c] = c < p.C ? acc[c] : 0.f;
+    }
+  }
+  block_minmax_store(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2);
+}
+
+// Pass 2: fold partials, normalise in place.  One thread = 4 consecutive floats of out.
+__global__ __launch_bounds__(256) void dynimg_norm_kernel(float* out, const float* part, int nblk, long long HW,
+                                                          int C, int Cpad) {
+  const int n = blockIdx.y;
+  __shared__ float s_mn, s_rng;
+  {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+      mn = fminf(mn, part[((long long)n * nblk + i) * 2]);
+      mx = fmaxf(mx, part[((long long)n * nblk + i) * 2 + 1]);
+    }
+    __shared__ float smn[4], smx[4];
+    mn = wave_reduce_min(mn);
+    mx = wave_reduce_max(mx);
+    if ((threadIdx.x & 63) == 0) {
+      smn[threadIdx.x >> 6] = mn;
+      smx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+      float b = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+      s_mn = a;
+      s_rng = b - a + 1e-6f;   // graph.py:49
+    }
+    __syncthreads();
+  }
+  const float mn = s_mn, rng = s_rng;
+  const long long total = HW * Cpad;
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  float* o = out + (long long)n * total + i4;
+  if ((total & 3) == 0) {
+    f32x4 v = *reinterpret_cast<f32x4*>(o);
+    float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int c = (int)((i4 + k) % Cpad);
+      e[k] = c < C ? (e[k] - mn) / rng : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(o) = f32x4{e[0], e[1], e[2], e[3]};
+  } else {
+    for (int k = 0; k < 4 && i4 + k < total; ++k) {
+      int c = (int)((i4 + k) % Cpad);
+      o[k] = c < C ? (o[k] - mn) / rng : 0.f;
+    }
+  }
+}
+
+extern "C" void geeco_dynimg_alpha(int K, float* alpha) {
+  // graph.py:17-28: float32 harmonic numbers summed in ascending order
+  auto H = [](int t) {
+    float h = 0.f;
+    for (int i = 1; i <= t; ++i) h = h + 1.0f / (float)i;
+    return h;
+  };
+  const float HT = H(K);
+  for (int t = 1; t <= K; ++t) alpha[t - 1] = (float)(2 * (K - t + 1)) - (float)(K + 1) * (HT - H(t - 1));
+}
+
+static int dyn_nblk(long long HW, int C) {
+  if (C == 3 && (HW & 3) == 0) return (int)cdiv64(HW >> 2, 256);
+  return (int)cdiv64(HW, 256);
+}
+
+extern "C" int64_t geeco_dynimg_ws_bytes(int N, int64_t hwc) {
+  // upper bound over both kernels: one partial pair per 256 pixels
+  return (int64_t)N * (cdiv64(hwc, 256) + 1) * 2 * 4;
+}
+
+extern "C" int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_stride,
+                                int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW, int C,
+                                int Cpad, float* out, void* ws, void* stream) {
+  GEECO_CHECK_ARG(frames && alpha_host && out && ws, "dynimg_fwd: null pointer");
+  GEECO_CHECK_ARG(K >= 1 && K <= DYN_MAXK, "dynimg_fwd: K=%d outside 1..%d", K, DYN_MAXK);
+  GEECO_CHECK_ARG(N >= 1 && HW >= 1 && C >= 1 && C <= Cpad && Cpad <= 8, "dynimg_fwd: bad dims");
+  GEECO_CHECK_ARG(!frames2 || K == 2, "dynimg_fwd: frames2 only with K == 2");
+  DynParams p = {};
+  p.frames = frames; p.frames2 = frames2; p.sample_stride = sample_stride; p.frame_stride = frame_stride;
+  p.N = N; p.K = K; p.HW = HW; p.C = C; p.Cpad = Cpad; p.out = out; p.part = (float*)ws;
+  p.nblk = dyn_nblk(HW, C);
+  for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)p.nblk, (unsigned)N);
+  const bool aligned = (sample_stride % 4 == 0) && (frame_stride % 4 == 0);
+  if (C == 3 && Cpad == 4 && (HW & 3) == 0 && aligned)
+    hipLaunchKernelGGL(dynimg_wsum3_kernel, grid, dim3(256), 0, s, p);
+  else {
+    GEECO_CHECK_ARG(C != 4 || aligned, "dynimg_fwd: C == 4 needs 16-byte aligned frames");
+    p.nblk = (int)cdiv64(HW, 256);
+    grid.x = p.nblk;
+    hipLaunchKernelGGL(dynimg_wsum_generic_kernel, grid, dim3(256), 0, s, p);
+  }
+  GEECO_LAUNCH_CHECK();
+  dim3 g2((unsigned)cdiv64(HW * Cpad, 1024), (unsigned)N);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, C, Cpad);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- pixel packing: [n][HW][C1] (+ [n][HW][C2]) -> [n][HW][Cpad] ---------------------------------
+__global__ __launch_bounds__(256) void pack_pixels_kernel(const float* src, long long s1, const float* src2,
+                                                          long long s2, long long HW, int C1, int C2, int Cpad,
+                                                          float* dst) {
+  const int n = blockIdx.y;
+  const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (px >= HW) return;
+  const float* a = src + (long long)n * s1 + px * C1;
+  const float* b = src2 ? src2 + (long long)n * s2 + px * C2 : nullptr;
+  float* o = dst + ((long long)n * HW + px) * Cpad;
+  if (Cpad == 4) {
+    float e[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e[c] = c < C1 ? a[c] : (b && c - C1 < C2 ? b[c - C1] : 0.f);
+    *reinterpret_cast<f32x4*>(o) = f32x4{e[0], e[1], e[2], e[3]};
+  } else {
+    for (int c = 0; c < Cpad; ++c) o[c] = c < C1 ? a[c] : (b && c - C1 < C2 ? b[c - C1] : 0.f);
+  }
+}
+
+extern "C" int geeco_pack_pixels(const float* src, int64_t src_sample_stride, const float* src2,
+                                 int64_t src2_sample_stride, int N, int64_t HW, int C1, int C2, int Cpad,
+                                 float* dst, void* stream) {
+  GEECO_CHECK_ARG(src && dst, "pack_pixels: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && HW >= 1 && C1 >= 1 && C1 + (src2 ? C2 : 0) <= Cpad, "pack_pixels: bad dims");
+  dim3 grid((unsigned)cdiv64(HW, 256), (unsigned)N);
+  hipLaunchKernelGGL(pack_pixels_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long long)src_sample_stride,
+                     src2, (long long)src2_sample_stride, (long long)HW, C1, C2, Cpad, dst);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,57 @@
+// Shared helpers for the gfx950 kernels (wave = 64 lanes, MFMA f32 16x16x4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/geeco_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void geeco_set_error(const char* fmt, ...);
+
+#define GEECO_CHECK_ARG(cond, ...)              \
+  do {                                          \
+    if (!(cond)) {                              \
+      geeco_set_error(__VA_ARGS__);             \
+      return GEECO_EINVAL;                      \
+    }                                           \
+  } while (0)
+
+#define GEECO_LAUNCH_CHECK()                                         \
+  do {                                                               \
+    hipError_t e_ = hipGetLastError();                               \
+    if (e_ != hipSuccess) {                                          \
+      geeco_set_error("launch failed: %s", hipGetErrorString(e_));   \
+      return (int)e_;                                                \
+    }                                                                \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// TF 'SAME' padding: out = ceil(in/s); pad_total = max((out-1)s + k - in, 0); before = total/2.
+static inline void same_pad(int size, int k, int s, int* out, int* before) {
+  int o = (size + s - 1) / s;
+  int tot = (o - 1) * s + k - size;
+  if (tot < 0) tot = 0;
+  *out = o;
+  *before = tot / 2;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,169 @@
+// Small HBM-bound helpers: kernel transposes/padding, fused TF-style Adam, reductions.
+#include "geeco_common.h"
+
+// ---- [G][9][A][B] -> [G][9][B][A] ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                             long long gs_w, long long gs_wt, int A, int B) {
+  __shared__ float tile[32][33];
+  const int g = blockIdx.z / 9, tap = blockIdx.z % 9;
+  const float* src = w + (long long)g * gs_w + (long long)tap * A * B;
+  float* dst = wt + (long long)g * gs_wt + (long long)tap * A * B;
+  const int tilesB = (B + 31) / 32;
+  const int ta = blockIdx.x / tilesB, tb = blockIdx.x % tilesB;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    int a = ta * 32 + ty + i, b = tb * 32 + tx;
+    if (a < A && b < B) tile[ty + i][tx] = src[(long long)a * B + b];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    int b = tb * 32 + ty + i, a = ta * 32 + tx;
+    if (a < A && b < B) dst[(long long)b * A + a] = tile[tx][ty + i];
+  }
+}
+
+extern "C" int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,
+                                    int Cout, void* stream) {
+  GEECO_CHECK_ARG(w && wt && groups >= 1 && Cin >= 1 && Cout >= 1, "transpose_hwio: bad arguments");
+  dim3 grid((unsigned)(cdiv(Cin, 32) * cdiv(Cout, 32)), 1, (unsigned)(groups * 9));
+  hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, (long long)gs_w,
+                     (long long)gs_wt, Cin, Cout);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- [A][B][C] -> [A][Bd][C] -----------------------------------------------------------------------
+__global__ void pad_mid_kernel(const float* __restrict__ src, float* __restrict__ dst, long long A, int B, int Bd,
+                               int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = A * Bd * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long ab = i / C;
+  const int b = (int)(ab % Bd);
+  const long long a = ab / Bd;
+  dst[i] = b < B ? src[(a * B + b) * C + c] : 0.f;
+}
+
+extern "C" int geeco_pad_mid(const float* src, float* dst, int64_t A, int B, int Bd, int C, void* stream) {
+  GEECO_CHECK_ARG(src && dst && A >= 1 && B >= 1 && Bd >= 1 && C >= 1, "pad_mid: bad arguments");
+  const long long total = (long long)A * Bd * C;
+  hipLaunchKernelGGL(pad_mid_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     (long long)A, B, Bd, C);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- Adam (tf.train.AdamOptimizer semantics) -------------------------------------------------------
+// scal[0] = lr_t for this step; the step counter lives in device memory so that a captured
+// hipGraph replays with the right bias correction.
+__global__ void adam_prepare_kernel(long long* step, float lr, float b1, float b2, float* scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long t = *step + 1;
+    *step = t;
+    double b1t = pow((double)b1, (double)t), b2t = pow((double)b2, (double)t);
+    scal[0] = (float)((double)lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+  }
+}
+
+extern "C" int geeco_adam_prepare(int64_t* global_step_dev, float lr, float beta1, float beta2, float* scal_dev,
+                                  void* stream) {
+  GEECO_CHECK_ARG(global_step_dev && scal_dev, "adam_prepare: null pointer");
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)global_step_dev, lr,
+                     beta1, beta2, scal_dev);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   const float* __restrict__ scal, float b1, float b2, float eps,
+                                                   float gscale, float l2) {
+  const float lr_t = scal[0];
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w};
+    float me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gg = ge[k] * gscale + l2 * pe[k];
+      me[k] = b1 * me[k] + (1.f - b1) * gg;
+      ve[k] = b2 * ve[k] + (1.f - b2) * gg * gg;
+      pe[k] = pe[k] - lr_t * me[k] / (sqrtf(ve[k]) + eps);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = f32x4{pe[0], pe[1], pe[2], pe[3]};
+    reinterpret_cast<f32x4*>(m)[i] = f32x4{me[0], me[1], me[2], me[3]};
+    reinterpret_cast<f32x4*>(v)[i] = f32x4{ve[0], ve[1], ve[2], ve[3]};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    float gg = g[i] * gscale + l2 * p[i];
+    float mm = b1 * m[i] + (1.f - b1) * gg;
+    float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+extern "C" int geeco_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_t_dev,
+                             float beta1, float beta2, float eps, float grad_scale, float l2, void* stream) {
+  GEECO_CHECK_ARG(p && g && m && v && lr_t_dev && n >= 1, "adam_tf: bad arguments");
+  GEECO_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                  "adam_tf: arenas must be 16-byte aligned");
+  long long blocks = cdiv64(n >> 2, 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                     lr_t_dev, beta1, beta2, eps, grad_scale, l2);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- sum of squares (L2 regularisation loss, graph.py:13-15) ---------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ p, long long n, float* out) {
+  __shared__ float sw[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += p[i] * p[i];
+  s = wave_reduce_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sw[0] + sw[1] + sw[2] + sw[3]);
+}
+
+extern "C" int geeco_sumsq(const float* p, int64_t n, float* out, void* stream) {
+  GEECO_CHECK_ARG(p && out && n >= 1, "sumsq: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  long long blocks = cdiv64(n, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (long long)n, out);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- column sums: out[j] = sum_i a[i][j] -----------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, long long lda, int M, int N,
+                                                     float* __restrict__ out, int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < M; ++i) s += a[(long long)i * lda + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+extern "C" int geeco_colsum(const float* a, int64_t lda, int M, int N, float* out, int accumulate, void* stream) {
+  GEECO_CHECK_ARG(a && out && M >= 1 && N >= 1, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                     (long long)lda, M, N, out, accumulate);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}

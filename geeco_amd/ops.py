@@ -1,0 +1,236 @@
+"""Thin tensor-level wrappers over the C-ABI (geeco_amd/_native.py).
+
+PyTorch is plumbing only: tensors own device memory, ``torch.cuda.current_stream()`` provides the
+HIP stream.  Every function enqueues HIP kernels from libgeeco_hip.so on that stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _native
+from ._native import check
+
+
+def _lib():
+  return _native.load()
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+  if t is None:
+    return None
+  assert t.is_cuda and t.dtype in (torch.float32, torch.int64), (t.device, t.dtype)
+  return ctypes.c_void_p(t.data_ptr())
+
+
+def _parr(ts):
+  arr = (ctypes.c_void_p * len(ts))()
+  for i, t in enumerate(ts):
+    arr[i] = t.data_ptr() if t is not None else None
+  return arr
+
+
+def _iarr(vals):
+  arr = (ctypes.c_int * len(vals))()
+  for i, v in enumerate(vals):
+    arr[i] = int(v)
+  return arr
+
+
+def same_out(size: int, stride: int) -> int:
+  return -(-size // stride)
+
+
+# --------------------------------------------------------------------------------------------
+# dynamic image
+# --------------------------------------------------------------------------------------------
+def dynimg_alpha(K: int):
+  buf = (ctypes.c_float * K)()
+  _lib().geeco_dynimg_alpha(K, ctypes.cast(buf, ctypes.c_void_p))
+  return [float(v) for v in buf]
+
+
+_ALPHA_CACHE = {}
+
+
+def _alpha_buf(K):
+  if K not in _ALPHA_CACHE:
+    buf = (ctypes.c_float * K)()
+    _lib().geeco_dynimg_alpha(K, ctypes.cast(buf, ctypes.c_void_p))
+    _ALPHA_CACHE[K] = buf
+  return _ALPHA_CACHE[K]
+
+
+def dynimg_ws(N, hwc, device):
+  nbytes = _lib().geeco_dynimg_ws_bytes(N, hwc)
+  return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def dynimg_into(out, frames, K, N, HW, C, Cpad, ws, sample_stride, frame_stride, frames2=None):
+  """out [N][HW][Cpad] <- normalised dynamic image of K frames (graph.py:30-55)."""
+  check(_lib().geeco_dynimg_fwd(_p(frames), _p(frames2), sample_stride, frame_stride,
+                                ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N, K, HW, C, Cpad, _p(out), _p(ws),
+                                _stream()), 'geeco_dynimg_fwd')
+
+
+def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
+  """frames [N,K,H,W,C] contiguous -> [N,H,W,Cpad]."""
+  N, K, H, W, C = frames.shape
+  Cpad = Cpad or C
+  out = torch.empty(N, H, W, Cpad, dtype=torch.float32, device=frames.device)
+  ws = dynimg_ws(N, H * W * C, frames.device)
+  dynimg_into(out, frames.contiguous(), K, N, H * W, C, Cpad, ws, K * H * W * C, H * W * C)
+  return out
+
+
+def pack_pixels_into(dst, src, src_sample_stride, N, HW, C1, Cpad, src2=None, src2_sample_stride=0, C2=0):
+  check(_lib().geeco_pack_pixels(_p(src), src_sample_stride, _p(src2), src2_sample_stride, N, HW, C1, C2, Cpad,
+                                 _p(dst), _stream()), 'geeco_pack_pixels')
+
+
+# --------------------------------------------------------------------------------------------
+# conv encoder
+# --------------------------------------------------------------------------------------------
+def conv3x3_fwd_into(y, x, w, b, G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, stride, relu=True):
+  check(_lib().geeco_conv3x3_fwd(_p(x), _p(w), _p(b), _p(y), G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout,
+                                 stride, 1 if relu else 0, _stream()), 'geeco_conv3x3_fwd')
+
+
+def conv3x3_dgrad_into(dx, dz, wt, ymask, G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout, stride):
+  check(_lib().geeco_conv3x3_dgrad(_p(dz), _p(wt), _p(ymask), _p(dx), G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout,
+                                   stride, _stream()), 'geeco_conv3x3_dgrad')
+
+
+def conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
+  return int(_lib().geeco_conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride))
+
+
+def conv3x3_wgrad_into(dw, db, x, dz, G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws):
+  check(_lib().geeco_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin,
+                                   Cout, stride, _p(ws), _stream()), 'geeco_conv3x3_wgrad')
+
+
+def transpose_hwio_into(wt, w, G, gs_w, gs_wt, Cin, Cout):
+  check(_lib().geeco_transpose_hwio(_p(w), _p(wt), G, gs_w, gs_wt, Cin, Cout, _stream()), 'geeco_transpose_hwio')
+
+
+def pad_mid_into(dst, src, A, B, Bd, C):
+  check(_lib().geeco_pad_mid(_p(src), _p(dst), A, B, Bd, C, _stream()), 'geeco_pad_mid')
+
+
+# convenience (allocating) forms used by the parity tests -------------------------------------
+def conv3x3(x, w, b, stride, relu=True):
+  """x [N,H,W,Cin] (Cin % 4 == 0), w [3,3,Cin,Cout], b [Cout] -> y [N,Ho,Wo,Cout]."""
+  N, H, W, Cin = x.shape
+  Cout = w.shape[3]
+  y = torch.empty(N, same_out(H, stride), same_out(W, stride), Cout, dtype=torch.float32, device=x.device)
+  conv3x3_fwd_into(y, x.contiguous(), w.contiguous(), b.contiguous(), 1, 0, 0, 0, 0, N, H, W, Cin, Cout, stride, relu)
+  return y
+
+
+def conv3x3_dgrad(dz, w, ymask, in_hw, stride):
+  """dz [N,Ho,Wo,Cout], w [3,3,Cin,Cout], ymask [N,H,W,Cin] or None -> dx [N,H,W,Cin]."""
+  N, Ho, Wo, Cout = dz.shape
+  Cin = w.shape[2]
+  H, W = in_hw
+  wt = torch.empty(3, 3, Cout, Cin, dtype=torch.float32, device=dz.device)
+  transpose_hwio_into(wt, w.contiguous(), 1, 0, 0, Cin, Cout)
+  dx = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dz.device)
+  conv3x3_dgrad_into(dx, dz.contiguous(), wt, ymask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride)
+  return dx
+
+
+def conv3x3_wgrad(x, dz, stride):
+  """x [N,H,W,Cin], dz [N,Ho,Wo,Cout] -> dw [3,3,Cin,Cout], db [Cout]."""
+  N, H, W, Cin = x.shape
+  Cout = dz.shape[3]
+  dw = torch.empty(3, 3, Cin, Cout, dtype=torch.float32, device=x.device)
+  db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+  ws = torch.empty(conv3x3_wgrad_ws_bytes(1, N, H, W, Cin, Cout, stride) // 4 + 4, dtype=torch.float32, device=x.device)
+  conv3x3_wgrad_into(dw, db, x.contiguous(), dz.contiguous(), 1, 0, 0, 0, 0, N, H, W, Cin, Cout, stride, ws)
+  return dw, db
+
+
+# --------------------------------------------------------------------------------------------
+# decoder pieces
+# --------------------------------------------------------------------------------------------
+def state_concat_fwd_into(state, feats, feat_ch, jnt_pos, jnt, jnt_stride, J, N, cells, state_stride, sub_from=None):
+  check(_lib().geeco_state_concat_fwd(_parr(feats), _iarr(feat_ch), len(feats), jnt_pos, _p(jnt), jnt_stride, J,
+                                      _p(sub_from), N, cells, _p(state), state_stride, _stream()),
+        'geeco_state_concat_fwd')
+
+
+def state_concat_bwd_into(dfeats, dstate, dstate_stride, feats_fwd, feat_ch, jnt_pos, J, N, cells, accumulate=False):
+  check(_lib().geeco_state_concat_bwd(_p(dstate), dstate_stride, _parr(feats_fwd), _parr(dfeats), _iarr(feat_ch),
+                                      len(feats_fwd), jnt_pos, J, N, cells, 1 if accumulate else 0, _stream()),
+        'geeco_state_concat_bwd')
+
+
+def gemm_ws_bytes(M, N, K):
+  return int(_lib().geeco_gemm_ws_bytes(M, N, K))
+
+
+def gemm_into(C, A, B, M, N, K, lda, ldb, ldc, ta=False, tb=False, accumulate=False, ws=None):
+  check(_lib().geeco_gemm_f32(_p(A), lda, 1 if ta else 0, _p(B), ldb, 1 if tb else 0, _p(C), ldc, M, N, K,
+                              1 if accumulate else 0, _p(ws), _stream()), 'geeco_gemm_f32')
+
+
+def gemm(A, B, ta=False, tb=False):
+  """Allocating form for tests: op(A) @ op(B) with row-major 2-D tensors."""
+  M, K = (A.shape[1], A.shape[0]) if ta else A.shape
+  N = B.shape[0] if tb else B.shape[1]
+  C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+  ws = torch.empty(gemm_ws_bytes(M, N, K) // 4 + 4, dtype=torch.float32, device=A.device)
+  gemm_into(C, A.contiguous(), B.contiguous(), M, N, K, A.shape[1], B.shape[1], N, ta, tb, False, ws)
+  return C
+
+
+def lstm_gates_fwd_into(c, h, gates, z, bias, c_prev, N, H):
+  check(_lib().geeco_lstm_gates_fwd(_p(z), _p(bias), _p(c_prev), _p(c), _p(h), _p(gates), N, H, _stream()),
+        'geeco_lstm_gates_fwd')
+
+
+def lstm_gates_bwd_into(dz, dc_prev, gates, c_prev, c, dh, dc, N, H):
+  check(_lib().geeco_lstm_gates_bwd(_p(gates), _p(c_prev), _p(c), _p(dh), _p(dc), _p(dz), _p(dc_prev), N, H,
+                                    _stream()), 'geeco_lstm_gates_bwd')
+
+
+def colsum_into(out, a, lda, M, N, accumulate=False):
+  check(_lib().geeco_colsum(_p(a), lda, M, N, _p(out), 1 if accumulate else 0, _stream()), 'geeco_colsum')
+
+
+def heads_ws_bytes(N, H, Hfc):
+  return int(_lib().geeco_heads_ws_bytes(N, H, Hfc))
+
+
+def heads_loss_into(preds, losses, h, fc1_w, fc1_b, heads_w, heads_b, cmd, ee_tgt, ee_stride, obj_tgt, obj_stride,
+                    lambda_aux, loss_scale, N, H, Hfc, ws, dh=None, d_fc1_w=None, d_fc1_b=None, d_heads_w=None,
+                    d_heads_b=None):
+  backward = dh is not None
+  check(_lib().geeco_heads_loss_fwd_bwd(
+      _p(h), _p(fc1_w), _p(fc1_b), _parr(heads_w), _parr(heads_b), _p(cmd), _p(ee_tgt), ee_stride, _p(obj_tgt),
+      obj_stride, lambda_aux, loss_scale, N, H, Hfc, _p(preds), _p(losses), 1 if backward else 0, _p(dh),
+      _p(d_fc1_w), _p(d_fc1_b), _parr(d_heads_w) if backward else None, _parr(d_heads_b) if backward else None,
+      _p(ws), _stream()), 'geeco_heads_loss_fwd_bwd')
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------------------------
+def adam_prepare(global_step, lr, scal, beta1=0.9, beta2=0.999):
+  check(_lib().geeco_adam_prepare(_p(global_step), lr, beta1, beta2, _p(scal), _stream()), 'geeco_adam_prepare')
+
+
+def adam_tf(p, g, m, v, n, scal, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
+  check(_lib().geeco_adam_tf(_p(p), _p(g), _p(m), _p(v), n, _p(scal), beta1, beta2, eps, grad_scale, l2, _stream()),
+        'geeco_adam_tf')
+
+
+def sumsq_into(out, p, n):
+  check(_lib().geeco_sumsq(_p(p), n, _p(out), _stream()), 'geeco_sumsq')

