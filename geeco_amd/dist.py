@@ -1,0 +1,71 @@
+"""Data-parallel plumbing: one process per GPU, RCCL over xGMI through ``torch.distributed``.
+
+The reference has no distributed code; the batch-of-windows shards naturally
+(samples are independent, all losses are batch means), so DP is: same weights on every rank,
+each rank runs the step on its own shard, ONE all-reduce(sum) of the flat gradient arena
+(30.2 MB for geeco-f), Adam with grad_scale = 1/world.  backend 'nccl' is RCCL on ROCm;
+'gloo' is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+  return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+  return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend=None):
+  """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1."""
+  ws = int(os.environ.get('WORLD_SIZE', '1'))
+  if ws <= 1 or dist.is_initialized():
+    return world_size()
+  os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+  os.environ.setdefault('MASTER_PORT', '29500')
+  if backend is None:
+    backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+  if backend == 'nccl':
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+  dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+  return ws
+
+
+def broadcast_variables(store, src=0):
+  """Every replica starts from rank 0's weights and optimiser state."""
+  if world_size() == 1:
+    return
+  for t in (store.params, store.adam_m, store.adam_v, store.global_step):
+    dist.broadcast(t, src=src)
+
+
+def allreduce_gradients(grads: torch.Tensor):
+  """SUM over ranks of the flat gradient arena, in place, on the current stream (the 1/world
+  factor is folded into the Adam kernel's grad_scale)."""
+  if world_size() == 1:
+    return
+  dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+
+
+def shard_bounds(n_items: int, r=None, w=None):
+  """Contiguous equal shards; requires n_items % world == 0 so that mean-of-means == global mean."""
+  r = rank() if r is None else r
+  w = world_size() if w is None else w
+  if n_items % w:
+    raise ValueError('global batch %d is not divisible by world size %d' % (n_items, w))
+  per = n_items // w
+  return r * per, (r + 1) * per
+
+
+def max_over_ranks(value: float, device) -> float:
+  if world_size() == 1:
+    return value
+  t = torch.tensor([value], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())

@@ -1,0 +1,111 @@
+"""Whole-graph parity on the GPU: forward outputs, loss, every variable's gradient and the
+post-Adam weights of geeco_amd (HIP) vs the fp64 CPU oracle on the same seeded inputs/weights.
+
+Tolerances (fp32 HIP vs fp64 oracle): loss 1e-4 relative (BASELINE.json north_star); gradients
+max(2e-4, 4 x the error of the SAME oracle run in fp32 on the CPU) of the variable's max |g|: on
+noise-like inputs (the K=16 dynamic image of random frames) fp32 rounding of the input flips a few
+ReLU masks in conv1-4, which moves those layers' gradients by ~1e-3 in ANY fp32 implementation, the
+CPU restatement included, so the fp32 CPU run is the yardstick there; Adam step 1 moves
+every weight by ~lr * sign(g) so weights are compared with atol = 2.5 * lr ("Adam step-1
+sign sensitivity").
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geeco_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(cfg_kw, goal, N, H, seed=1):
+  cfg_kw = dict(cfg_kw, img_height=H, img_width=H, batch_size=N)
+  ocfg = O.make_config(**cfg_kw)
+  shapes = O.model_param_shapes(ocfg, goal)
+  P = O.init_params(shapes, seed=seed)
+  # non-zero biases so that bias paths are exercised
+  r = np.random.default_rng(seed + 1)
+  for k in P:
+    if k.endswith('/bias'):
+      P[k] = (0.05 * r.standard_normal(P[k].shape)).astype(np.float32)
+  feats, labels = O.synthetic_batch(ocfg, goal, N, seed=seed + 2, H=H, W=H)
+  return ocfg, P, feats, labels
+
+
+def _build(ocfg, goal, P, feats, labels, dev):
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  cfg = create_e2evmc_config(ocfg._asdict())
+  N = feats['rgb'].shape[0]
+  model = (graph.GoalE2EVMC if goal else graph.E2EVMC)(cfg, N, dev, training=True)
+  assert list(model.store.shapes.keys()) == list(P.keys())
+  model.store.load_numpy(P)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  return model
+
+
+def _rel_max(a, b):
+  a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+  return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+CASES = [
+    ('geeco-f rgb', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=4), True, 2, 160),
+    ('geeco-f rgbd', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_channels=4, lambda_aux=0.5), True, 2, 136),
+    ('e2e_vmc rgb', dict(window_size=3), False, 2, 144),
+    ('geeco-f rgb 256', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 2, 256),
+]
+
+
+@pytest.mark.parametrize('name,cfg_kw,goal,N,H', CASES, ids=[c[0] for c in CASES])
+def test_train_step_parity(dev, name, cfg_kw, goal, N, H):
+  ocfg, P, feats, labels = _mk(cfg_kw, goal, N, H)
+  model = _build(ocfg, goal, P, feats, labels, dev)
+  oracle = O.OracleTrainer(ocfg, goal, P, dtype=torch.float64)
+  _, _, grads_ref32, _, _ = O.OracleTrainer(ocfg, goal, P, dtype=torch.float32).loss_and_grads(feats, labels)
+
+  # ---- forward + gradients ------------------------------------------------------------------
+  collect = {}
+  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = oracle.loss_and_grads(feats, labels, collect)
+  model.forward(backward_too=True)
+  model.backward()
+  torch.cuda.synchronize()
+  if goal:
+    ep = model.endpoints()
+    for k in ('dynbuff', 'dyndiff'):
+      assert _rel_max(ep[k].cpu().numpy(), ep_ref[k].numpy()) < 2e-5, k
+  preds = {k: v.cpu().numpy() for k, v in model.predictions().items()}
+  for k, v in pred_ref.items():
+    np.testing.assert_allclose(preds[k], v.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+  parts = {k: float(v) for k, v in model.loss_parts().items()}
+  assert abs(parts['loss'] - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (parts['loss'], float(loss_ref))
+  for k in ('loss_cmd_ee', 'loss_cmd_grp', 'loss_pos_ee', 'loss_pos_obj'):
+    assert abs(parts[k] - float(parts_ref[k])) <= 1e-4 * abs(float(parts_ref[k])) + 1e-7, k
+  grads = model.store.to_numpy('grads')
+  worst = ('', 0.0)
+  for k, g in grads_ref.items():
+    e = _rel_max(grads[k], g.numpy())
+    tol = max(2e-4, 4.0 * _rel_max(grads_ref32[k].numpy(), g.numpy()))
+    assert e <= tol, (k, e, tol)
+    if e > worst[1]:
+      worst = (k, e)
+  print('%s: loss %.6f (ref %.6f), worst gradient error %.2e at %s' % (name, parts['loss'], float(loss_ref), worst[1], worst[0]))
+
+  # ---- two optimiser steps -------------------------------------------------------------------
+  lr = ocfg.lr
+  for step in range(2):
+    model.train_step()
+    torch.cuda.synchronize()
+    l_ref, _ = oracle.train_step(feats, labels)
+    l_hip = float(model.loss)
+    assert abs(l_hip - l_ref) <= 1e-4 * abs(l_ref), (step, l_hip, l_ref)
+  assert int(model.store.global_step.item()) == 2
+  Pn = model.store.to_numpy('params')
+  for k, v in oracle.P.items():
+    np.testing.assert_allclose(Pn[k], v.numpy(), rtol=0, atol=2.5 * lr, err_msg=k)
+  # the typical weight moved by ~lr per step in the same direction as the oracle's
+  k0 = [k for k in P if k.endswith('conv2/kernel')][0]
+  moved_ref = oracle.P[k0].numpy() - P[k0]
+  moved = Pn[k0] - P[k0]
+  agree = np.mean(np.sign(moved) == np.sign(moved_ref))
+  assert agree > 0.995, agree
