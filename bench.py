@@ -99,7 +99,7 @@ def roofline_conv2(model, iters):
 
   def launch():
     ops.conv3x3_fwd_into(y, x, w, b, enc.G, x[0].numel(), enc.gs_p, enc.gs_p, y[0].numel(), enc.Nf, L['H'], L['W'],
-                         L['Cin'], L['Cout'], L['stride'], relu=True)
+                         L['Cin'], L['Cout'], L['stride'], relu=True, ws=enc.fws)
   for _ in range(3):
     launch()
   ms = time_region(launch, iters)

@@ -23,23 +23,34 @@
 //       land in different bank halves (conflict free).
 #include "geeco_common.h"
 
+// One parity class of a launch (forward: a single class with all 9 taps; dgrad of a stride-s conv:
+// s*s classes, each with its own subset of taps and its own sub-grid of destination pixels).
+struct ConvClass {
+  long long M;          // N*Hc*Wc rows
+  int Hc, Wc;           // iteration grid: rows enumerate (n, Y', X')
+  int oy0, ox0;         // destination pixel = (Y'*ds + oy0, X'*ds + ox0)
+  int ntaps;
+  int tile0;            // first M-tile (blockIdx.x) of this class
+  int dy[9], dx[9], wslab[9];
+};
+
 struct ConvGemmParams {
   const float* x;
   const float* w;
   const float* bias;
   const float* mask;
   float* out;
+  float* part;          // split-K slabs [ksplit][G][N*Hd*Wd][Nout] (ksplit > 1)
   long long gs_x, gs_w, gs_b, gs_out;
   int N, Hs, Ws, C;     // source tensor [N][Hs][Ws][C]
   int Hd, Wd, Nout;     // destination tensor [N][Hd][Wd][Nout]
-  int Hc, Wc;           // iteration grid: rows enumerate (n, Y', X')
   int ss;               // source pixel = (Y'*ss + dy, X'*ss + dx)
-  int ds, oy0, ox0;     // destination pixel = (Y'*ds + oy0, X'*ds + ox0)
-  int ntaps;
+  int ds;
   int relu;
-  long long M;          // N*Hc*Wc
-  int Ktot;             // ntaps*C
-  int dy[9], dx[9], wslab[9];
+  int ncls;
+  int ksplit;           // K-steps are dealt to ksplit blocks (blockIdx.y = ntile * ksplit + split)
+  int groups;
+  ConvClass cls[4];
 };
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -69,17 +80,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int g = blockIdx.z;
   const float* __restrict__ xg = p.x + (long long)g * p.gs_x;
   const float* __restrict__ wg = p.w + (long long)g * p.gs_w;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  int ci = 0;
+#pragma unroll
+  for (int c = 1; c < 4; ++c)
+    if (c < p.ncls && (int)blockIdx.x >= p.cls[c].tile0) ci = c;
+  const ConvClass& cl = p.cls[ci];
+  const long long clsM = cl.M;
+  const int clsHc = cl.Hc, clsWc = cl.Wc, ntaps = cl.ntaps;
+  const long long m0 = (long long)((int)blockIdx.x - cl.tile0) * BM;
+  const int ntile = blockIdx.y / p.ksplit;
+  const int split = blockIdx.y - ntile * p.ksplit;
+  const int n0 = ntile * BN;
   const int C = p.C, C4 = p.C >> 2;
 
   if (tid < 9) {
     int t = tid;
-    bool ok = t < p.ntaps;
-    sTap[t] = ok ? p.dy[t] : 0;
-    sTap[12 + t] = ok ? p.dx[t] : 0;
-    sTap[24 + t] = ok ? (p.dy[t] * p.Ws + p.dx[t]) * C : 0;
-    sTap[36 + t] = ok ? p.wslab[t] * C : 0;
+    bool ok = t < ntaps;
+    sTap[t] = ok ? cl.dy[t] : 0;
+    sTap[12 + t] = ok ? cl.dx[t] : 0;
+    sTap[24 + t] = ok ? (cl.dy[t] * p.Ws + cl.dx[t]) * C : 0;
+    sTap[36 + t] = ok ? cl.wslab[t] * C : 0;
   }
   __syncthreads();
 
@@ -88,15 +108,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   long long rb[PA];
   int iy0[PA], ix0[PA];
   {
-    const long long HcWc = (long long)p.Hc * p.Wc;
+    const long long HcWc = (long long)clsHc * clsWc;
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
       long long m = m0 + tid / SPR + j * RPP;
-      if (m < p.M) {
+      if (m < clsM) {
         long long n = m / HcWc;
         int rem = (int)(m - n * HcWc);
-        int yp = rem / p.Wc;
-        int xp = rem - yp * p.Wc;
+        int yp = rem / clsWc;
+        int xp = rem - yp * clsWc;
         iy0[j] = yp * p.ss;
         ix0[j] = xp * p.ss;
         rb[j] = ((n * p.Hs + iy0[j]) * p.Ws + ix0[j]) * (long long)C;
@@ -107,8 +127,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       }
     }
   }
-  int a_tap = kq / C4;
-  int a_cq = kq - a_tap * C4;
+  const int nk_all = (ntaps * C + BK - 1) / BK;
+  const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+  const int ks_beg = split * per;
+  const int nk = ks_beg >= nk_all ? 0 : (nk_all - ks_beg < per ? nk_all - ks_beg : per);
+  const int slot0 = ks_beg * SPR + kq;
+  int a_tap = slot0 / C4;
+  int a_cq = slot0 - a_tap * C4;
 
   int b_row[PB], b_c4[PB], b_tap[PB], b_c[PB];
 #pragma unroll
@@ -116,8 +141,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     int idx = tid + i * 256;
     b_row[i] = idx / BN4;
     b_c4[i] = idx - b_row[i] * BN4;
-    b_tap[i] = b_row[i] / C;
-    b_c[i] = b_row[i] - b_tap[i] * C;
+    const int k0 = ks_beg * BK + b_row[i];
+    b_tap[i] = k0 / C;
+    b_c[i] = k0 - b_tap[i] * C;
   }
 
   f32x4 ra[PA], rbv[PB];
@@ -126,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   auto load_tiles = [&]() {
     {
       const int t = a_tap < 9 ? a_tap : 8;
-      const bool tv = a_tap < p.ntaps;
+      const bool tv = a_tap < ntaps;
       const int dy = sTap[t], dx = sTap[12 + t], toff = sTap[24 + t] + a_cq * 4;
 #pragma unroll
       for (int j = 0; j < PA; ++j) {
@@ -137,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      bool v = (tid + i * 256 < NB4) && (b_tap[i] < p.ntaps) && (n0 + b_c4[i] * 4 < p.Nout);
+      bool v = (tid + i * 256 < NB4) && (b_tap[i] < ntaps) && (n0 + b_c4[i] * 4 < p.Nout);
       const int t = b_tap[i] < 9 ? b_tap[i] : 8;
       rbv[i] = v ? *reinterpret_cast<const f32x4*>(wg + (long long)(sTap[36 + t] + b_c[i]) * p.Nout + n0 +
                                                    b_c4[i] * 4)
@@ -185,7 +211,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = zero4;
 
-  const int nk = (p.Ktot + BK - 1) / BK;
   if (nk > 0) {
     load_tiles();
     advance();
@@ -229,21 +254,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   float* __restrict__ og = p.out + (long long)g * p.gs_out;
   const float* __restrict__ mg = p.mask ? p.mask + (long long)g * p.gs_out : nullptr;
   const float* __restrict__ bg = p.bias ? p.bias + (long long)g * p.gs_b : nullptr;
-  const long long HcWc = (long long)p.Hc * p.Wc;
+  const long long HcWc = (long long)clsHc * clsWc;
+  const int oy0 = cl.oy0, ox0 = cl.ox0;
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     long long m = m0 + pixbase + j * 16 + r;
-    if (m >= p.M) continue;
+    if (m >= clsM) continue;
     long long n = m / HcWc;
     int rem = (int)(m - n * HcWc);
-    int yp = rem / p.Wc;
-    int xp = rem - yp * p.Wc;
-    long long opix = (n * p.Hd + (yp * p.ds + p.oy0)) * p.Wd + (xp * p.ds + p.ox0);
+    int yp = rem / clsWc;
+    int xp = rem - yp * clsWc;
+    long long opix = (n * p.Hd + (yp * p.ds + oy0)) * p.Wd + (xp * p.ds + ox0);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       int co = n0 + cobase + i * 16 + 4 * q;
       if (co >= p.Nout) continue;
       f32x4 v = acc[i][j];
+      if (p.ksplit > 1) {   // raw partial sums; conv_splitk_epilogue applies bias / ReLU / mask
+        const long long npix = (long long)p.N * p.Hd * p.Wd;
+        *reinterpret_cast<f32x4*>(p.part + (((long long)split * p.groups + g) * npix + opix) * p.Nout + co) = v;
+        continue;
+      }
       if (bg) v += *reinterpret_cast<const f32x4*>(bg + co);
       if (p.relu) {
         v.x = fmaxf(v.x, 0.f);
@@ -263,82 +294,140 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
 }
 
+// Sums the split-K slabs and applies the epilogue (bias, ReLU, mask).  One thread = 4 channels.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvGemmParams p) {
+  const int g = blockIdx.y;
+  const long long npix = (long long)p.N * p.Hd * p.Wd;
+  const long long total4 = npix * p.Nout / 4;
+  const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= total4) return;
+  const long long e = i4 * 4;
+  const int co = (int)(e % p.Nout);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.ksplit; ++s)
+    v += *reinterpret_cast<const f32x4*>(p.part + ((long long)s * p.groups + g) * npix * p.Nout + e);
+  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + co);
+  if (p.relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  if (p.mask) {
+    f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_out + e);
+    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(p.out + (long long)g * p.gs_out + e) = v;
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
-static void launch_cfg(const ConvGemmParams& p, int groups, hipStream_t s) {
-  dim3 grid((unsigned)cdiv64(p.M, BM), (unsigned)cdiv(p.Nout, BN), (unsigned)groups);
+static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
+  int tiles = 0;
+  for (int c = 0; c < p.ncls; ++c) {
+    p.cls[c].tile0 = tiles;
+    tiles += (int)cdiv64(p.cls[c].M, BM);
+  }
+  dim3 grid((unsigned)tiles, (unsigned)(cdiv(p.Nout, BN) * p.ksplit), (unsigned)groups);
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, s, p);
 }
 
-static int launch_conv_gemm(const ConvGemmParams& p, int groups, hipStream_t s) {
-  if (p.M <= 0) return 0;
-  const bool small = p.M * groups < 128 * 256;  // not enough 128-row tiles to fill the chip
-  if (p.Nout % 64 == 0) {
-    if (small)
+struct ConvPlan {
+  int bm, bn, ksplit;
+};
+
+// Tile choice and split-K factor.  Split only when the launch cannot fill the chip (tiny-M layers
+// conv6..8 and their dgrads): blocks < 256 CUs and enough K-steps to share.
+static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
+  ConvPlan pl;
+  long long Mtot = 0;
+  int maxtaps = 0;
+  for (int c = 0; c < p.ncls; ++c) {
+    Mtot += p.cls[c].M;
+    if (p.cls[c].ntaps > maxtaps) maxtaps = p.cls[c].ntaps;
+  }
+  pl.bn = (p.Nout % 64 == 0) ? 64 : (p.Nout % 48 == 0) ? 48 : (p.Nout % 32 == 0) ? 32 : 16;
+  pl.bm = 128;
+  if (pl.bn == 64 && Mtot * groups < 128 * 256) pl.bm = 64;
+  long long blocks = 0;
+  for (int c = 0; c < p.ncls; ++c) blocks += cdiv64(p.cls[c].M, pl.bm);
+  blocks *= (long long)cdiv(p.Nout, pl.bn) * groups;
+  const int nk = cdiv(maxtaps * p.C, 16);
+  pl.ksplit = 1;
+  if (blocks < 256 && nk >= 16) {
+    long long want = cdiv64(768, blocks);
+    long long maxs = nk / 8;   // at least 8 K-steps per block
+    if (want > maxs) want = maxs;
+    if (want > 1) pl.ksplit = (int)want;
+  }
+  return pl;
+}
+
+static int64_t conv_ws_bytes(const ConvGemmParams& p, int groups) {
+  ConvPlan pl = conv_plan(p, groups);
+  if (pl.ksplit <= 1) return 0;
+  return (int64_t)pl.ksplit * groups * p.N * p.Hd * p.Wd * p.Nout * 4;
+}
+
+static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t s) {
+  ConvPlan pl = conv_plan(p, groups);
+  if (!ws) pl.ksplit = 1;
+  p.ksplit = pl.ksplit;
+  p.groups = groups;
+  p.part = (float*)ws;
+  if (pl.bn == 64) {
+    if (pl.bm == 64)
       launch_cfg<64, 64, 16, 2, 2>(p, groups, s);
     else
       launch_cfg<128, 64, 16, 2, 2>(p, groups, s);
-  } else if (p.Nout % 48 == 0) {
+  } else if (pl.bn == 48) {
     launch_cfg<128, 48, 16, 4, 1>(p, groups, s);
-  } else if (p.Nout % 32 == 0) {
+  } else if (pl.bn == 32) {
     launch_cfg<128, 32, 16, 4, 1>(p, groups, s);
   } else {
     launch_cfg<128, 16, 16, 4, 1>(p, groups, s);
   }
   GEECO_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    const long long total4 = (long long)p.N * p.Hd * p.Wd * p.Nout / 4;
+    dim3 grid((unsigned)cdiv64(total4, 256), (unsigned)groups);
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, grid, dim3(256), 0, s, p);
+    GEECO_LAUNCH_CHECK();
+  }
   return 0;
 }
 
-extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int groups,
-                                 int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H,
-                                 int W, int Cin, int Cout, int stride, int relu, void* stream) {
-  GEECO_CHECK_ARG(x && w && y, "conv3x3_fwd: null pointer");
-  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_fwd: bad dims");
-  GEECO_CHECK_ARG(Cin % 4 == 0 && Cin >= 4, "conv3x3_fwd: Cin=%d must be a multiple of 4", Cin);
-  GEECO_CHECK_ARG(Cout % 16 == 0, "conv3x3_fwd: Cout=%d must be a multiple of 16", Cout);
-  GEECO_CHECK_ARG(stride >= 1 && stride <= 4, "conv3x3_fwd: stride=%d", stride);
-  ConvGemmParams p = {};
+static int fill_fwd(ConvGemmParams* p, int N, int H, int W, int Cin, int Cout, int stride) {
   int Ho, Wo, pt, pl;
   same_pad(H, 3, stride, &Ho, &pt);
   same_pad(W, 3, stride, &Wo, &pl);
-  p.x = x; p.w = w; p.bias = b; p.mask = nullptr; p.out = y;
-  p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_out = gs_y;
-  p.N = N; p.Hs = H; p.Ws = W; p.C = Cin;
-  p.Hd = Ho; p.Wd = Wo; p.Nout = Cout;
-  p.Hc = Ho; p.Wc = Wo; p.ss = stride; p.ds = 1; p.oy0 = 0; p.ox0 = 0;
-  p.ntaps = 9; p.relu = relu;
-  p.M = (long long)N * Ho * Wo;
-  p.Ktot = 9 * Cin;
+  p->N = N; p->Hs = H; p->Ws = W; p->C = Cin;
+  p->Hd = Ho; p->Wd = Wo; p->Nout = Cout;
+  p->ss = stride; p->ds = 1; p->ncls = 1;
+  ConvClass& c = p->cls[0];
+  c.Hc = Ho; c.Wc = Wo; c.oy0 = 0; c.ox0 = 0; c.ntaps = 9;
+  c.M = (long long)N * Ho * Wo;
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) {
-      p.dy[ky * 3 + kx] = ky - pt;
-      p.dx[ky * 3 + kx] = kx - pl;
-      p.wslab[ky * 3 + kx] = ky * 3 + kx;
+      c.dy[ky * 3 + kx] = ky - pt;
+      c.dx[ky * 3 + kx] = kx - pl;
+      c.wslab[ky * 3 + kx] = ky * 3 + kx;
     }
-  return launch_conv_gemm(p, groups, (hipStream_t)stream);
+  return 0;
 }
 
-extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float* ymask, float* dx,
-                                   int groups, int64_t gs_dz, int64_t gs_wt, int64_t gs_dx, int N, int H,
-                                   int W, int Cin, int Cout, int stride, void* stream) {
-  GEECO_CHECK_ARG(dz && wt && dx, "conv3x3_dgrad: null pointer");
-  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_dgrad: bad dims");
-  GEECO_CHECK_ARG(Cout % 4 == 0, "conv3x3_dgrad: Cout=%d must be a multiple of 4", Cout);
-  GEECO_CHECK_ARG(Cin % 16 == 0, "conv3x3_dgrad: Cin=%d must be a multiple of 16", Cin);
-  GEECO_CHECK_ARG(stride >= 1 && stride <= 4, "conv3x3_dgrad: stride=%d", stride);
+static int fill_dgrad(ConvGemmParams* p, int N, int H, int W, int Cin, int Cout, int stride) {
   int Ho, Wo, pt, pl;
   same_pad(H, 3, stride, &Ho, &pt);
   same_pad(W, 3, stride, &Wo, &pl);
   const int s = stride;
+  p->N = N; p->Hs = Ho; p->Ws = Wo; p->C = Cout;
+  p->Hd = H; p->Wd = W; p->Nout = Cin;
+  p->ss = 1; p->ds = s; p->relu = 0;
+  int nc = 0;
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
-      ConvGemmParams p = {};
-      p.x = dz; p.w = wt; p.bias = nullptr; p.mask = ymask; p.out = dx;
-      p.gs_x = gs_dz; p.gs_w = gs_wt; p.gs_b = 0; p.gs_out = gs_dx;
-      p.N = N; p.Hs = Ho; p.Ws = Wo; p.C = Cout;
-      p.Hd = H; p.Wd = W; p.Nout = Cin;
-      p.Hc = (H - py + s - 1) / s;
-      p.Wc = (W - px + s - 1) / s;
-      p.ss = 1; p.ds = s; p.oy0 = py; p.ox0 = px; p.relu = 0;
+      ConvClass c = {};
+      c.Hc = (H - py + s - 1) / s;
+      c.Wc = (W - px + s - 1) / s;
+      c.oy0 = py; c.ox0 = px;
       int nt = 0;
       for (int ky = 0; ky < 3; ++ky) {
         int vy = py + pt - ky;
@@ -346,18 +435,62 @@ extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float
         for (int kx = 0; kx < 3; ++kx) {
           int vx = px + pl - kx;
           if (((vx % s) + s) % s != 0) continue;
-          p.dy[nt] = (vy >= 0 ? vy : vy - (s - 1)) / s;   // exact (vy % s == 0)
-          p.dx[nt] = (vx >= 0 ? vx : vx - (s - 1)) / s;
-          p.wslab[nt] = ky * 3 + kx;
+          c.dy[nt] = (vy >= 0 ? vy : vy - (s - 1)) / s;   // exact (vy % s == 0)
+          c.dx[nt] = (vx >= 0 ? vx : vx - (s - 1)) / s;
+          c.wslab[nt] = ky * 3 + kx;
           ++nt;
         }
       }
-      p.ntaps = nt;
-      p.M = (long long)N * p.Hc * p.Wc;
-      p.Ktot = nt * Cout;
-      if (p.M <= 0) continue;
-      int rc = launch_conv_gemm(p, groups, (hipStream_t)stream);
-      if (rc) return rc;
+      c.ntaps = nt;
+      c.M = (long long)N * c.Hc * c.Wc;
+      if (c.M <= 0) continue;
+      p->cls[nc++] = c;
     }
+  p->ncls = nc;
   return 0;
+}
+
+extern "C" int64_t geeco_conv3x3_fwd_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
+  ConvGemmParams p = {};
+  fill_fwd(&p, N, H, W, Cin, Cout, stride);
+  return conv_ws_bytes(p, groups);
+}
+
+extern "C" int64_t geeco_conv3x3_dgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
+  if (stride > 2) return 0;
+  ConvGemmParams p = {};
+  fill_dgrad(&p, N, H, W, Cin, Cout, stride);
+  return conv_ws_bytes(p, groups);
+}
+
+extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int groups,
+                                 int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H,
+                                 int W, int Cin, int Cout, int stride, int relu, void* ws, void* stream) {
+  GEECO_CHECK_ARG(x && w && y, "conv3x3_fwd: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_fwd: bad dims");
+  GEECO_CHECK_ARG(Cin % 4 == 0 && Cin >= 4, "conv3x3_fwd: Cin=%d must be a multiple of 4", Cin);
+  GEECO_CHECK_ARG(Cout % 16 == 0, "conv3x3_fwd: Cout=%d must be a multiple of 16", Cout);
+  GEECO_CHECK_ARG(stride >= 1 && stride <= 4, "conv3x3_fwd: stride=%d", stride);
+  ConvGemmParams p = {};
+  fill_fwd(&p, N, H, W, Cin, Cout, stride);
+  p.x = x; p.w = w; p.bias = b; p.mask = nullptr; p.out = y;
+  p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_out = gs_y;
+  p.relu = relu;
+  return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
+}
+
+extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float* ymask, float* dx,
+                                   int groups, int64_t gs_dz, int64_t gs_wt, int64_t gs_dx, int N, int H,
+                                   int W, int Cin, int Cout, int stride, void* ws, void* stream) {
+  GEECO_CHECK_ARG(dz && wt && dx, "conv3x3_dgrad: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_dgrad: bad dims");
+  GEECO_CHECK_ARG(Cout % 4 == 0, "conv3x3_dgrad: Cout=%d must be a multiple of 4", Cout);
+  GEECO_CHECK_ARG(Cin % 16 == 0, "conv3x3_dgrad: Cin=%d must be a multiple of 16", Cin);
+  GEECO_CHECK_ARG(stride >= 1 && stride <= 2, "conv3x3_dgrad: stride=%d (1 or 2)", stride);
+  ConvGemmParams p = {};
+  fill_dgrad(&p, N, H, W, Cin, Cout, stride);
+  p.x = dz; p.w = wt; p.bias = nullptr; p.mask = ymask; p.out = dx;
+  p.gs_x = gs_dz; p.gs_w = gs_wt; p.gs_b = 0; p.gs_out = gs_dx;
+  if (p.ncls == 0) return 0;
+  return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
 }

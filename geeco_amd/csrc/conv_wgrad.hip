@@ -30,9 +30,8 @@ struct WgradParams {
   int row_tiles, col_tiles;
 };
 
-template <int BR, int BC>
+template <int BR, int BC, int MK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  constexpr int MK = 16;
   constexpr int LDA = (BR % 32 == 16) ? BR : BR + 16;
   constexpr int LDBZ = (BC % 32 == 16) ? BC : BC + 16;
   constexpr int BR4 = BR / 4, BC4 = BC / 4;
@@ -193,19 +192,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                    long long gs_dw, long long gs_db, int S, long long KC, int Cout) {
+// Sums the S partial slabs in a fixed order.  One thread per element; for large S the slabs of an
+// element are split over the 4 waves of the block and combined through LDS (order still fixed).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ db, long long gs_dw, long long gs_db,
+                                                           int S, long long KC, int Cout) {
+  __shared__ float sred[4][64];
   const int g = blockIdx.y;
   const long long slab = KC + Cout;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= slab) return;
-  const float* src = part + (long long)g * S * slab + i;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += src[(long long)k * slab];
-  if (i < KC)
-    dw[(long long)g * gs_dw + i] = s;
-  else if (db)
-    db[(long long)g * gs_db + (i - KC)] = s;
+  if (i < slab) {
+    const float* src = part + (long long)g * S * slab + i;
+    const int per = (S + 3) / 4;
+    const int k0 = wid * per, k1 = (k0 + per < S) ? k0 + per : S;
+    for (int k = k0; k < k1; ++k) s += src[(long long)k * slab];
+  }
+  sred[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && i < slab) {
+    s = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
+    if (i < KC)
+      dw[(long long)g * gs_dw + i] = s;
+    else if (db)
+      db[(long long)g * gs_db + (i - KC)] = s;
+  }
 }
 
 static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride, WgradParams* p, int* bc) {
@@ -221,13 +233,13 @@ static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int s
   p->row_tiles = cdiv(p->Krows, 64);
   p->col_tiles = cdiv(Cout, BC);
   long long tiles = (long long)groups * p->row_tiles * p->col_tiles;
-  long long S = 1536 / tiles;
+  long long S = 1024 / tiles;
   if (S < 1) S = 1;
-  long long maxS = p->M / 256;          // at least 256 pixels per slice
+  long long maxS = p->M / 512;          // at least 512 pixels per slice
   if (maxS < 1) maxS = 1;
   if (S > maxS) S = maxS;
   long long mps = cdiv64(p->M, S);
-  mps = cdiv64(mps, 16) * 16;
+  mps = cdiv64(mps, 64) * 64;   // multiple of every MK
   S = cdiv64(p->M, mps);
   p->S = (int)S;
   p->m_per_split = mps;
@@ -254,14 +266,14 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)p.S, (unsigned)(p.row_tiles * p.col_tiles), (unsigned)groups);
   switch (BC) {
-    case 64: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, s, p); break;
-    case 48: hipLaunchKernelGGL((conv_wgrad_kernel<64, 48>), grid, dim3(256), 0, s, p); break;
-    case 32: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32>), grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((conv_wgrad_kernel<64, 16>), grid, dim3(256), 0, s, p); break;
+    case 64: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32>), grid, dim3(256), 0, s, p); break;
+    case 48: hipLaunchKernelGGL((conv_wgrad_kernel<64, 48, 32>), grid, dim3(256), 0, s, p); break;
+    case 32: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64>), grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((conv_wgrad_kernel<64, 16, 64>), grid, dim3(256), 0, s, p); break;
   }
   GEECO_LAUNCH_CHECK();
   const long long KC = (long long)p.Krows * Cout;
-  dim3 rgrid((unsigned)cdiv64(KC + Cout, 256), (unsigned)groups);
+  dim3 rgrid((unsigned)cdiv64(KC + Cout, 64), (unsigned)groups);
   hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, s, (const float*)ws, dw, db, (long long)gs_dw,
                      (long long)gs_db, p.S, KC, Cout);
   GEECO_LAUNCH_CHECK();

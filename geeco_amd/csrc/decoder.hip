@@ -367,25 +367,61 @@ struct HeadsParams {
   float* dpred; // ws: [N][12]
 };
 
+// C[M][N] = A[M][K] B[K][N] inside ONE workgroup on MFMA 16x16x4: waves take 16x16 output tiles
+// round-robin; operands are fetched straight from global memory (everything is L2-resident and
+// tiny), 2 loads per MFMA per lane.  a_at(i, k), b_at(k, j) return elements; st(i, j, v) stores.
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void block_mfma_gemm(int M, int N, int K, FA a_at, FB b_at, FS st) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int tn = (N + 15) >> 4, nt = ((M + 15) >> 4) * tn;
+  for (int t = wave; t < nt; t += nw) {
+    const int ti = t / tn, tj = t - ti * tn;
+    const int i = ti * 16 + r, j = tj * 16 + r;
+    const bool iv = i < M, jv = j < N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const int k = k0 + q;
+      const float a = (iv && k < K) ? a_at(i, k) : 0.f;
+      const float b = (jv && k < K) ? b_at(k, j) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    const float e[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int io = ti * 16 + 4 * q + k;
+      if (io < M && jv) st(io, j, e[k]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   const int tid = threadIdx.x, NT = 1024;
   const int N = p.N, H = p.H, F = p.Hfc;
   __shared__ float s_red[16][4];
+  const float* __restrict__ hw0 = p.hw[0];
+  const float* __restrict__ hw1 = p.hw[1];
+  const float* __restrict__ hw2 = p.hw[2];
+  const float* __restrict__ hw3 = p.hw[3];
+  // element (f, o) of the [F][12] matrix formed by the four [F][3] head kernels
+  auto head_w = [&](int f, int o) -> float {
+    const int hd = o / 3, c = o - hd * 3;
+    const float* w = hd == 0 ? hw0 : (hd == 1 ? hw1 : (hd == 2 ? hw2 : hw3));
+    return w[f * 3 + c];
+  };
   // P1: a1 = relu(h W1 + b1)                                   graph.py:229-230
-  for (int i = tid; i < N * F; i += NT) {
-    const int n = i / F, j = i - n * F;
-    float s = p.fc1_b[j];
-    for (int k = 0; k < H; ++k) s = fmaf(p.h[n * H + k], p.fc1_w[k * F + j], s);
-    p.a1[i] = fmaxf(s, 0.f);
-  }
+  block_mfma_gemm(N, F, H, [&](int n, int k) { return p.h[n * H + k]; },
+                  [&](int k, int j) { return p.fc1_w[k * F + j]; },
+                  [&](int n, int j, float v) { p.a1[n * F + j] = fmaxf(v + p.fc1_b[j], 0.f); });
   __syncthreads();
   // P2: preds[n][4 heads x 3]                                  graph.py:233-259
-  for (int i = tid; i < N * 12; i += NT) {
-    const int n = i / 12, o = i - n * 12, hd = o / 3, c = o - hd * 3;
-    float s = p.hb[hd][c];
-    for (int j = 0; j < F; ++j) s = fmaf(p.a1[n * F + j], p.hw[hd][j * 3 + c], s);
-    p.preds[i] = s;
-  }
+  block_mfma_gemm(N, 12, F, [&](int n, int k) { return p.a1[n * F + k]; }, head_w,
+                  [&](int n, int o, float v) {
+                    const int hd = o / 3, c = o - hd * 3;
+                    const float* b = hd == 0 ? p.hb[0] : (hd == 1 ? p.hb[1] : (hd == 2 ? p.hb[2] : p.hb[3]));
+                    p.preds[n * 12 + o] = v + b[c];
+                  });
   __syncthreads();
   // P3: losses and d(loss)/d(pred)                              graph.py:452-500, estimator.py:206-239
   float l_ee = 0.f, l_grp = 0.f, l_pe = 0.f, l_po = 0.f;
@@ -414,12 +450,12 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
     const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
     const float se = e0 + e1 + e2;
     const float lse = mx + logf(se);
-    const float picked = label == 0 ? l0 : (label == 1 ? l1 : (label == 2 ? l2 : 0.f));
-    l_grp += (label >= 0 && label < 3) ? (lse - picked) : lse * 0.f;   // one_hot of an out-of-range label is all-zero
-    dp[3] = (e0 / se - (label == 0 ? 1.f : 0.f)) * invn * p.loss_scale;
-    dp[4] = (e1 / se - (label == 1 ? 1.f : 0.f)) * invn * p.loss_scale;
-    dp[5] = (e2 / se - (label == 2 ? 1.f : 0.f)) * invn * p.loss_scale;
-    if (label < 0 || label > 2) { dp[3] = dp[4] = dp[5] = 0.f; }
+    const bool lv = label >= 0 && label < 3;   // one_hot of an out-of-range label is all-zero
+    const float picked = label == 0 ? l0 : (label == 1 ? l1 : l2);
+    l_grp += lv ? (lse - picked) : 0.f;
+    dp[3] = lv ? (e0 / se - (label == 0 ? 1.f : 0.f)) * invn * p.loss_scale : 0.f;
+    dp[4] = lv ? (e1 / se - (label == 1 ? 1.f : 0.f)) * invn * p.loss_scale : 0.f;
+    dp[5] = lv ? (e2 / se - (label == 2 ? 1.f : 0.f)) * invn * p.loss_scale : 0.f;
   }
   l_ee = wave_reduce_sum(l_ee); l_grp = wave_reduce_sum(l_grp);
   l_pe = wave_reduce_sum(l_pe); l_po = wave_reduce_sum(l_po);
@@ -436,44 +472,37 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   }
   if (!p.backward) return;
   __syncthreads();
-  // P4: head gradients and d(a1) with fc1's ReluGrad
-  for (int i = tid; i < F * 12; i += NT) {
-    const int j = i / 12, o = i - j * 12, hd = o / 3, c = o - hd * 3;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(p.a1[n * F + j], p.dpred[n * 12 + o], s);
-    p.dhw[hd][j * 3 + c] = s;
-  }
+  // P4: head gradients  d_hw[f][o] = sum_n a1[n][f] dpred[n][o];  da1 = (dpred Wh^T) * relu'
+  block_mfma_gemm(F, 12, N, [&](int f, int n) { return p.a1[n * F + f]; },
+                  [&](int n, int o) { return p.dpred[n * 12 + o]; },
+                  [&](int f, int o, float v) {
+                    const int hd = o / 3, c = o - hd * 3;
+                    float* d = hd == 0 ? p.dhw[0] : (hd == 1 ? p.dhw[1] : (hd == 2 ? p.dhw[2] : p.dhw[3]));
+                    d[f * 3 + c] = v;
+                  });
   for (int o = tid; o < 12; o += NT) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += p.dpred[n * 12 + o];
-    p.dhb[o / 3][o % 3] = s;
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += p.dpred[n * 12 + o];
+    const int hd = o / 3;
+    float* d = hd == 0 ? p.dhb[0] : (hd == 1 ? p.dhb[1] : (hd == 2 ? p.dhb[2] : p.dhb[3]));
+    d[o - hd * 3] = sum;
   }
-  for (int i = tid; i < N * F; i += NT) {
-    const int n = i / F, j = i - n * F;
-    float s = 0.f;
-#pragma unroll
-    for (int o = 0; o < 12; ++o) s = fmaf(p.dpred[n * 12 + o], p.hw[o / 3][j * 3 + (o % 3)], s);
-    p.da1[i] = p.a1[i] > 0.f ? s : 0.f;
-  }
+  block_mfma_gemm(N, F, 12, [&](int n, int o) { return p.dpred[n * 12 + o]; },
+                  [&](int o, int f) { return head_w(f, o); },
+                  [&](int n, int f, float v) { p.da1[n * F + f] = p.a1[n * F + f] > 0.f ? v : 0.f; });
   __syncthreads();
   // P5: fc1 gradients and d(h)
-  for (int i = tid; i < H * F; i += NT) {
-    const int k = i / F, j = i - k * F;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(p.h[n * H + k], p.da1[n * F + j], s);
-    p.d_fc1_w[i] = s;
-  }
+  block_mfma_gemm(H, F, N, [&](int k, int n) { return p.h[n * H + k]; },
+                  [&](int n, int j) { return p.da1[n * F + j]; },
+                  [&](int k, int j, float v) { p.d_fc1_w[k * F + j] = v; });
   for (int j = tid; j < F; j += NT) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += p.da1[n * F + j];
-    p.d_fc1_b[j] = s;
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += p.da1[n * F + j];
+    p.d_fc1_b[j] = sum;
   }
-  for (int i = tid; i < N * H; i += NT) {
-    const int n = i / H, k = i - n * H;
-    float s = 0.f;
-    for (int j = 0; j < F; ++j) s = fmaf(p.da1[n * F + j], p.fc1_w[k * F + j], s);
-    p.dh[i] = s;
-  }
+  block_mfma_gemm(N, H, F, [&](int n, int j) { return p.da1[n * F + j]; },
+                  [&](int j, int k) { return p.fc1_w[k * F + j]; },
+                  [&](int n, int k, float v) { p.dh[n * H + k] = v; });
 }
 
 extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {

@@ -106,7 +106,11 @@ class ConvEncoderStack:
         self.dw1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
       wsb = max(ops.conv3x3_wgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
                 for L in self.layers)
+      wsb = max([wsb] + [ops.conv3x3_dgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
+                         for L in self.layers[1:]])
       self.ws = torch.empty(wsb // 4 + 4, **f32)
+    fsb = max(ops.conv3x3_fwd_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) for L in self.layers)
+    self.fws = torch.empty(fsb // 4 + 4, **f32)
 
   def _w(self, l, g=0):
     return self.store.var('%s/conv%d/kernel' % (self.scopes[g], l + 1))
@@ -141,7 +145,7 @@ class ConvEncoderStack:
       else:
         w, gs_w = self._w(l), self.gs_p
       ops.conv3x3_fwd_into(y, x, w, self._b(l), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(), Nf, L['H'], L['W'],
-                           L['Cin'], L['Cout'], L['stride'], relu=True)
+                           L['Cin'], L['Cout'], L['stride'], relu=True, ws=self.fws)
 
   def backward(self):
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied)."""
@@ -165,7 +169,7 @@ class ConvEncoderStack:
       ops.transpose_hwio_into(wt, self._w(l), G, self.gs_p, wt[0].numel(), L['Cin'], L['Cout'])
       dx = self.dz[l - 1]
       ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
-                             L['Cin'], L['Cout'], L['stride'])
+                             L['Cin'], L['Cout'], L['stride'], ws=self.ws)
 
 
 # ================================================================================================

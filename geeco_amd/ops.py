@@ -97,14 +97,26 @@ def pack_pixels_into(dst, src, src_sample_stride, N, HW, C1, Cpad, src2=None, sr
 # --------------------------------------------------------------------------------------------
 # conv encoder
 # --------------------------------------------------------------------------------------------
-def conv3x3_fwd_into(y, x, w, b, G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, stride, relu=True):
+def conv3x3_fwd_into(y, x, w, b, G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, stride, relu=True, ws=None):
   check(_lib().geeco_conv3x3_fwd(_p(x), _p(w), _p(b), _p(y), G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout,
-                                 stride, 1 if relu else 0, _stream()), 'geeco_conv3x3_fwd')
+                                 stride, 1 if relu else 0, _p(ws), _stream()), 'geeco_conv3x3_fwd')
 
 
-def conv3x3_dgrad_into(dx, dz, wt, ymask, G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout, stride):
+def conv3x3_fwd_ws_bytes(G, N, H, W, Cin, Cout, stride):
+  return int(_lib().geeco_conv3x3_fwd_ws_bytes(G, N, H, W, Cin, Cout, stride))
+
+
+def conv3x3_dgrad_into(dx, dz, wt, ymask, G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout, stride, ws=None):
   check(_lib().geeco_conv3x3_dgrad(_p(dz), _p(wt), _p(ymask), _p(dx), G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout,
-                                   stride, _stream()), 'geeco_conv3x3_dgrad')
+                                   stride, _p(ws), _stream()), 'geeco_conv3x3_dgrad')
+
+
+def conv3x3_dgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
+  return int(_lib().geeco_conv3x3_dgrad_ws_bytes(G, N, H, W, Cin, Cout, stride))
+
+
+def _ws(nbytes, device):
+  return torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=device) if nbytes > 0 else None
 
 
 def conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
@@ -130,7 +142,9 @@ def conv3x3(x, w, b, stride, relu=True):
   N, H, W, Cin = x.shape
   Cout = w.shape[3]
   y = torch.empty(N, same_out(H, stride), same_out(W, stride), Cout, dtype=torch.float32, device=x.device)
-  conv3x3_fwd_into(y, x.contiguous(), w.contiguous(), b.contiguous(), 1, 0, 0, 0, 0, N, H, W, Cin, Cout, stride, relu)
+  ws = _ws(conv3x3_fwd_ws_bytes(1, N, H, W, Cin, Cout, stride), x.device)
+  conv3x3_fwd_into(y, x.contiguous(), w.contiguous(), b.contiguous(), 1, 0, 0, 0, 0, N, H, W, Cin, Cout, stride, relu,
+                   ws)
   return y
 
 
@@ -142,7 +156,8 @@ def conv3x3_dgrad(dz, w, ymask, in_hw, stride):
   wt = torch.empty(3, 3, Cout, Cin, dtype=torch.float32, device=dz.device)
   transpose_hwio_into(wt, w.contiguous(), 1, 0, 0, Cin, Cout)
   dx = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dz.device)
-  conv3x3_dgrad_into(dx, dz.contiguous(), wt, ymask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride)
+  ws = _ws(conv3x3_dgrad_ws_bytes(1, N, H, W, Cin, Cout, stride), dz.device)
+  conv3x3_dgrad_into(dx, dz.contiguous(), wt, ymask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride, ws)
   return dx
 
 

@@ -58,15 +58,20 @@ int geeco_pack_pixels(const float* src, int64_t src_sample_stride, const float* 
  * even sizes).  Requires Cin % 4 == 0, Cout % 16 == 0. */
 int geeco_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int groups,
                       int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W,
-                      int Cin, int Cout, int stride, int relu, void* stream);
+                      int Cin, int Cout, int stride, int relu, void* ws, void* stream);
+/* `ws` (may be NULL): device workspace of geeco_conv3x3_fwd_ws_bytes(...) bytes; layers whose
+ * output is too small to fill 256 CUs (conv6..8) split their K loop over blocks through it. */
+int64_t geeco_conv3x3_fwd_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
 
 /* Conv2DBackpropInput fused with the ReluGrad of the layer below (autodiff of graph.py:76-115 via
  * estimator.py:243-244):  dx = conv3x3_transpose(dz, w) * (ymask > 0).
  * dz [G][N][Ho][Wo][Cout], wt [G][3][3][Cout][Cin] (= geeco_transpose_hwio(w)),
- * ymask [G][N][H][W][Cin] = forward output of the layer below (NULL: no mask), dx like ymask. */
+ * ymask [G][N][H][W][Cin] = forward output of the layer below (NULL: no mask), dx like ymask.
+ * stride 1 or 2; all stride*stride parity classes run in one launch; `ws` as for the forward. */
 int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float* ymask, float* dx,
                         int groups, int64_t gs_dz, int64_t gs_wt, int64_t gs_dx, int N, int H,
-                        int W, int Cin, int Cout, int stride, void* stream);
+                        int W, int Cin, int Cout, int stride, void* ws, void* stream);
+int64_t geeco_conv3x3_dgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
 
 /* Conv2DBackpropFilter + BiasAddGrad:  dw[ky][kx][ci][co] = sum_m x[pix(m,ky,kx)][ci] dz[m][co],
  * db[co] = sum_m dz[m][co].  dw/db are OVERWRITTEN (not accumulated).
