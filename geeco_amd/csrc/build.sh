@@ -15,4 +15,5 @@ $HIPCC $FLAGS -x hip -c errors.cpp -o build/errors.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
-echo "built $(realpath $OUT)"
+g++ -O2 -fPIC -shared -o ../libgeeco_host.so host_io.cpp
+echo "built $(realpath $OUT) and $(realpath ../libgeeco_host.so)"

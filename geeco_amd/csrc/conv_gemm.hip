@@ -22,6 +22,7 @@
 //   sB[k][BN + 4]: ds_read_b32, row pitch = 4 (mod 8) dwords => the two k-rows of a 32-lane half
 //       land in different bank halves (conflict free).
 #include "geeco_common.h"
+#include <stdlib.h>
 
 // One parity class of a launch (forward: a single class with all 9 taps; dgrad of a stride-s conv:
 // s*s classes, each with its own subset of taps and its own sub-grid of destination pixels).
@@ -372,7 +373,21 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
   p.ksplit = pl.ksplit;
   p.groups = groups;
   p.part = (float*)ws;
-  if (pl.bn == 64) {
+  static const int bk32 = getenv("GEECO_CONV_BK32") ? 1 : 0;   // measured 3.6 % slower (LDS halves occupancy)
+  if (bk32 && p.C % 8 == 0 && p.ksplit == 1) {
+    if (pl.bn == 64) {
+      if (pl.bm == 64)
+        launch_cfg<64, 64, 32, 2, 2>(p, groups, s);
+      else
+        launch_cfg<128, 64, 32, 2, 2>(p, groups, s);
+    } else if (pl.bn == 48) {
+      launch_cfg<128, 48, 32, 4, 1>(p, groups, s);
+    } else if (pl.bn == 32) {
+      launch_cfg<128, 32, 32, 4, 1>(p, groups, s);
+    } else {
+      launch_cfg<128, 16, 16, 4, 1>(p, groups, s);
+    }
+  } else if (pl.bn == 64) {
     if (pl.bm == 64)
       launch_cfg<64, 64, 16, 2, 2>(p, groups, s);
     else

@@ -1,0 +1,367 @@
+"""Estimator-style training harness and the two ``model_fn``s.
+
+Mirrors the call surface that the reference's ``scripts/train_e2evmc.py:210-291`` touches:
+``Estimator(model_fn=, model_dir=, config=, params=)``, ``.train(input_fn=)``,
+``.evaluate(input_fn=) -> {'loss', 'cmd_ee', 'pos_ee', 'pos_obj', 'cmd_grp', 'global_step'}``,
+``RunConfig``, ``GPUOptions`` / ``ConfigProto``, ``ModeKeys``, ``EstimatorSpec``,
+``latest_checkpoint`` -- and ``e2evmc_model_fn`` / ``goal_e2evmc_model_fn`` with the signature
+``model_fn(features, labels, mode, params)`` of ``src/models/e2evmc/estimator.py:14,144``.
+
+Graph-mode semantics are kept: ``model_fn`` is called ONCE per (mode, batch size) with the static
+device buffers that will hold every batch; it builds the model on the HIP kernels and returns an
+``EstimatorSpec`` whose ``train_op`` replays the captured step.  The Estimator's loop then only
+copies each batch into those buffers and calls ``train_op()``  (= ``session.run(train_op)``).
+State lives in ``model_dir`` as ``model.ckpt-<step>.pt`` + a TF-style ``checkpoint`` index file.
+"""
+from __future__ import annotations
+
+import collections
+import json
+import os
+import re
+import time
+
+import torch
+
+from . import dist as gdist
+from . import graph
+from .runtime import EvalStepRunner, TrainStepRunner
+
+
+class ModeKeys:
+  TRAIN = 'train'
+  EVAL = 'eval'
+  PREDICT = 'infer'
+
+
+class GPUOptions:
+  """tf.GPUOptions(allow_growth, per_process_gpu_memory_fraction) (train_e2evmc.py:217-219)."""
+
+  def __init__(self, allow_growth=True, per_process_gpu_memory_fraction=None):
+    self.allow_growth = allow_growth
+    self.per_process_gpu_memory_fraction = per_process_gpu_memory_fraction
+
+
+class ConfigProto:
+
+  def __init__(self, gpu_options=None):
+    self.gpu_options = gpu_options or GPUOptions()
+
+
+class RunConfig:
+  """tf.estimator.RunConfig(session_config, save_checkpoints_steps, keep_checkpoint_max) (train_e2evmc.py:221-224)."""
+
+  def __init__(self, session_config=None, save_checkpoints_steps=None, keep_checkpoint_max=5, device=None,
+               use_hipgraph=True, init_seed=0):
+    self.session_config = session_config or ConfigProto()
+    self.save_checkpoints_steps = save_checkpoints_steps
+    self.keep_checkpoint_max = keep_checkpoint_max
+    self.device = device
+    self.use_hipgraph = use_hipgraph
+    self.init_seed = init_seed
+
+
+EstimatorSpec = collections.namedtuple(
+    'EstimatorSpec', ['mode', 'loss', 'train_op', 'eval_metric_ops', 'predictions', 'training_hooks',
+                      'evaluation_hooks', 'model'])
+EstimatorSpec.__new__.__defaults__ = (None,) * 7
+
+
+# ================================================================================================
+# checkpoints (TF-style names so that _export_snapshot-like tooling works unchanged)
+# ================================================================================================
+def latest_checkpoint(model_dir):
+  """tf.train.latest_checkpoint: '<model_dir>/model.ckpt-<step>' or None (train_e2evmc.py:160)."""
+  index = os.path.join(model_dir, 'checkpoint')
+  if not os.path.exists(index):
+    return None
+  with open(index) as f:
+    m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', f.read())
+  if not m:
+    return None
+  path = os.path.join(model_dir, os.path.basename(m.group(1)))
+  return path if os.path.exists(path + '.pt') else None
+
+
+def save_checkpoint(store, model_dir, keep_max):
+  step = int(store.global_step.item())
+  name = 'model.ckpt-%d' % step
+  tmp = os.path.join(model_dir, name + '.pt.tmp')
+  torch.save(store.state_dict(), tmp)
+  os.replace(tmp, os.path.join(model_dir, name + '.pt'))
+  existing = sorted((int(re.match(r'model\.ckpt-(\d+)\.pt$', fn).group(1)) for fn in os.listdir(model_dir)
+                     if re.match(r'model\.ckpt-(\d+)\.pt$', fn)))
+  if keep_max and len(existing) > keep_max:
+    for s in existing[:-keep_max]:
+      os.remove(os.path.join(model_dir, 'model.ckpt-%d.pt' % s))
+    existing = existing[-keep_max:]
+  with open(os.path.join(model_dir, 'checkpoint'), 'w') as f:
+    f.write('model_checkpoint_path: "%s"\n' % name)
+    for s in existing:
+      f.write('all_model_checkpoint_paths: "model.ckpt-%d"\n' % s)
+  return os.path.join(model_dir, name)
+
+
+def load_checkpoint(store, prefix):
+  store.load_state_dict(torch.load(prefix + '.pt', map_location='cpu'))
+
+
+# ================================================================================================
+# model_fn (estimator.py:14-141 and 144-279)
+# ================================================================================================
+class _SummarySaverHook:
+  """Counterpart of the per-loss-term SummarySaverHooks (estimator.py:305-313): one JSON line per
+  ``log_steps`` steps in <model_dir>/events.jsonl."""
+
+  def __init__(self, model, every):
+    self.model, self.every = model, max(int(every), 1)
+
+  def after_run(self, step, model_dir):
+    if step % self.every or gdist.rank() != 0:
+      return
+    parts = {k: float(v) for k, v in self.model.loss_parts().items()}
+    parts['global_step'] = step
+    parts['wall_time'] = time.time()
+    if model_dir:
+      with open(os.path.join(model_dir, 'events.jsonl'), 'a') as f:
+        f.write(json.dumps(parts) + '\n')
+    print('INFO: loss = %.6f, step = %d' % (parts['loss'], step), flush=True)
+
+
+def _model_fn(features, labels, mode, params, goal):
+  cfg = params['e2evmc_config']
+  if cfg.img_channels not in (3, 4):
+    raise ValueError("Unsupported number of channels for input frame: %d!" % cfg.img_channels)
+  if mode not in (ModeKeys.TRAIN, ModeKeys.EVAL, ModeKeys.PREDICT):
+    raise RuntimeError("Unknown estimator mode: %s" % (mode,))
+  rgb = features['rgb']
+  if not rgb.is_cuda:
+    raise RuntimeError('geeco_amd needs a GPU: model_fn got features on %s (no CPU fallback)' % rgb.device)
+  N = int(rgb.shape[0])
+  training = mode == ModeKeys.TRAIN
+  ctor = graph.GoalE2EVMC if goal else graph.E2EVMC
+  model = ctor(cfg, N, rgb.device, training=training, store=params.get('_variable_store'))
+  # adopt the caller's static buffers as the model inputs (placeholders)
+  for k in list(model.inputs.keys()):
+    src = labels.get(k) if (labels is not None and k == 'cmd') else features.get(k)
+    if src is None:
+      if mode == ModeKeys.PREDICT and k in ('cmd', 'ee_state', 'obj_state'):
+        continue   # label-side inputs are not needed for predictions
+      raise KeyError("model_fn: missing input '%s'" % k)
+    if (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and
+        tuple(src.shape) == tuple(model.inputs[k].shape)):
+      model.inputs[k] = src
+    else:
+      raise ValueError("model_fn: input '%s' must be a contiguous float32 device tensor of shape %s" %
+                       (k, tuple(model.inputs[k].shape)))
+  model._bind_labels()
+  # the reference computes `reset` from features['step'] (estimator.py:41-42); it is numerically
+  # inert (both tf.cond branches are zeros, graph.py:218-220), so it is validated and dropped.
+  if 'step' in features and features['step'].dtype != torch.int64:
+    raise ValueError("features['step'] must be int64")
+  print('>>> Graph Summary (%d trainable parameters):' % (model.store.count_parameters(),))
+  if mode == ModeKeys.TRAIN:
+    runner = TrainStepRunner(model, use_graph=params.get('use_hipgraph', True))
+    hooks = [_SummarySaverHook(model, params.get('log_steps', 1000))]
+    return EstimatorSpec(mode=mode, loss=model.loss, train_op=runner.step, training_hooks=hooks, model=model)
+  runner = EvalStepRunner(model, use_graph=params.get('use_hipgraph', True))
+  if mode == ModeKeys.EVAL:
+    return EstimatorSpec(mode=mode, loss=model.loss, train_op=runner.step, eval_metric_ops=_eval_metric_fn(model),
+                         evaluation_hooks=[], model=model)
+  return EstimatorSpec(mode=mode, predictions=model.predictions(), train_op=runner.step, model=model)
+
+
+def e2evmc_model_fn(features, labels, mode, params):
+  """Unconditional reflex (scope 'VMC'); reference estimator.py:14-141."""
+  return _model_fn(features, labels, mode, params, goal=False)
+
+
+def goal_e2evmc_model_fn(features, labels, mode, params):
+  """Goal-conditioned controller (scope 'GoalVMC'); reference estimator.py:144-279."""
+  return _model_fn(features, labels, mode, params, goal=True)
+
+
+def _eval_metric_fn(model):
+  """Per-batch sufficient statistics for tf.metrics.mean_squared_error / accuracy
+  (estimator.py:246-254): returns a callable giving {key: (sum, count)} device tensors."""
+  K = model.K
+
+  def batch_stats():
+    p = model.predictions()
+    cmd = model.inputs['cmd']
+    tgt = {'cmd_ee': cmd[:, :3], 'pos_ee': model.inputs['ee_state'][:, K - 1, :3],
+           'pos_obj': model.inputs['obj_state'][:, K - 1, :3]}
+    out = {}
+    for k, t in tgt.items():
+      out[k] = (((p[k] - t) ** 2).sum(), float(t.numel()))
+    label = torch.round(cmd[:, 3]).to(torch.int64) + 1
+    out['cmd_grp'] = ((p['logits_cmd_grp'].argmax(dim=-1) == label).float().sum(), float(label.numel()))
+    return out
+  return batch_stats
+
+
+# ================================================================================================
+# Estimator
+# ================================================================================================
+class Estimator:
+  """tf.estimator.Estimator counterpart (train_e2evmc.py:260-264, 284-291)."""
+
+  def __init__(self, model_fn, model_dir=None, config=None, params=None):
+    self._model_fn = model_fn
+    self.model_dir = model_dir
+    self.config = config or RunConfig()
+    self.params = dict(params or {})
+    self._specs = {}          # (mode, N) -> (spec, feature buffers, label buffers)
+    self._store = None
+    self._restored = False
+    if model_dir and gdist.rank() == 0:
+      os.makedirs(model_dir, exist_ok=True)
+    frac = getattr(self.config.session_config.gpu_options, 'per_process_gpu_memory_fraction', None)
+    if frac and torch.cuda.is_available() and 0.0 < frac < 1.0:
+      torch.cuda.set_per_process_memory_fraction(float(frac))   # --memcap (train_e2evmc.py:102-104)
+
+  # -- device / batches ------------------------------------------------------------------------
+  def _device(self):
+    if self.config.device is not None:
+      return torch.device(self.config.device)
+    if not torch.cuda.is_available():
+      raise RuntimeError('geeco_amd.Estimator needs an MI355X (torch.cuda.is_available() is False); '
+                         'there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+  @staticmethod
+  def _shard(batch, world, rank):
+    feats, labels = batch
+    n = int(next(iter(feats.values())).shape[0])
+    if world == 1:
+      return feats, labels, n
+    if n % world:
+      return None, None, 0       # ragged global batch: dropped under data parallelism
+    lo, hi = gdist.shard_bounds(n, rank, world)
+    sl = lambda d: {k: v[lo:hi] for k, v in d.items()} if d is not None else None
+    return sl(feats), sl(labels), hi - lo
+
+  def _get_spec(self, mode, feats, labels, n):
+    key = (mode, n)
+    if key in self._specs:
+      return self._specs[key]
+    dev = self._device()
+    to_dev = lambda d: {k: torch.as_tensor(v).to(dev).contiguous() for k, v in d.items()} if d is not None else None
+    fbuf, lbuf = to_dev(feats), to_dev(labels)
+    params = dict(self.params)
+    params['_variable_store'] = self._store
+    params.setdefault('use_hipgraph', self.config.use_hipgraph)
+    spec = self._model_fn(fbuf, lbuf, mode, params)
+    if self._store is None:
+      self._store = spec.model.store
+      self._store.initialize(seed=self.config.init_seed)
+    self._restore_once()
+    # only the buffers the model adopted are fed per batch
+    used = {id(v) for v in spec.model.inputs.values()}
+    fbuf = {k: v for k, v in fbuf.items() if id(v) in used}
+    lbuf = {k: v for k, v in (lbuf or {}).items() if id(v) in used}
+    self._specs[key] = (spec, fbuf, lbuf)
+    return self._specs[key]
+
+  def _restore_once(self):
+    if self._restored:
+      return
+    self._restored = True
+    ckpt = latest_checkpoint(self.model_dir) if self.model_dir else None
+    if ckpt:
+      load_checkpoint(self._store, ckpt)
+      print('INFO: restored parameters from %s' % ckpt)
+    gdist.broadcast_variables(self._store)
+
+  @staticmethod
+  def _feed(bufs, batch):
+    if batch is None:
+      return
+    for k, buf in bufs.items():
+      buf.copy_(torch.as_tensor(batch[k]), non_blocking=True)
+
+  # -- public API --------------------------------------------------------------------------------
+  def latest_checkpoint(self):
+    return latest_checkpoint(self.model_dir)
+
+  def get_variable_value(self, name):
+    return self._store.var(name).detach().cpu().numpy()
+
+  def get_variable_names(self):
+    return list(self._store.shapes.keys())
+
+  def train(self, input_fn, steps=None, max_steps=None):
+    world, rank = gdist.world_size(), gdist.rank()
+    t0, nsteps, step = time.time(), 0, None
+    for batch in input_fn():
+      feats, labels, n = self._shard(batch, world, rank)
+      if n == 0:
+        continue
+      spec, fbuf, lbuf = self._get_spec(ModeKeys.TRAIN, feats, labels, n)
+      self._feed(fbuf, feats)
+      self._feed(lbuf, labels)
+      spec.train_op()
+      nsteps += 1
+      if spec.training_hooks or self.config.save_checkpoints_steps:
+        step = int(self._store.global_step.item()) if (nsteps == 1 or step is None) else step + 1
+        for h in spec.training_hooks or []:
+          h.after_run(step, self.model_dir)
+        if (self.config.save_checkpoints_steps and step % self.config.save_checkpoints_steps == 0 and rank == 0
+            and self.model_dir):
+          save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max)
+      if steps is not None and nsteps >= steps:
+        break
+      if max_steps is not None and step is not None and step >= max_steps:
+        break
+    if nsteps and torch.cuda.is_available():
+      torch.cuda.synchronize()
+    if nsteps and rank == 0 and self.model_dir:
+      path = save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max)
+      print('INFO: saved %s after %d steps (%.1f steps/s)' % (path, nsteps, nsteps / max(time.time() - t0, 1e-9)))
+    return self
+
+  def evaluate(self, input_fn, steps=None):
+    """Streams the eval metrics of estimator.py:246-254; 'loss' = mean of per-batch losses [TF1.15]."""
+    world, rank = gdist.world_size(), gdist.rank()
+    sums, nb, loss_sum = {}, 0, None
+    for batch in input_fn():
+      feats, labels, n = self._shard(batch, world, rank)
+      if n == 0:
+        continue
+      spec, fbuf, lbuf = self._get_spec(ModeKeys.EVAL, feats, labels, n)
+      self._feed(fbuf, feats)
+      self._feed(lbuf, labels)
+      spec.train_op()
+      loss_sum = spec.loss.clone() if loss_sum is None else loss_sum + spec.loss
+      for k, (s, c) in spec.eval_metric_ops().items():
+        if k in sums:
+          sums[k][0] += s
+          sums[k][1] += c
+        else:
+          sums[k] = [s.clone(), c]
+      nb += 1
+      if steps is not None and nb >= steps:
+        break
+    if nb == 0:
+      raise RuntimeError('evaluate(): input_fn produced no batches')
+    dev = loss_sum.device
+    vec = torch.stack([loss_sum, torch.tensor(float(nb), device=dev)] +
+                      [x for k in sorted(sums) for x in (sums[k][0], torch.tensor(float(sums[k][1]), device=dev))])
+    if world > 1:
+      torch.distributed.all_reduce(vec)
+    vec = vec.double().cpu()
+    out = {'loss': float(vec[0] / vec[1])}
+    for i, k in enumerate(sorted(sums)):
+      out[k] = float(vec[2 + 2 * i] / vec[3 + 2 * i])
+    out['global_step'] = int(self._store.global_step.item())
+    return out
+
+  def predict(self, input_fn):
+    for batch in input_fn():
+      feats = batch[0] if isinstance(batch, tuple) else batch
+      n = int(next(iter(feats.values())).shape[0])
+      spec, fbuf, _ = self._get_spec(ModeKeys.PREDICT, feats, None, n)
+      self._feed(fbuf, feats)
+      spec.train_op()
+      torch.cuda.synchronize()
+      yield {k: v.detach().cpu().numpy().copy() for k, v in spec.predictions.items()}

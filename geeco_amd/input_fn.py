@@ -1,0 +1,263 @@
+"""Input pipelines: the GEECO pick&place dataset reader (encoding v4) and a synthetic generator.
+
+Counterpart of the reference's ``src/data/geeco_gym.py`` live path: ``pickplace_input_fn`` (:234-279)
+-> ``pickplace_input_fn_v4`` (:401-474) with ``_get_meta_v4`` (:283), ``_parse_v4`` (:291),
+``_preprocess_states_v4`` (:317), ``_preprocess_targets_v3`` (:598), ``_window_v3`` (:615),
+``_prepare_v4`` (:373) and ``_collect_tfrecords_v2`` (:780).  Same dataset directory layout, same
+feature / label dictionaries (shapes and key names), same ordering semantics: record-level shuffle
+in 'train' mode only, NO sample-level shuffle (it is commented out in the reference, :447-448), so
+a batch holds consecutive windows of one episode; the final batch may be ragged (no drop_remainder).
+
+Unlike the reference (which materialises every K-frame window on the host: 84 windows x 12.6 MB
+for K = 16), an episode's frames are kept once and every batch is sliced from them; windows are
+built per batch, not per episode.
+"""
+from __future__ import annotations
+
+import collections
+import json
+import os
+import queue
+import threading
+
+import numpy as np
+
+from . import tfrecord
+
+PickAndPlaceMetaV4 = collections.namedtuple('PickAndPlaceMetaV4', [
+    'episode_length', 'img_height', 'img_width', 'monitored_joints', 'actuated_joints', 'monitored_mocaps',
+    'monitored_objects', 'dim_cmd', 'dim_ctrl'])
+
+_ARM_JOINTS = ['shoulder_pan_joint', 'shoulder_lift_joint', 'upperarm_roll_joint', 'elbow_flex_joint',
+               'forearm_roll_joint', 'wrist_flex_joint', 'wrist_roll_joint']          # geeco_gym.py:336-344
+_FINGER_JOINTS = ['l_gripper_finger_joint', 'r_gripper_finger_joint']                # geeco_gym.py:364-367
+
+
+def get_meta_v4(dataset_dir):
+  """geeco_gym.py:283-289."""
+  with open(os.path.join(dataset_dir, 'meta', 'meta_info.json'), 'r') as fp:
+    return PickAndPlaceMetaV4(**json.load(fp))
+
+
+def collect_tfrecords(dataset_dir, split_name, mode):
+  """geeco_gym.py:780-793: record file names listed in splits/<split>/<mode>.txt (or all of data/)."""
+  record_dir = os.path.join(dataset_dir, 'data')
+  if split_name is None and mode is None:
+    names = [fn for fn in os.listdir(record_dir) if fn.endswith('.tfrecord.zlib')]
+  else:
+    with open(os.path.join(dataset_dir, 'splits', split_name, '%s.txt' % (mode,))) as fp:
+      names = fp.read().split('\n')
+  return [os.path.join(record_dir, fn) for fn in names if fn.endswith('.tfrecord.zlib')]
+
+
+def load_episode(path, meta, fetch_target):
+  """One episode -> dict of per-frame arrays after _parse_v4 + _preprocess_states_v4 +
+  _preprocess_targets_v3 (i.e. the last frame already dropped: T = episode_length - 1)."""
+  H, W = meta.img_height, meta.img_width
+  payload = next(iter(tfrecord.read_records(path, 'zlib')))
+  _, fl = tfrecord.parse_sequence_example(payload)
+
+  def stack(key, shape=None, dtype=np.float32):
+    if key not in fl:
+      raise KeyError("%s: feature list '%s' missing" % (path, key))
+    arr = np.stack([np.asarray(f, dtype=dtype) for f in fl[key]], axis=0)
+    return arr.reshape((arr.shape[0],) + tuple(shape)) if shape is not None else arr
+
+  ex = {
+      'step': stack('step', (), np.int64),
+      'ts': stack('ts', ()),
+      'rgb': stack('rgb', (H, W, 3)) / np.float32(255.0),           # :312 RGB recorded as uint8 0..255
+      'depth': stack('depth', (H, W, 1)),
+      'cmd': stack('cmd', (meta.dim_cmd,)),
+      'ctrl': stack('ctrl', (meta.dim_ctrl,)),
+      'ee_state': stack('mocap_qpos-robot0:mocap', (7,)),
+      'goal_state': stack('goal_qpos', (7,)),
+      'obj_state': stack('obj_qpos', (7,)),
+  }
+  ex['jnt_state'] = np.stack([stack('joint_qpos-robot0:%s' % j, ()) for j in _ARM_JOINTS], axis=1)
+  ex['vel_state'] = np.stack([stack('joint_qvel-robot0:%s' % j, ()) for j in _ARM_JOINTS], axis=1)
+  ex['grp_state'] = np.stack([stack('joint_qpos-robot0:%s' % j, ()) for j in _FINGER_JOINTS], axis=1)
+  target = None
+  if fetch_target:      # :313-315: target = LAST frame of the full episode
+    target = {'target_rgb': ex['rgb'][-1].copy(), 'target_depth': ex['depth'][-1].copy()}
+  # _preprocess_targets_v3 (:598-613): next-frame states as targets, then drop the last frame
+  ex['vel_target'] = np.roll(ex['vel_state'], -1, axis=0)
+  ex['ee_target'] = np.roll(ex['ee_state'], -1, axis=0)
+  ex['grp_target'] = np.roll(ex['grp_state'], -1, axis=0)
+  ex = {k: v[:-1] for k, v in ex.items()}
+  if target:
+    ex.update(target)
+  return ex
+
+
+_FEATURE_KEYS = ['step', 'ts', 'rgb', 'depth', 'jnt_state', 'vel_state', 'ee_state', 'grp_state', 'goal_state',
+                 'obj_state', 'cmd', 'ctrl']
+_LABEL_KEYS = ['cmd', 'ctrl', 'vel_target', 'ee_target', 'grp_target']
+
+
+def episode_windows(ex, window_size, starts):
+  """(features, labels) for the windows beginning at ``starts`` (_window_v3 :615-631, _prepare_v4 :373-399)."""
+  K = window_size
+  idx = np.asarray(starts)[:, None] + np.arange(K)[None, :]
+  feats = {k: ex[k][idx] for k in _FEATURE_KEYS}
+  if 'target_rgb' in ex:
+    n = len(starts)
+    feats['target_rgb'] = np.broadcast_to(ex['target_rgb'], (n,) + ex['target_rgb'].shape).copy()
+    feats['target_depth'] = np.broadcast_to(ex['target_depth'], (n,) + ex['target_depth'].shape).copy()
+  last = np.asarray(starts) + K - 1
+  labels = {k: ex[k][last] for k in _LABEL_KEYS}
+  return feats, labels
+
+
+class _Prefetcher:
+  """Runs an iterator factory in background threads (tf.data's num_parallel_calls / prefetch)."""
+
+  def __init__(self, make_iter, depth):
+    self._q = queue.Queue(maxsize=max(int(depth), 1))
+    self._t = threading.Thread(target=self._run, args=(make_iter,), daemon=True)
+    self._t.start()
+
+  def _run(self, make_iter):
+    try:
+      for item in make_iter():
+        self._q.put(('item', item))
+      self._q.put(('end', None))
+    except BaseException as e:   # surfaced in the consumer
+      self._q.put(('error', e))
+
+  def __iter__(self):
+    while True:
+      kind, val = self._q.get()
+      if kind == 'item':
+        yield val
+      elif kind == 'end':
+        return
+      else:
+        raise val
+
+
+def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size=4, fetch_target=False,
+                       shuffle_buffer=128, batch_size=1, num_epochs=1, num_threads=4, prefetch_size=4, seed=None,
+                       shard=None):
+  """Same signature as the reference's pickplace_input_fn (geeco_gym.py:234-279).  Returns an iterable of
+  (features, labels) numpy batches.  ``shard = (rank, world)`` makes each data-parallel rank read a
+  disjoint, rank-strided subset of the episodes."""
+  if encoding != 'v4':
+    # v1-v3 are dead code in the reference (undefined PickAndPlaceEncodingV1/2/3 -> NameError)
+    raise KeyError(encoding)
+  if dataset_dir.startswith('synthetic:'):
+    return synthetic_from_spec(dataset_dir, mode, window_size, fetch_target, batch_size, seed)
+  meta = get_meta_v4(dataset_dir)
+  paths = collect_tfrecords(dataset_dir, split_name, mode)
+  if mode == 'train':   # record-level shuffle only (:436-437)
+    np.random.default_rng(seed).shuffle(paths)
+  if shard is not None:
+    paths = paths[shard[0]::shard[1]]
+  print('[pickplace_input_fn_v4] #tfrecords: %d' % len(paths))
+  K = window_size
+
+  def batches():
+    carry_f, carry_l = None, None   # windows left over from the previous episode (batch() spans episodes)
+    for _ in range(num_epochs):
+      for path in paths:
+        ex = load_episode(path, meta, fetch_target)
+        T = ex['step'].shape[0]
+        nwin = T - K + 1
+        pos = 0
+        while pos < nwin:
+          need = batch_size - (0 if carry_f is None else len(carry_f['step']))
+          take = min(need, nwin - pos)
+          f, l = episode_windows(ex, K, np.arange(pos, pos + take))
+          pos += take
+          if carry_f is not None:
+            f = {k: np.concatenate([carry_f[k], f[k]], axis=0) for k in f}
+            l = {k: np.concatenate([carry_l[k], l[k]], axis=0) for k in l}
+            carry_f = carry_l = None
+          if len(f['step']) == batch_size:
+            yield f, l
+          else:
+            carry_f, carry_l = f, l
+    if carry_f is not None:   # ragged final batch (dataset.batch without drop_remainder, :471)
+      yield carry_f, carry_l
+
+  return _Prefetcher(batches, prefetch_size)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic data
+# ------------------------------------------------------------------------------------------------
+def synthetic_batches(batch_size, window_size, num_batches, img_hw=(256, 256), channels=3, fetch_target=True, seed=1234):
+  """Seeded random batches with the feature / label dictionaries of _prepare_v4."""
+  H, W = img_hw
+  K = window_size
+
+  def gen():
+    r = np.random.default_rng(seed)
+    for b in range(num_batches):
+      N = batch_size
+      f = {
+          'step': (np.arange(K)[None, :] + r.integers(1, 80, size=[N, 1])).astype(np.int64),
+          'ts': r.random([N, K], dtype=np.float32),
+          'rgb': r.integers(0, 256, size=[N, K, H, W, 3]).astype(np.float32) / np.float32(255.0),
+          'depth': (0.5 + 2.5 * r.random([N, K, H, W, 1], dtype=np.float32)),
+          'jnt_state': r.standard_normal([N, K, 7]).astype(np.float32),
+          'vel_state': r.standard_normal([N, K, 7]).astype(np.float32),
+          'ee_state': 1.5 * r.random([N, K, 7], dtype=np.float32),
+          'grp_state': 0.05 * r.random([N, K, 2], dtype=np.float32),
+          'goal_state': 1.5 * r.random([N, K, 7], dtype=np.float32),
+          'obj_state': 1.5 * r.random([N, K, 7], dtype=np.float32),
+          'ctrl': r.standard_normal([N, K, 2]).astype(np.float32),
+      }
+      cmd = np.concatenate([0.3 * r.standard_normal([N, K, 3]), r.integers(-1, 2, size=[N, K, 1])], axis=2)
+      f['cmd'] = cmd.astype(np.float32)
+      if fetch_target:
+        f['target_rgb'] = r.integers(0, 256, size=[N, H, W, 3]).astype(np.float32) / np.float32(255.0)
+        f['target_depth'] = (0.5 + 2.5 * r.random([N, H, W, 1], dtype=np.float32))
+      l = {'cmd': f['cmd'][:, -1], 'ctrl': f['ctrl'][:, -1], 'vel_target': r.standard_normal([N, 7]).astype(np.float32),
+           'ee_target': r.random([N, 7], dtype=np.float32), 'grp_target': r.random([N, 2], dtype=np.float32)}
+      yield f, l
+  return gen
+
+
+def synthetic_from_spec(spec, mode, window_size, fetch_target, batch_size, seed):
+  """``--dataset_dir synthetic:<num_batches>[:<H>x<W>]`` (no dataset on disk; used by the benches and tests)."""
+  parts = spec.split(':')
+  nb = int(parts[1]) if len(parts) > 1 and parts[1] else 8
+  hw = tuple(int(x) for x in parts[2].split('x')) if len(parts) > 2 else (256, 256)
+  if mode != 'train':
+    nb = max(1, nb // 4)
+  base = 1234 if seed is None else seed
+  return synthetic_batches(batch_size, window_size, nb, hw, 3, fetch_target, seed=base + (0 if mode == 'train' else 1))()
+
+
+def write_episode(path, meta, frames_rgb_u8, depth, cmd, ctrl, joints_qpos, joints_qvel, mocap_qpos, obj_qpos,
+                  goal_qpos, ts=None, task_goal='goal', task_object='object'):
+  """Writes one episode in the reference's on-disk format (PickAndPlaceEncodingV4: geeco_gym.py:117-176,
+  data_recorder.py:37-59,134-156).  Used to build fixtures and synthetic datasets, not by training."""
+  T = frames_rgb_u8.shape[0]
+  ctx = collections.OrderedDict([
+      ('episode_length', np.array([meta.episode_length], np.int64)), ('img_height', np.array([meta.img_height], np.int64)),
+      ('img_width', np.array([meta.img_width], np.int64)), ('monitored_joints', list(meta.monitored_joints)),
+      ('actuated_joints', list(meta.actuated_joints)), ('monitored_mocaps', list(meta.monitored_mocaps)),
+      ('monitored_objects', list(meta.monitored_objects)), ('dim_cmd', np.array([meta.dim_cmd], np.int64)),
+      ('dim_ctrl', np.array([meta.dim_ctrl], np.int64)), ('task_goal', task_goal), ('task_object', task_object)])
+  frames = []
+  for t in range(T):
+    fr = collections.OrderedDict()
+    fr['step'] = np.array([t], np.int64)
+    fr['ts'] = np.array([0.04 * t if ts is None else ts[t]], np.float32)
+    fr['rgb'] = frames_rgb_u8[t]          # uint8 -> float list (tfrecord.py:73-74)
+    fr['depth'] = depth[t].astype(np.float32)
+    fr['cmd'] = cmd[t].astype(np.float32)
+    fr['ctrl'] = ctrl[t].astype(np.float32)
+    fr['goal_qpos'] = goal_qpos[t].astype(np.float32)
+    fr['obj_qpos'] = obj_qpos[t].astype(np.float32)
+    for j, name in enumerate(meta.monitored_joints):
+      fr['joint_qpos-%s' % name] = np.array([joints_qpos[t, j]], np.float32)
+      fr['joint_qvel-%s' % name] = np.array([joints_qvel[t, j]], np.float32)
+    for name in meta.monitored_mocaps:
+      fr['mocap_qpos-%s' % name] = mocap_qpos[t].astype(np.float32)
+    for name in meta.monitored_objects:
+      fr['object_qpos-%s' % name] = obj_qpos[t].astype(np.float32)
+    frames.append(fr)
+  tfrecord.write_records(path, [tfrecord.encode_sequence_example(ctx, frames)], 'zlib')

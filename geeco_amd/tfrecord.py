@@ -1,0 +1,240 @@
+"""TFRecord(+zlib) framing and the ``tf.train.SequenceExample`` wire format, without TensorFlow.
+
+The reference stores one episode per ``*.tfrecord.zlib`` file (writer:
+``src/data/data_recorder.py:134-156`` with ``TfrSequenceEncoding.encode`` :37-59 and
+``src/data/utils/tfrecord.py:42-81``; reader: ``tf.data.TFRecordDataset(compression_type='ZLIB')`` +
+``tf.parse_single_sequence_example``, ``src/data/geeco_gym.py:291-315, 442-445``).
+
+File layout [TF1.15 record format]: one zlib stream containing records
+  u64 length | u32 masked_crc32c(length) | payload | u32 masked_crc32c(payload)      (little endian)
+Payload = protobuf ``SequenceExample { Features context = 1; FeatureLists feature_lists = 2; }`` with
+  Features     { map<string, Feature> feature = 1; }
+  FeatureLists { map<string, FeatureList> feature_list = 1; }
+  FeatureList  { repeated Feature feature = 1; }
+  Feature      { oneof kind { BytesList bytes_list = 1; FloatList float_list = 2; Int64List int64_list = 3; } }
+  BytesList { repeated bytes value = 1; }  FloatList { repeated float value = 1 [packed]; }
+  Int64List { repeated int64 value = 1 [packed]; }
+Packed float lists are decoded zero-copy with ``numpy.frombuffer`` (an RGB frame is a 196 608-float
+list: images are written as floats, tfrecord.py:73-74).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import struct
+import zlib
+
+import numpy as np
+
+_HOST_LIB = None
+
+
+def _host():
+  global _HOST_LIB
+  if _HOST_LIB is None:
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libgeeco_host.so')
+    if not os.path.exists(path):
+      raise RuntimeError('%s is missing: run geeco_amd/csrc/build.sh' % path)
+    lib = ctypes.CDLL(path)
+    lib.geeco_masked_crc32c.restype = ctypes.c_uint32
+    lib.geeco_masked_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.geeco_crc32c.restype = ctypes.c_uint32
+    lib.geeco_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    _HOST_LIB = lib
+  return _HOST_LIB
+
+
+def masked_crc32c(data: bytes) -> int:
+  return int(_host().geeco_masked_crc32c(bytes(data) if not isinstance(data, bytes) else data, len(data)))
+
+
+# ------------------------------------------------------------------------------------------------
+# record framing
+# ------------------------------------------------------------------------------------------------
+def read_records(path, compression='zlib', verify=True):
+  """Yields the payload bytes of every record of a TFRecord file."""
+  with open(path, 'rb') as f:
+    raw = f.read()
+  if compression == 'zlib':
+    raw = zlib.decompress(raw)
+  elif compression == 'gzip':
+    raw = zlib.decompress(raw, 16 + zlib.MAX_WBITS)
+  elif compression not in (None, 'none', ''):
+    raise ValueError('unknown compression %r' % (compression,))
+  view = memoryview(raw)
+  pos, n = 0, len(raw)
+  while pos < n:
+    if pos + 12 > n:
+      raise IOError('%s: truncated record header at byte %d' % (path, pos))
+    (length,) = struct.unpack_from('<Q', raw, pos)
+    (lcrc,) = struct.unpack_from('<I', raw, pos + 8)
+    if verify and masked_crc32c(raw[pos:pos + 8]) != lcrc:
+      raise IOError('%s: corrupted record length at byte %d' % (path, pos))
+    beg, end = pos + 12, pos + 12 + length
+    if end + 4 > n:
+      raise IOError('%s: truncated record at byte %d' % (path, pos))
+    (dcrc,) = struct.unpack_from('<I', raw, end)
+    payload = view[beg:end]
+    if verify and int(_host().geeco_masked_crc32c(raw[beg:end], length)) != dcrc:
+      raise IOError('%s: corrupted record payload at byte %d' % (path, pos))
+    yield payload
+    pos = end + 4
+
+
+def write_records(path, payloads, compression='zlib'):
+  out = bytearray()
+  for p in payloads:
+    p = bytes(p)
+    hdr = struct.pack('<Q', len(p))
+    out += hdr + struct.pack('<I', masked_crc32c(hdr)) + p + struct.pack('<I', masked_crc32c(p))
+  data = bytes(out)
+  if compression == 'zlib':
+    data = zlib.compress(data)
+  with open(path, 'wb') as f:
+    f.write(data)
+
+
+# ------------------------------------------------------------------------------------------------
+# protobuf wire helpers
+# ------------------------------------------------------------------------------------------------
+def _varint(buf, pos):
+  result, shift = 0, 0
+  while True:
+    b = buf[pos]
+    pos += 1
+    result |= (b & 0x7f) << shift
+    if not b & 0x80:
+      return result, pos
+    shift += 7
+
+
+def _fields(buf):
+  """Yields (field_number, wire_type, value) of one message; value is an int or a memoryview."""
+  pos, n = 0, len(buf)
+  while pos < n:
+    key, pos = _varint(buf, pos)
+    fnum, wt = key >> 3, key & 7
+    if wt == 0:
+      val, pos = _varint(buf, pos)
+    elif wt == 2:
+      ln, pos = _varint(buf, pos)
+      val = buf[pos:pos + ln]
+      pos += ln
+    elif wt == 5:
+      val = buf[pos:pos + 4]
+      pos += 4
+    elif wt == 1:
+      val = buf[pos:pos + 8]
+      pos += 8
+    else:
+      raise ValueError('unsupported wire type %d' % wt)
+    yield fnum, wt, val
+
+
+def _decode_feature(buf):
+  """Feature -> numpy array (float32 / int64) or list of bytes."""
+  for fnum, wt, val in _fields(buf):
+    if fnum == 2:      # FloatList
+      chunks = []
+      for f2, w2, v2 in _fields(val):
+        if f2 == 1 and w2 == 2:
+          chunks.append(np.frombuffer(v2, dtype='<f4'))
+        elif f2 == 1 and w2 == 5:
+          chunks.append(np.frombuffer(v2, dtype='<f4'))
+      return chunks[0] if len(chunks) == 1 else (np.concatenate(chunks) if chunks else np.zeros([0], np.float32))
+    if fnum == 3:      # Int64List
+      vals = []
+      for f2, w2, v2 in _fields(val):
+        if f2 == 1 and w2 == 2:
+          p = 0
+          while p < len(v2):
+            x, p = _varint(v2, p)
+            vals.append(x - (1 << 64) if x >= (1 << 63) else x)
+        elif f2 == 1 and w2 == 0:
+          vals.append(v2 - (1 << 64) if v2 >= (1 << 63) else v2)
+      return np.asarray(vals, np.int64)
+    if fnum == 1:      # BytesList
+      return [bytes(v2) for f2, w2, v2 in _fields(val) if f2 == 1]
+  return np.zeros([0], np.float32)
+
+
+def _decode_map_entry(buf):
+  key, value = None, None
+  for fnum, wt, val in _fields(buf):
+    if fnum == 1:
+      key = bytes(val).decode('utf-8')
+    elif fnum == 2:
+      value = val
+  return key, value
+
+
+def parse_sequence_example(payload, keys=None):
+  """-> (context: {name: array|[bytes]}, feature_lists: {name: [per-frame array]}).
+  ``keys``: optional set of feature_list names to decode (others are skipped)."""
+  context, lists = {}, {}
+  for fnum, wt, val in _fields(memoryview(payload)):
+    if fnum == 1:      # context: Features
+      for f2, w2, entry in _fields(val):
+        if f2 == 1:
+          k, v = _decode_map_entry(entry)
+          context[k] = _decode_feature(v) if v is not None else None
+    elif fnum == 2:    # feature_lists
+      for f2, w2, entry in _fields(val):
+        if f2 != 1:
+          continue
+        k, v = _decode_map_entry(entry)
+        if keys is not None and k not in keys:
+          continue
+        frames = []
+        if v is not None:
+          for f3, w3, feat in _fields(v):
+            if f3 == 1:
+              frames.append(_decode_feature(feat))
+        lists[k] = frames
+  return context, lists
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder (writer side of the same format; used to build fixtures and synthetic datasets)
+# ------------------------------------------------------------------------------------------------
+def _enc_varint(x):
+  x &= (1 << 64) - 1
+  out = bytearray()
+  while True:
+    b = x & 0x7f
+    x >>= 7
+    if x:
+      out.append(b | 0x80)
+    else:
+      out.append(b)
+      return bytes(out)
+
+
+def _enc_len(fnum, payload):
+  return _enc_varint((fnum << 3) | 2) + _enc_varint(len(payload)) + payload
+
+
+def encode_feature(value):
+  """numpy float/uint8 arrays -> FloatList; int arrays -> Int64List; str / [str] -> BytesList
+  (the type dispatch of the reference's convert_to_feature, tfrecord.py:42-81)."""
+  if isinstance(value, str):
+    value = [value]
+  if isinstance(value, (list, tuple)) and value and isinstance(value[0], (str, bytes)):
+    body = b''.join(_enc_len(1, v.encode('utf-8') if isinstance(v, str) else v) for v in value)
+    return _enc_len(1, body)
+  arr = np.asarray(value)
+  if arr.dtype.kind in 'iu' and arr.dtype != np.uint8:
+    body = _enc_len(1, b''.join(_enc_varint(int(x)) for x in arr.reshape(-1)))
+    return _enc_len(3, body)
+  body = _enc_len(1, np.ascontiguousarray(arr.reshape(-1), dtype='<f4').tobytes())
+  return _enc_len(2, body)
+
+
+def encode_sequence_example(context: dict, frames: list):
+  """context: {name: value}; frames: list of {name: value} with identical keys."""
+  ctx = b''.join(_enc_len(1, _enc_len(1, k.encode()) + _enc_len(2, encode_feature(v))) for k, v in context.items())
+  fl = b''
+  for k in (frames[0].keys() if frames else []):
+    feats = b''.join(_enc_len(1, encode_feature(fr[k])) for fr in frames)
+    fl += _enc_len(1, _enc_len(1, k.encode()) + _enc_len(2, feats))
+  return _enc_len(1, ctx) + _enc_len(2, fl)

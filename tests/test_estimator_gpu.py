@@ -1,0 +1,90 @@
+"""Boundary test on the GPU: Estimator.train / evaluate / checkpoint-resume through the model_fn
+surface, and the train_e2evmc.py counterpart end to end on synthetic windows."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _params(**kw):
+  from geeco_amd.params import create_e2evmc_config
+  base = dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=4, lr=1e-3)
+  base.update(kw)
+  return {'e2evmc_config': create_e2evmc_config(base), 'log_steps': 2, 'debug': False}
+
+
+def test_estimator_train_eval_resume(dev, tmp_path):
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import synthetic_batches
+  params = _params()
+  train_in = synthetic_batches(4, 3, 6, (136, 136), 3, True, seed=5)
+  eval_in = synthetic_batches(4, 3, 2, (136, 136), 3, True, seed=6)
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(save_checkpoints_steps=4, keep_checkpoint_max=2), params)
+  r0 = None
+  for epoch in range(3):
+    e.train(input_fn=train_in)
+    r = e.evaluate(input_fn=eval_in)
+    assert set(r) == {'loss', 'cmd_ee', 'pos_ee', 'pos_obj', 'cmd_grp', 'global_step'}
+    r0 = r0 or r
+  assert r['global_step'] == 18
+  assert r['loss'] < r0['loss']            # same batches every epoch: the loss must go down
+  assert 0.0 <= r['cmd_grp'] <= 1.0
+  ck = est.latest_checkpoint(str(tmp_path))
+  assert os.path.basename(ck) == 'model.ckpt-18' and os.path.exists(ck + '.pt')
+  kept = sorted(fn for fn in os.listdir(tmp_path) if fn.endswith('.pt'))
+  assert len(kept) == 2, kept
+  assert os.path.exists(tmp_path / 'events.jsonl')
+  # a fresh Estimator on the same model_dir resumes from the checkpoint: same eval result
+  e2 = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(), params)
+  r2 = e2.evaluate(input_fn=eval_in)
+  assert r2['global_step'] == 18
+  np.testing.assert_allclose(r2['loss'], r['loss'], rtol=1e-6)
+  # hipGraph replay and eager launches give the same numbers
+  e3 = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(use_hipgraph=False), params)
+  r3 = e3.evaluate(input_fn=eval_in)
+  np.testing.assert_allclose(r3['loss'], r['loss'], rtol=1e-6)
+
+
+def test_estimator_errors(dev, tmp_path):
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import synthetic_batches
+  from geeco_amd.params import create_e2evmc_config
+  bad = {'e2evmc_config': create_e2evmc_config(dict(proc_obs='nope', proc_tgt='dyndiff', window_size=3, img_height=136,
+                                                    img_width=136)), 'log_steps': 1, 'debug': False}
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(), bad)
+  with pytest.raises(ValueError):
+    e.train(input_fn=synthetic_batches(2, 3, 1, (136, 136), 3, True))
+  bad2 = {'e2evmc_config': create_e2evmc_config(dict(img_channels=5)), 'log_steps': 1, 'debug': False}
+  with pytest.raises(ValueError):
+    est.Estimator(est.e2evmc_model_fn, str(tmp_path), est.RunConfig(), bad2).train(
+        input_fn=synthetic_batches(2, 4, 1, (136, 136), 3, False))
+
+
+def test_train_script_synthetic(dev, tmp_path):
+  md = str(tmp_path / 'run')
+  cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'train_e2evmc.py'), '--dataset_dir', 'synthetic:4:136x136',
+         '--model_dir', md, '--goal_condition', 'target', '--proc_obs', 'dynimg', '--proc_tgt', 'dyndiff',
+         '--window_size', '3', '--batch_size', '4', '--train_epochs', '2', '--log_steps', '2', '--num_best_ckpt', '1']
+  # image size comes from the config defaults (256); override through a pre-seeded config JSON (restart protocol)
+  os.makedirs(md)
+  from geeco_amd.params import create_e2evmc_config
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136,
+                                  batch_size=4))
+  with open(os.path.join(md, 'e2evmc_config.json'), 'w') as f:
+    json.dump(cfg._asdict(), f)
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  assert os.path.exists(os.path.join(md, 'snapshots', 'snapshot_index.json'))
+  idx = json.load(open(os.path.join(md, 'snapshots', 'snapshot_index.json')))
+  assert len(idx) == 1
+  (name, info), = idx.items()
+  assert os.path.exists(os.path.join(info['dir'], name + '.pt'))
+  assert os.path.exists(os.path.join(info['dir'], 'checkpoint'))
+  assert any(fn.endswith('runcmd.json') for fn in os.listdir(info['dir']))
