@@ -1,0 +1,57 @@
+"""The C-ABI library must load without a GPU and export every symbol include/geeco_hip.h declares
+(no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+  src = open(os.path.join(ROOT, 'include', 'geeco_hip.h')).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  return sorted(set(re.findall(r'\b(geeco_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+  from geeco_amd import _native
+  names = _declared()
+  assert len(names) >= 25
+  lib = ctypes.CDLL(_native.LIB_PATH)
+  missing = [n for n in names if not hasattr(lib, n)]
+  assert not missing, missing
+  # the Python binding types exactly the declared set
+  assert sorted(_native.SIGNATURES.keys()) == names
+
+
+def test_binding_loads_and_reports_version():
+  from geeco_amd import _native
+  lib = _native.load()
+  assert lib.geeco_abi_version() == 1
+  assert lib.geeco_dynimg_ws_bytes(2, 1024) > 0
+  assert lib.geeco_conv3x3_wgrad_ws_bytes(3, 2, 64, 64, 32, 48, 2) > 0
+  assert lib.geeco_conv3x3_fwd_ws_bytes(3, 32, 256, 256, 4, 32, 1) == 0       # big layers never split K
+  assert lib.geeco_conv3x3_fwd_ws_bytes(3, 32, 4, 4, 256, 256, 2) > 0         # conv8 does
+
+
+def test_host_side_argument_checks_need_no_gpu():
+  """Bad arguments are rejected before any launch, with a message (error behaviour of the boundary)."""
+  from geeco_amd import _native
+  lib = _native.load()
+  rc = lib.geeco_conv3x3_fwd(None, None, None, None, 1, 0, 0, 0, 0, 1, 8, 8, 4, 16, 1, 1, None, None)
+  assert rc == -1 and b'null pointer' in lib.geeco_last_error()
+  one = ctypes.c_void_p(16)
+  rc = lib.geeco_conv3x3_fwd(one, one, one, one, 1, 0, 0, 0, 0, 1, 8, 8, 3, 16, 1, 1, None, None)
+  assert rc == -1 and b'multiple of 4' in lib.geeco_last_error()
+  rc = lib.geeco_dynimg_fwd(one, None, 0, 0, one, 1, 65, 16, 3, 4, one, one, None)
+  assert rc == -1 and b'K=65' in lib.geeco_last_error()
+
+
+def test_alpha_matches_oracle():
+  from geeco_amd import _native
+  from oracle import geeco_oracle as O
+  lib = _native.load()
+  for K in (2, 4, 16, 32):
+    buf = (ctypes.c_float * K)()
+    lib.geeco_dynimg_alpha(K, ctypes.cast(buf, ctypes.c_void_p))
+    assert [float(v) for v in buf] == [float(v) for v in O.dynimg_alpha(K)]    # bit-exact float32

@@ -1,0 +1,173 @@
+"""Host-side logic that needs no GPU: config mirror, variable arena, TFRecord codec, the dataset
+reader's windowing against a literal restatement of the reference's pipeline, checkpoints."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geeco_oracle as O
+
+
+def test_params_mirror():
+  from geeco_amd import params as P
+  assert list(P.E2EVMCConfig._fields) == list(O.DEFAULT_PARAMS.keys())           # same names, same order
+  assert P.E2E_VMC_DEFAULT_CONFIG._asdict() == dict(O.DEFAULT_PARAMS)
+  c = P.create_e2evmc_config({'window_size': 16, 'unknown': 1})
+  assert c.window_size == 16 and not hasattr(c, 'unknown')
+
+
+def test_variable_store_matches_tf_names_and_counts():
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.variables import VariableStore
+  for goal, kw in ((True, dict(proc_obs='dynimg', proc_tgt='dyndiff')), (False, {}), (True, dict(img_channels=4, proc_obs='dynimg'))):
+    cfg = create_e2evmc_config(kw)
+    shapes = model_variable_shapes(cfg, goal)
+    ref = O.model_param_shapes(O.make_config(**kw), goal)
+    assert list(shapes.items()) == list(ref.items())
+  st = VariableStore(model_variable_shapes(create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff')), True), 'cpu')
+  assert st.count_parameters() == 7552796
+  assert all(o % 4 == 0 for o in st.offsets.values())                           # 16-byte aligned variables
+  st.initialize(seed=3)
+  k = st.var('GoalVMC/ConvEncoder/conv1/kernel')
+  lim = np.sqrt(6.0 / (27 + 9 * 32))
+  assert float(k.abs().max()) <= lim and float(k.abs().max()) > 0.9 * lim       # glorot-uniform limits
+  assert float(st.var('GoalVMC/ConvEncoder/conv1/bias').abs().max()) == 0.0
+  sd = st.state_dict()
+  st2 = VariableStore(st.shapes, 'cpu')
+  st2.load_state_dict(sd)
+  assert torch.equal(st.params, st2.params)
+  with pytest.raises(ValueError):
+    VariableStore(model_variable_shapes(create_e2evmc_config({}), False), 'cpu').load_state_dict(sd)
+  with pytest.raises(ValueError):
+    model_variable_shapes(create_e2evmc_config(dict(proc_obs='bad')), True)
+  with pytest.raises(ValueError):
+    model_variable_shapes(create_e2evmc_config(dict(img_channels=2)), True)
+
+
+def test_tfrecord_roundtrip_and_corruption(tmp_path):
+  from geeco_amd import tfrecord as T
+  assert T._host().geeco_crc32c(b'123456789', 9, 0) == 0xe3069283                # CRC-32C check value
+  assert T._host().geeco_crc32c(b'\x00' * 32, 32, 0) == 0x8a9136aa                # RFC 3720 B.4
+  ctx = {'episode_length': np.array([2], np.int64), 'task_goal': 'pad', 'names': ['a', 'bc']}
+  frames = [{'step': np.array([i], np.int64), 'neg': np.array([-3 - i], np.int64),
+             'rgb': (np.arange(12) + i).astype(np.uint8), 'x': np.array([0.25 * i, -1.5], np.float32)} for i in range(2)]
+  fn = str(tmp_path / 'a.tfrecord.zlib')
+  T.write_records(fn, [T.encode_sequence_example(ctx, frames), b'second'])
+  recs = [bytes(r) for r in T.read_records(fn)]
+  assert recs[1] == b'second'
+  c, fl = T.parse_sequence_example(recs[0])
+  assert c['task_goal'] == [b'pad'] and c['names'] == [b'a', b'bc'] and c['episode_length'].tolist() == [2]
+  assert [f.tolist() for f in fl['neg']] == [[-3], [-4]]
+  assert fl['rgb'][1].dtype == np.float32 and fl['rgb'][1].tolist() == list(map(float, range(1, 13)))
+  assert fl['x'][1].tolist() == [0.25, -1.5]
+  # flip one payload byte inside the zlib stream's plaintext -> CRC mismatch
+  import zlib
+  raw = bytearray(zlib.decompress(open(fn, 'rb').read()))
+  raw[20] ^= 0x01
+  open(fn, 'wb').write(zlib.compress(bytes(raw)))
+  with pytest.raises(IOError):
+    list(T.read_records(fn))
+  assert len(list(T.read_records(fn, verify=False))) == 2
+
+
+def _make_dataset(root, n_eps=2, T=9, H=8, W=8):
+  from geeco_amd import input_fn as I
+  joints = ['robot0:%s' % j for j in I._ARM_JOINTS + I._FINGER_JOINTS]
+  meta = I.PickAndPlaceMetaV4(episode_length=T, img_height=H, img_width=W, monitored_joints=joints,
+                              actuated_joints=joints[:2], monitored_mocaps=['robot0:mocap'],
+                              monitored_objects=['object0:joint'], dim_cmd=4, dim_ctrl=2)
+  os.makedirs(os.path.join(root, 'meta')); os.makedirs(os.path.join(root, 'data')); os.makedirs(os.path.join(root, 'splits', 'default'))
+  json.dump(meta._asdict(), open(os.path.join(root, 'meta', 'meta_info.json'), 'w'))
+  r = np.random.default_rng(0)
+  eps = []
+  for e in range(n_eps):
+    d = dict(rgb=r.integers(0, 256, [T, H, W, 3]).astype(np.uint8), depth=r.random([T, H, W, 1]).astype(np.float32),
+             cmd=np.concatenate([r.standard_normal([T, 3]), r.integers(-1, 2, [T, 1])], 1).astype(np.float32),
+             ctrl=r.standard_normal([T, 2]).astype(np.float32), qpos=r.standard_normal([T, 9]).astype(np.float32),
+             qvel=r.standard_normal([T, 9]).astype(np.float32), mocap=r.standard_normal([T, 7]).astype(np.float32),
+             obj=r.standard_normal([T, 7]).astype(np.float32), goal=r.standard_normal([T, 7]).astype(np.float32))
+    I.write_episode(os.path.join(root, 'data', 'ep%03d.tfrecord.zlib' % e), meta, d['rgb'], d['depth'], d['cmd'], d['ctrl'],
+                    d['qpos'], d['qvel'], d['mocap'], d['obj'], d['goal'])
+    eps.append(d)
+  names = '\n'.join('ep%03d.tfrecord.zlib' % e for e in range(n_eps))
+  for mode in ('train', 'eval'):
+    open(os.path.join(root, 'splits', 'default', mode + '.txt'), 'w').write(names + '\n')
+  return meta, eps
+
+
+def test_pickplace_input_fn_windows(tmp_path):
+  """Windows, labels and batching vs a literal restatement of geeco_gym.py:291-399, 598-631."""
+  from geeco_amd.input_fn import pickplace_input_fn
+  T, K, B = 9, 3, 4
+  meta, eps = _make_dataset(str(tmp_path), n_eps=2, T=T)
+  got = list(pickplace_input_fn(str(tmp_path), 'default', 'eval', window_size=K, fetch_target=True, batch_size=B))
+  # expected: per episode, drop the last frame (T-1 = 8 frames), 8-K+1 = 6 windows; batches of 4 span episodes: 4,4,4
+  assert [len(f['step']) for f, _ in got] == [4, 4, 4]
+  exp_f, exp_l = [], []
+  for d in eps:
+    rgb = d['rgb'].astype(np.float32) / np.float32(255.0)
+    ee_t, vel_t, grp_t = np.roll(d['mocap'], -1, 0), np.roll(d['qvel'][:, :7], -1, 0), np.roll(d['qpos'][:, 7:9], -1, 0)
+    for i in range((T - 1) - K + 1):
+      sl = slice(i, i + K)
+      exp_f.append(dict(rgb=rgb[:-1][sl], depth=d['depth'][:-1][sl], jnt_state=d['qpos'][:-1, :7][sl],
+                        vel_state=d['qvel'][:-1, :7][sl], grp_state=d['qpos'][:-1, 7:9][sl], ee_state=d['mocap'][:-1][sl],
+                        obj_state=d['obj'][:-1][sl], goal_state=d['goal'][:-1][sl], cmd=d['cmd'][:-1][sl],
+                        step=np.arange(T - 1)[sl], target_rgb=rgb[-1], target_depth=d['depth'][-1]))
+      exp_l.append(dict(cmd=d['cmd'][i + K - 1], ctrl=d['ctrl'][i + K - 1], vel_target=vel_t[i + K - 1],
+                        ee_target=ee_t[i + K - 1], grp_target=grp_t[i + K - 1]))
+  flat_f = [{k: f[k][j] for k in f} for f, _ in got for j in range(len(f['step']))]
+  flat_l = [{k: l[k][j] for k in l} for _, l in got for j in range(len(l['cmd']))]
+  assert len(flat_f) == len(exp_f) == 12
+  for a, b in zip(flat_f, exp_f):
+    for k, v in b.items():
+      np.testing.assert_array_equal(a[k], v, err_msg=k)
+  for a, b in zip(flat_l, exp_l):
+    for k, v in b.items():
+      np.testing.assert_array_equal(a[k], v, err_msg=k)
+  f0 = got[0][0]
+  assert f0['rgb'].shape == (4, K, 8, 8, 3) and f0['rgb'].dtype == np.float32 and f0['step'].dtype == np.int64
+  assert f0['target_rgb'].shape == (4, 8, 8, 3) and f0['depth'].shape == (4, K, 8, 8, 1)
+  # ragged final batch (no drop_remainder) and rank-strided sharding
+  got5 = list(pickplace_input_fn(str(tmp_path), 'default', 'eval', window_size=K, batch_size=5))
+  assert [len(f['step']) for f, _ in got5] == [5, 5, 2]
+  sh = list(pickplace_input_fn(str(tmp_path), 'default', 'eval', window_size=K, batch_size=6, shard=(1, 2)))
+  assert len(sh) == 1 and 'target_rgb' not in sh[0][0]
+  np.testing.assert_array_equal(sh[0][0]['cmd'][0], eps[1]['cmd'][:K])
+  with pytest.raises(KeyError):
+    pickplace_input_fn(str(tmp_path), 'default', 'eval', encoding='v2')
+
+
+def test_checkpoint_files_and_latest(tmp_path):
+  from geeco_amd import estimator as est
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.variables import VariableStore
+  st = VariableStore(model_variable_shapes(create_e2evmc_config({}), False), 'cpu')
+  st.initialize(1)
+  assert est.latest_checkpoint(str(tmp_path)) is None
+  for step in (3, 7, 12):
+    st.global_step.fill_(step)
+    est.save_checkpoint(st, str(tmp_path), keep_max=2)
+  assert sorted(f for f in os.listdir(tmp_path) if f.endswith('.pt')) == ['model.ckpt-12.pt', 'model.ckpt-7.pt']
+  ck = est.latest_checkpoint(str(tmp_path))
+  assert os.path.basename(ck) == 'model.ckpt-12'
+  assert 'model_checkpoint_path: "model.ckpt-12"' in open(tmp_path / 'checkpoint').read()
+  st2 = VariableStore(st.shapes, 'cpu')
+  est.load_checkpoint(st2, ck)
+  assert torch.equal(st2.params, st.params) and int(st2.global_step) == 12
+
+
+def test_estimator_refuses_cpu(tmp_path):
+  """No silent CPU fallback: the product path fails loudly without a GPU."""
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import synthetic_batches
+  from geeco_amd.params import create_e2evmc_config
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  e = est.Estimator(est.e2evmc_model_fn, str(tmp_path), est.RunConfig(),
+                    {'e2evmc_config': create_e2evmc_config(dict(img_height=136, img_width=136)), 'log_steps': 1})
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    e.train(input_fn=synthetic_batches(2, 4, 1, (136, 136), 3, False))

@@ -1,0 +1,122 @@
+"""Known-answer tests pinning the CPU oracle: analytic facts derivable from the
+reference source + the TF-1.15 op semantics it relies on.  The reference itself has no tests, so
+these (and the self-golden fixtures) are all that pins the oracle: PARITY UNPINNED."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import geeco_oracle as O
+
+
+def test_alpha_tables():
+  np.testing.assert_allclose(O.dynimg_alpha(2), [-0.5, 0.5], atol=1e-7)
+  np.testing.assert_allclose(O.dynimg_alpha(4), [-2.416667, 0.583333, 1.083333, 0.75], atol=2e-6)
+  a16 = [-25.472393, -10.472393, -3.972393, -0.305726, 1.944274, 3.344274, 4.177607, 4.606179, 4.731179, 4.620067,
+         4.320067, 3.865522, 3.282189, 2.589881, 1.804167, 0.9375]
+  np.testing.assert_allclose(O.dynimg_alpha(16), a16, atol=1e-5)
+  for T in (2, 3, 4, 8, 16, 32):
+    a = O.dynimg_alpha(T).astype(np.float64)
+    assert abs(float(a.sum())) < 1e-6 * T * (T + 1)                          # sum alpha = 0 up to float32 rounding
+
+
+def test_dynimg_known_answers():
+  const = torch.full((2, 5, 4, 4, 3), 0.3)
+  assert float(O.dynimg(const.double()).abs().max()) < 1e-9                   # constant sequence -> 0
+  cur = torch.rand(1, 6, 6, 3, dtype=torch.float64)
+  assert float(O.dynimg(torch.stack([cur, cur], 1)).abs().max()) == 0.0      # dyndiff(cur == tgt) == 0
+  tgt = torch.rand(1, 6, 6, 3, dtype=torch.float64)
+  d = 0.5 * (tgt - cur)
+  ref = (d - d.min()) / (d.max() - d.min() + 1e-6)
+  torch.testing.assert_close(O.dynimg(torch.stack([cur, tgt], 1)), ref)
+
+
+def test_same_padding_alignment_probe():
+  # even input, stride 2: output o covers inputs {2o, 2o+1, 2o+2}; delta at (1,1) lights ONLY output (0,0)
+  assert O.same_pad(256, 3, 2) == (128, 0, 1)
+  assert O.same_pad(256, 3, 1) == (256, 1, 1)
+  assert O.same_pad(5, 3, 2) == (3, 1, 1)
+  w = torch.zeros(3, 3, 1, 1, dtype=torch.float64)
+  w[:, :, 0, 0] = 1.0
+  for pos, expect in (((0, 0), [(0, 0)]), ((1, 1), [(0, 0)]), ((2, 2), [(0, 0), (0, 1), (1, 0), (1, 1)])):
+    x = torch.zeros(1, 8, 8, 1, dtype=torch.float64)
+    x[0, pos[0], pos[1], 0] = 1.0
+    y = O.conv2d_same(x, w, torch.zeros(1, dtype=torch.float64), 2, relu=False)[0, :, :, 0]
+    lit = sorted((int(i), int(j)) for i, j in torch.nonzero(y))
+    assert lit == expect, (pos, lit)
+
+
+def test_conv_torch_path_matches_independent_numpy():
+  r = np.random.default_rng(0)
+  for (H, W, Ci, Co, s) in ((8, 8, 3, 5, 1), (8, 10, 4, 6, 2), (7, 5, 2, 3, 2)):
+    x = r.standard_normal([2, H, W, Ci]); w = r.standard_normal([3, 3, Ci, Co]); b = r.standard_normal([Co])
+    a = O.conv2d_same(torch.tensor(x), torch.tensor(w), torch.tensor(b), s).numpy()
+    np.testing.assert_allclose(a, O.conv2d_same_numpy(x, w, b, s), rtol=1e-10, atol=1e-10)
+
+
+def test_parameter_counts():
+  enc = O.count_parameters(O.encoder_param_shapes('x', 3, 256))
+  assert enc == 1960496
+  f = O.make_config(proc_obs='dynimg', proc_tgt='dyndiff')
+  assert O.count_parameters(O.model_param_shapes(f, True)) == 7552796
+  assert O.count_parameters(O.model_param_shapes(O.make_config(), False)) == 2583228
+  s = O.model_param_shapes(f, True)
+  assert s['GoalVMC/LSTMDecoder/lstm_cell/kernel'] == (3228, 512)
+  assert s['GoalVMC/DynDiffEncoder/conv2/kernel'] == (3, 3, 32, 48)
+
+
+def test_concat_layouts():
+  obs = torch.arange(2 * 4 * 3, dtype=torch.float64).reshape(2, 2, 2, 3)
+  dyn, tgt = obs + 100, obs + 200
+  jnt = torch.tensor([[7., 8.], [9., 10.]], dtype=torch.float64)
+  v2 = O.representation_concatenation_v2(obs, dyn, jnt, tgt)
+  assert v2.shape == (2, 4 * 11)
+  cell1 = v2[0, 11:22]       # cell (h=0,w=1): [obs(3) | dyn(3) | jnt(2) | tgt(3)]
+  assert cell1.tolist() == [3, 4, 5, 103, 104, 105, 7, 8, 203, 204, 205]
+  v1 = O.representation_concatenation(obs, tgt, jnt)
+  assert v1[0, :8].tolist() == [0, 1, 2, 7, 8, 200, 201, 202]                 # jnt in the MIDDLE
+  sc = O.state_concatenation(obs, jnt)
+  assert sc[1, :5].tolist() == [12, 13, 14, 9, 10]
+
+
+def test_lstm_zero_weights():
+  N, D, H = 3, 5, 4
+  c0 = torch.randn(N, H, dtype=torch.float64)
+  c, h = O.lstm_cell(torch.randn(N, D, dtype=torch.float64), c0, torch.zeros(N, H, dtype=torch.float64),
+                     torch.zeros(D + H, 4 * H, dtype=torch.float64), torch.zeros(4 * H, dtype=torch.float64))
+  sig1 = 1 / (1 + math.exp(-1.0))
+  torch.testing.assert_close(c, sig1 * c0)                                    # c' = sigmoid(0 + forget_bias) c
+  torch.testing.assert_close(h, 0.5 * torch.tanh(c))                          # h' = sigmoid(0) tanh(c')
+
+
+def test_loss_known_answers():
+  N = 5
+  logits = torch.zeros(N, 3, dtype=torch.float64)
+  assert abs(float(O.softmax_xent(logits, torch.tensor([0, 1, 2, 1, 0]), 3)) - math.log(3.0)) < 1e-12   # ln 3
+  t = torch.randn(N, 3, dtype=torch.float64)
+  assert abs(float(O.mse(torch.zeros_like(t), t)) - float((t ** 2).mean())) < 1e-15
+  cmd = torch.tensor([[0., 0., 0., -1.], [0., 0., 0., 0.49], [0., 0., 0., 0.51], [0., 0., 0., 1.]])
+  tg = O.build_targets({'ee_state': torch.zeros(4, 2, 7), 'obj_state': torch.zeros(4, 2, 7)}, {'cmd': cmd}, O.make_config())
+  assert tg['cmd_grp'].tolist() == [0, 1, 2, 2]                               # rint + 1
+  assert torch.round(torch.tensor([0.5, 1.5, -0.5])).tolist() == [0.0, 2.0, -0.0]   # half-to-even like tf.math.rint
+
+
+def test_adam_step_one():
+  lr = 1e-4
+  g = np.array([1e-3, -2.0, 3e-7, 0.0])
+  p, m, v = np.zeros(4), np.zeros(4), np.zeros(4)
+  O.adam_step_tf(p, g, m, v, 1, lr)
+  expect = -lr * g / (np.abs(g) + 1e-8 / math.sqrt(1 - 0.999))               # = -lr g / (|g| + 3.1623e-7)
+  np.testing.assert_allclose(p, expect, rtol=1e-9, atol=1e-18)
+  assert abs(1e-8 / math.sqrt(1 - 0.999) - 3.1623e-7) < 1e-10
+
+
+def test_error_surface():
+  import pytest
+  with pytest.raises(ValueError):
+    O.model_param_shapes(O.make_config(proc_obs='nope'), True)
+  with pytest.raises(ValueError):
+    O.model_param_shapes(O.make_config(proc_tgt='nope'), True)
+  with pytest.raises(ValueError):
+    O.decoder_param_shapes('s', 10, O.make_config(control_mode='nope'))
+  assert O.make_config(bogus_key=3) == O.make_config()                        # unknown keys silently dropped
