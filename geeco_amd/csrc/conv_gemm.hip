@@ -26,6 +26,10 @@
 
 // One parity class of a launch (forward: a single class with all 9 taps; dgrad of a stride-s conv:
 // s*s classes, each with its own subset of taps and its own sub-grid of destination pixels).
+int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
+                       int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
+                       int relu, hipStream_t stream, int* handled);
+
 struct ConvClass {
   long long M;          // N*Hc*Wc rows
   int Hc, Wc;           // iteration grid: rows enumerate (n, Y', X')
@@ -486,6 +490,12 @@ extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b,
   GEECO_CHECK_ARG(Cin % 4 == 0 && Cin >= 4, "conv3x3_fwd: Cin=%d must be a multiple of 4", Cin);
   GEECO_CHECK_ARG(Cout % 16 == 0, "conv3x3_fwd: Cout=%d must be a multiple of 16", Cout);
   GEECO_CHECK_ARG(stride >= 1 && stride <= 4, "conv3x3_fwd: stride=%d", stride);
+  {
+    int handled = 0;
+    int rc = geeco_try_halo_fwd(x, w, b, y, groups, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, stride, relu,
+                                (hipStream_t)stream, &handled);
+    if (rc || handled) return rc;
+  }
   ConvGemmParams p = {};
   fill_fwd(&p, N, H, W, Cin, Cout, stride);
   p.x = x; p.w = w; p.bias = b; p.mask = nullptr; p.out = y;

@@ -32,6 +32,10 @@ CONV_CASES = [
     (2, 4, 4, 192, 256, 2),     # small-M path
     (4, 2, 2, 256, 256, 2),     # conv8-like: 2x2 -> 1x1
     (1, 10, 10, 16, 64, 1),     # stride 1, 16 channels
+    (2, 64, 64, 32, 48, 2),     # conv2 halo kernel, exact tiles
+    (3, 40, 72, 32, 48, 2),     # conv2 halo kernel, ragged tiles (Ho = 20, Wo = 36)
+    (2, 32, 32, 4, 32, 1),      # conv1 shape
+    (1, 20, 44, 4, 32, 1),      # conv1 shape, ragged
 ]
 
 
