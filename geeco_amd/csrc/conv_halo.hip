@@ -273,3 +273,275 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// conv2-type filter/bias gradient with an LDS halo (stride 2, CIN == 32, COUT % 16 == 0).
+//   dw[tap][ci][co] = sum_pixels x[halo(pixel, tap)][ci] * dz[pixel][co]       db[co] = sum dz
+// A block walks a contiguous range of 4x16-pixel tiles of ONE encoder and keeps its partial dw in
+// registers (wave = (output row of the tile, 16-channel half of ci): 9 taps x COUT/16 MFMA tiles =
+// 108 accumulator registers); per tile it stages the x halo (same LDS image as the forward kernel,
+// read here with ds_read_b32: bank = 8 (cq % 4) + 4 (pixel % 8) + (ci % 4), conflict free) and the
+// dz tile [64 pixels][COUT] (row pitch COUT = 16 mod 32).  MFMA k = 4 consecutive pixels.
+// At the end the four row-waves of each ci half are summed through LDS and the block writes one
+// slab; wgrad_reduce_kernel (conv_wgrad.hip) sums the slabs in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct HaloWgradParams {
+  const float* x;
+  const float* dz;
+  float* part;               // [G][S][9*CIN*COUT + COUT]
+  long long gs_x, gs_dz;
+  int N, H, W, Ho, Wo;
+  int tiles_x, tiles_y;
+  int tiles_per_group;
+  int S;                     // blocks (slabs) per group
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWgradParams p) {
+  constexpr int NT = 512;
+  constexpr int TH = 4, TW = 16;
+  constexpr int CQ = CIN / 4;
+  constexpr int HY = 2 * TH + 1, HX2 = TW + 1;
+  constexpr int PLANE = HY * 2 * HX2;
+  constexpr int HALO_F4 = CQ * PLANE;
+  constexpr int NPIX = HY * (2 * TW + 1);
+  constexpr int NLOAD = (NPIX * CQ + NT - 1) / NT;        // halo float4 per thread
+  constexpr int C4 = COUT / 4;
+  constexpr int DZ_F4 = TH * TW * C4;                     // dz tile float4
+  constexpr int NDZ = (DZ_F4 + NT - 1) / NT;
+  constexpr int TI = COUT / 16;
+  static_assert(CIN == 32, "two ci halves <-> two wave groups");
+  static_assert(COUT % 32 == 16, "dz row pitch must be 16 (mod 32) floats");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sH = reinterpret_cast<f32x4*>(smem);            // 2 halo buffers
+  f32x4* sZ = sH + 2 * HALO_F4;                           // 2 dz tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int strip = wid & 3, cit = wid >> 2;
+  const int g = blockIdx.y, split = blockIdx.x;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int per = (p.tiles_per_group + p.S - 1) / p.S;
+  int tile = split * per;
+  const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
+  const long long slab = 9ll * CIN * COUT + COUT;
+  float* part = p.part + ((long long)g * p.S + split) * slab;
+
+  int n, ty, tx;
+  {
+    int per_img = p.tiles_x * p.tiles_y;
+    n = tile / per_img;
+    int rem = tile - n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        ++n_;
+      }
+    }
+  };
+
+  int l_off[NLOAD], l_src[NLOAD];
+  short l_hy[NLOAD], l_hx[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    int idx = tid + NT * i;
+    int pix = idx / CQ, cq = idx - pix * CQ;
+    int hy = pix / (2 * TW + 1), hx = pix - hy * (2 * TW + 1);
+    l_hy[i] = (short)hy; l_hx[i] = (short)hx;
+    l_off[i] = (pix < NPIX) ? cq * PLANE + (hy * 2 + (hx & 1)) * HX2 + (hx >> 1) : -1;
+    l_src[i] = (hy * p.W + hx) * CIN + cq * 4;
+  }
+  int z_px[NDZ], z_c4[NDZ];
+#pragma unroll
+  for (int i = 0; i < NDZ; ++i) {
+    int idx = tid + NT * i;
+    z_px[i] = idx < DZ_F4 ? idx / C4 : -1;
+    z_c4[i] = idx % C4;
+  }
+  f32x4 stage[NLOAD], zst[NDZ], dbsum[NDZ];
+#pragma unroll
+  for (int i = 0; i < NDZ; ++i) dbsum[i] = zero4;
+
+  auto load_tile = [&](int n_, int ty_, int tx_) {
+    const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
+    const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      bool v = l_off[i] >= 0 && iy0 + l_hy[i] < p.H && ix0 + l_hx[i] < p.W;
+      stage[i] = v ? *reinterpret_cast<const f32x4*>(xg + l_src[i]) : zero4;
+    }
+    const float* zg = p.dz + (long long)g * p.gs_dz;
+#pragma unroll
+    for (int i = 0; i < NDZ; ++i) {
+      int oy = ty_ * TH + (z_px[i] >> 4), ox = tx_ * TW + (z_px[i] & 15);
+      bool v = z_px[i] >= 0 && oy < p.Ho && ox < p.Wo;
+      zst[i] = v ? *reinterpret_cast<const f32x4*>(zg + (((long long)n_ * p.Ho + oy) * p.Wo + ox) * COUT + z_c4[i] * 4)
+                 : zero4;
+    }
+  };
+
+  f32x4 acc[9][TI];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[t][i] = zero4;
+
+  if (tile < tend) {
+    load_tile(n, ty, tx);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i)
+      if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
+#pragma unroll
+    for (int i = 0; i < NDZ; ++i)
+      if (z_px[i] >= 0) {
+        sZ[z_px[i] * C4 + z_c4[i]] = zst[i];
+        dbsum[i] += zst[i];
+      }
+  }
+  __syncthreads();
+
+  // B-operand (x) float index of lane: plane cq = 4 cit + r/4, component r%4; A-operand (dz): co = r
+  const int xb_lane = (((cit * 4 + (r >> 2)) * PLANE + (4 * strip) * HX2 + q) << 2) + (r & 3);
+  const int za_lane = (16 * strip + q) * COUT + r;
+  int buf = 0;
+  for (; tile < tend; ++tile) {
+    const bool more = tile + 1 < tend;
+    int n2 = n, ty2 = ty, tx2 = tx;
+    if (more) {
+      advance(n2, ty2, tx2);
+      load_tile(n2, ty2, tx2);
+    }
+    const float* hx = reinterpret_cast<const float*>(sH + buf * HALO_F4) + xb_lane;
+    const float* hz = reinterpret_cast<const float*>(sZ + buf * DZ_F4) + za_lane;
+    f32x4* hN = sH + (buf ^ 1) * HALO_F4;
+    f32x4* zN = sZ + (buf ^ 1) * DZ_F4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a[TI], b[9];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[i] = hz[(4 * s) * COUT + 16 * i];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        b[t] = hx[(((ky * 2 + (kx & 1)) * HX2 + 4 * s + (kx >> 1)) << 2)];
+      }
+      if (more) {      // stage the next tile into the other LDS buffers behind this group's MFMAs
+        if (s == 1) {
+#pragma unroll
+          for (int i = 0; i < NLOAD; ++i)
+            if (i < 3 && l_off[i] >= 0) hN[l_off[i]] = stage[i];
+        } else if (s == 2) {
+#pragma unroll
+          for (int i = 3; i < NLOAD; ++i)
+            if (l_off[i] >= 0) hN[l_off[i]] = stage[i];
+        } else if (s == 3) {
+#pragma unroll
+          for (int i = 0; i < NDZ; ++i)
+            if (z_px[i] >= 0) {
+              zN[z_px[i] * C4 + z_c4[i]] = zst[i];
+              dbsum[i] += zst[i];
+            }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < TI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t], acc[t][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();
+    n = n2; ty = ty2; tx = tx2;
+    buf ^= 1;
+  }
+
+  // ---- block reduction: sum the 4 row-waves of each ci half, 3 taps per round, through LDS -------
+  f32x4* sR = sH;     // [wave 8][k 3*TI][lane 64]
+  constexpr int RK = 3 * TI;
+#pragma unroll
+  for (int rd = 0; rd < 3; ++rd) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) sR[(wid * RK + t * TI + i) * 64 + lane] = acc[rd * 3 + t][i];
+    __syncthreads();
+    for (int e = tid; e < 2 * RK * 64; e += NT) {
+      const int ln = e & 63, k = (e >> 6) % RK, c = e / (64 * RK);
+      f32x4 s4 = sR[((c * 4 + 0) * RK + k) * 64 + ln];
+      s4 += sR[((c * 4 + 1) * RK + k) * 64 + ln];
+      s4 += sR[((c * 4 + 2) * RK + k) * 64 + ln];
+      s4 += sR[((c * 4 + 3) * RK + k) * 64 + ln];
+      const int tap = rd * 3 + k / TI, ti = k % TI;
+      const int ci = 16 * c + (ln & 15), co = 16 * ti + 4 * (ln >> 4);
+      *reinterpret_cast<f32x4*>(part + ((long long)tap * CIN + ci) * COUT + co) = s4;
+    }
+  }
+  // ---- bias gradient: per-thread dz sums -> LDS [pixel slot][COUT] -> fixed-order column sums ------
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NDZ; ++i)
+    if (z_px[i] >= 0) sZ[z_px[i] * C4 + z_c4[i]] = dbsum[i];
+  __syncthreads();
+  if (tid < COUT) {
+    const float* zf = reinterpret_cast<const float*>(sZ);
+    float s1 = 0.f;
+    for (int px = 0; px < TH * TW; ++px) s1 += zf[px * COUT + tid];
+    part[9ll * CIN * COUT + tid] = s1;
+  }
+}
+
+void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
+                               long long KC, int Cout, int groups, hipStream_t s);
+
+static int halo_wgrad_S(int groups) {
+  int S = 256 / groups;
+  return S < 1 ? 1 : S;
+}
+
+int64_t geeco_halo_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
+  if (stride == 2 && Cin == 32 && Cout == 48 && H % 2 == 0 && W % 2 == 0)
+    return (int64_t)groups * halo_wgrad_S(groups) * (9ll * Cin * Cout + Cout) * 4;
+  return 0;
+}
+
+int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, int groups, int64_t gs_x,
+                         int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout,
+                         int stride, void* ws, hipStream_t stream, int* handled) {
+  *handled = 0;
+  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  if (disabled) return 0;
+  if (stride == 2 && Cin == 32 && Cout == 48 && (H % 2 == 0) && (W % 2 == 0)) {
+    HaloWgradParams p = {};
+    p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
+    p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+    p.tiles_x = cdiv(p.Wo, 16); p.tiles_y = cdiv(p.Ho, 4);
+    p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+    p.S = halo_wgrad_S(groups);
+    constexpr int CQ = 8, PLANE = 9 * 2 * 17;
+    const size_t lds = (size_t)(2 * CQ * PLANE + 2 * 4 * 16 * 12) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_wgrad_kernel<32, 48>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_s2_halo_wgrad_kernel<32, 48>), dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds,
+                       stream, p);
+    GEECO_LAUNCH_CHECK();
+    geeco_launch_wgrad_reduce((const float*)ws, dw, db, gs_dw, gs_db, p.S, 9ll * Cin * Cout, Cout, groups, stream);
+    GEECO_LAUNCH_CHECK();
+    *handled = 1;
+  }
+  return 0;
+}

@@ -220,6 +220,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
+                               long long KC, int Cout, int groups, hipStream_t s) {
+  dim3 rgrid((unsigned)cdiv64(KC + Cout, 64), (unsigned)groups);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
+}
+
+int64_t geeco_halo_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
+int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, int groups, int64_t gs_x,
+                         int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout,
+                         int stride, void* ws, hipStream_t stream, int* handled);
+
 static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride, WgradParams* p, int* bc) {
   int Ho, Wo, pt, pl;
   same_pad(H, 3, stride, &Ho, &pt);
@@ -249,7 +260,9 @@ extern "C" int64_t geeco_conv3x3_wgrad_ws_bytes(int groups, int N, int H, int W,
   WgradParams p = {};
   int bc;
   wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &bc);
-  return (int64_t)groups * p.S * ((int64_t)p.Krows * Cout + Cout) * 4;
+  int64_t a = (int64_t)groups * p.S * ((int64_t)p.Krows * Cout + Cout) * 4;
+  int64_t b = geeco_halo_wgrad_ws_bytes(groups, N, H, W, Cin, Cout, stride);
+  return a > b ? a : b;
 }
 
 extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, int groups,
@@ -259,6 +272,12 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_wgrad: bad dims");
   GEECO_CHECK_ARG(Cin % 4 == 0 && Cin >= 4, "conv3x3_wgrad: Cin=%d must be a multiple of 4", Cin);
   GEECO_CHECK_ARG(Cout % 16 == 0, "conv3x3_wgrad: Cout=%d must be a multiple of 16", Cout);
+  {
+    int handled = 0;
+    int rc = geeco_try_halo_wgrad(x, dz, dw, db, groups, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws,
+                                  (hipStream_t)stream, &handled);
+    if (rc || handled) return rc;
+  }
   WgradParams p = {};
   int BC;
   wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &BC);

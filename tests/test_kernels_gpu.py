@@ -71,7 +71,7 @@ def test_conv3x3_dgrad(dev, N, H, W, Cin, Cout, stride):
   _close(dx, ref, 2e-5, 2e-5, 'conv dgrad')
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', CONV_CASES + [(2, 64, 64, 4, 32, 1), (3, 32, 32, 32, 48, 2)])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', CONV_CASES + [(2, 64, 64, 4, 32, 1), (3, 32, 32, 32, 48, 2), (5, 128, 128, 32, 48, 2)])
 def test_conv3x3_wgrad(dev, N, H, W, Cin, Cout, stride):
   from geeco_amd import ops
   r = np.random.default_rng(9)
