@@ -30,6 +30,10 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
                        int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                        int relu, hipStream_t stream, int* handled);
 
+int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,
+                         int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
+                         int stride, hipStream_t stream, int* handled);
+
 struct ConvClass {
   long long M;          // N*Hc*Wc rows
   int Hc, Wc;           // iteration grid: rows enumerate (n, Y', X')
@@ -504,14 +508,20 @@ extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b,
   return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
 }
 
-extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float* ymask, float* dx,
-                                   int groups, int64_t gs_dz, int64_t gs_wt, int64_t gs_dx, int N, int H,
-                                   int W, int Cin, int Cout, int stride, void* ws, void* stream) {
+extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* w, const float* wt, const float* ymask, float* dx,
+                                   int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_wt, int64_t gs_dx, int N,
+                                   int H, int W, int Cin, int Cout, int stride, void* ws, void* stream) {
   GEECO_CHECK_ARG(dz && wt && dx, "conv3x3_dgrad: null pointer");
   GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_dgrad: bad dims");
   GEECO_CHECK_ARG(Cout % 4 == 0, "conv3x3_dgrad: Cout=%d must be a multiple of 4", Cout);
   GEECO_CHECK_ARG(Cin % 16 == 0, "conv3x3_dgrad: Cin=%d must be a multiple of 16", Cin);
   GEECO_CHECK_ARG(stride >= 1 && stride <= 2, "conv3x3_dgrad: stride=%d (1 or 2)", stride);
+  {
+    int handled = 0;
+    int rc = geeco_try_halo_dgrad(dz, w, ymask, dx, groups, gs_dz, gs_w, gs_dx, N, H, W, Cin, Cout, stride,
+                                  (hipStream_t)stream, &handled);
+    if (rc || handled) return rc;
+  }
   ConvGemmParams p = {};
   fill_dgrad(&p, N, H, W, Cin, Cout, stride);
   p.x = dz; p.w = wt; p.bias = nullptr; p.mask = ymask; p.out = dx;

@@ -545,3 +545,244 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// conv2-type input gradient with an LDS halo (stride 2, CIN == 32, COUT % 16 == 0, even H/W), fused
+// with the ReluGrad of the layer below:   dx[y][x][ci] = (ymask > 0) * sum_{taps} dz[oy][ox][:] . w[tap][ci][:]
+// For TF SAME / stride 2 / even sizes (pad_before = 0) input row y = 2 Y' + py receives
+//   py = 0: (ky = 0, oy = Y'), (ky = 2, oy = Y' - 1);   py = 1: (ky = 1, oy = Y')          (same in x),
+// i.e. four parity classes with 4 / 2 / 2 / 1 taps.  A block owns 8 x 64 input pixels (4 x 32 per
+// class), stages the 5 x 33 dz halo as [co/4][row][col] float4 planes and keeps the HWIO kernel
+// resident as [tap][ci][15 float4] rows (b128 B-fragments straight from the TF layout, pitch 15 =
+// -1 mod 16 => at most one 2-way conflict per read).  Wave = (column half, Y' row): 4 classes x 2
+// ci tiles = 8 accumulator tiles, 27 (tap, 16-co block) steps of 8 MFMAs per tile.
+// ------------------------------------------------------------------------------------------------
+struct HaloDgradParams {
+  const float* dz;
+  const float* w;      // HWIO [G][9][CIN][COUT]
+  const float* mask;   // [G][N][H][W][CIN] or null
+  float* dx;
+  long long gs_dz, gs_w, gs_dx;
+  int N, H, W, Ho, Wo;
+  int tiles_x, tiles_y;
+  long long ntiles;
+  int tiles_per_group;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512, 2) void conv_s2_halo_dgrad_kernel(const HaloDgradParams p) {
+  constexpr int NT = 512;
+  constexpr int COQ = COUT / 4;
+  constexpr int KB = COUT / 16;
+  constexpr int HR = 5, HC = 33;                       // dz halo rows / cols
+  constexpr int PLANE = HR * HC;                       // 165 float4
+  constexpr int HALO_F4 = COQ * PLANE;
+  constexpr int NLOAD = (HALO_F4 + NT - 1) / NT;
+  constexpr int WP = 15;                               // float4 pitch of a (tap, ci) kernel row
+  constexpr int W_F4 = 9 * CIN * WP;
+  static_assert(CIN == 32 && COQ <= WP, "shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sW = reinterpret_cast<f32x4*>(smem);
+  f32x4* sH = sW + W_F4;                               // 2 halo buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row = wid & 3, half = wid >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const long long per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+  long long tile = (long long)blockIdx.x * per;
+  const long long tend = tile + per < p.ntiles ? tile + per : p.ntiles;
+  if (tile >= tend) return;
+  int g, n, ty, tx;
+  {
+    g = (int)(tile / p.tiles_per_group);
+    int rem = (int)(tile - (long long)g * p.tiles_per_group);
+    int per_img = p.tiles_x * p.tiles_y;
+    n = rem / per_img;
+    rem -= n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  auto advance = [&](int& g_, int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        if (++n_ == p.N) {
+          n_ = 0;
+          ++g_;
+        }
+      }
+    }
+  };
+
+  int l_off[NLOAD], l_src[NLOAD];
+  short l_hy[NLOAD], l_hx[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    int idx = tid + NT * i;
+    int pix = idx / COQ, cq = idx - pix * COQ;
+    int hy = pix / HC, hx = pix - hy * HC;
+    l_hy[i] = (short)hy; l_hx[i] = (short)hx;
+    l_off[i] = (idx < HALO_F4) ? cq * PLANE + hy * HC + hx : -1;
+    l_src[i] = (hy * p.Wo + hx) * COUT + cq * 4;
+  }
+  f32x4 stage[NLOAD];
+  auto load_halo = [&](int g_, int n_, int ty_, int tx_) {
+    const int oy0 = ty_ * 4 - 1, ox0 = tx_ * 32 - 1;
+    const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n_ * p.Ho + oy0) * p.Wo + ox0) * COUT;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      int oy = oy0 + l_hy[i], ox = ox0 + l_hx[i];
+      bool v = l_off[i] >= 0 && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+      stage[i] = v ? *reinterpret_cast<const f32x4*>(zg + l_src[i]) : zero4;
+    }
+  };
+  auto load_weights = [&](int g_) {
+    const f32x4* wg = reinterpret_cast<const f32x4*>(p.w + (long long)g_ * p.gs_w);
+    for (int e = tid; e < 9 * CIN * COQ; e += NT) {
+      int rowi = e / COQ, c4 = e - rowi * COQ;
+      sW[rowi * WP + c4] = wg[e];
+    }
+  };
+
+  load_halo(g, n, ty, tx);
+  load_weights(g);
+  int g_w = g;
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i)
+    if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
+  __syncthreads();
+
+  // lane r = X' column inside the wave's 16-column strip; q selects the co quad of a 16-co block
+  const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;    // + kb*4*PLANE + dy*HC + dx
+  const int b_lane = r * WP + q;                                          // + (tap*CIN + 16 cit)*WP + 4 kb
+  int buf = 0;
+  for (;;) {
+    const bool more = tile + 1 < tend;
+    int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
+    if (more) {
+      advance(g2, n2, ty2, tx2);
+      load_halo(g2, n2, ty2, tx2);
+    }
+    // ReluGrad mask of this wave's 4 x 2 output float4s: issued now, consumed in the epilogue
+    const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + r);
+    f32x4 mk[4][2];
+    bool okc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int y = yb + (c >> 1), x = xb + (c & 1);
+      okc[c] = y < p.H && x < p.W;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        mk[c][t] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.mask && okc[c])
+          mk[c][t] = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_dx +
+                                                     (((long long)n * p.H + y) * p.W + x) * CIN + 16 * t + 4 * q);
+      }
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[c][t] = zero4;
+    const f32x4* hA = sH + buf * HALO_F4 + a_lane;
+    const f32x4* hB = sW + b_lane;
+    f32x4* hN = sH + (buf ^ 1) * HALO_F4;
+
+    // static schedule: 9 taps x KB blocks; tap (ky, kx) feeds class (py, px) = (ky & 1, kx & 1) with
+    // source offset dy = -(ky >> 1), dx = -(kx >> 1)
+    f32x4 a_cur, b_cur[2], a_nxt, b_nxt[2];
+    auto frag = [&](int it, f32x4& a, f32x4 (&b)[2]) {
+      const int tap = it / KB, kb = it - tap * KB;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      a = hA[kb * 4 * PLANE - (ky >> 1) * HC - (kx >> 1)];
+      b[0] = hB[(tap * CIN) * WP + 4 * kb];
+      b[1] = hB[(tap * CIN + 16) * WP + 4 * kb];
+    };
+    constexpr int NIT = 9 * KB;
+    frag(0, a_cur, b_cur);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it + 1 < NIT) frag(it + 1, a_nxt, b_nxt);
+      if (more && it >= NIT - NLOAD - 4 && it < NIT - 4) {
+        const int j = it - (NIT - NLOAD - 4);
+        if (l_off[j] >= 0) hN[l_off[j]] = stage[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int tap = it / KB;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int c = (ky & 1) * 2 + (kx & 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[t][s], a_cur[s], acc[c][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+      b_cur[0] = b_nxt[0];
+      b_cur[1] = b_nxt[1];
+    }
+    // epilogue: class c -> pixel (yb + py, xb + px); lane owns ci = 16 t + 4 q .. +3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!okc[c]) continue;
+      const int y = yb + (c >> 1), x = xb + (c & 1);
+      float* o = p.dx + (long long)g * p.gs_dx + (((long long)n * p.H + y) * p.W + x) * CIN + 4 * q;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 v = acc[c][t];
+        const f32x4 m = mk[c][t];
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(o + 16 * t) = v;
+      }
+    }
+    if (!more) break;
+    lds_barrier();      // next halo complete; everyone is done with this buffer (and sW)
+    if (g2 != g_w) {
+      load_weights(g2);
+      g_w = g2;
+      __syncthreads();
+    }
+    g = g2; n = n2; ty = ty2; tx = tx2;
+    buf ^= 1;
+    ++tile;
+  }
+}
+
+int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,
+                         int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
+                         int stride, hipStream_t stream, int* handled) {
+  *handled = 0;
+  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  if (disabled || !w_hwio) return 0;
+  if (stride == 2 && Cin == 32 && Cout == 48 && (H % 2 == 0) && (W % 2 == 0)) {
+    HaloDgradParams p = {};
+    p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx;
+    p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
+    p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+    p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
+    p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+    p.ntiles = (long long)groups * p.tiles_per_group;
+    const size_t lds = (size_t)(9 * 32 * 15 + 2 * 12 * 165) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_kernel<32, 48>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      attr_set = true;
+    }
+    long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+    hipLaunchKernelGGL((conv_s2_halo_dgrad_kernel<32, 48>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+    GEECO_LAUNCH_CHECK();
+    *handled = 1;
+  }
+  return 0;
+}

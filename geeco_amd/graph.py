@@ -169,7 +169,7 @@ class ConvEncoderStack:
       ops.transpose_hwio_into(wt, self._w(l), G, self.gs_p, wt[0].numel(), L['Cin'], L['Cout'])
       dx = self.dz[l - 1]
       ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
-                             L['Cin'], L['Cout'], L['stride'], ws=self.ws)
+                             L['Cin'], L['Cout'], L['stride'], ws=self.ws, w=self._w(l), gs_w=self.gs_p)
 
 
 # ================================================================================================

@@ -106,9 +106,9 @@ def conv3x3_fwd_ws_bytes(G, N, H, W, Cin, Cout, stride):
   return int(_lib().geeco_conv3x3_fwd_ws_bytes(G, N, H, W, Cin, Cout, stride))
 
 
-def conv3x3_dgrad_into(dx, dz, wt, ymask, G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout, stride, ws=None):
-  check(_lib().geeco_conv3x3_dgrad(_p(dz), _p(wt), _p(ymask), _p(dx), G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout,
-                                   stride, _p(ws), _stream()), 'geeco_conv3x3_dgrad')
+def conv3x3_dgrad_into(dx, dz, wt, ymask, G, gs_dz, gs_wt, gs_dx, N, H, W, Cin, Cout, stride, ws=None, w=None, gs_w=0):
+  check(_lib().geeco_conv3x3_dgrad(_p(dz), _p(w), _p(wt), _p(ymask), _p(dx), G, gs_dz, gs_w, gs_wt, gs_dx, N, H, W,
+                                   Cin, Cout, stride, _p(ws), _stream()), 'geeco_conv3x3_dgrad')
 
 
 def conv3x3_dgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
@@ -157,7 +157,7 @@ def conv3x3_dgrad(dz, w, ymask, in_hw, stride):
   transpose_hwio_into(wt, w.contiguous(), 1, 0, 0, Cin, Cout)
   dx = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dz.device)
   ws = _ws(conv3x3_dgrad_ws_bytes(1, N, H, W, Cin, Cout, stride), dz.device)
-  conv3x3_dgrad_into(dx, dz.contiguous(), wt, ymask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride, ws)
+  conv3x3_dgrad_into(dx, dz.contiguous(), wt, ymask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride, ws, w=w.contiguous())
   return dx
 
 

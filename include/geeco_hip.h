@@ -65,12 +65,14 @@ int64_t geeco_conv3x3_fwd_ws_bytes(int groups, int N, int H, int W, int Cin, int
 
 /* Conv2DBackpropInput fused with the ReluGrad of the layer below (autodiff of graph.py:76-115 via
  * estimator.py:243-244):  dx = conv3x3_transpose(dz, w) * (ymask > 0).
- * dz [G][N][Ho][Wo][Cout], wt [G][3][3][Cout][Cin] (= geeco_transpose_hwio(w)),
+ * dz [G][N][Ho][Wo][Cout], wt [G][3][3][Cout][Cin] (= geeco_transpose_hwio(w)), w (optional) the
+ * HWIO kernel itself: the LDS-halo kernel of the 32->48 stride-2 layer reads it directly,
  * ymask [G][N][H][W][Cin] = forward output of the layer below (NULL: no mask), dx like ymask.
  * stride 1 or 2; all stride*stride parity classes run in one launch; `ws` as for the forward. */
-int geeco_conv3x3_dgrad(const float* dz, const float* wt, const float* ymask, float* dx,
-                        int groups, int64_t gs_dz, int64_t gs_wt, int64_t gs_dx, int N, int H,
-                        int W, int Cin, int Cout, int stride, void* ws, void* stream);
+int geeco_conv3x3_dgrad(const float* dz, const float* w, const float* wt, const float* ymask,
+                        float* dx, int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_wt,
+                        int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
+                        void* stream);
 int64_t geeco_conv3x3_dgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
 
 /* Conv2DBackpropFilter + BiasAddGrad:  dw[ky][kx][ci][co] = sum_m x[pix(m,ky,kx)][ci] dz[m][co],

@@ -53,7 +53,7 @@ def test_conv3x3_fwd(dev, N, H, W, Cin, Cout, stride):
   _close(y, ref, 2e-5, 2e-5, 'conv fwd')
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [c for c in CONV_CASES if c[3] % 16 == 0])
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [c for c in CONV_CASES if c[3] % 16 == 0] + [(3, 128, 192, 32, 48, 2)])
 def test_conv3x3_dgrad(dev, N, H, W, Cin, Cout, stride):
   from geeco_amd import ops
   r = np.random.default_rng(8)
