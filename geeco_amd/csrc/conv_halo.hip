@@ -786,3 +786,279 @@ int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymas
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// conv1-type kernels: stride 1, CIN == 4 (RGB padded, or RGB-D), COUT == 32.
+// K per tap is exactly one MFMA step (4 channels), so the 9 taps are 9 MFMA k-steps.
+// Forward is bound by the 128 B/pixel output stream (805 MB per step at N = 32), wgrad by reading
+// it back: both keep the tiny input halo in LDS and the kernel in registers.
+// ------------------------------------------------------------------------------------------------
+struct Conv1FwdParams {
+  const float* x;       // [G][N][H][W][4]
+  const float* w;       // [G][9][4][32]
+  const float* bias;
+  float* y;             // [G][N][H][W][32]
+  long long gs_x, gs_w, gs_b, gs_y;
+  int N, H, W, tiles_x, tiles_y, relu;
+};
+
+__global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParams p) {
+  constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH = TH + 2;
+  __shared__ __attribute__((aligned(16))) float sX[HH * HW_ * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int g = blockIdx.y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const float* xg = p.x + (long long)g * p.gs_x + (long long)n * p.H * p.W * 4;
+  for (int i = tid; i < HH * HW_; i += 256) {
+    const int hy = i / HW_, hx = i - hy * HW_;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;        // TF SAME, stride 1: pad 1 on every side
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      v = *reinterpret_cast<const f32x4*>(xg + ((long long)iy * p.W + ix) * 4);
+    *reinterpret_cast<f32x4*>(sX + i * 4) = v;
+  }
+  // kernel fragments: lane (r = co, q = channel) of tap t, co tile i
+  const float* wg = p.w + (long long)g * p.gs_w;
+  float wf[9][2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[tp][i] = wg[(tp * 4 + q) * 32 + i * 16 + r];
+  f32x4 bias_r[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + i * 16 + 4 * q);
+  __syncthreads();
+  // wave w: rows 2w, 2w+1; 2 column halves => 4 strips of 16 pixels
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int oyl = 2 * wid + (st >> 1), oxl = 16 * (st & 1) + r;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float* base = sX + ((oyl * HW_ + oxl) << 2) + q;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int ky = tp / 3, kx = tp - ky * 3;
+      const float xv = base[(ky * HW_ + kx) << 2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tp][i], xv, acc[i], 0, 0, 0);
+    }
+    const int oy = y0 + oyl, ox = x0 + oxl;
+    if (oy < p.H && ox < p.W) {
+      float* yo = p.y + (long long)g * p.gs_y + (((long long)n * p.H + oy) * p.W + ox) * 32 + 4 * q;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4 v = acc[i] + bias_r[i];
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(yo + i * 16) = v;
+      }
+    }
+  }
+}
+
+int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
+                        int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
+                        int relu, hipStream_t stream, int* handled) {
+  *handled = 0;
+  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  if (disabled || !b || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
+  Conv1FwdParams p = {};
+  p.x = x; p.w = w; p.bias = b; p.y = y; p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
+  p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.relu = relu;
+  dim3 grid((unsigned)(N * p.tiles_x * p.tiles_y), (unsigned)groups);
+  hipLaunchKernelGGL(conv1_halo_fwd_kernel, grid, dim3(256), 0, stream, p);
+  GEECO_LAUNCH_CHECK();
+  *handled = 1;
+  return 0;
+}
+
+// ---- conv1 filter/bias gradient --------------------------------------------------------------------
+// dw[(tap, c)][co] = sum_pixels x[halo(pixel, tap)][c] dz[pixel][co]: MFMA row i = co (2 tiles), column
+// j = (tap, c) (36 of 48 = 3 tiles), k = 4 consecutive pixels.  Persistent blocks (wave = row of a
+// 4 x 16 tile) keep the 6 accumulator tiles in registers over their whole tile range.
+struct Conv1WgradParams {
+  const float* x;
+  const float* dz;
+  float* part;             // [G][S][9*4*32 + 32]
+  long long gs_x, gs_dz;
+  int N, H, W, tiles_x, tiles_y, tiles_per_group, S;
+};
+
+__global__ __launch_bounds__(256) void conv1_halo_wgrad_kernel(const Conv1WgradParams p) {
+  constexpr int TH = 4, TW = 16, HWD = TW + 2, HH = TH + 2;
+  constexpr int ZP = 48;                                   // dz row pitch (floats): 16 mod 32
+  constexpr int XF = HH * HWD * 4, ZF = TH * TW * ZP;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (XF + ZF)];
+  float* sX = smem;                 // 2 x halo
+  float* sZ = smem + 2 * XF;        // 2 x dz tile
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int g = blockIdx.y, split = blockIdx.x;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int per = (p.tiles_per_group + p.S - 1) / p.S;
+  int tile = split * per;
+  const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
+  const long long slab = 9 * 4 * 32 + 32;
+  float* part = p.part + ((long long)g * p.S + split) * slab;
+  int n, ty, tx;
+  {
+    int per_img = p.tiles_x * p.tiles_y;
+    n = tile / per_img;
+    int rem = tile - n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  // staging slots: halo (108 pixels, one float4 each) and dz tile (64 pixels x 8 float4)
+  const bool xs = tid < HH * HWD;
+  const int x_hy = tid / HWD, x_hx = tid - x_hy * HWD;
+  int z_px[2], z_c4[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx = tid + 256 * i;
+    z_px[i] = idx >> 3;
+    z_c4[i] = idx & 7;
+  }
+  f32x4 xst = zero4, zst[2], dbsum[2] = {zero4, zero4};
+  auto load_tile = [&](int n_, int ty_, int tx_) {
+    const float* xg = p.x + (long long)g * p.gs_x + (long long)n_ * p.H * p.W * 4;
+    const int iy = ty_ * TH + x_hy - 1, ix = tx_ * TW + x_hx - 1;
+    xst = (xs && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+              ? *reinterpret_cast<const f32x4*>(xg + ((long long)iy * p.W + ix) * 4) : zero4;
+    const float* zg = p.dz + (long long)g * p.gs_dz + (long long)n_ * p.H * p.W * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = ty_ * TH + (z_px[i] >> 4), ox = tx_ * TW + (z_px[i] & 15);
+      zst[i] = (oy < p.H && ox < p.W) ? *reinterpret_cast<const f32x4*>(zg + ((long long)oy * p.W + ox) * 32 + z_c4[i] * 4)
+                                      : zero4;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    if (xs) *reinterpret_cast<f32x4*>(sX + buf * XF + tid * 4) = xst;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(sZ + buf * ZF + z_px[i] * ZP + z_c4[i] * 4) = zst[i];
+      dbsum[i] += zst[i];
+    }
+  };
+  // lane's three (tap, c) columns: jj = 16 tj + r
+  int xoff[3];
+  bool xval[3];
+#pragma unroll
+  for (int tj = 0; tj < 3; ++tj) {
+    const int jj = 16 * tj + r;
+    const int tap = jj >> 2, c = jj & 3;
+    xval[tj] = jj < 36;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    xoff[tj] = xval[tj] ? ((ky * HWD + kx) << 2) + c : 0;
+  }
+  f32x4 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = zero4;
+
+  if (tile < tend) {
+    load_tile(n, ty, tx);
+    store_tile(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < tend; ++tile) {
+    const bool more = tile + 1 < tend;
+    int n2 = n, ty2 = ty, tx2 = tx;
+    if (more) {
+      if (++tx2 == p.tiles_x) {
+        tx2 = 0;
+        if (++ty2 == p.tiles_y) {
+          ty2 = 0;
+          ++n2;
+        }
+      }
+      load_tile(n2, ty2, tx2);
+    }
+    const float* hx = sX + buf * XF + ((wid * HWD + q) << 2);           // wave = tile row; pixel 4 s + q
+    const float* hz = sZ + buf * ZF + (16 * wid + q) * ZP + r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a[2], b[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = hz[(4 * s) * ZP + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float v = hx[((4 * s) << 2) + xoff[j]];
+        b[j] = xval[j] ? v : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    lds_barrier();
+    n = n2; ty = ty2; tx = tx2;
+    buf ^= 1;
+  }
+  // reduce the 4 waves through LDS: [wave][6 tiles][64 lanes] float4 = 24 KB (fits in the staging area)
+  __syncthreads();
+  f32x4* sR = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sR[(wid * 6 + i * 3 + j) * 64 + lane] = acc[i][j];
+  __syncthreads();
+  for (int e = tid; e < 6 * 64; e += 256) {
+    const int ln = e & 63, k = e >> 6;
+    f32x4 s4 = sR[(0 * 6 + k) * 64 + ln];
+    s4 += sR[(1 * 6 + k) * 64 + ln];
+    s4 += sR[(2 * 6 + k) * 64 + ln];
+    s4 += sR[(3 * 6 + k) * 64 + ln];
+    const int i = k / 3, j = k - i * 3;
+    const int jj = 16 * j + (ln & 15), co = 16 * i + 4 * (ln >> 4);
+    if (jj < 36) *reinterpret_cast<f32x4*>(part + jj * 32 + co) = s4;
+  }
+  __syncthreads();
+  float* sD = smem;   // [64 pixel slots][32]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(sD + z_px[i] * 32 + z_c4[i] * 4) = dbsum[i];
+  __syncthreads();
+  if (tid < 32) {
+    float s1 = 0.f;
+    for (int px = 0; px < 64; ++px) s1 += sD[px * 32 + tid];
+    part[9 * 4 * 32 + tid] = s1;
+  }
+}
+
+static int conv1_wgrad_S(int groups) {
+  int S = 768 / groups;
+  return S < 1 ? 1 : S;
+}
+
+int64_t geeco_conv1_wgrad_ws_bytes(int groups, int Cin, int Cout, int stride) {
+  if (stride == 1 && Cin == 4 && Cout == 32) return (int64_t)groups * conv1_wgrad_S(groups) * (9 * 4 * 32 + 32) * 4;
+  return 0;
+}
+
+int geeco_try_conv1_wgrad(const float* x, const float* dz, float* dw, float* db, int groups, int64_t gs_x,
+                          int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout,
+                          int stride, void* ws, hipStream_t stream, int* handled) {
+  *handled = 0;
+  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  if (disabled || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
+  Conv1WgradParams p = {};
+  p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
+  p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 4);
+  p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+  p.S = conv1_wgrad_S(groups);
+  hipLaunchKernelGGL(conv1_halo_wgrad_kernel, dim3((unsigned)p.S, (unsigned)groups), dim3(256), 0, stream, p);
+  GEECO_LAUNCH_CHECK();
+  geeco_launch_wgrad_reduce((const float*)ws, dw, db, gs_dw, gs_db, p.S, 9 * 4 * 32, 32, groups, stream);
+  GEECO_LAUNCH_CHECK();
+  *handled = 1;
+  return 0;
+}
