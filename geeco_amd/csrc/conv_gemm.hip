@@ -65,7 +65,10 @@ struct ConvGemmParams {
   ConvClass cls[4];
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
+// UT ("uniform tap"): C % BK == 0, so every K-step lies inside ONE tap; the per-row validity and the
+// source / kernel pointers are then recomputed only when the tap changes (every C/BK steps) and the
+// K loop itself is pointer bumps + loads: removes most of the gather's address VALU work.
+template <int BM, int BN, int BK, int WM, int WN, bool UT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int SPR = BK / 4;     // float4 slots per row per K-step
   constexpr int RPP = 256 / SPR;  // rows staged per pass
@@ -161,7 +164,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   f32x4 ra[PA], rbv[PB];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+  // ---- UT state: current tap, channel offset inside it, per-row / per-slot pointers ----------------
+  int u_tap = 0, u_cc = 0;
+  const float* u_ap[PA];
+  bool u_av[PA];
+  const float* u_bp[PB];
+  bool u_bv[PB];
+  auto ut_setup = [&]() {     // (re)derive pointers for tap u_tap at channel offset u_cc
+    const int t = u_tap < 9 ? u_tap : 8;
+    const bool tv = u_tap < ntaps;
+    const int dy = sTap[t], dx = sTap[12 + t], toff = sTap[24 + t];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      int iy = iy0[j] + dy, ix = ix0[j] + dx;
+      u_av[j] = tv && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+      u_ap[j] = xg + rb[j] + toff + u_cc + kq * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      u_bv[i] = (tid + i * 256 < NB4) && tv && (n0 + b_c4[i] * 4 < p.Nout);
+      u_bp[i] = wg + (long long)(sTap[36 + t] + u_cc + b_row[i]) * p.Nout + n0 + b_c4[i] * 4;
+    }
+  };
+  if constexpr (UT) {
+    const int k0 = ks_beg * BK;
+    u_tap = k0 / C;
+    u_cc = k0 - u_tap * C;
+    ut_setup();
+  }
+
   auto load_tiles = [&]() {
+    if constexpr (UT) {
+#pragma unroll
+      for (int j = 0; j < PA; ++j) ra[j] = u_av[j] ? *reinterpret_cast<const f32x4*>(u_ap[j]) : zero4;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rbv[i] = u_bv[i] ? *reinterpret_cast<const f32x4*>(u_bp[i]) : zero4;
+      return;
+    }
     {
       const int t = a_tap < 9 ? a_tap : 8;
       const bool tv = a_tap < ntaps;
@@ -183,6 +222,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     }
   };
   auto advance = [&]() {
+    if constexpr (UT) {
+      u_cc += BK;
+      if (u_cc >= C) {          // wave-uniform: next tap
+        u_cc = 0;
+        ++u_tap;
+        ut_setup();
+      } else {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) u_ap[j] += BK;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) u_bp[i] += (long long)BK * p.Nout;
+      }
+      return;
+    }
     a_cq += SPR;
     while (a_cq >= C4) {
       a_cq -= C4;
@@ -338,7 +391,11 @@ static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
     tiles += (int)cdiv64(p.cls[c].M, BM);
   }
   dim3 grid((unsigned)tiles, (unsigned)(cdiv(p.Nout, BN) * p.ksplit), (unsigned)groups);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, s, p);
+  static const int no_ut = getenv("GEECO_CONV_NO_UT") ? 1 : 0;
+  if (p.C % BK == 0 && !no_ut)
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, true>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, false>), grid, dim3(256), 0, s, p);
 }
 
 struct ConvPlan {
@@ -358,6 +415,9 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
   pl.bn = (p.Nout % 64 == 0) ? 64 : (p.Nout % 48 == 0) ? 48 : (p.Nout % 32 == 0) ? 32 : 16;
   pl.bm = 128;
   if (pl.bn == 64 && Mtot * groups < 128 * 256) pl.bm = 64;
+  // 128-wide N tiles halve the gathered A bytes per MFMA; only when they still fill the chip
+  static const int no_bn128 = getenv("GEECO_CONV_BN128") ? 0 : 1;   // measured neutral-to-slower: off by default
+  if (!no_bn128 && p.Nout % 128 == 0 && pl.bm == 128 && (Mtot / 128) * (p.Nout / 128) * groups >= 512) pl.bn = 128;
   long long blocks = 0;
   for (int c = 0; c < p.ncls; ++c) blocks += cdiv64(p.cls[c].M, pl.bm);
   blocks *= (long long)cdiv(p.Nout, pl.bn) * groups;
@@ -398,6 +458,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
     } else {
       launch_cfg<128, 16, 16, 4, 1>(p, groups, s);
     }
+  } else if (pl.bn == 128) {
+    launch_cfg<128, 128, 16, 2, 2>(p, groups, s);
   } else if (pl.bn == 64) {
     if (pl.bm == 64)
       launch_cfg<64, 64, 16, 2, 2>(p, groups, s);

@@ -16,6 +16,7 @@
 // ds_read_b32; the row pitch is 16 (mod 32) dwords so the two pixels of a 32-lane half use
 // different bank halves.
 #include "geeco_common.h"
+#include <stdlib.h>
 
 struct WgradParams {
   const float* x;
@@ -37,8 +38,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int BR4 = BR / 4, BC4 = BC / 4;
   constexpr int NA4 = MK * BR4, NB4 = MK * BC4;
   constexpr int PAS = (NA4 + 255) / 256, PBS = (NB4 + 255) / 256;
-  constexpr int TI = BC / 16;   // co tiles per wave (each wave: 16 k-rows x BC)
-  static_assert(BR == 64, "one 16-row strip per wave");
+  constexpr int TI = BC / 16;   // co tiles per wave
+  constexpr int TJW = BR / 64;  // 16-row k-strips per wave (wave w owns strips w*TJW .. +TJW-1)
+  static_assert(BR % 64 == 0, "whole strips per wave");
 
   __shared__ __attribute__((aligned(16))) float smem[2 * MK * (LDA + LDBZ)];
   float* sA = smem;
@@ -134,9 +136,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       }
   };
 
-  f32x4 acc[TI];
+  f32x4 acc[TJW][TI];
 #pragma unroll
-  for (int i = 0; i < TI; ++i) acc[i] = zero4;
+  for (int j = 0; j < TJW; ++j)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[j][i] = zero4;
   const int r = lane & 15, q = lane >> 4;
 
   const long long nchunk = (mend > mbeg) ? (mend - mbeg + MK - 1) / MK : 0;
@@ -153,12 +157,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const float* b = sB + buf * MK * LDBZ;
 #pragma unroll
     for (int blk = 0; blk < MK / 4; ++blk) {
-      float xv = a[(blk * 4 + q) * LDA + wid * 16 + r];
-      float zv[TI];
+      float xv[TJW], zv[TI];
+#pragma unroll
+      for (int j = 0; j < TJW; ++j) xv[j] = a[(blk * 4 + q) * LDA + (wid * TJW + j) * 16 + r];
 #pragma unroll
       for (int i = 0; i < TI; ++i) zv[i] = b[(blk * 4 + q) * LDBZ + i * 16 + r];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[i], xv, acc[i], 0, 0, 0);
+      for (int j = 0; j < TJW; ++j)
+#pragma unroll
+        for (int i = 0; i < TI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[i], xv[j], acc[j][i], 0, 0, 0);
     }
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
@@ -167,12 +174,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // ---- epilogue: lane owns k-row (lane & 15) of its wave's strip, co = 16 i + 4 q .. +3 ---------
   const long long slab = (long long)p.Krows * Cout + Cout;
   float* __restrict__ part = p.part + ((long long)g * p.S + split) * slab;
-  const int krow = rt * BR + wid * 16 + r;
-  if (krow < p.Krows) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      int co = co0 + i * 16 + 4 * q;
-      if (co < Cout) *reinterpret_cast<f32x4*>(part + (long long)krow * Cout + co) = acc[i];
+  for (int j = 0; j < TJW; ++j) {
+    const int krow = rt * BR + (wid * TJW + j) * 16 + r;
+    if (krow < p.Krows) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        int co = co0 + i * 16 + 4 * q;
+        if (co < Cout) *reinterpret_cast<f32x4*>(part + (long long)krow * Cout + co) = acc[j][i];
+      }
     }
   }
   if (rt == 0) {
@@ -244,9 +254,14 @@ static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int s
   p->stride = stride; p->pt = pt; p->pl = pl;
   p->M = (long long)N * Ho * Wo;
   p->Krows = 9 * Cin;
-  int BC = (Cout % 64 == 0) ? 64 : (Cout % 48 == 0) ? 48 : (Cout % 32 == 0) ? 32 : 16;
-  *bc = BC;
-  p->row_tiles = cdiv(p->Krows, 64);
+  int BC = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 48 == 0) ? 48 : (Cout % 32 == 0) ? 32 : 16;
+  // 128-row tiles halve the dz traffic per MFMA; use them unless padding 9*Cin up to 128 wastes > 12 %
+  int BR = (BC >= 64 && (long long)cdiv(p->Krows, 128) * 128 * 100 <= (long long)p->Krows * 112) ? 128 : 64;
+  // measured on MI355X: the 128-row / 128-col tiles lose ~1.5 % of the step (occupancy beats traffic here)
+  static const int big_tiles = getenv("GEECO_WGRAD_BIG") ? 1 : 0;
+  if (!big_tiles) { BR = 64; if (BC == 128) BC = 64; }
+  *bc = BC + 1000 * BR;
+  p->row_tiles = cdiv(p->Krows, BR);
   p->col_tiles = cdiv(Cout, BC);
   long long tiles = (long long)groups * p->row_tiles * p->col_tiles;
   long long S = 1024 / tiles;
@@ -295,9 +310,12 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)p.S, (unsigned)(p.row_tiles * p.col_tiles), (unsigned)groups);
   switch (BC) {
-    case 64: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32>), grid, dim3(256), 0, s, p); break;
-    case 48: hipLaunchKernelGGL((conv_wgrad_kernel<64, 48, 32>), grid, dim3(256), 0, s, p); break;
-    case 32: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64>), grid, dim3(256), 0, s, p); break;
+    case 128128: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 16>), grid, dim3(256), 0, s, p); break;
+    case 128064: hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 16>), grid, dim3(256), 0, s, p); break;
+    case 64128: hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 16>), grid, dim3(256), 0, s, p); break;
+    case 64064: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32>), grid, dim3(256), 0, s, p); break;
+    case 64048: hipLaunchKernelGGL((conv_wgrad_kernel<64, 48, 32>), grid, dim3(256), 0, s, p); break;
+    case 64032: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64>), grid, dim3(256), 0, s, p); break;
     default: hipLaunchKernelGGL((conv_wgrad_kernel<64, 16, 64>), grid, dim3(256), 0, s, p); break;
   }
   GEECO_LAUNCH_CHECK();

@@ -34,6 +34,8 @@ CONV_CASES = [
     (1, 10, 10, 16, 64, 1),     # stride 1, 16 channels
     (2, 64, 64, 32, 48, 2),     # conv2 halo kernel, exact tiles
     (3, 40, 72, 32, 48, 2),     # conv2 halo kernel, ragged tiles (Ho = 20, Wo = 36)
+    (16, 64, 64, 64, 128, 2),   # conv4-like at a size that takes the 128x128 tile path
+    (8, 32, 32, 128, 192, 2),   # conv5-like (128-row wgrad tiles)
     (2, 32, 32, 4, 32, 1),      # conv1 shape
     (1, 20, 44, 4, 32, 1),      # conv1 shape, ragged
 ]
