@@ -423,8 +423,8 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
   blocks *= (long long)cdiv(p.Nout, pl.bn) * groups;
   const int nk = cdiv(maxtaps * p.C, 16);
   pl.ksplit = 1;
-  if (blocks < 256 && nk >= 16) {
-    long long want = cdiv64(768, blocks);
+  if (blocks < 640 && nk >= 16) {   // fewer than 2.5 blocks per CU: long serial K loops and a ragged tail
+    long long want = cdiv64(1024, blocks);
     long long maxs = nk / 8;   // at least 8 K-steps per block
     if (want > maxs) want = maxs;
     if (want > 1) pl.ksplit = (int)want;

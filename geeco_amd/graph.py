@@ -15,6 +15,7 @@ launch over all groups; RGB inputs are channel-padded to 4 so conv1 gathers floa
 from __future__ import annotations
 
 import collections
+import os
 
 import torch
 
@@ -66,6 +67,7 @@ class ConvEncoderStack:
   def __init__(self, store: VariableStore, scopes, Nf, H, W, Cin, dim_out, training):
     self.store, self.scopes, self.G, self.Nf = store, list(scopes), len(scopes), Nf
     self.H, self.W, self.Cin = H, W, Cin
+    self.two_streams = os.environ.get('GEECO_ONE_STREAM') is None
     self.Cpad = -(-Cin // 4) * 4
     self.training = training
     dev = store.device
@@ -106,9 +108,13 @@ class ConvEncoderStack:
         self.dw1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
       wsb = max(ops.conv3x3_wgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
                 for L in self.layers)
-      wsb = max([wsb] + [ops.conv3x3_dgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
-                         for L in self.layers[1:]])
       self.ws = torch.empty(wsb // 4 + 4, **f32)
+      dsb = max(ops.conv3x3_dgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
+                for L in self.layers[1:])
+      self.dws = torch.empty(dsb // 4 + 4, **f32)
+      # wgrad(l) and dgrad(l) only share their input dz[l]: they run on two streams (two branches of
+      # the captured hipGraph) so the small top layers overlap instead of leaving CUs idle in their tails
+      self.side = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
     fsb = max(ops.conv3x3_fwd_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) for L in self.layers)
     self.fws = torch.empty(fsb // 4 + 4, **f32)
 
@@ -150,6 +156,8 @@ class ConvEncoderStack:
   def backward(self):
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied)."""
     G, Nf = self.G, self.Nf
+    main = torch.cuda.current_stream()
+    side = self.side if self.two_streams else None
     for l in range(7, -1, -1):
       L = self.layers[l]
       x = self.x_in if l == 0 else self.acts[l - 1]
@@ -158,18 +166,23 @@ class ConvEncoderStack:
         dw, gs_dw = self.dw1p, self.dw1p[0].numel()
       else:
         dw, gs_dw = self._dw(l), self.gs_p
-      ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
-                             L['W'], L['Cin'], L['Cout'], L['stride'], self.ws)
-      if l == 0:
-        if self.pad1:
+      if side is not None:
+        side.wait_stream(main)          # dz[l] is ready
+      with torch.cuda.stream(side if side is not None else main):
+        ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
+                               L['W'], L['Cin'], L['Cout'], L['stride'], self.ws)
+        if l == 0 and self.pad1:
           for g in range(G):
             ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
+      if l == 0:
         break   # conv1's input is data: no dgrad
       wt = self.wt[l]
       ops.transpose_hwio_into(wt, self._w(l), G, self.gs_p, wt[0].numel(), L['Cin'], L['Cout'])
       dx = self.dz[l - 1]
       ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
-                             L['Cin'], L['Cout'], L['stride'], ws=self.ws, w=self._w(l), gs_w=self.gs_p)
+                             L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
+    if side is not None:
+      main.wait_stream(side)
 
 
 # ================================================================================================
