@@ -39,15 +39,15 @@ SIGNATURES = {
     'geeco_transpose_hwio': (_I, [_P, _P, _I, _L, _L, _I, _I, _P]),
     'geeco_pad_mid': (_I, [_P, _P, _L, _I, _I, _I, _P]),
     'geeco_state_concat_fwd': (_I, [_PP, POINTER(_I), _I, _I, _P, _L, _I, _P, _I, _I, _P, _L, _P]),
-    'geeco_state_concat_bwd': (_I, [_P, _L, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _I, _I, _P]),
+    'geeco_state_concat_bwd': (_I, [_P, _L, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _I, _I, _F, _P]),
     'geeco_gemm_ws_bytes': (_L, [_I, _I, _I]),
     'geeco_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _P]),
     'geeco_lstm_gates_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'geeco_lstm_gates_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'geeco_colsum': (_I, [_P, _L, _I, _I, _P, _I, _P]),
     'geeco_heads_ws_bytes': (_L, [_I, _I, _I]),
-    'geeco_heads_loss_fwd_bwd': (_I, [_P, _P, _P, _PP, _PP, _P, _P, _L, _P, _L, _F, _F, _I, _I, _I, _P, _P, _I,
-                                      _P, _P, _P, _PP, _PP, _P, _P]),
+    'geeco_heads_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _PP, _PP, POINTER(_I), POINTER(_I), POINTER(_F), _PP,
+                                      POINTER(_L), _F, _I, _I, _I, _P, _P, _I, _P, _P, _P, _PP, _PP, _P, _P]),
     'geeco_adam_prepare': (_I, [_P, _F, _F, _F, _P, _P]),
     'geeco_adam_tf': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     'geeco_sumsq': (_I, [_P, _L, _P, _P]),

@@ -20,6 +20,7 @@ struct ConcatParams {
   float* state;
   long long state_stride;
   int accumulate;
+  float scale;
 };
 
 __global__ __launch_bounds__(256) void concat_fwd_kernel(const ConcatParams p) {
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void concat_bwd_kernel(const ConcatParams p, i
   const int rem = (int)(i - (long long)n * per);
   const int cell = rem / p.ch[f], c = rem - cell * p.ch[f];
   float d = p.state[(long long)n * p.state_stride + cell * p.Ctot + p.off[f] + c];
-  d = p.feats[f][i] > 0.f ? d : 0.f;      // ReluGrad of the encoder's last layer
+  d = p.feats[f][i] > 0.f ? d * p.scale : 0.f;      // ReluGrad of the encoder's last layer
   p.dfeats[f][i] = p.accumulate ? p.dfeats[f][i] + d : d;
 }
 
@@ -97,13 +98,14 @@ extern "C" int geeco_state_concat_fwd(const float* const* feats, const int* feat
 
 extern "C" int geeco_state_concat_bwd(const float* dstate, int64_t dstate_stride, const float* const* feats_fwd,
                                       float* const* dfeats, const int* feat_ch, int nfeat, int jnt_pos, int J, int N,
-                                      int cells, int accumulate, void* stream) {
+                                      int cells, int accumulate, float scale, void* stream) {
   GEECO_CHECK_ARG(dstate && feats_fwd && dfeats && feat_ch, "state_concat_bwd: null pointer");
   GEECO_CHECK_ARG(nfeat >= 1 && nfeat <= 3 && jnt_pos >= 0 && jnt_pos <= nfeat, "state_concat_bwd: nfeat/jnt_pos");
   ConcatParams p = {};
   fill_concat(&p, feat_ch, nfeat, jnt_pos, J);
   p.state = const_cast<float*>(dstate); p.state_stride = dstate_stride; p.N = N; p.cells = cells;
   p.accumulate = accumulate;
+  p.scale = scale;
   for (int i = 0; i < nfeat; ++i) {
     p.feats[i] = feats_fwd[i];
     p.dfeats[i] = dfeats[i];
@@ -343,29 +345,36 @@ extern "C" int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, con
 // =====================================================================================================
 // fc1 + heads + losses, forward and backward, one workgroup (everything is tiny: N x 128)
 // =====================================================================================================
+#define GEECO_MAX_HEADS 5
 struct HeadsParams {
   const float* h;
   const float* fc1_w;
   const float* fc1_b;
-  const float* hw[4];
-  const float* hb[4];
-  const float* cmd;
-  const float* ee;
-  const float* obj;
-  long long ee_stride, obj_stride;
-  float lambda_aux, loss_scale;
+  const float* hw[GEECO_MAX_HEADS];
+  const float* hb[GEECO_MAX_HEADS];
+  const float* tgt[GEECO_MAX_HEADS];
+  long long tstride[GEECO_MAX_HEADS];
+  int size[GEECO_MAX_HEADS], off[GEECO_MAX_HEADS], kind[GEECO_MAX_HEADS];
+  float weight[GEECO_MAX_HEADS];
+  int nheads, OT;
+  float loss_scale;
   int N, H, Hfc, backward;
   float* preds;
   float* losses;
   float* dh;
   float* d_fc1_w;
   float* d_fc1_b;
-  float* dhw[4];
-  float* dhb[4];
+  float* dhw[GEECO_MAX_HEADS];
+  float* dhb[GEECO_MAX_HEADS];
   float* a1;    // ws: [N][Hfc]
   float* da1;   // ws: [N][Hfc]
-  float* dpred; // ws: [N][12]
+  float* dpred; // ws: [N][OT]
 };
+
+template <class T>
+__device__ __forceinline__ T sel5(T const (&a)[GEECO_MAX_HEADS], int i) {
+  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : (i == 3 ? a[3] : a[4])));
+}
 
 // C[M][N] = A[M][K] B[K][N] inside ONE workgroup on MFMA 16x16x4: waves take 16x16 output tiles
 // round-robin; operands are fetched straight from global memory (everything is L2-resident and
@@ -398,96 +407,101 @@ __device__ __forceinline__ void block_mfma_gemm(int M, int N, int K, FA a_at, FB
 
 __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   const int tid = threadIdx.x, NT = 1024;
-  const int N = p.N, H = p.H, F = p.Hfc;
-  __shared__ float s_red[16][4];
-  const float* __restrict__ hw0 = p.hw[0];
-  const float* __restrict__ hw1 = p.hw[1];
-  const float* __restrict__ hw2 = p.hw[2];
-  const float* __restrict__ hw3 = p.hw[3];
-  // element (f, o) of the [F][12] matrix formed by the four [F][3] head kernels
+  const int N = p.N, H = p.H, F = p.Hfc, OT = p.OT;
+  __shared__ float s_red[16][GEECO_MAX_HEADS];
+  auto head_of = [&](int o) {
+    int hd = 0;
+#pragma unroll
+    for (int k = 1; k < GEECO_MAX_HEADS; ++k)
+      if (k < p.nheads && o >= p.off[k]) hd = k;
+    return hd;
+  };
+  // element (f, o) of the [F][OT] matrix formed by the head kernels [F][size_h]
   auto head_w = [&](int f, int o) -> float {
-    const int hd = o / 3, c = o - hd * 3;
-    const float* w = hd == 0 ? hw0 : (hd == 1 ? hw1 : (hd == 2 ? hw2 : hw3));
-    return w[f * 3 + c];
+    const int hd = head_of(o);
+    return sel5(p.hw, hd)[f * sel5(p.size, hd) + (o - sel5(p.off, hd))];
   };
   // P1: a1 = relu(h W1 + b1)                                   graph.py:229-230
   block_mfma_gemm(N, F, H, [&](int n, int k) { return p.h[n * H + k]; },
                   [&](int k, int j) { return p.fc1_w[k * F + j]; },
                   [&](int n, int j, float v) { p.a1[n * F + j] = fmaxf(v + p.fc1_b[j], 0.f); });
   __syncthreads();
-  // P2: preds[n][4 heads x 3]                                  graph.py:233-259
-  block_mfma_gemm(N, 12, F, [&](int n, int k) { return p.a1[n * F + k]; }, head_w,
+  // P2: preds[n][sum of head sizes]                             graph.py:233-259
+  block_mfma_gemm(N, OT, F, [&](int n, int k) { return p.a1[n * F + k]; }, head_w,
                   [&](int n, int o, float v) {
-                    const int hd = o / 3, c = o - hd * 3;
-                    const float* b = hd == 0 ? p.hb[0] : (hd == 1 ? p.hb[1] : (hd == 2 ? p.hb[2] : p.hb[3]));
-                    p.preds[n * 12 + o] = v + b[c];
+                    const int hd = head_of(o);
+                    p.preds[n * OT + o] = v + sel5(p.hb, hd)[o - sel5(p.off, hd)];
                   });
   __syncthreads();
-  // P3: losses and d(loss)/d(pred)                              graph.py:452-500, estimator.py:206-239
-  float l_ee = 0.f, l_grp = 0.f, l_pe = 0.f, l_po = 0.f;
-  const float inv3n = 1.f / (3.f * N), invn = 1.f / N;
-  for (int n = tid; n < N; n += NT) {
-    const float* pr = p.preds + n * 12;
-    float* dp = p.dpred + n * 12;
-    const float* cm = p.cmd + n * 4;
-    const float* ee = p.ee + (long long)n * p.ee_stride;
-    const float* ob = p.obj + (long long)n * p.obj_stride;
+  // P3: losses and d(loss)/d(pred)           graph.py:430-500, estimator.py:206-239
+  //   kind 0: tf.losses.mean_squared_error (mean over N*size); kind 1: softmax cross-entropy against
+  //   one_hot(rint(target) + 1) (mean over N)
+  float lsum[GEECO_MAX_HEADS];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float d = pr[c] - cm[c];
-      l_ee += d * d;
-      dp[c] = 2.f * d * inv3n * p.loss_scale;
-      float d2 = pr[6 + c] - ee[c];
-      l_pe += d2 * d2;
-      dp[6 + c] = 2.f * d2 * inv3n * p.lambda_aux * p.loss_scale;
-      float d3 = pr[9 + c] - ob[c];
-      l_po += d3 * d3;
-      dp[9 + c] = 2.f * d3 * inv3n * p.lambda_aux * p.loss_scale;
+  for (int k = 0; k < GEECO_MAX_HEADS; ++k) lsum[k] = 0.f;
+  const float invn = 1.f / N;
+  for (int n = tid; n < N; n += NT) {
+    const float* pr = p.preds + n * OT;
+    float* dp = p.dpred + n * OT;
+#pragma unroll
+    for (int hd = 0; hd < GEECO_MAX_HEADS; ++hd) {
+      if (hd >= p.nheads) break;
+      const int sz = p.size[hd], of = p.off[hd];
+      const float* tg = p.tgt[hd] + (long long)n * p.tstride[hd];
+      const float wsc = p.weight[hd] * p.loss_scale;
+      if (p.kind[hd] == 0) {
+        const float c2 = 2.f / (float)(N * sz) * wsc;
+        for (int c = 0; c < sz; ++c) {
+          const float d = pr[of + c] - tg[c];
+          lsum[hd] += d * d;
+          dp[of + c] = d * c2;
+        }
+      } else {
+        const int label = (int)rintf(tg[0]) + 1;             // estimator.py:213-215
+        float mx = pr[of];
+        for (int c = 1; c < sz; ++c) mx = fmaxf(mx, pr[of + c]);
+        float se = 0.f;
+        for (int c = 0; c < sz; ++c) se += expf(pr[of + c] - mx);
+        const bool lv = label >= 0 && label < sz;             // one_hot of an out-of-range label is all-zero
+        if (lv) lsum[hd] += mx + logf(se) - pr[of + label];
+        for (int c = 0; c < sz; ++c)
+          dp[of + c] = lv ? (expf(pr[of + c] - mx) / se - (c == label ? 1.f : 0.f)) * invn * wsc : 0.f;
+      }
     }
-    const int label = (int)rintf(cm[3]) + 1;                  // estimator.py:213-215
-    const float l0 = pr[3], l1 = pr[4], l2 = pr[5];
-    const float mx = fmaxf(l0, fmaxf(l1, l2));
-    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), e2 = expf(l2 - mx);
-    const float se = e0 + e1 + e2;
-    const float lse = mx + logf(se);
-    const bool lv = label >= 0 && label < 3;   // one_hot of an out-of-range label is all-zero
-    const float picked = label == 0 ? l0 : (label == 1 ? l1 : l2);
-    l_grp += lv ? (lse - picked) : 0.f;
-    dp[3] = lv ? (e0 / se - (label == 0 ? 1.f : 0.f)) * invn * p.loss_scale : 0.f;
-    dp[4] = lv ? (e1 / se - (label == 1 ? 1.f : 0.f)) * invn * p.loss_scale : 0.f;
-    dp[5] = lv ? (e2 / se - (label == 2 ? 1.f : 0.f)) * invn * p.loss_scale : 0.f;
   }
-  l_ee = wave_reduce_sum(l_ee); l_grp = wave_reduce_sum(l_grp);
-  l_pe = wave_reduce_sum(l_pe); l_po = wave_reduce_sum(l_po);
-  if ((tid & 63) == 0) {
-    s_red[tid >> 6][0] = l_ee; s_red[tid >> 6][1] = l_grp; s_red[tid >> 6][2] = l_pe; s_red[tid >> 6][3] = l_po;
+#pragma unroll
+  for (int k = 0; k < GEECO_MAX_HEADS; ++k) {
+    lsum[k] = wave_reduce_sum(lsum[k]);
+    if ((tid & 63) == 0) s_red[tid >> 6][k] = lsum[k];
   }
   __syncthreads();
   if (tid == 0) {
-    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-    for (int w = 0; w < 16; ++w) { a += s_red[w][0]; b += s_red[w][1]; c += s_red[w][2]; d += s_red[w][3]; }
-    a *= inv3n; b *= invn; c *= inv3n; d *= inv3n;
-    p.losses[1] = a; p.losses[2] = b; p.losses[3] = c; p.losses[4] = d;
-    p.losses[0] = (a + b) + p.lambda_aux * (c + d);             // estimator.py:224-225
+    float total = 0.f;
+    for (int hd = 0; hd < p.nheads; ++hd) {
+      float a = 0.f;
+      for (int w = 0; w < 16; ++w) a += s_red[w][hd];
+      a *= p.kind[hd] == 0 ? 1.f / (float)(N * p.size[hd]) : invn;
+      p.losses[1 + hd] = a;
+      total += p.weight[hd] * a;
+    }
+    p.losses[0] = total;
   }
   if (!p.backward) return;
   __syncthreads();
   // P4: head gradients  d_hw[f][o] = sum_n a1[n][f] dpred[n][o];  da1 = (dpred Wh^T) * relu'
-  block_mfma_gemm(F, 12, N, [&](int f, int n) { return p.a1[n * F + f]; },
-                  [&](int n, int o) { return p.dpred[n * 12 + o]; },
+  block_mfma_gemm(F, OT, N, [&](int f, int n) { return p.a1[n * F + f]; },
+                  [&](int n, int o) { return p.dpred[n * OT + o]; },
                   [&](int f, int o, float v) {
-                    const int hd = o / 3, c = o - hd * 3;
-                    float* d = hd == 0 ? p.dhw[0] : (hd == 1 ? p.dhw[1] : (hd == 2 ? p.dhw[2] : p.dhw[3]));
-                    d[f * 3 + c] = v;
+                    const int hd = head_of(o);
+                    sel5(p.dhw, hd)[f * sel5(p.size, hd) + (o - sel5(p.off, hd))] = v;
                   });
-  for (int o = tid; o < 12; o += NT) {
+  for (int o = tid; o < OT; o += NT) {
     float sum = 0.f;
-    for (int n = 0; n < N; ++n) sum += p.dpred[n * 12 + o];
-    const int hd = o / 3;
-    float* d = hd == 0 ? p.dhb[0] : (hd == 1 ? p.dhb[1] : (hd == 2 ? p.dhb[2] : p.dhb[3]));
-    d[o - hd * 3] = sum;
+    for (int n = 0; n < N; ++n) sum += p.dpred[n * OT + o];
+    const int hd = head_of(o);
+    sel5(p.dhb, hd)[o - sel5(p.off, hd)] = sum;
   }
-  block_mfma_gemm(N, F, 12, [&](int n, int o) { return p.dpred[n * 12 + o]; },
+  block_mfma_gemm(N, F, OT, [&](int n, int o) { return p.dpred[n * OT + o]; },
                   [&](int o, int f) { return head_w(f, o); },
                   [&](int n, int f, float v) { p.da1[n * F + f] = p.a1[n * F + f] > 0.f ? v : 0.f; });
   __syncthreads();
@@ -507,29 +521,40 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
 
 extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {
   (void)H;
-  return ((int64_t)2 * N * Hfc + (int64_t)N * 12) * 4;
+  return ((int64_t)2 * N * Hfc + (int64_t)N * 32) * 4;
 }
 
-extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b,
-                                        const float* const* heads_w, const float* const* heads_b, const float* cmd,
-                                        const float* ee_tgt, int64_t ee_stride, const float* obj_tgt,
-                                        int64_t obj_stride, float lambda_aux, float loss_scale, int N, int H, int Hfc,
-                                        float* preds, float* losses, int backward, float* dh, float* d_fc1_w,
-                                        float* d_fc1_b, float* const* d_heads_w, float* const* d_heads_b, float* ws,
-                                        void* stream) {
-  GEECO_CHECK_ARG(h && fc1_w && fc1_b && heads_w && heads_b && cmd && ee_tgt && obj_tgt && preds && losses && ws,
-                  "heads_loss: null pointer");
+extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b, int nheads,
+                                        const float* const* heads_w, const float* const* heads_b,
+                                        const int* head_size, const int* head_kind, const float* head_weight,
+                                        const float* const* targets, const int64_t* target_stride, float loss_scale,
+                                        int N, int H, int Hfc, float* preds, float* losses, int backward, float* dh,
+                                        float* d_fc1_w, float* d_fc1_b, float* const* d_heads_w,
+                                        float* const* d_heads_b, float* ws, void* stream) {
+  GEECO_CHECK_ARG(h && fc1_w && fc1_b && heads_w && heads_b && head_size && head_kind && head_weight && targets &&
+                      target_stride && preds && losses && ws, "heads_loss: null pointer");
+  GEECO_CHECK_ARG(nheads >= 1 && nheads <= GEECO_MAX_HEADS, "heads_loss: nheads=%d outside 1..%d", nheads, GEECO_MAX_HEADS);
   GEECO_CHECK_ARG(N >= 1 && N <= 4096 && H >= 1 && Hfc >= 1, "heads_loss: bad dims");
   GEECO_CHECK_ARG(!backward || (dh && d_fc1_w && d_fc1_b && d_heads_w && d_heads_b), "heads_loss: null gradient pointer");
   HeadsParams p = {};
-  p.h = h; p.fc1_w = fc1_w; p.fc1_b = fc1_b; p.cmd = cmd; p.ee = ee_tgt; p.obj = obj_tgt;
-  p.ee_stride = ee_stride; p.obj_stride = obj_stride; p.lambda_aux = lambda_aux; p.loss_scale = loss_scale;
+  p.h = h; p.fc1_w = fc1_w; p.fc1_b = fc1_b; p.nheads = nheads; p.loss_scale = loss_scale;
   p.N = N; p.H = H; p.Hfc = Hfc; p.backward = backward; p.preds = preds; p.losses = losses;
   p.dh = dh; p.d_fc1_w = d_fc1_w; p.d_fc1_b = d_fc1_b;
-  for (int i = 0; i < 4; ++i) {
-    p.hw[i] = heads_w[i]; p.hb[i] = heads_b[i];
-    if (backward) { p.dhw[i] = d_heads_w[i]; p.dhb[i] = d_heads_b[i]; }
+  int off = 0;
+  for (int i = 0; i < nheads; ++i) {
+    GEECO_CHECK_ARG(head_size[i] >= 1 && head_size[i] <= 16, "heads_loss: head %d size %d", i, head_size[i]);
+    GEECO_CHECK_ARG(head_kind[i] == 0 || head_kind[i] == 1, "heads_loss: head %d kind %d", i, head_kind[i]);
+    GEECO_CHECK_ARG(heads_w[i] && heads_b[i] && targets[i], "heads_loss: head %d null pointer", i);
+    p.hw[i] = heads_w[i]; p.hb[i] = heads_b[i]; p.tgt[i] = targets[i]; p.tstride[i] = target_stride[i];
+    p.size[i] = head_size[i]; p.off[i] = off; p.kind[i] = head_kind[i]; p.weight[i] = head_weight[i];
+    off += head_size[i];
+    if (backward) {
+      GEECO_CHECK_ARG(d_heads_w[i] && d_heads_b[i], "heads_loss: head %d null gradient pointer", i);
+      p.dhw[i] = d_heads_w[i]; p.dhb[i] = d_heads_b[i];
+    }
   }
+  GEECO_CHECK_ARG(off <= 32, "heads_loss: %d outputs > 32", off);
+  p.OT = off;
   p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
   hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
   GEECO_LAUNCH_CHECK();

@@ -143,9 +143,9 @@ def _model_fn(features, labels, mode, params, goal):
   model = ctor(cfg, N, rgb.device, training=training, store=params.get('_variable_store'))
   # adopt the caller's static buffers as the model inputs (placeholders)
   for k in list(model.inputs.keys()):
-    src = labels.get(k) if (labels is not None and k == 'cmd') else features.get(k)
+    src = labels.get(k) if (labels is not None and k in model.label_keys) else features.get(k)
     if src is None:
-      if mode == ModeKeys.PREDICT and k in ('cmd', 'ee_state', 'obj_state'):
+      if mode == ModeKeys.PREDICT and k in model.label_keys + ['ee_state', 'obj_state']:
         continue   # label-side inputs are not needed for predictions
       raise KeyError("model_fn: missing input '%s'" % k)
     if (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and
@@ -188,14 +188,18 @@ def _eval_metric_fn(model):
 
   def batch_stats():
     p = model.predictions()
-    cmd = model.inputs['cmd']
-    tgt = {'cmd_ee': cmd[:, :3], 'pos_ee': model.inputs['ee_state'][:, K - 1, :3],
-           'pos_obj': model.inputs['obj_state'][:, K - 1, :3]}
+    inp = model.inputs
+    tgt = {'pos_ee': inp['ee_state'][:, K - 1, :3], 'pos_obj': inp['obj_state'][:, K - 1, :3]}
+    if model.cfg.control_mode == 'cartesian':
+      tgt['cmd_ee'] = inp['cmd'][:, :3]
+    else:                                                     # estimator.py:117-120 / 255-258
+      tgt.update({'cmd_vel': inp['vel_target'], 'cmd_ee': inp['ee_target'][:, :3], 'cmd_grp': inp['grp_target']})
     out = {}
     for k, t in tgt.items():
       out[k] = (((p[k] - t) ** 2).sum(), float(t.numel()))
-    label = torch.round(cmd[:, 3]).to(torch.int64) + 1
-    out['cmd_grp'] = ((p['logits_cmd_grp'].argmax(dim=-1) == label).float().sum(), float(label.numel()))
+    if model.cfg.control_mode == 'cartesian':
+      label = torch.round(inp['cmd'][:, 3]).to(torch.int64) + 1
+      out['cmd_grp'] = ((p['logits_cmd_grp'].argmax(dim=-1) == label).float().sum(), float(label.numel()))
     return out
   return batch_stats
 

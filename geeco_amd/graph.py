@@ -186,19 +186,31 @@ class ConvEncoderStack:
 
 
 # ================================================================================================
-# LSTM decoder + heads + losses (graph.py:198-260, 452-500; estimator.py:206-239)
+# LSTM decoder + heads + losses (graph.py:198-260, 430-500; estimator.py:206-239)
 # ================================================================================================
+def head_table(cfg):
+  """(variable name, prediction key, size, kind, loss weight) per head, in variable creation order.
+  kind 0 = mean_squared_error, 1 = softmax cross-entropy (graph.py:233-259, 430-500; estimator.py:224-237)."""
+  if cfg.control_mode == 'cartesian':
+    lam = float(cfg.lambda_aux)
+    return [('pred_cmd_ee', 'cmd_ee', 3, 0, 1.0), ('logits_cmd_grp', 'logits_cmd_grp', cfg.num_grp_states, 1, 1.0),
+            ('pred_aux_ee', 'pos_ee', 3, 0, lam), ('pred_aux_obj', 'pos_obj', 3, 0, lam)]
+  if cfg.control_mode == 'velocity':   # mse_loss sums all five terms unweighted (graph.py:446-449)
+    return [('pred_cmd_vel', 'cmd_vel', cfg.dim_jnt_state, 0, 1.0), ('pred_cmd_ee', 'cmd_ee', 3, 0, 1.0),
+            ('pred_cmd_grp', 'cmd_grp', cfg.dim_grp_command, 0, 1.0), ('pred_aux_ee', 'pos_ee', 3, 0, 1.0),
+            ('pred_aux_obj', 'pos_obj', 3, 0, 1.0)]
+  raise ValueError("Unknown control mode '%s'" % (cfg.control_mode,))
+
+
 class LSTMDecoder:
   """T LSTM steps over states [T][N][D] from a zero state, fc1 + heads on the last output."""
 
   def __init__(self, store: VariableStore, scope, cfg, N, T, D, training):
-    if cfg.control_mode != 'cartesian':
-      raise NotImplementedError("control_mode '%s' is not built yet (cartesian only)" % cfg.control_mode)
-    if cfg.num_grp_states != 3:
-      raise NotImplementedError('num_grp_states != 3')
     self.store, self.scope, self.cfg, self.N, self.T, self.D = store, scope, cfg, N, T, D
     self.H, self.F = cfg.dim_h_lstm, cfg.dim_h_fc
     self.training = training
+    self.heads = head_table(cfg)
+    self.OT = sum(h[2] for h in self.heads)
     dev = store.device
     f32 = dict(dtype=torch.float32, device=dev)
     H, F = self.H, self.F
@@ -207,7 +219,7 @@ class LSTMDecoder:
     self.gates = torch.empty(T, N, 4 * H, **f32)
     self.c = torch.empty(T, N, H, **f32)
     self.h = torch.empty(T, N, H, **f32)
-    self.preds = torch.empty(N, 12, **f32)
+    self.preds = torch.empty(N, self.OT, **f32)
     self.losses = torch.zeros(8, **f32)
     self.heads_ws = torch.empty(ops.heads_ws_bytes(N, H, F) // 4 + 4, **f32)
     gemm_shapes = [(T * N, 4 * H, D), (N, 4 * H, H)]
@@ -218,10 +230,7 @@ class LSTMDecoder:
       self.dc = torch.empty(N, H, **f32)
       gemm_shapes += [(D, 4 * H, T * N), (H, 4 * H, max((T - 1) * N, 1)), (T * N, D, 4 * H), (N, H, 4 * H)]
     self.gemm_ws = torch.empty(max(ops.gemm_ws_bytes(*s) for s in gemm_shapes) // 4 + 4, **f32)
-    self.head_names = ['pred_cmd_ee', 'logits_cmd_grp', 'pred_aux_ee', 'pred_aux_obj']
-    # label pointers (bound by the model)
-    self.cmd = self.ee_tgt = self.obj_tgt = None
-    self.ee_stride = self.obj_stride = 0
+    self.targets, self.target_strides = None, None     # bound by the model
     self.loss_scale = 1.0
 
   def _v(self, n):
@@ -242,16 +251,15 @@ class LSTMDecoder:
         ops.gemm_into(self.z[t], self.h[t - 1], Wh, N, 4 * H, H, H, 4 * H, 4 * H, accumulate=True, ws=self.gemm_ws)
       ops.lstm_gates_fwd_into(self.c[t], self.h[t], self.gates[t], self.z[t], bias,
                               self.c[t - 1] if t > 0 else None, N, H)
-    hw = [self._v(n + '/kernel') for n in self.head_names]
-    hb = [self._v(n + '/bias') for n in self.head_names]
+    names = [h[0] for h in self.heads]
     kw = {}
     if backward_too:
       kw = dict(dh=self.dh, d_fc1_w=self._g('fc1/kernel'), d_fc1_b=self._g('fc1/bias'),
-                d_heads_w=[self._g(n + '/kernel') for n in self.head_names],
-                d_heads_b=[self._g(n + '/bias') for n in self.head_names])
-    ops.heads_loss_into(self.preds, self.losses, self.h[T - 1], self._v('fc1/kernel'), self._v('fc1/bias'), hw, hb,
-                        self.cmd, self.ee_tgt, self.ee_stride, self.obj_tgt, self.obj_stride,
-                        float(self.cfg.lambda_aux), float(self.loss_scale), N, H, F, self.heads_ws, **kw)
+                d_heads_w=[self._g(n + '/kernel') for n in names], d_heads_b=[self._g(n + '/bias') for n in names])
+    ops.heads_loss_into(self.preds, self.losses, self.h[T - 1], self._v('fc1/kernel'), self._v('fc1/bias'),
+                        [self._v(n + '/kernel') for n in names], [self._v(n + '/bias') for n in names],
+                        [h[2] for h in self.heads], [h[3] for h in self.heads], [h[4] for h in self.heads],
+                        self.targets, self.target_strides, float(self.loss_scale), N, H, F, self.heads_ws, **kw)
 
   def backward(self):
     """After forward(backward_too=True): fills d(states) and the LSTM variable gradients."""
@@ -295,23 +303,36 @@ class _ModelBase:
         'jnt_state': torch.zeros(N, K, cfg.dim_jnt_state, **f32),
         'ee_state': torch.zeros(N, K, 7, **f32),
         'obj_state': torch.zeros(N, K, 7, **f32),
-        'cmd': torch.zeros(N, 4, **f32),
     }
+    if cfg.control_mode == 'cartesian':        # labels consumed by the losses (estimator.py:206-216, 230-236)
+      self.label_keys = ['cmd']
+      self.inputs['cmd'] = torch.zeros(N, 4, **f32)
+    elif cfg.control_mode == 'velocity':
+      self.label_keys = ['vel_target', 'ee_target', 'grp_target']
+      self.inputs['vel_target'] = torch.zeros(N, cfg.dim_jnt_state, **f32)
+      self.inputs['ee_target'] = torch.zeros(N, 7, **f32)
+      self.inputs['grp_target'] = torch.zeros(N, cfg.dim_grp_command, **f32)
+    else:
+      raise ValueError("Unknown control mode '%s'" % (cfg.control_mode,))
     if self.C == 4:
       self.inputs['depth'] = torch.zeros(N, K, H, W, 1, **f32)
     if goal:
       self.inputs['target_rgb'] = torch.zeros(N, H, W, 3, **f32)
       if self.C == 4:
         self.inputs['target_depth'] = torch.zeros(N, H, W, 1, **f32)
-    self.scal = torch.zeros(4, **f32)          # [0] = Adam lr_t
+    self.scal = torch.zeros(4, **f32)          # [0] = Adam lr_t, [1] = sum of squares of the arena
     self.world = 1
+    if self.C == 4:
+      self.obs4 = torch.empty(N, K, H, W, 4, **f32)      # rgb || depth (estimator.py:36,169)
+      if goal:
+        self.tgt4 = torch.empty(N, H, W, 4, **f32)       # target_rgb || target_depth (estimator.py:172)
 
   def load_batch(self, features, labels=None):
     """Copies one batch into the static input buffers (H2D or D2D; torch is plumbing here)."""
     for k, buf in self.inputs.items():
-      src = labels.get(k) if (labels is not None and k == 'cmd') else features.get(k)
+      src = labels.get(k) if (labels is not None and k in self.label_keys) else features.get(k)
       if src is None:
-        if k == 'cmd':
+        if k in self.label_keys:
           continue
         raise KeyError("missing feature '%s'" % k)
       src = torch.as_tensor(src)
@@ -319,13 +340,28 @@ class _ModelBase:
         raise ValueError("feature '%s': expected shape %s, got %s" % (k, tuple(buf.shape), tuple(src.shape)))
       buf.copy_(src, non_blocking=True)
 
+  def _frames(self):
+    """obs_frames / tgt_frame of the model_fn (estimator.py:30-39, 161-175): rgb, or rgb||depth packed to 4 channels."""
+    N, K, HW = self.N, self.K, self.H * self.W
+    if self.C == 3:
+      return self.inputs['rgb'], self.inputs.get('target_rgb')
+    ops.pack_pixels_into(self.obs4, self.inputs['rgb'], HW * 3, N * K, HW, 3, 4, self.inputs['depth'], HW, 1)
+    if self.goal:
+      ops.pack_pixels_into(self.tgt4, self.inputs['target_rgb'], HW * 3, N, HW, 3, 4, self.inputs['target_depth'], HW, 1)
+      return self.obs4, self.tgt4
+    return self.obs4, None
+
   def _bind_labels(self):
-    K = self.K
-    d = self.decoder
-    d.cmd = self.inputs['cmd']
-    d.ee_tgt = self.inputs['ee_state'][:, K - 1]      # features['ee_state'][:, -1, :3]  (estimator.py:209)
-    d.obj_tgt = self.inputs['obj_state'][:, K - 1]
-    d.ee_stride = d.obj_stride = K * 7
+    K, inp = self.K, self.inputs
+    ee_last, obj_last = inp['ee_state'][:, K - 1], inp['obj_state'][:, K - 1]   # features[...][:, -1, :3]
+    if self.cfg.control_mode == 'cartesian':
+      cmd = inp['cmd']
+      tg = [(cmd, 4), (cmd[:, 3:], 4), (ee_last, K * 7), (obj_last, K * 7)]
+    else:
+      tg = [(inp['vel_target'], inp['vel_target'].shape[1]), (inp['ee_target'], 7),
+            (inp['grp_target'], inp['grp_target'].shape[1]), (ee_last, K * 7), (obj_last, K * 7)]
+    self.decoder.targets = [t for t, _ in tg]
+    self.decoder.target_strides = [s for _, s in tg]
 
   # -- optimiser step (estimator.py:243-244) -------------------------------------------------
   def apply_gradients(self):
@@ -335,18 +371,33 @@ class _ModelBase:
                 l2=float(cfg.l2_regularizer))
 
   def predictions(self):
-    """estimator.py:183-189."""
-    p = self.decoder.preds
-    return {'cmd_ee': p[:, 0:3], 'logits_cmd_grp': p[:, 3:6], 'pos_ee': p[:, 6:9], 'pos_obj': p[:, 9:12]}
+    """estimator.py:48-61 / 183-197."""
+    p, out, off = self.decoder.preds, {}, 0
+    for _, key, size, _, _ in self.decoder.heads:
+      out[key] = p[:, off:off + size]
+      off += size
+    return out
+
+  def _finish_forward(self):
+    if self.cfg.l2_regularizer > 0.0:    # loss_reg = l2 * sum(v^2)/2 over every variable (graph.py:13-15, estimator.py:66,202)
+      ops.sumsq_into(self.scal[1:2], self.store.params, self.store.size)
 
   @property
   def loss(self):
-    """Device scalar: total loss of the last forward (local batch mean; without the L2 term)."""
-    return self.decoder.losses[0]
+    """Device scalar: total loss of the last forward (local batch mean + L2 term, estimator.py:101,239)."""
+    l = self.decoder.losses[0]
+    if self.cfg.l2_regularizer > 0.0:
+      l = l + (0.5 * float(self.cfg.l2_regularizer)) * self.scal[1]
+    return l
 
   def loss_parts(self):
     l = self.decoder.losses
-    return {'loss': l[0], 'loss_cmd_ee': l[1], 'loss_cmd_grp': l[2], 'loss_pos_ee': l[3], 'loss_pos_obj': l[4]}
+    out = {'loss': self.loss}
+    for i, (_, key, _, _, _) in enumerate(self.decoder.heads):
+      out['loss_' + key.replace('logits_', '')] = l[1 + i]
+    if self.cfg.l2_regularizer > 0.0:
+      out['loss_reg'] = (0.5 * float(self.cfg.l2_regularizer)) * self.scal[1]
+    return out
 
   def train_step(self):
     self.forward(backward_too=True)
@@ -355,69 +406,123 @@ class _ModelBase:
 
 
 class GoalE2EVMC(_ModelBase):
-  """``goal_e2evmc`` (graph.py:321-416), proc_obs='dynimg' branch (geeco-f; :386-407)."""
+  """``goal_e2evmc`` (graph.py:321-416), every proc_obs x proc_tgt branch (scope 'GoalVMC')."""
 
   def __init__(self, cfg, N, device, training=True, store=None):
     super().__init__(cfg, N, device, goal=True, training=training, store=store)
-    if cfg.proc_obs != 'dynimg':
-      if cfg.proc_obs == 'sequence':
-        raise NotImplementedError("proc_obs='sequence' for goal_e2evmc is not built yet")
-      raise ValueError("Unknown processing mode for frame buffer: %s!" % (cfg.proc_obs,))
     if cfg.proc_tgt not in ('constant', 'residual', 'dyndiff'):
       raise ValueError("Unknown processing mode for target image: %s!" % (cfg.proc_tgt,))
-    if not (cfg.dim_s_obs == cfg.dim_s_dyn == cfg.dim_s_diff):
-      raise NotImplementedError('dim_s_obs, dim_s_dyn and dim_s_diff must be equal (grouped encoders)')
+    if cfg.proc_obs not in ('sequence', 'dynimg'):
+      raise ValueError("Unknown processing mode for frame buffer: %s!" % (cfg.proc_obs,))
     root = 'GoalVMC'
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
-    self.enc = ConvEncoderStack(self.store, [root + '/ConvEncoder', root + '/DynBuffEncoder', root + '/DynDiffEncoder'],
-                                N, H, W, C, cfg.dim_s_obs, training)
-    self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_dyn, cfg.dim_s_diff]
-    D = _CELLS * (sum(self.feat_ch) + cfg.dim_jnt_state)
-    self.decoder = LSTMDecoder(self.store, root + '/LSTMDecoder', cfg, N, 1, D, training)
+    jn = cfg.dim_jnt_state
+    self.mode = cfg.proc_obs if cfg.proc_obs == 'dynimg' else 'seq_' + cfg.proc_tgt
+    if self.mode == 'dynimg':             # geeco-f (:386-407); proc_tgt is ignored by this branch
+      if not (cfg.dim_s_obs == cfg.dim_s_dyn == cfg.dim_s_diff):
+        raise NotImplementedError('dim_s_obs, dim_s_dyn and dim_s_diff must be equal (grouped encoders)')
+      scopes, Nf, T = [root + '/ConvEncoder', root + '/DynBuffEncoder', root + '/DynDiffEncoder'], N, 1
+      self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_dyn, cfg.dim_s_diff]
+    elif self.mode in ('seq_constant', 'seq_residual'):   # target goes through the SAME ConvEncoder (:354, 364)
+      scopes, Nf, T = [root + '/ConvEncoder'], (K + 1) * N, K
+      self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_obs] if self.mode == 'seq_constant' else [cfg.dim_s_obs]
+    else:                                  # seq_dyndiff (:371-381)
+      if cfg.dim_s_obs != cfg.dim_s_diff:
+        raise NotImplementedError('dim_s_obs and dim_s_diff must be equal (grouped encoders)')
+      scopes, Nf, T = [root + '/ConvEncoder', root + '/DynDiffEncoder'], K * N, K
+      self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_diff]
+    self.enc = ConvEncoderStack(self.store, scopes, Nf, H, W, C, cfg.dim_s_obs, training)
+    D = _CELLS * (sum(self.feat_ch) + jn)
+    self.decoder = LSTMDecoder(self.store, root + '/LSTMDecoder', cfg, N, T, D, training)
     self._bind_labels()
-    f32 = dict(dtype=torch.float32, device=self.device)
-    self.dyn_ws = ops.dynimg_ws(N, H * W * max(C, 4), self.device)
-    if C == 4:
-      self.obs4 = torch.empty(N, K, H, W, 4, **f32)      # rgb || depth (estimator.py:169)
-      self.tgt4 = torch.empty(N, H, W, 4, **f32)         # target_rgb || target_depth (estimator.py:172)
+    self.dyn_ws = ops.dynimg_ws(N, H * W * 4, self.device)
 
   def forward(self, backward_too=False):
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
     HW = H * W
     x_in = self.enc.x_in
-    if C == 3:
-      frames, tgt = self.inputs['rgb'], self.inputs['target_rgb']
-    else:
-      ops.pack_pixels_into(self.obs4, self.inputs['rgb'], HW * 3, N * K, HW, 3, 4, self.inputs['depth'], HW, 1)
-      ops.pack_pixels_into(self.tgt4, self.inputs['target_rgb'], HW * 3, N, HW, 3, 4, self.inputs['target_depth'], HW, 1)
-      frames, tgt = self.obs4, self.tgt4
-    cur = frames[:, K - 1]                                  # rgb_frame_list[-1] (graph.py:387)
-    # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)
-    ops.pack_pixels_into(x_in[0], cur, K * HW * C, N, HW, C, 4)
-    ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, self.dyn_ws, K * HW * C, HW * C)
-    ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)
-    self.enc.forward()
-    feats = self.enc.features                               # [3][N][2][2][256]
+    frames, tgt = self._frames()
     jn = self.cfg.dim_jnt_state
-    jnt = self.inputs['jnt_state'][:, K - 1]                # jnt_state_list[-1] (graph.py:388)
+    jnts = self.inputs['jnt_state']
     d = self.decoder
-    # representation_concatenation_v2: [obs | dyn | jnt | tgt] (graph.py:169-192)
-    ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], self.feat_ch, 2, jnt, K * jn, jn, N, _CELLS,
-                              d.D)
+    if self.mode == 'dynimg':
+      cur = frames[:, K - 1]                                  # rgb_frame_list[-1] (graph.py:387)
+      # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)
+      ops.pack_pixels_into(x_in[0], cur, K * HW * C, N, HW, C, 4)
+      ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, self.dyn_ws, K * HW * C, HW * C)
+      ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)
+      self.enc.forward()
+      feats = self.enc.features                               # [3][N][2][2][256]
+      # representation_concatenation_v2: [obs | dyn | jnt | tgt] (graph.py:169-192); jnt_state_list[-1] (:388)
+      ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], self.feat_ch, 2, jnts[:, K - 1], K * jn,
+                                jn, N, _CELLS, d.D)
+    elif self.mode in ('seq_constant', 'seq_residual'):
+      xs = x_in[0].view(K + 1, N, H, W, 4)                    # time-major; slot K = target frame
+      for t in range(K):
+        ops.pack_pixels_into(xs[t], frames[:, t], K * HW * C, N, HW, C, 4)
+      ops.pack_pixels_into(xs[K], tgt, HW * C, N, HW, C, 4)
+      self.enc.forward()
+      feats = self.enc.features[0].view(K + 1, N, _CELLS, self.feat_ch[0])
+      for t in range(K):
+        if self.mode == 'seq_constant':   # representation_concatenation: [obs | jnt | tgt] (:146-167, 367)
+          ops.state_concat_fwd_into(d.states[t], [feats[t], feats[K]], self.feat_ch, 1, jnts[:, t], K * jn, jn, N,
+                                    _CELLS, d.D)
+        else:                             # state_concatenation(tgt_feat - feat, jnt) (:369-370)
+          ops.state_concat_fwd_into(d.states[t], [feats[t]], self.feat_ch, 1, jnts[:, t], K * jn, jn, N, _CELLS, d.D,
+                                    sub_from=feats[K])
+    else:                                 # seq_dyndiff
+      xs = x_in.view(2, K, N, H, W, 4)
+      for t in range(K):
+        ops.pack_pixels_into(xs[0][t], frames[:, t], K * HW * C, N, HW, C, 4)
+        ops.dynimg_into(xs[1][t], frames[:, t], 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)   # :373-376
+      self.enc.forward()
+      feats = self.enc.features.view(2, K, N, _CELLS, self.feat_ch[0])
+      for t in range(K):                  # representation_concatenation(feat, tgt_feat, jnt) (:381)
+        ops.state_concat_fwd_into(d.states[t], [feats[0][t], feats[1][t]], self.feat_ch, 1, jnts[:, t], K * jn, jn, N,
+                                  _CELLS, d.D)
     d.forward(backward_too)
+    self._finish_forward()
 
   def backward(self):
+    N, K, jn = self.N, self.K, self.cfg.dim_jnt_state
     d = self.decoder
     d.backward()
-    feats, dfe = self.enc.features, self.enc.dfeatures
-    ops.state_concat_bwd_into([dfe[0], dfe[1], dfe[2]], d.dstates[0], d.D, [feats[0], feats[1], feats[2]], self.feat_ch,
-                              2, self.cfg.dim_jnt_state, self.N, _CELLS)
+    if self.mode == 'dynimg':
+      feats, dfe = self.enc.features, self.enc.dfeatures
+      ops.state_concat_bwd_into([dfe[0], dfe[1], dfe[2]], d.dstates[0], d.D, [feats[0], feats[1], feats[2]],
+                                self.feat_ch, 2, jn, N, _CELLS)
+    elif self.mode in ('seq_constant', 'seq_residual'):
+      ch = self.feat_ch[0]
+      feats = self.enc.features[0].view(K + 1, N, _CELLS, ch)
+      dfe = self.enc.dfeatures[0].view(K + 1, N, _CELLS, ch)
+      for t in range(K):
+        if self.mode == 'seq_constant':
+          ops.state_concat_bwd_into([dfe[t], None], d.dstates[t], d.D, [feats[t], feats[K]], self.feat_ch, 1, jn, N, _CELLS)
+          ops.state_concat_bwd_into([None, dfe[K]], d.dstates[t], d.D, [feats[t], feats[K]], self.feat_ch, 1, jn, N,
+                                    _CELLS, accumulate=t > 0)
+        else:   # d(tgt - feat): -1 into feat_t, +1 (summed over the window) into the target features
+          ops.state_concat_bwd_into([dfe[t]], d.dstates[t], d.D, [feats[t]], self.feat_ch, 1, jn, N, _CELLS, scale=-1.0)
+          ops.state_concat_bwd_into([dfe[K]], d.dstates[t], d.D, [feats[K]], self.feat_ch, 1, jn, N, _CELLS,
+                                    accumulate=t > 0, scale=1.0)
+    else:
+      ch = self.feat_ch[0]
+      feats = self.enc.features.view(2, K, N, _CELLS, ch)
+      dfe = self.enc.dfeatures.view(2, K, N, _CELLS, ch)
+      for t in range(K):
+        ops.state_concat_bwd_into([dfe[0][t], dfe[1][t]], d.dstates[t], d.D, [feats[0][t], feats[1][t]], self.feat_ch,
+                                  1, jn, N, _CELLS)
     self.enc.backward()
 
   def endpoints(self):
-    """dynbuff / dyndiff debug endpoints (graph.py:393,401)."""
-    return {'dynbuff': self.enc.x_in[1][..., :self.C], 'dyndiff': self.enc.x_in[2][..., :self.C],
-            'conv8': self.enc.features}
+    """dynbuff / dyndiff debug endpoints (graph.py:377,393,401): the LAST computed images."""
+    C, K, N = self.C, self.K, self.N
+    ep = {'conv8': self.enc.features}
+    if self.mode == 'dynimg':
+      ep['dynbuff'] = self.enc.x_in[1][..., :C]
+      ep['dyndiff'] = self.enc.x_in[2][..., :C]
+    elif self.mode == 'seq_dyndiff':
+      ep['dyndiff'] = self.enc.x_in.view(2, K, N, self.H, self.W, 4)[1][K - 1][..., :C]
+    return ep
 
 
 class E2EVMC(_ModelBase):
@@ -436,13 +541,9 @@ class E2EVMC(_ModelBase):
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
     HW = H * W
     x_in = self.enc.x_in[0].view(K, N, H, W, 4)
-    rgb = self.inputs['rgb']
-    dep = self.inputs.get('depth')
+    frames, _ = self._frames()
     for t in range(K):
-      if C == 3:
-        ops.pack_pixels_into(x_in[t], rgb[:, t], K * HW * 3, N, HW, 3, 4)
-      else:
-        ops.pack_pixels_into(x_in[t], rgb[:, t], K * HW * 3, N, HW, 3, 4, dep[:, t], K * HW, 1)
+      ops.pack_pixels_into(x_in[t], frames[:, t], K * HW * C, N, HW, C, 4)
     self.enc.forward()
     feats = self.enc.features[0].view(K, N, _CELLS, 256)
     jn = self.cfg.dim_jnt_state
@@ -451,6 +552,7 @@ class E2EVMC(_ModelBase):
       ops.state_concat_fwd_into(d.states[t], [feats[t]], [256], 1, self.inputs['jnt_state'][:, t], K * jn, jn, N,
                                 _CELLS, d.D)
     d.forward(backward_too)
+    self._finish_forward()
 
   def backward(self):
     N, K = self.N, self.K

@@ -181,10 +181,11 @@ def state_concat_fwd_into(state, feats, feat_ch, jnt_pos, jnt, jnt_stride, J, N,
         'geeco_state_concat_fwd')
 
 
-def state_concat_bwd_into(dfeats, dstate, dstate_stride, feats_fwd, feat_ch, jnt_pos, J, N, cells, accumulate=False):
+def state_concat_bwd_into(dfeats, dstate, dstate_stride, feats_fwd, feat_ch, jnt_pos, J, N, cells, accumulate=False,
+                          scale=1.0):
   check(_lib().geeco_state_concat_bwd(_p(dstate), dstate_stride, _parr(feats_fwd), _parr(dfeats), _iarr(feat_ch),
-                                      len(feats_fwd), jnt_pos, J, N, cells, 1 if accumulate else 0, _stream()),
-        'geeco_state_concat_bwd')
+                                      len(feats_fwd), jnt_pos, J, N, cells, 1 if accumulate else 0, float(scale),
+                                      _stream()), 'geeco_state_concat_bwd')
 
 
 def gemm_ws_bytes(M, N, K):
@@ -224,13 +225,17 @@ def heads_ws_bytes(N, H, Hfc):
   return int(_lib().geeco_heads_ws_bytes(N, H, Hfc))
 
 
-def heads_loss_into(preds, losses, h, fc1_w, fc1_b, heads_w, heads_b, cmd, ee_tgt, ee_stride, obj_tgt, obj_stride,
-                    lambda_aux, loss_scale, N, H, Hfc, ws, dh=None, d_fc1_w=None, d_fc1_b=None, d_heads_w=None,
+def heads_loss_into(preds, losses, h, fc1_w, fc1_b, heads_w, heads_b, head_size, head_kind, head_weight, targets,
+                    target_stride, loss_scale, N, H, Hfc, ws, dh=None, d_fc1_w=None, d_fc1_b=None, d_heads_w=None,
                     d_heads_b=None):
+  """fc1 + heads + losses (+ their gradients when ``dh`` is given); see include/geeco_hip.h."""
   backward = dh is not None
+  nh = len(heads_w)
+  farr = (ctypes.c_float * nh)(*[float(v) for v in head_weight])
+  larr = (ctypes.c_int64 * nh)(*[int(v) for v in target_stride])
   check(_lib().geeco_heads_loss_fwd_bwd(
-      _p(h), _p(fc1_w), _p(fc1_b), _parr(heads_w), _parr(heads_b), _p(cmd), _p(ee_tgt), ee_stride, _p(obj_tgt),
-      obj_stride, lambda_aux, loss_scale, N, H, Hfc, _p(preds), _p(losses), 1 if backward else 0, _p(dh),
+      _p(h), _p(fc1_w), _p(fc1_b), nh, _parr(heads_w), _parr(heads_b), _iarr(head_size), _iarr(head_kind), farr,
+      _parr(targets), larr, loss_scale, N, H, Hfc, _p(preds), _p(losses), 1 if backward else 0, _p(dh),
       _p(d_fc1_w), _p(d_fc1_b), _parr(d_heads_w) if backward else None, _parr(d_heads_b) if backward else None,
       _p(ws), _stream()), 'geeco_heads_loss_fwd_bwd')
 

@@ -88,9 +88,12 @@ class _PredictorBase:
     self._runner.step()
     torch.cuda.synchronize()
     preds = {k: v.detach().cpu().numpy().squeeze(0).copy() for k, v in self._model.predictions().items()}
-    out = {'cmd_ee': preds['cmd_ee'], 'pos_ee': preds['pos_ee'], 'pos_obj': preds['pos_obj']}
-    # re-map the discrete gripper command: argmax class - 1 (predictor.py:183-189)
-    out['cmd_grp'] = np.asarray([np.argmax(preds['logits_cmd_grp']) - 1], dtype=np.float32)
+    if self._cfg.control_mode == 'cartesian':
+      out = {'cmd_ee': preds['cmd_ee'], 'pos_ee': preds['pos_ee'], 'pos_obj': preds['pos_obj']}
+      # re-map the discrete gripper command: argmax class - 1 (predictor.py:183-189)
+      out['cmd_grp'] = np.asarray([np.argmax(preds['logits_cmd_grp']) - 1], dtype=np.float32)
+    else:                      # velocity mode fetches (predictor.py:157-164)
+      out = {k: preds[k] for k in ('cmd_vel', 'cmd_ee', 'cmd_grp', 'pos_ee', 'pos_obj')}
     return out
 
   def predict(self, rgb_frame, jnt_state):

@@ -100,11 +100,13 @@ int geeco_pad_mid(const float* src, float* dst, int64_t A, int B, int Bd, int C,
 int geeco_state_concat_fwd(const float* const* feats, const int* feat_ch, int nfeat, int jnt_pos,
                            const float* jnt, int64_t jnt_stride, int J, const float* sub_from,
                            int N, int cells, float* state, int64_t state_stride, void* stream);
-/* Scatter d(state) back into d(feat_i), applying the ReLU mask of the encoder's last layer
- * (feats_fwd_i > 0).  dfeats[i] may be NULL to skip.  accumulate != 0 adds into dfeats. */
+/* Scatter scale * d(state) back into d(feat_i), applying the ReLU mask of the encoder's last layer
+ * (feats_fwd_i > 0).  dfeats[i] may be NULL to skip.  accumulate != 0 adds into dfeats.  The
+ * 'residual' target mode (graph.py:369: tgt_feat - feat) calls it with scale = -1 for feat and once
+ * more with feats_fwd = tgt_feat, scale = +1, accumulate over the window. */
 int geeco_state_concat_bwd(const float* dstate, int64_t dstate_stride, const float* const* feats_fwd,
                            float* const* dfeats, const int* feat_ch, int nfeat, int jnt_pos, int J,
-                           int N, int cells, int accumulate, void* stream);
+                           int N, int cells, int accumulate, float scale, void* stream);
 
 /* ---- dense GEMM used by the LSTM gate matmul and its backward (graph.py:217-225) ---------------
  * C[M][N] (ldc) = op(A) op(B) (+ C if accumulate).  ta/tb: 0 = as stored, 1 = transposed.
@@ -128,20 +130,23 @@ int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c
 int geeco_colsum(const float* a, int64_t lda, int M, int N, float* out, int accumulate, void* stream);
 
 /* ---- fc1 + heads + losses, forward and backward in one launch ----------------------------------
- * graph.py:229-259 (fc1 ReLU, linear heads), :452-500 (losses), estimator.py:206-239 (targets,
- * loss composition).  Cartesian control mode:
- *   heads (kernel [Hfc][3], bias[3]) in the order pred_cmd_ee, logits_cmd_grp, pred_aux_ee,
- *   pred_aux_obj;  loss = MSE(cmd_ee) + CE(cmd_grp) + lambda_aux (MSE(pos_ee) + MSE(pos_obj)),
- *   every term a mean over the LOCAL batch N scaled by `loss_scale` (1/world for data parallel).
- * h [N][H]; fc1_w [H][Hfc]; heads_w/heads_b: 4 pointers each; cmd [N][4] (labels['cmd']);
- * ee_tgt/obj_tgt: rows of >= 3 floats at the given strides (features[...][:, -1, :3]).
- * Outputs: preds [N][12] (4 heads x 3), losses[5] = {total, cmd_ee, cmd_grp, pos_ee, pos_obj}
- * (unscaled local means); when `backward` != 0 also dh [N][H] and the gradients d_fc1_w, d_fc1_b,
- * d_heads_w[4], d_heads_b[4] (overwritten).  Single workgroup; requires N <= 1024, H, Hfc <= 256. */
-int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b,
+ * graph.py:229-259 (fc1 ReLU, linear heads), :430-500 (losses), estimator.py:206-239 (targets,
+ * loss composition).  `nheads` <= 5 linear heads [Hfc][size_i] are described by parallel arrays:
+ *   head_kind 0: tf.losses.mean_squared_error against target rows (size_i floats at
+ *                targets[i] + n * target_stride[i]);
+ *   head_kind 1: softmax cross-entropy against one_hot(rint(targets[i][n * stride]) + 1)
+ *                (the gripper command, estimator.py:213-215);
+ *   loss = sum_i head_weight[i] * L_i (cartesian: 1, 1, lambda_aux, lambda_aux; velocity: all 1),
+ *   every L_i a mean over the LOCAL batch N; gradients are scaled by `loss_scale`.
+ * Cartesian mode heads: pred_cmd_ee (MSE vs cmd[:, :3]), logits_cmd_grp (CE vs cmd[:, 3]),
+ * pred_aux_ee, pred_aux_obj (MSE vs features[...][:, -1, :3]).
+ * Outputs: preds [N][sum size_i], losses[1 + nheads] = {total, L_0, ...} (unscaled local means); when
+ * `backward` != 0 also dh [N][H] and d_fc1_w, d_fc1_b, d_heads_w[i], d_heads_b[i] (overwritten).
+ * Single workgroup (in-block MFMA tiles); N <= 4096, sum size_i <= 32. */
+int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b, int nheads,
                              const float* const* heads_w, const float* const* heads_b,
-                             const float* cmd, const float* ee_tgt, int64_t ee_stride,
-                             const float* obj_tgt, int64_t obj_stride, float lambda_aux,
+                             const int* head_size, const int* head_kind, const float* head_weight,
+                             const float* const* targets, const int64_t* target_stride,
                              float loss_scale, int N, int H, int Hfc, float* preds, float* losses,
                              int backward, float* dh, float* d_fc1_w, float* d_fc1_b,
                              float* const* d_heads_w, float* const* d_heads_b, float* ws, void* stream);
