@@ -30,6 +30,7 @@ SIGNATURES = {
     'geeco_dynimg_ws_bytes': (_L, [_I, _L]),
     'geeco_dynimg_fwd': (_I, [_P, _P, _L, _L, _P, _I, _I, _L, _I, _I, _P, _P, _P]),
     'geeco_pack_pixels': (_I, [_P, _L, _P, _L, _I, _L, _I, _I, _I, _P, _P]),
+    'geeco_gather_windows': (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),
     'geeco_conv3x3_fwd': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv3x3_fwd_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_dgrad': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -244,3 +244,44 @@ extern "C" int geeco_pack_pixels(const float* src, int64_t src_sample_stride, co
   GEECO_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- on-device window builder ---------------------------------------------------------------------
+// The reference materialises every K-frame window of an episode on the host (_window_v3,
+// src/data/geeco_gym.py:615-631) and feeds 12.6 MB per sample over PCIe.  Here an episode's frames
+// are uploaded ONCE (RGB as the uint8 values the recorder stored, data_recorder / tfrecord.py:73-74)
+// and each batch's windows are gathered in HBM:  out[n][k][:] = conv(src[starts[n] + k][:]),
+// conv(u8) = float(u8) / 255.0f  (the division of _parse_v4, geeco_gym.py:312, bit-exact).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_windows_kernel(const T* __restrict__ src, const int* __restrict__ starts,
+                                                             int K, long long frame_elems, float divisor,
+                                                             float* __restrict__ out) {
+  const int n = blockIdx.z, k = blockIdx.y;
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= frame_elems) return;
+  const T* s = src + (long long)(starts[n] + k) * frame_elems + i4;
+  float* o = out + ((long long)n * K + k) * frame_elems + i4;
+  if (i4 + 4 <= frame_elems) {
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = divisor != 1.f ? (float)s[j] / divisor : (float)s[j];
+    *reinterpret_cast<f32x4*>(o) = f32x4{e[0], e[1], e[2], e[3]};
+  } else {
+    for (int j = 0; i4 + j < frame_elems; ++j) o[j] = divisor != 1.f ? (float)s[j] / divisor : (float)s[j];
+  }
+}
+
+extern "C" int geeco_gather_windows(const void* src, int src_is_u8, const int* starts_dev, int N, int K,
+                                    int64_t frame_elems, float divisor, float* out, void* stream) {
+  GEECO_CHECK_ARG(src && starts_dev && out, "gather_windows: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && K >= 1 && frame_elems >= 4 && frame_elems % 4 == 0, "gather_windows: bad dims");
+  GEECO_CHECK_ARG(divisor != 0.f, "gather_windows: divisor == 0");
+  dim3 grid((unsigned)cdiv64(frame_elems, 1024), (unsigned)K, (unsigned)N);
+  if (src_is_u8)
+    hipLaunchKernelGGL(gather_windows_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, starts_dev, K, (long long)frame_elems, divisor, out);
+  else
+    hipLaunchKernelGGL(gather_windows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                       starts_dev, K, (long long)frame_elems, divisor, out);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}

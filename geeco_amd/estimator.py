@@ -236,7 +236,7 @@ class Estimator:
   @staticmethod
   def _shard(batch, world, rank):
     feats, labels = batch
-    n = int(next(iter(feats.values())).shape[0])
+    n = int(feats['step'].shape[0]) if 'step' in feats else int(next(iter(feats.values())).shape[0])
     if world == 1:
       return feats, labels, n
     if n % world:
@@ -250,7 +250,16 @@ class Estimator:
     if key in self._specs:
       return self._specs[key]
     dev = self._device()
-    to_dev = lambda d: {k: torch.as_tensor(v).to(dev).contiguous() for k, v in d.items()} if d is not None else None
+    def to_dev(d):
+      if d is None:
+        return None
+      out = {}
+      for k, v in d.items():
+        if hasattr(v, 'materialize_into'):      # input_fn.DeviceWindows: windows are gathered in HBM
+          out[k] = torch.empty(tuple(v.shape), dtype=torch.float32, device=dev)
+        else:
+          out[k] = torch.as_tensor(v).to(dev).contiguous()
+      return out
     fbuf, lbuf = to_dev(feats), to_dev(labels)
     params = dict(self.params)
     params['_variable_store'] = self._store
@@ -282,7 +291,11 @@ class Estimator:
     if batch is None:
       return
     for k, buf in bufs.items():
-      buf.copy_(torch.as_tensor(batch[k]), non_blocking=True)
+      src = batch[k]
+      if hasattr(src, 'materialize_into'):
+        src.materialize_into(buf.view((len(src), src.K) + src.frame_shape))
+      else:
+        buf.copy_(torch.as_tensor(src), non_blocking=True)
 
   # -- public API --------------------------------------------------------------------------------
   def latest_checkpoint(self):

@@ -50,9 +50,11 @@ def collect_tfrecords(dataset_dir, split_name, mode):
   return [os.path.join(record_dir, fn) for fn in names if fn.endswith('.tfrecord.zlib')]
 
 
-def load_episode(path, meta, fetch_target):
+def load_episode(path, meta, fetch_target, raw_rgb=False):
   """One episode -> dict of per-frame arrays after _parse_v4 + _preprocess_states_v4 +
-  _preprocess_targets_v3 (i.e. the last frame already dropped: T = episode_length - 1)."""
+  _preprocess_targets_v3 (i.e. the last frame already dropped: T = episode_length - 1).
+  ``raw_rgb``: keep 'rgb' / 'target_rgb' as the recorded 0..255 values (the device path divides by
+  255 on the GPU)."""
   H, W = meta.img_height, meta.img_width
   payload = next(iter(tfrecord.read_records(path, 'zlib')))
   _, fl = tfrecord.parse_sequence_example(payload)
@@ -66,7 +68,7 @@ def load_episode(path, meta, fetch_target):
   ex = {
       'step': stack('step', (), np.int64),
       'ts': stack('ts', ()),
-      'rgb': stack('rgb', (H, W, 3)) / np.float32(255.0),           # :312 RGB recorded as uint8 0..255
+      'rgb': stack('rgb', (H, W, 3)) / np.float32(1.0 if raw_rgb else 255.0),   # :312 RGB recorded as uint8 0..255
       'depth': stack('depth', (H, W, 1)),
       'cmd': stack('cmd', (meta.dim_cmd,)),
       'ctrl': stack('ctrl', (meta.dim_ctrl,)),
@@ -95,10 +97,104 @@ _FEATURE_KEYS = ['step', 'ts', 'rgb', 'depth', 'jnt_state', 'vel_state', 'ee_sta
 _LABEL_KEYS = ['cmd', 'ctrl', 'vel_target', 'ee_target', 'grp_target']
 
 
-def episode_windows(ex, window_size, starts):
-  """(features, labels) for the windows beginning at ``starts`` (_window_v3 :615-631, _prepare_v4 :373-399)."""
+class DeviceWindows:
+  """A batch of K-frame windows that lives in HBM as (episode frames, start indices) segments.
+
+  Stands in for a dense [n, K, *frame_shape] float32 array in the features dict: the Estimator
+  materialises it straight into the model's static input buffer with geeco_gather_windows (frames
+  were uploaded once per episode, RGB as uint8), so no window ever crosses PCIe."""
+
+  def __init__(self, K, frame_shape, divisor, squeeze_k=False):
+    self.K, self.frame_shape, self.divisor, self.squeeze_k = K, tuple(frame_shape), float(divisor), squeeze_k
+    self.segments = []      # (device tensor [T, frame_elems], np.int32 starts)
+    self.n = 0
+
+  def add(self, frames_dev, starts):
+    starts = np.asarray(starts, np.int32)
+    self.segments.append((frames_dev, starts))
+    self.n += len(starts)
+
+  @property
+  def shape(self):
+    return (self.n,) + (() if self.squeeze_k else (self.K,)) + self.frame_shape
+
+  def __len__(self):
+    return self.n
+
+  @staticmethod
+  def concat(a, b):
+    out = DeviceWindows(a.K, a.frame_shape, a.divisor, a.squeeze_k)
+    out.segments = a.segments + b.segments
+    out.n = a.n + b.n
+    return out
+
+  def materialize_into(self, out):
+    import torch
+    from . import ops
+    fe = int(np.prod(self.frame_shape))
+    off = 0
+    for frames_dev, starts in self.segments:
+      n = len(starts)
+      st = torch.as_tensor(starts, device=out.device)
+      ops.gather_windows_into(out[off:off + n], frames_dev, st, n, self.K, fe, self.divisor)
+      off += n
+
+  def numpy(self):
+    """Dense host copy (tests / debugging)."""
+    import torch
+    dev = self.segments[0][0].device
+    out = torch.empty((self.n, self.K) + self.frame_shape, dtype=torch.float32, device=dev)
+    self.materialize_into(out)
+    torch.cuda.synchronize()
+    arr = out.cpu().numpy()
+    return arr[:, 0] if self.squeeze_k else arr
+
+
+def _concat_feature(a, b):
+  if isinstance(a, DeviceWindows):
+    return DeviceWindows.concat(a, b)
+  return np.concatenate([a, b], axis=0)
+
+
+def episode_to_device(ex, device):
+  """Uploads the image streams of one episode: RGB as uint8 when the recorded values are integral
+  (they are: the recorder stores uint8 frames as float lists), depth as float32."""
+  import torch
+  T = ex['rgb'].shape[0]
+  dev = {}
+  rgb = ex['rgb'].reshape(T, -1)
+  as_u8 = bool(np.all(rgb == np.rint(rgb)) and rgb.min() >= 0 and rgb.max() <= 255)
+  dev['rgb'] = torch.as_tensor(rgb.astype(np.uint8) if as_u8 else rgb / np.float32(255.0)).to(device)
+  dev['rgb_div'] = 255.0 if as_u8 else 1.0
+  dev['depth'] = torch.as_tensor(np.ascontiguousarray(ex['depth'].reshape(T, -1))).to(device)
+  if 'target_rgb' in ex:
+    t = ex['target_rgb'].reshape(1, -1)
+    t_u8 = bool(np.all(t == np.rint(t)) and t.min() >= 0 and t.max() <= 255)
+    dev['target_rgb'] = torch.as_tensor(t.astype(np.uint8) if t_u8 else t / np.float32(255.0)).to(device)
+    dev['target_rgb_div'] = 255.0 if t_u8 else 1.0
+    dev['target_depth'] = torch.as_tensor(np.ascontiguousarray(ex['target_depth'].reshape(1, -1))).to(device)
+  return dev
+
+
+def episode_windows(ex, window_size, starts, dev=None):
+  """(features, labels) for the windows beginning at ``starts`` (_window_v3 :615-631, _prepare_v4 :373-399).
+  With ``dev`` (episode_to_device) the image features are DeviceWindows instead of host arrays."""
   K = window_size
   idx = np.asarray(starts)[:, None] + np.arange(K)[None, :]
+  if dev is not None:
+    feats = {k: ex[k][idx] for k in _FEATURE_KEYS if k not in ('rgb', 'depth')}
+    H, W = ex['rgb'].shape[1:3]
+    for key, shp, div in (('rgb', (H, W, 3), dev['rgb_div']), ('depth', (H, W, 1), 1.0)):
+      dw = DeviceWindows(K, shp, div)
+      dw.add(dev[key], starts)
+      feats[key] = dw
+    if 'target_rgb' in dev:
+      for key, shp, div in (('target_rgb', (H, W, 3), dev['target_rgb_div']), ('target_depth', (H, W, 1), 1.0)):
+        dw = DeviceWindows(1, shp, div, squeeze_k=True)
+        dw.add(dev[key], np.zeros(len(starts), np.int32))
+        feats[key] = dw
+    last = np.asarray(starts) + K - 1
+    return feats, {k: ex[k][last] for k in _LABEL_KEYS}
   feats = {k: ex[k][idx] for k in _FEATURE_KEYS}
   if 'target_rgb' in ex:
     n = len(starts)
@@ -138,10 +234,11 @@ class _Prefetcher:
 
 def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size=4, fetch_target=False,
                        shuffle_buffer=128, batch_size=1, num_epochs=1, num_threads=4, prefetch_size=4, seed=None,
-                       shard=None):
+                       shard=None, device=None):
   """Same signature as the reference's pickplace_input_fn (geeco_gym.py:234-279).  Returns an iterable of
   (features, labels) numpy batches.  ``shard = (rank, world)`` makes each data-parallel rank read a
-  disjoint, rank-strided subset of the episodes."""
+  disjoint, rank-strided subset of the episodes.  ``device`` (e.g. 'cuda'): upload every episode's
+  frames once and hand out image features as DeviceWindows (windows are gathered in HBM)."""
   if encoding != 'v4':
     # v1-v3 are dead code in the reference (undefined PickAndPlaceEncodingV1/2/3 -> NameError)
     raise KeyError(encoding)
@@ -160,17 +257,18 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
     carry_f, carry_l = None, None   # windows left over from the previous episode (batch() spans episodes)
     for _ in range(num_epochs):
       for path in paths:
-        ex = load_episode(path, meta, fetch_target)
+        ex = load_episode(path, meta, fetch_target, raw_rgb=device is not None)
+        dev = episode_to_device(ex, device) if device is not None else None
         T = ex['step'].shape[0]
         nwin = T - K + 1
         pos = 0
         while pos < nwin:
           need = batch_size - (0 if carry_f is None else len(carry_f['step']))
           take = min(need, nwin - pos)
-          f, l = episode_windows(ex, K, np.arange(pos, pos + take))
+          f, l = episode_windows(ex, K, np.arange(pos, pos + take), dev)
           pos += take
           if carry_f is not None:
-            f = {k: np.concatenate([carry_f[k], f[k]], axis=0) for k in f}
+            f = {k: _concat_feature(carry_f[k], f[k]) for k in f}
             l = {k: np.concatenate([carry_l[k], l[k]], axis=0) for k in l}
             carry_f = carry_l = None
           if len(f['step']) == batch_size:

@@ -94,6 +94,14 @@ def pack_pixels_into(dst, src, src_sample_stride, N, HW, C1, Cpad, src2=None, sr
                                  _p(dst), _stream()), 'geeco_pack_pixels')
 
 
+def gather_windows_into(out, src, starts_dev, N, K, frame_elems, divisor=1.0):
+  """out[n][k] <- src[starts[n] + k] / divisor for an episode resident in HBM (uint8 or float32 frames)."""
+  assert src.is_cuda and src.dtype in (torch.uint8, torch.float32) and starts_dev.dtype == torch.int32
+  check(_lib().geeco_gather_windows(ctypes.c_void_p(src.data_ptr()), 1 if src.dtype == torch.uint8 else 0,
+                                    ctypes.c_void_p(starts_dev.data_ptr()), N, K, frame_elems, float(divisor), _p(out),
+                                    _stream()), 'geeco_gather_windows')
+
+
 # --------------------------------------------------------------------------------------------
 # conv encoder
 # --------------------------------------------------------------------------------------------

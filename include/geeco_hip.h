@@ -52,6 +52,13 @@ int geeco_pack_pixels(const float* src, int64_t src_sample_stride, const float* 
                       int64_t src2_sample_stride, int N, int64_t HW, int C1, int C2, int Cpad,
                       float* dst, void* stream);
 
+/* On-device window builder (replaces the host-side _window_v3 of src/data/geeco_gym.py:615-631):
+ * out[n][k][:] = float(src[starts_dev[n] + k][:]) / divisor.  `src` = an episode's frames resident in
+ * HBM ([T][frame_elems], uint8 if src_is_u8 else float32); `starts_dev` = N int32 frame indices on the
+ * device; divisor 255 reproduces `rgb /= 255.0` (geeco_gym.py:312) bit-exactly, 1 copies. */
+int geeco_gather_windows(const void* src, int src_is_u8, const int* starts_dev, int N, int K,
+                         int64_t frame_elems, float divisor, float* out, void* stream);
+
 /* ---- conv encoder: graph.py:76-115 (tf.layers.conv2d 3x3, padding='SAME', bias, ReLU) ----------
  * x [G][N][H][W][Cin], w [G][3][3][Cin][Cout] (HWIO), b [G][Cout], y [G][N][Ho][Wo][Cout],
  * Ho = ceil(H/stride); TF SAME padding (pad_before = pad_total/2, i.e. 0 top/left for stride 2 on

@@ -157,7 +157,9 @@ def main(args):
         dataset_dir=args.dataset_dir, split_name=args.split_name, mode=estimator_mode, encoding=args.data_encoding,
         window_size=e2evmc_config.window_size, fetch_target=(args.goal_condition == 'target'),
         shuffle_buffer=args.shuffle_buffer, batch_size=args.batch_size, num_epochs=1, num_threads=args.num_threads,
-        prefetch_size=args.prefetch_size, seed=None)
+        prefetch_size=args.prefetch_size, seed=None,
+        # episodes are uploaded once and windows are gathered in HBM unless GEECO_HOST_WINDOWS is set
+        device=None if os.environ.get('GEECO_HOST_WINDOWS') else 'cuda')
   train_input = lambda: input_fn(estimator_mode='train')
   eval_input = lambda: input_fn(estimator_mode='eval')
 

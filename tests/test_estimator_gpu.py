@@ -88,3 +88,38 @@ def test_train_script_synthetic(dev, tmp_path):
   assert os.path.exists(os.path.join(info['dir'], name + '.pt'))
   assert os.path.exists(os.path.join(info['dir'], 'checkpoint'))
   assert any(fn.endswith('runcmd.json') for fn in os.listdir(info['dir']))
+
+
+def test_device_windows_match_host_pipeline(dev, tmp_path):
+  """pickplace_input_fn(device='cuda') (episode uploaded once as uint8, windows gathered in HBM by
+  geeco_gather_windows) yields bit-identical batches to the host pipeline, and the Estimator trains from it."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_host_logic_cpu import _make_dataset
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import DeviceWindows, pickplace_input_fn
+  root = str(tmp_path / 'ds')
+  os.makedirs(root)
+  _make_dataset(root, n_eps=2, T=9, H=136, W=136)
+  kw = dict(window_size=3, fetch_target=True, batch_size=4)
+  host = list(pickplace_input_fn(root, 'default', 'eval', **kw))
+  devb = list(pickplace_input_fn(root, 'default', 'eval', device='cuda', **kw))
+  assert len(host) == len(devb) == 3
+  for (fh, lh), (fd, ld) in zip(host, devb):
+    for k in fh:
+      got = fd[k].numpy() if isinstance(fd[k], DeviceWindows) else fd[k]
+      assert isinstance(fd[k], DeviceWindows) == (k in ('rgb', 'depth', 'target_rgb', 'target_depth')), k
+      np.testing.assert_array_equal(got, fh[k], err_msg=k)          # incl. the /255.0 of geeco_gym.py:312
+    for k in lh:
+      np.testing.assert_array_equal(ld[k], lh[k])
+  from geeco_amd.params import create_e2evmc_config
+  params = {'e2evmc_config': create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136,
+                                                       img_width=136, batch_size=4)), 'log_steps': 1, 'debug': False}
+  res = []
+  for device in (None, 'cuda'):
+    md = str(tmp_path / ('m_%s' % device))
+    e = est.Estimator(est.goal_e2evmc_model_fn, md, est.RunConfig(), params)
+    e.train(input_fn=lambda: pickplace_input_fn(root, 'default', 'train', seed=3, device=device, **kw))
+    res.append(e.evaluate(input_fn=lambda: pickplace_input_fn(root, 'default', 'eval', device=device, **kw)))
+  assert res[0]['global_step'] == res[1]['global_step'] == 3
+  np.testing.assert_allclose(res[0]['loss'], res[1]['loss'], rtol=1e-6)
