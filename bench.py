@@ -182,7 +182,10 @@ def main():
   synthetic_batch(model, 1234 + rank)
 
   log('model built: %d parameters, batch %d/GPU, world %d' % (model.store.count_parameters(), args.batch, world))
-  runner = TrainStepRunner(model, use_graph=not args.no_graph, warmup=min(2, max(args.warmup, 0)))
+  runner = TrainStepRunner(model, use_graph=not args.no_graph, warmup=2)
+  runner.prepare()     # 2 eager steps + hipGraph capture, outside warm-up and timed region
+  torch.cuda.synchronize()
+  log('graphs captured' if not args.no_graph else 'eager mode')
   for i in range(args.warmup):
     runner.step()
     if i < 3:
@@ -228,7 +231,7 @@ def main():
       if not args.skip_cpu:
         out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)
-  if world > 1:
+  if torch.distributed.is_available() and torch.distributed.is_initialized():
     torch.distributed.destroy_process_group()
 
 

@@ -25,7 +25,8 @@ def rank() -> int:
 def init_from_env(backend=None):
   """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1."""
   ws = int(os.environ.get('WORLD_SIZE', '1'))
-  if ws <= 1 or dist.is_initialized():
+  force = os.environ.get('GEECO_FORCE_DIST') and 'RANK' in os.environ      # exercise the RCCL path with one rank
+  if (ws <= 1 and not force) or dist.is_initialized():
     return world_size()
   os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
   os.environ.setdefault('MASTER_PORT', '29500')

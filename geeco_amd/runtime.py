@@ -38,6 +38,12 @@ class TrainStepRunner:
       self.model.apply_gradients()
     self._ga, self._gb = ga, gb
 
+  def prepare(self):
+    """Untimed set-up for benchmarks: run the eager warm-up steps and capture the graphs now, so that
+    no later call pays for the capture."""
+    while self.use_graph and self._ga is None:
+      self.step()
+
   def step(self):
     """One optimiser step on the batch currently in ``model.inputs``."""
     if self.use_graph and self._ga is None and self._calls >= self._warm:
