@@ -834,12 +834,16 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
 #pragma unroll
   for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + i * 16 + 4 * q);
   __syncthreads();
-  // wave w: rows 2w, 2w+1; 2 column halves => 4 strips of 16 pixels
+  // wave w: rows 2w, 2w+1; 2 column halves => 4 strips of 16 pixels.  The 16 x 32 output strip is 2 KB
+  // contiguous in NHWC memory: it is transposed through LDS so that each store instruction writes 1 KB
+  // of consecutive bytes (lane l -> pixel l / 8 (+8), channel quad l % 8) instead of 16 separate 64 B pieces.
+  __shared__ __attribute__((aligned(16))) float sO[4][16 * 36];   // per wave: [pixel][32 + 4 pad]
+  float* so = sO[wid];
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
-    const int oyl = 2 * wid + (st >> 1), oxl = 16 * (st & 1) + r;
+    const int oyl = 2 * wid + (st >> 1), oxl0 = 16 * (st & 1);
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const float* base = sX + ((oyl * HW_ + oxl) << 2) + q;
+    const float* base = sX + ((oyl * HW_ + oxl0 + r) << 2) + q;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int ky = tp / 3, kx = tp - ky * 3;
@@ -847,17 +851,23 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tp][i], xv, acc[i], 0, 0, 0);
     }
-    const int oy = y0 + oyl, ox = x0 + oxl;
-    if (oy < p.H && ox < p.W) {
-      float* yo = p.y + (long long)g * p.gs_y + (((long long)n * p.H + oy) * p.W + ox) * 32 + 4 * q;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x4 v = acc[i] + bias_r[i];
-        if (p.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<f32x4*>(yo + i * 16) = v;
+    for (int i = 0; i < 2; ++i) {
+      f32x4 v = acc[i] + bias_r[i];
+      if (p.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
+      *reinterpret_cast<f32x4*>(so + r * 36 + i * 16 + 4 * q) = v;      // lane owns pixel r, channels 16 i + 4 q
+    }
+    // same-wave LDS round trip: the compiler's lgkmcnt wait orders the reads behind the writes
+    const int oy = y0 + oyl;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int px = 8 * h + (lane >> 3), c4 = lane & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(so + px * 36 + c4 * 4);
+      const int ox = x0 + oxl0 + px;
+      if (oy < p.H && ox < p.W)
+        *reinterpret_cast<f32x4*>(p.y + (long long)g * p.gs_y + (((long long)n * p.H + oy) * p.W + ox) * 32 + c4 * 4) = v;
     }
   }
 }
