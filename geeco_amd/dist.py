@@ -44,6 +44,7 @@ def broadcast_variables(store, src=0):
     return
   for t in (store.params, store.adam_m, store.adam_v, store.global_step):
     dist.broadcast(t, src=src)
+  store.version += 1
 
 
 def allreduce_gradients(grads: torch.Tensor):

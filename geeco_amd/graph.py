@@ -68,6 +68,14 @@ class ConvEncoderStack:
     self.store, self.scopes, self.G, self.Nf = store, list(scopes), len(scopes), Nf
     self.H, self.W, self.Cin = H, W, Cin
     self.two_streams = os.environ.get('GEECO_ONE_STREAM') is None
+    self.derived_version = -1
+    # Only the FIRST training stack built on a store may rely on the post-Adam refresh of its derived
+    # weight copies; eval / predict stacks and any later training stack (e.g. the model built for a
+    # ragged final batch) share the parameters but not the copies, so they re-derive on every forward.
+    self.lazy_refresh = (training and getattr(store, 'primary_stack', None) is None and
+                         os.environ.get('GEECO_EAGER_DERIVED') is None)
+    if self.lazy_refresh:
+      store.primary_stack = self
     self.Cpad = -(-Cin // 4) * 4
     self.training = training
     dev = store.device
@@ -139,14 +147,29 @@ class ConvEncoderStack:
   def dfeatures(self):
     return self.dz[7]
 
+  def refresh_derived(self):
+    """Re-derives the weight copies the kernels read (conv1's kernel padded to 4 input channels; the
+    per-tap transposed kernels of the dgrad GEMMs).  Training calls it right after Adam (inside the
+    Adam hipGraph), so the forward / backward graphs contain no pad or transpose launches."""
+    G = self.G
+    if self.pad1:
+      L = self.layers[0]
+      for g in range(G):
+        ops.pad_mid_into(self.w1p[g], self._w(0, g), 9, self.Cin, self.Cpad, L['Cout'])
+    if self.training:
+      for l in range(1, 8):
+        L, wt = self.layers[l], self.wt[l]
+        ops.transpose_hwio_into(wt, self._w(l), G, self.gs_p, wt[0].numel(), L['Cin'], L['Cout'])
+    self.derived_version = self.store.version
+
   def forward(self):
     G, Nf = self.G, self.Nf
+    if not self.lazy_refresh or self.derived_version != self.store.version:
+      self.refresh_derived()
     for l, L in enumerate(self.layers):
       x = self.x_in if l == 0 else self.acts[l - 1]
       y = self.acts[l]
       if l == 0 and self.pad1:
-        for g in range(G):
-          ops.pad_mid_into(self.w1p[g], self._w(0, g), 9, self.Cin, self.Cpad, L['Cout'])
         w, gs_w = self.w1p, self.w1p[0].numel()
       else:
         w, gs_w = self._w(l), self.gs_p
@@ -177,7 +200,6 @@ class ConvEncoderStack:
       if l == 0:
         break   # conv1's input is data: no dgrad
       wt = self.wt[l]
-      ops.transpose_hwio_into(wt, self._w(l), G, self.gs_p, wt[0].numel(), L['Cin'], L['Cout'])
       dx = self.dz[l - 1]
       ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
                              L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
@@ -369,6 +391,9 @@ class _ModelBase:
     ops.adam_prepare(s.global_step, float(cfg.lr), self.scal)
     ops.adam_tf(s.params, s.grads, s.adam_m, s.adam_v, s.size, self.scal, grad_scale=1.0 / self.world,
                 l2=float(cfg.l2_regularizer))
+    # weights changed: re-derive the padded / transposed copies now (the version stamp is unchanged, so
+    # the next forward, eager or replayed, launches no pad / transpose kernels)
+    self.enc.refresh_derived()
 
   def predictions(self):
     """estimator.py:48-61 / 183-197."""

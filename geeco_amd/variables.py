@@ -71,6 +71,7 @@ class VariableStore:
     self.adam_m = torch.zeros(self.size, dtype=torch.float32, device=self.device)
     self.adam_v = torch.zeros(self.size, dtype=torch.float32, device=self.device)
     self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+    self.version = 0      # bumped whenever the parameters are (re)written from the host side
 
   # -- views ------------------------------------------------------------------------------
   def _view(self, arena, name):
@@ -103,10 +104,12 @@ class VariableStore:
         lim = math.sqrt(6.0 / (fan_in + fan_out))
         val = rng.uniform(-lim, lim, size=shp).astype(np.float32)
       self.var(name).copy_(torch.from_numpy(val))
+    self.version += 1
 
   def load_numpy(self, values: dict):
     for name in self.shapes:
       self.var(name).copy_(torch.from_numpy(np.ascontiguousarray(values[name], dtype=np.float32)))
+    self.version += 1
 
   def to_numpy(self, which='params'):
     arena = {'params': self.params, 'grads': self.grads, 'adam_m': self.adam_m, 'adam_v': self.adam_v}[which]
@@ -131,3 +134,4 @@ class VariableStore:
     self.adam_m.copy_(sd['adam_m'])
     self.adam_v.copy_(sd['adam_v'])
     self.global_step.copy_(sd['global_step'])
+    self.version += 1
