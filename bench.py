@@ -105,10 +105,26 @@ def roofline_conv2(model, iters):
   ms = time_region(launch, iters)
   macs = enc.G * enc.Nf * L['Ho'] * L['Wo'] * L['Cout'] * 9 * L['Cin']
   achieved = 2.0 * macs / (ms * 1e-3) / 1e12
-  return {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<128,48,16,4,1> (conv2 forward, %d frames)' % (enc.G * enc.Nf),
+  halo = os.environ.get('GEECO_NO_HALO') is None and L['H'] % 2 == 0 and L['W'] % 2 == 0
+  kname = 'conv_s2_halo_fwd_kernel<32,48>' if halo else 'conv_gemm_kernel<128,48,16,4,1,true>'
+  return {'bound': 'mfma', 'kernel': '%s (conv2 forward, %d frames)' % (kname, enc.G * enc.Nf),
           'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-          'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+          'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': recorded_traffic(kname),
           'avg_launch_ms': round(ms, 4), 'flop_per_launch': 2 * macs}
+
+
+def recorded_traffic(kname):
+  """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+  (profiles/r01/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on
+  gfx950, + WRITE_SIZE; separate --pmc passes).  PMC counters cannot be read from inside this process,
+  so this is the recorded measurement of the same kernel and shape, or null when there is none."""
+  path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_roofline_kernel.json')
+  try:
+    with open(path) as f:
+      rec = json.load(f)
+    return rec['traffic_bytes'] if rec.get('kernel') == kname else None
+  except (OSError, ValueError, KeyError):
+    return None
 
 
 def encoder_forward_tflops(model, iters, channels):

@@ -378,9 +378,11 @@ __device__ __forceinline__ T sel5(T const (&a)[GEECO_MAX_HEADS], int i) {
 
 // C[M][N] = A[M][K] B[K][N] inside ONE workgroup on MFMA 16x16x4: waves take 16x16 output tiles
 // round-robin; operands are fetched straight from global memory (everything is L2-resident and
-// tiny), 2 loads per MFMA per lane.  a_at(i, k), b_at(k, j) return elements; st(i, j, v) stores.
-template <class FA, class FB, class FS>
-__device__ __forceinline__ void block_mfma_gemm(int M, int N, int K, FA a_at, FB b_at, FS st) {
+// tiny), 2 loads per MFMA per lane.  A(i, k) = a[i * a_rs + k * a_ks], B(k, j) = b[k * b_ks + j * b_cs]
+// (pointer + strides, so the K loop is pure pointer bumps); st(i, j, v) stores.
+template <class FS>
+__device__ __forceinline__ void block_mfma_gemm(int M, int N, int K, const float* a, int a_rs, int a_ks,
+                                                const float* b, int b_ks, int b_cs, FS st) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int tn = (N + 15) >> 4, nt = ((M + 15) >> 4) * tn;
@@ -388,13 +390,15 @@ __device__ __forceinline__ void block_mfma_gemm(int M, int N, int K, FA a_at, FB
     const int ti = t / tn, tj = t - ti * tn;
     const int i = ti * 16 + r, j = tj * 16 + r;
     const bool iv = i < M, jv = j < N;
+    const float* ap = a + (long long)(iv ? i : 0) * a_rs + q * a_ks;
+    const float* bp = b + (long long)(jv ? j : 0) * b_cs + q * b_ks;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
     for (int k0 = 0; k0 < K; k0 += 4) {
-      const int k = k0 + q;
-      const float a = (iv && k < K) ? a_at(i, k) : 0.f;
-      const float b = (jv && k < K) ? b_at(k, j) : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      const bool kv = k0 + q < K;
+      const float av = (iv && kv) ? ap[(long long)k0 * a_ks] : 0.f;
+      const float bv = (jv && kv) ? bp[(long long)k0 * b_ks] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
     const float e[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
@@ -409,29 +413,31 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   const int tid = threadIdx.x, NT = 1024;
   const int N = p.N, H = p.H, F = p.Hfc, OT = p.OT;
   __shared__ float s_red[16][GEECO_MAX_HEADS];
-  auto head_of = [&](int o) {
+  __shared__ float s_hb[32];
+  __shared__ int s_hd[32], s_hc[32];
+  float* whm = p.dpred + (long long)N * OT;     // ws: [OT][F] = the head kernels side by side, transposed
+  // P0: per-output-column tables and the packed [OT][F] head matrix
+  if (tid < OT) {
     int hd = 0;
 #pragma unroll
     for (int k = 1; k < GEECO_MAX_HEADS; ++k)
-      if (k < p.nheads && o >= p.off[k]) hd = k;
-    return hd;
-  };
-  // element (f, o) of the [F][OT] matrix formed by the head kernels [F][size_h]
-  auto head_w = [&](int f, int o) -> float {
-    const int hd = head_of(o);
-    return sel5(p.hw, hd)[f * sel5(p.size, hd) + (o - sel5(p.off, hd))];
-  };
+      if (k < p.nheads && tid >= p.off[k]) hd = k;
+    s_hd[tid] = hd;
+    s_hc[tid] = tid - sel5(p.off, hd);
+    s_hb[tid] = sel5(p.hb, hd)[tid - sel5(p.off, hd)];
+  }
+  __syncthreads();
+  for (int e = tid; e < OT * F; e += NT) {
+    const int o = e / F, f = e - o * F;
+    const int hd = s_hd[o];
+    whm[e] = sel5(p.hw, hd)[f * sel5(p.size, hd) + s_hc[o]];
+  }
   // P1: a1 = relu(h W1 + b1)                                   graph.py:229-230
-  block_mfma_gemm(N, F, H, [&](int n, int k) { return p.h[n * H + k]; },
-                  [&](int k, int j) { return p.fc1_w[k * F + j]; },
+  block_mfma_gemm(N, F, H, p.h, H, 1, p.fc1_w, F, 1,
                   [&](int n, int j, float v) { p.a1[n * F + j] = fmaxf(v + p.fc1_b[j], 0.f); });
   __syncthreads();
   // P2: preds[n][sum of head sizes]                             graph.py:233-259
-  block_mfma_gemm(N, OT, F, [&](int n, int k) { return p.a1[n * F + k]; }, head_w,
-                  [&](int n, int o, float v) {
-                    const int hd = head_of(o);
-                    p.preds[n * OT + o] = v + sel5(p.hb, hd)[o - sel5(p.off, hd)];
-                  });
+  block_mfma_gemm(N, OT, F, p.a1, F, 1, whm, 1, F, [&](int n, int o, float v) { p.preds[n * OT + o] = v + s_hb[o]; });
   __syncthreads();
   // P3: losses and d(loss)/d(pred)           graph.py:430-500, estimator.py:206-239
   //   kind 0: tf.losses.mean_squared_error (mean over N*size); kind 1: softmax cross-entropy against
@@ -489,39 +495,31 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   if (!p.backward) return;
   __syncthreads();
   // P4: head gradients  d_hw[f][o] = sum_n a1[n][f] dpred[n][o];  da1 = (dpred Wh^T) * relu'
-  block_mfma_gemm(F, OT, N, [&](int f, int n) { return p.a1[n * F + f]; },
-                  [&](int n, int o) { return p.dpred[n * OT + o]; },
-                  [&](int f, int o, float v) {
-                    const int hd = head_of(o);
-                    sel5(p.dhw, hd)[f * sel5(p.size, hd) + (o - sel5(p.off, hd))] = v;
-                  });
+  block_mfma_gemm(F, OT, N, p.a1, 1, F, p.dpred, OT, 1, [&](int f, int o, float v) {
+    const int hd = s_hd[o];
+    sel5(p.dhw, hd)[f * sel5(p.size, hd) + s_hc[o]] = v;
+  });
   for (int o = tid; o < OT; o += NT) {
     float sum = 0.f;
     for (int n = 0; n < N; ++n) sum += p.dpred[n * OT + o];
-    const int hd = head_of(o);
-    sel5(p.dhb, hd)[o - sel5(p.off, hd)] = sum;
+    sel5(p.dhb, s_hd[o])[s_hc[o]] = sum;
   }
-  block_mfma_gemm(N, F, OT, [&](int n, int o) { return p.dpred[n * OT + o]; },
-                  [&](int o, int f) { return head_w(f, o); },
+  block_mfma_gemm(N, F, OT, p.dpred, OT, 1, whm, F, 1,
                   [&](int n, int f, float v) { p.da1[n * F + f] = p.a1[n * F + f] > 0.f ? v : 0.f; });
   __syncthreads();
   // P5: fc1 gradients and d(h)
-  block_mfma_gemm(H, F, N, [&](int k, int n) { return p.h[n * H + k]; },
-                  [&](int n, int j) { return p.da1[n * F + j]; },
-                  [&](int k, int j, float v) { p.d_fc1_w[k * F + j] = v; });
+  block_mfma_gemm(H, F, N, p.h, 1, H, p.da1, F, 1, [&](int k, int j, float v) { p.d_fc1_w[k * F + j] = v; });
   for (int j = tid; j < F; j += NT) {
     float sum = 0.f;
     for (int n = 0; n < N; ++n) sum += p.da1[n * F + j];
     p.d_fc1_b[j] = sum;
   }
-  block_mfma_gemm(N, H, F, [&](int n, int j) { return p.da1[n * F + j]; },
-                  [&](int j, int k) { return p.fc1_w[k * F + j]; },
-                  [&](int n, int k, float v) { p.dh[n * H + k] = v; });
+  block_mfma_gemm(N, H, F, p.da1, F, 1, p.fc1_w, 1, F, [&](int n, int k, float v) { p.dh[n * H + k] = v; });
 }
 
 extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {
   (void)H;
-  return ((int64_t)2 * N * Hfc + (int64_t)N * 32) * 4;
+  return ((int64_t)2 * N * Hfc + (int64_t)N * 32 + (int64_t)32 * Hfc) * 4;
 }
 
 extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b, int nheads,
