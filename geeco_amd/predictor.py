@@ -24,6 +24,19 @@ from .utils import load_model_config
 TOL_FRAME_RANGE = 1e-6  # tolerance for value range of fed frames (predictor.py:18)
 
 
+def _latest_tf_bundle(model_dir):
+  """'<model_dir>/model.ckpt-<step>' named by a TF ``checkpoint`` file whose bundle (.index) exists."""
+  import re
+  index = os.path.join(model_dir, 'checkpoint')
+  if not os.path.exists(index):
+    return None
+  m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', open(index).read())
+  if not m:
+    return None
+  path = os.path.join(model_dir, os.path.basename(m.group(1)))
+  return path if os.path.exists(path + '.index') else None
+
+
 class _PredictorBase:
   _goal = False
 
@@ -40,9 +53,15 @@ class _PredictorBase:
     ctor = graph.GoalE2EVMC if self._goal else graph.E2EVMC
     self._model = ctor(self._cfg, 1, dev, training=False)
     ckpt = os.path.join(model_dir, checkpoint_name) if checkpoint_name else est.latest_checkpoint(model_dir)
+    if ckpt is None and not checkpoint_name:
+      ckpt = _latest_tf_bundle(model_dir)
     if ckpt is None:
       raise FileNotFoundError('no checkpoint in %s' % model_dir)
-    est.load_checkpoint(self._model.store, ckpt)
+    if os.path.exists(ckpt + '.pt'):
+      est.load_checkpoint(self._model.store, ckpt)
+    else:     # a TensorFlow-1.15 tensor bundle (e.g. the published geeco_models_icra21 weights)
+      from . import tf_checkpoint
+      tf_checkpoint.import_checkpoint(self._model.store, ckpt, load_optimizer=False)
     print('>>> Restored model parameters from %s' % (ckpt,))
     self._runner = EvalStepRunner(self._model, use_graph=True, warmup=1)
     self._buffer_size = self._cfg.window_size

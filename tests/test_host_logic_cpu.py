@@ -171,3 +171,42 @@ def test_estimator_refuses_cpu(tmp_path):
                     {'e2evmc_config': create_e2evmc_config(dict(img_height=136, img_width=136)), 'log_steps': 1})
   with pytest.raises(RuntimeError, match='no CPU fallback'):
     e.train(input_fn=synthetic_batches(2, 4, 1, (136, 136), 3, False))
+
+
+def test_tf_checkpoint_bundle_roundtrip(tmp_path):
+  """TF-1.15 tensor-bundle writer -> reader (multi-block index, checksums, dtype/shape/offset fields) and
+  the mapping to / from the variable store.  (Not verified against a TF-written file: none exists here.)"""
+  import struct
+  from geeco_amd import tf_checkpoint as C
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.variables import VariableStore
+  st = VariableStore(model_variable_shapes(create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff')), True), 'cpu')
+  st.initialize(2)
+  st.adam_m.normal_(); st.adam_v.uniform_(); st.global_step.fill_(4321)
+  prefix = str(tmp_path / 'model.ckpt-4321')
+  C.export_checkpoint(st, prefix, lstm_memory_name='GoalVMC/LSTMDecoder/lstm_memory', batch_size=32)
+  raw = open(prefix + '.index', 'rb').read()
+  assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw) > 4096 + 1024   # more than one data block
+  t = C.read_checkpoint(prefix)
+  assert len(t) == 3 * 60 + 4                                          # vars + 2 slots each, global_step, beta powers, lstm_memory
+  assert t['global_step'].dtype == np.int64 and int(t['global_step']) == 4321
+  assert t['GoalVMC/LSTMDecoder/lstm_memory'].shape == (32, 256)
+  np.testing.assert_array_equal(t['GoalVMC/DynDiffEncoder/conv4/kernel'], st.to_numpy()['GoalVMC/DynDiffEncoder/conv4/kernel'])
+  st2 = VariableStore(st.shapes, 'cpu')
+  extra = C.import_checkpoint(st2, prefix)
+  assert 'GoalVMC/LSTMDecoder/lstm_memory' in extra and 'beta1_power' in extra
+  assert torch.equal(st2.params, st.params) and torch.equal(st2.adam_m, st.adam_m) and torch.equal(st2.adam_v, st.adam_v)
+  assert int(st2.global_step) == 4321
+  # corruption is detected (flip a data byte; flip an index byte)
+  d = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read()); d[100] ^= 1
+  open(prefix + '.data-00000-of-00001', 'wb').write(bytes(d))
+  with pytest.raises(IOError):
+    C.read_checkpoint(prefix)
+  i = bytearray(raw); i[50] ^= 1
+  open(prefix + '.index', 'wb').write(bytes(i))
+  with pytest.raises(IOError):
+    C.read_checkpoint(prefix)
+  with pytest.raises(KeyError):
+    C.write_checkpoint(str(tmp_path / 'small'), {'a': np.zeros([2, 2], np.float32)})
+    C.import_checkpoint(st2, str(tmp_path / 'small'))
