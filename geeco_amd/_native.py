@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgeeco_hip.so')
+LIB_PATH = os.path.join(_HERE, os.environ.get('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_LIB: A/B builds side by side
 
 
 class GeecoNativeError(RuntimeError):

@@ -20,6 +20,12 @@
 // vector-memory counter (vmcnt(0)), which would expose the latency of the epilogue's global stores
 // and of the next tile's prefetch loads once per tile (cdna_hip_programming.md, "Pipelining across
 // barriers").  The "memory" clobber keeps the compiler from moving LDS accesses across it.
+#ifdef GEECO_HALO_SETPRIO
+#define SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define SETPRIO(x)
+#endif
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------

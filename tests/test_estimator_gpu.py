@@ -123,3 +123,34 @@ def test_device_windows_match_host_pipeline(dev, tmp_path):
     res.append(e.evaluate(input_fn=lambda: pickplace_input_fn(root, 'default', 'eval', device=device, **kw)))
   assert res[0]['global_step'] == res[1]['global_step'] == 3
   np.testing.assert_allclose(res[0]['loss'], res[1]['loss'], rtol=1e-6)
+
+
+def test_ragged_final_batch_and_shared_store(dev, tmp_path):
+  """dataset.batch() keeps a ragged final batch (geeco_gym.py:471); the Estimator builds a second graph for
+  it on the SAME variables.  A 4+4+2 epoch must equal the same three steps taken through one-off models."""
+  from geeco_amd import estimator as est
+  from geeco_amd import graph
+  from geeco_amd.input_fn import synthetic_batches
+  params = _params(window_size=2)
+  full = list(synthetic_batches(4, 2, 3, (136, 136), 3, True, seed=8)())
+  f3, l3 = full[2]
+  ragged = full[:2] + [({k: v[:2] for k, v in f3.items()}, {k: v[:2] for k, v in l3.items()})]
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path / 'a'), est.RunConfig(use_hipgraph=True), params)
+  e.train(input_fn=lambda: iter(ragged))
+  assert int(e._store.global_step.item()) == 3 and len(e._specs) == 2
+  got = e._store.to_numpy('params')
+  # reference: the same three steps, eager, fresh model objects sharing one store
+  cfg = params['e2evmc_config']
+  store = None
+  for f, l in ragged:
+    n = f['rgb'].shape[0]
+    m = graph.GoalE2EVMC(cfg, n, dev, training=True, store=store)
+    if store is None:
+      store = m.store
+      store.initialize(seed=0)
+    m.load_batch({k: torch.from_numpy(v) for k, v in f.items()}, {k: torch.from_numpy(v) for k, v in l.items()})
+    m.train_step()
+  torch.cuda.synchronize()
+  want = store.to_numpy('params')
+  for k in want:
+    np.testing.assert_allclose(got[k], want[k], rtol=0, atol=1e-7, err_msg=k)
