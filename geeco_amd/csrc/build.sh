@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../libgeeco_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
-mkdir -p build
+rm -rf build && mkdir -p build
 pids=()
 for f in conv_gemm conv_halo conv_wgrad dynimg decoder misc; do
   $HIPCC $FLAGS -c $f.hip -o build/$f.o &
