@@ -1,0 +1,80 @@
+"""Data-parallel training step on the REAL HIP path with two ranks sharing the one GPU of the test box
+(gloo transport: RCCL refuses two ranks on one device; the exchange code path -- broadcast, shard, SUM
+all-reduce of the gradient arena between the two graph replays, 1/world in the Adam kernel -- is the
+product's).  Two ranks x N/2 must reproduce the single-process step on the global batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=4, lr=1e-3)
+
+
+def _batch(n):
+  sys.path.insert(0, ROOT)
+  from oracle import geeco_oracle as O
+  return O.synthetic_batch(O.make_config(**KW), True, n, seed=31, H=136, W=136)
+
+
+def _worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from geeco_amd import dist as gdist
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import TrainStepRunner
+  torch.cuda.set_device(0)
+  gdist.init_from_env('gloo')
+  feats, labels = _batch(4)
+  lo, hi = gdist.shard_bounds(4)
+  model = graph.GoalE2EVMC(create_e2evmc_config(KW), hi - lo, 'cuda:0', training=True)
+  if rank == 0:
+    model.store.initialize(seed=9)
+  gdist.broadcast_variables(model.store)
+  model.load_batch({k: torch.from_numpy(v[lo:hi]) for k, v in feats.items()}, {k: torch.from_numpy(v[lo:hi]) for k, v in labels.items()})
+  runner = TrainStepRunner(model, use_graph=True, warmup=1)     # step 1 eager, steps 2-3 replayed
+  losses = []
+  for _ in range(3):
+    runner.step()
+    torch.cuda.synchronize()
+    losses.append(float(model.loss))
+  q.put((rank, model.store.params.detach().cpu().numpy(), losses))
+  torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process(dev):
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29600 + os.getpid() % 1000
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  feats, labels = _batch(4)
+  model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, dev, training=True)
+  model.store.initialize(seed=9)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  ref_losses = []
+  for _ in range(3):
+    model.train_step()
+    torch.cuda.synchronize()
+    ref_losses.append(float(model.loss))
+  ref = model.store.params.detach().cpu().numpy()
+  np.testing.assert_array_equal(res[0][1], res[1][1])                               # replicas stay identical
+  # lr = 1e-3, 3 Adam steps: summation-order differences between N=4 and 2 x N=2 move weights by << lr
+  np.testing.assert_allclose(res[0][1], ref, rtol=0, atol=3e-4)
+  frac_close = np.mean(np.abs(res[0][1] - ref) < 2e-5)
+  assert frac_close > 0.99, frac_close
+  # global loss = mean of the two shard losses
+  for s in range(3):
+    assert abs(0.5 * (res[0][2][s] + res[1][2][s]) - ref_losses[s]) < 2e-4 * abs(ref_losses[s]) + 1e-5

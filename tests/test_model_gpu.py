@@ -60,6 +60,9 @@ CASES = [
     ('goal seq dyndiff', dict(proc_obs='sequence', proc_tgt='dyndiff', window_size=2), True, 2, 136),
     ('e2e_vmc velocity', dict(window_size=2, control_mode='velocity'), False, 3, 136),
     ('geeco-f l2', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, l2_regularizer=1e-3), True, 2, 136),
+    # degenerate sizes: one sample, one-frame window (alpha = [0] => the buffer image is identically 0)
+    ('geeco-f N=1 K=1', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=1), True, 1, 136),
+    ('e2e_vmc N=1 K=1', dict(window_size=1), False, 1, 136),
 ]
 
 
