@@ -47,29 +47,43 @@ struct HaloFwdParams {
   int debug;   // ablation switches (GEECO_HALO_DEBUG): 1 = skip MFMAs, 2 = skip halo loads, 4 = skip output stores
 };
 
+__device__ float g_zero_page[64];   // source of LDS-DMA lanes that fall outside the image (TF SAME zero padding)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Barrier that also retires this wave's LDS-DMA (global_load_lds) writes before anyone reads them.
+__device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdParams p) {
   constexpr int NT = 512;                             // 8 waves = 4 output rows x 2 halves of the channel (K) range
   constexpr int TH = 4, TW = 16;
   constexpr int CQ = CIN / 4;
-  constexpr int HY = 2 * TH + 1, HX2 = TW + 1;        // halo rows; columns per parity plane
-  constexpr int PLANE = HY * 2 * HX2;                 // float4 per channel-quad plane (306)
-  constexpr int HALO_F4 = CQ * PLANE;
-  constexpr int NPIX = HY * (2 * TW + 1);             // 9 * 33 halo pixels
-  constexpr int NLOAD = (NPIX * CQ + NT - 1) / NT;    // float4 loads per thread per tile
+  static_assert(CQ == 8, "pair-swizzled halo image is laid out for 8 channel quads");
+  // Halo image (filled by LDS-DMA, no VGPR staging): row hy = 17 pixel PAIRS x 16 float4; the 16 quads of
+  // a pair (2 pixels x 8 quads) are XOR-swizzled by (pair & 15) so that the b128 fragment reads of 16
+  // consecutive output columns (input pixels 2 r + kx) hit distinct 16-byte slots.
+  constexpr int HY = 2 * TH + 1;
+  constexpr int ROW = 17 * 16;                        // float4 per halo row
+  constexpr int HALO_USED = HY * ROW;                 // 2448
+  constexpr int NDMA = (HALO_USED + 63) / 64;         // 1 KiB LDS-DMA pieces per tile (39)
+  constexpr int HALO_F4 = NDMA * 64;                  // 2496 (the last piece spills into padding)
+  constexpr int NSLOT = (NDMA + 7) / 8;               // pieces per wave
   constexpr int W_F4 = 9 * CQ * COUT;
   constexpr int TI = COUT / 16;
   constexpr int KB = CIN / 16;
   constexpr int KBW = KB / 2;                         // 16-channel blocks per wave
   constexpr int NIT = 9 * KBW;
   constexpr int RED_F4 = 4 * TI * 64;                 // partial accumulators of waves 4..7
-  static_assert(KB % 2 == 0 && NIT >= NLOAD + 2, "K split / write interleave");
+  static_assert(KB % 2 == 0, "K split");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sW = reinterpret_cast<f32x4*>(smem);
   f32x4* sH = sW + W_F4;                              // 2 halo buffers
   f32x4* sR = sH + 2 * HALO_F4;                       // 2 reduction buffers
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int strip = wid & 3, khalf = wid >> 2;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -102,27 +116,31 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
     }
   };
 
-  // per-thread halo slots: idx -> (pixel, cq); pixel -> (hy, hx)
-  int l_off[NLOAD], l_src[NLOAD];
-  short l_hy[NLOAD], l_hx[NLOAD];
+  // this wave's LDS-DMA pieces: piece k = wid + 8 i covers halo slots [64 k, 64 k + 64); lane -> (hy, hx, cq)
+  int d_src[NSLOT];
+  short d_hy[NSLOT], d_hx[NSLOT];
 #pragma unroll
-  for (int i = 0; i < NLOAD; ++i) {
-    int idx = tid + NT * i;
-    int pix = idx / CQ, cq = idx - pix * CQ;
-    int hy = pix / (2 * TW + 1), hx = pix - hy * (2 * TW + 1);
-    l_hy[i] = (short)hy; l_hx[i] = (short)hx;
-    l_off[i] = (pix < NPIX) ? cq * PLANE + (hy * 2 + (hx & 1)) * HX2 + (hx >> 1) : -1;
-    l_src[i] = (hy * p.W + hx) * CIN + cq * 4;
+  for (int i = 0; i < NSLOT; ++i) {
+    const int sl = (wid + 8 * i) * 64 + lane;
+    const int row = sl / ROW, rem = sl - row * ROW;
+    const int pair = rem >> 4, u = (rem & 15) ^ (pair & 15);
+    const int hx = 2 * pair + (u >> 3), cq = u & 7;
+    const bool ok = sl < HALO_USED && hx <= 2 * TW;
+    d_hy[i] = (short)(ok ? row : 30000);              // out-of-range marker fails the per-tile bounds test
+    d_hx[i] = (short)hx;
+    d_src[i] = (row * p.W + hx) * CIN + cq * 4;
   }
-  f32x4 stage[NLOAD];
-
-  auto load_halo = [&](int g_, int n_, int ty_, int tx_) {
+  auto dma_halo = [&](int buf, int g_, int n_, int ty_, int tx_) {
     const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;      // TF SAME, stride 2, even input: pad_before = 0
     const float* xg = p.x + (long long)g_ * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN;
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      bool v = l_off[i] >= 0 && iy0 + l_hy[i] < p.H && ix0 + l_hx[i] < p.W;
-      stage[i] = v ? *reinterpret_cast<const f32x4*>(xg + l_src[i]) : zero4;
+    for (int i = 0; i < NSLOT; ++i) {
+      if (wid + 8 * i < NDMA) {                         // wave-uniform
+        const bool v = iy0 + d_hy[i] < p.H && ix0 + d_hx[i] < p.W;
+        const float* src = v ? xg + d_src[i] : g_zero_page;
+        f32x4* dst = sH + buf * HALO_F4 + (wid + 8 * i) * 64;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      }
     }
   };
   auto load_weights = [&](int g_) {
@@ -136,41 +154,37 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
     }
   };
 
-  load_halo(g, n, ty, tx);
+  dma_halo(0, g, n, ty, tx);
   load_weights(g);
   int g_w = g;
-#pragma unroll
-  for (int i = 0; i < NLOAD; ++i)
-    if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
-  __syncthreads();
   f32x4 bias_r[TI];
 #pragma unroll
   for (int i = 0; i < TI; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + i * 16 + 4 * q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // lane r = output column of row `strip`; this wave sums channels [khalf*CIN/2, (khalf+1)*CIN/2)
-  const int a_lane = (khalf * KBW * 4 + q) * PLANE + (4 * strip) * HX2 + r;
-  const f32x4* hB = sW + (khalf * KBW * 4 + q) * COUT + r;
+  const int cq_lane = khalf * KBW * 4 + q;
+  const f32x4* hB = sW + cq_lane * COUT + r;
   int buf = 0;
   for (;;) {
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
     if (more) {
       advance(g2, n2, ty2, tx2);
-      if (!(p.debug & 2)) load_halo(g2, n2, ty2, tx2);
+      dma_halo(buf ^ 1, g2, n2, ty2, tx2);     // lands in the other buffer while this tile computes
     }
     const bool reload_w = more && g2 != g_w;
     f32x4 acc[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) acc[i] = zero4;
-    const f32x4* hA = sH + buf * HALO_F4 + a_lane;
-    f32x4* hN = sH + (buf ^ 1) * HALO_F4;
-    // software-pipelined fragment reads; the next tile's halo is written to the other LDS buffer one
-    // 16-byte store per MFMA group in the second half of the loop (its global loads were issued above)
+    const f32x4* hA = sH + buf * HALO_F4 + (2 * strip) * ROW;
     f32x4 a_cur, b_cur[TI], a_nxt, b_nxt[TI];
     auto frag = [&](int it, f32x4& a, f32x4 (&b)[TI]) {
       const int tap = it / KBW, kb = it - tap * KBW;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a = hA[kb * 4 * PLANE + (ky * 2 + (kx & 1)) * HX2 + (kx >> 1)];
+      const int pair = r + (kx >> 1);
+      a = hA[ky * ROW + pair * 16 + (((((kx & 1) << 3) | (cq_lane + 4 * kb))) ^ (pair & 15))];
 #pragma unroll
       for (int i = 0; i < TI; ++i) b[i] = hB[(tap * CQ + kb * 4) * COUT + i * 16];
     };
@@ -178,21 +192,12 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       if (it + 1 < NIT) frag(it + 1, a_nxt, b_nxt);
-      if (more && it >= NIT - NLOAD) {
-        const int j = it - (NIT - NLOAD);
-        if (l_off[j] >= 0) hN[l_off[j]] = stage[j];
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads / staging store ABOVE this group's MFMAs
-      if (!(p.debug & 1)) {
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ABOVE this group's MFMAs
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int i = 0; i < TI; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[i][s], a_cur[s], acc[i], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) acc[i] += b_cur[i] * a_cur.x;
-      }
+        for (int i = 0; i < TI; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[i][s], a_cur[s], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       a_cur = a_nxt;
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
 #pragma unroll
       for (int i = 0; i < TI; ++i) red[(strip * TI + i) * 64 + lane] = acc[i];
     }
-    lds_barrier();   // partial sums visible; next halo complete; everyone is done with buf and sW
+    dma_barrier();   // partial sums visible; next halo landed; everyone is done with buf and sW
     if (khalf == 0) {
       // epilogue: pixel (oy, ox) = (ty*4 + strip, tx*16 + r); channels 16 i + 4 q .. +3
       const int oy = ty * TH + strip, ox = tx * TW + r;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
         if (p.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (ok && !(p.debug & 4)) *reinterpret_cast<f32x4*>(yo + i * 16 + 4 * q) = v;
+        if (ok) *reinterpret_cast<f32x4*>(yo + i * 16 + 4 * q) = v;
       }
     }
     if (!more) break;
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
 template <int CIN, int COUT>
 static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
   constexpr int CQ = CIN / 4;
-  constexpr int PLANE = 9 * 2 * 17;
-  const size_t lds = (size_t)(9 * CQ * COUT + 2 * CQ * PLANE + 2 * 4 * (COUT / 16) * 64) * 16;
+  constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
+  const size_t lds = (size_t)(9 * CQ * COUT + 2 * HALO_F4 + 2 * 4 * (COUT / 16) * 64) * 16;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_kernel<CIN, COUT>),
