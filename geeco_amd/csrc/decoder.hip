@@ -3,6 +3,7 @@
 // Replaces reference src/models/e2evmc/graph.py:123-192 (concats), :198-260 (lstm_decoder),
 // :452-500 (losses) and the loss composition of src/models/e2evmc/estimator.py:206-239.
 #include "geeco_common.h"
+#include <stdlib.h>
 
 // =====================================================================================================
 // state concat (graph.py:138-141, 162-165, 187-190)
@@ -517,6 +518,165 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   block_mfma_gemm(N, H, F, p.da1, F, 1, p.fc1_w, 1, F, [&](int n, int k, float v) { p.dh[n * H + k] = v; });
 }
 
+// Same computation with every operand resident in LDS (N <= 32, H <= 128, Hfc <= 128: the shapes of
+// all BASELINE.json configs with batch <= 32).  The phases of heads_loss_kernel hand their results
+// over through global memory (~1-2 us of store->load latency per phase, and an L2 round trip per
+// MFMA operand); here h, fc1/kernel, the packed head matrix and every intermediate live in LDS, so a
+// phase costs LDS latency only.  Gradients and predictions are written straight to their outputs.
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void block_mfma_gemm_f(int M, int N, int K, FA A, FB B, FS st) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int tn = (N + 15) >> 4, nt = ((M + 15) >> 4) * tn;
+  for (int t = wave; t < nt; t += nw) {
+    const int ti = t / tn, tj = t - ti * tn;
+    const int i = ti * 16 + r, j = tj * 16 + r;
+    const bool iv = i < M, jv = j < N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const bool kv = k0 + q < K;
+      const float av = (iv && kv) ? A(i, k0 + q) : 0.f;
+      const float bv = (jv && kv) ? B(k0 + q, j) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    const float e[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int io = ti * 16 + 4 * q + k;
+      if (io < M && jv) st(io, j, e[k]);
+    }
+  }
+}
+
+constexpr int HL_NMAX = 32, HL_DMAX = 128, HL_OMAX = 32;
+constexpr int HL_WP = HL_DMAX + 16;     // row pitch of fc1/kernel: q-th k-row starts 16 banks further
+constexpr int HL_RP = HL_DMAX + 1;      // row pitch of the [n][..] activations: rows on different banks
+constexpr int HL_LDS_FLOATS = HL_DMAX * HL_WP + 3 * HL_NMAX * HL_RP + HL_OMAX * HL_RP + 2 * HL_NMAX * (HL_OMAX + 1);
+
+__global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams p) {
+  const int tid = threadIdx.x, NT = 1024;
+  const int N = p.N, H = p.H, F = p.Hfc, OT = p.OT;
+  extern __shared__ __attribute__((aligned(16))) float hl_smem[];
+  float* sW1 = hl_smem;                          // [H][HL_WP]   fc1/kernel [h][f]
+  float* sH = sW1 + HL_DMAX * HL_WP;             // [N][HL_RP]   LSTM output
+  float* sA1 = sH + HL_NMAX * HL_RP;             // [N][HL_RP]   relu(fc1)
+  float* sDA = sA1 + HL_NMAX * HL_RP;            // [N][HL_RP]   d(loss)/d(fc1 pre-activation)
+  float* sWh = sDA + HL_NMAX * HL_RP;            // [OT][HL_RP]  head kernels side by side, transposed
+  float* sPr = sWh + HL_OMAX * HL_RP;            // [N][HL_OMAX + 1] predictions
+  float* sDp = sPr + HL_NMAX * (HL_OMAX + 1);    // [N][HL_OMAX + 1] d(loss)/d(pred)
+  constexpr int OP = HL_OMAX + 1;
+  __shared__ float s_red[16][GEECO_MAX_HEADS];
+  __shared__ float s_hb[32], s_b1[HL_DMAX];
+  __shared__ int s_hd[32], s_hc[32];
+  if (tid < OT) {
+    int hd = 0;
+#pragma unroll
+    for (int k = 1; k < GEECO_MAX_HEADS; ++k)
+      if (k < p.nheads && tid >= p.off[k]) hd = k;
+    s_hd[tid] = hd;
+    s_hc[tid] = tid - sel5(p.off, hd);
+    s_hb[tid] = sel5(p.hb, hd)[tid - sel5(p.off, hd)];
+  }
+  for (int e = tid; e < F; e += NT) s_b1[e] = p.fc1_b[e];
+  for (int e = tid; e < H * F; e += NT) sW1[(e / F) * HL_WP + (e % F)] = p.fc1_w[e];
+  for (int e = tid; e < N * H; e += NT) sH[(e / H) * HL_RP + (e % H)] = p.h[e];
+  __syncthreads();
+  for (int e = tid; e < OT * F; e += NT) {
+    const int o = e / F, f = e - o * F;
+    const int hd = s_hd[o];
+    sWh[o * HL_RP + f] = sel5(p.hw, hd)[f * sel5(p.size, hd) + s_hc[o]];
+  }
+  // P1: a1 = relu(h W1 + b1)                                   graph.py:229-230
+  block_mfma_gemm_f(N, F, H, [&](int n, int k) { return sH[n * HL_RP + k]; }, [&](int k, int j) { return sW1[k * HL_WP + j]; },
+                    [&](int n, int j, float v) { sA1[n * HL_RP + j] = fmaxf(v + s_b1[j], 0.f); });
+  __syncthreads();
+  // P2: preds                                                   graph.py:233-259
+  block_mfma_gemm_f(N, OT, F, [&](int n, int k) { return sA1[n * HL_RP + k]; }, [&](int k, int o) { return sWh[o * HL_RP + k]; },
+                    [&](int n, int o, float v) {
+                      v += s_hb[o];
+                      sPr[n * OP + o] = v;
+                      p.preds[n * OT + o] = v;
+                    });
+  __syncthreads();
+  // P3: losses and d(loss)/d(pred)           graph.py:430-500, estimator.py:206-239 (as heads_loss_kernel)
+  float lsum[GEECO_MAX_HEADS];
+#pragma unroll
+  for (int k = 0; k < GEECO_MAX_HEADS; ++k) lsum[k] = 0.f;
+  const float invn = 1.f / N;
+  for (int n = tid; n < N; n += NT) {
+    const float* pr = sPr + n * OP;
+    float* dp = sDp + n * OP;
+#pragma unroll
+    for (int hd = 0; hd < GEECO_MAX_HEADS; ++hd) {
+      if (hd >= p.nheads) break;
+      const int sz = p.size[hd], of = p.off[hd];
+      const float* tg = p.tgt[hd] + (long long)n * p.tstride[hd];
+      const float wsc = p.weight[hd] * p.loss_scale;
+      if (p.kind[hd] == 0) {
+        const float c2 = 2.f / (float)(N * sz) * wsc;
+        for (int c = 0; c < sz; ++c) {
+          const float d = pr[of + c] - tg[c];
+          lsum[hd] += d * d;
+          dp[of + c] = d * c2;
+        }
+      } else {
+        const int label = (int)rintf(tg[0]) + 1;             // estimator.py:213-215
+        float mx = pr[of];
+        for (int c = 1; c < sz; ++c) mx = fmaxf(mx, pr[of + c]);
+        float se = 0.f;
+        for (int c = 0; c < sz; ++c) se += expf(pr[of + c] - mx);
+        const bool lv = label >= 0 && label < sz;
+        if (lv) lsum[hd] += mx + logf(se) - pr[of + label];
+        for (int c = 0; c < sz; ++c)
+          dp[of + c] = lv ? (expf(pr[of + c] - mx) / se - (c == label ? 1.f : 0.f)) * invn * wsc : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GEECO_MAX_HEADS; ++k) {
+    lsum[k] = wave_reduce_sum(lsum[k]);
+    if ((tid & 63) == 0) s_red[tid >> 6][k] = lsum[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.f;
+    for (int hd = 0; hd < p.nheads; ++hd) {
+      float a = 0.f;
+      for (int w = 0; w < 16; ++w) a += s_red[w][hd];
+      a *= p.kind[hd] == 0 ? 1.f / (float)(N * p.size[hd]) : invn;
+      p.losses[1 + hd] = a;
+      total += p.weight[hd] * a;
+    }
+    p.losses[0] = total;
+  }
+  if (!p.backward) return;
+  // P4: head gradients  d_hw[f][o] = sum_n a1[n][f] dpred[n][o];  da1 = (dpred Wh^T) * relu'
+  block_mfma_gemm_f(F, OT, N, [&](int f, int n) { return sA1[n * HL_RP + f]; }, [&](int n, int o) { return sDp[n * OP + o]; },
+                    [&](int f, int o, float v) {
+                      const int hd = s_hd[o];
+                      sel5(p.dhw, hd)[f * sel5(p.size, hd) + s_hc[o]] = v;
+                    });
+  for (int o = tid; o < OT; o += NT) {
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += sDp[n * OP + o];
+    sel5(p.dhb, s_hd[o])[s_hc[o]] = sum;
+  }
+  block_mfma_gemm_f(N, F, OT, [&](int n, int o) { return sDp[n * OP + o]; }, [&](int o, int f) { return sWh[o * HL_RP + f]; },
+                    [&](int n, int f, float v) { sDA[n * HL_RP + f] = sA1[n * HL_RP + f] > 0.f ? v : 0.f; });
+  __syncthreads();
+  // P5: fc1 gradients and d(h)
+  block_mfma_gemm_f(H, F, N, [&](int k, int n) { return sH[n * HL_RP + k]; }, [&](int n, int j) { return sDA[n * HL_RP + j]; },
+                    [&](int k, int j, float v) { p.d_fc1_w[k * F + j] = v; });
+  for (int j = tid; j < F; j += NT) {
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += sDA[n * HL_RP + j];
+    p.d_fc1_b[j] = sum;
+  }
+  block_mfma_gemm_f(N, H, F, [&](int n, int f) { return sDA[n * HL_RP + f]; }, [&](int f, int k) { return sW1[k * HL_WP + f]; },
+                    [&](int n, int k, float v) { p.dh[n * H + k] = v; });
+}
+
 extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {
   (void)H;
   return ((int64_t)2 * N * Hfc + (int64_t)N * 32 + (int64_t)32 * Hfc) * 4;
@@ -554,7 +714,23 @@ extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, cons
   GEECO_CHECK_ARG(off <= 32, "heads_loss: %d outputs > 32", off);
   p.OT = off;
   p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
-  hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+  static const int no_lds = getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
+  if (!no_lds && N <= HL_NMAX && H <= HL_DMAX && Hfc <= HL_DMAX) {
+    const size_t lds = (size_t)HL_LDS_FLOATS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&heads_loss_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(heads_loss_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+  }
   GEECO_LAUNCH_CHECK();
   return 0;
 }

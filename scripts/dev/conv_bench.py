@@ -1,6 +1,6 @@
 """Time one conv layer's forward / dgrad / wgrad launches (G=3, N=32 like the bench). usage: conv_bench.py L [iters]"""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from geeco_amd import graph, ops
 from geeco_amd.params import create_e2evmc_config
 l = int(sys.argv[1]) - 1
@@ -10,6 +10,7 @@ m = graph.GoalE2EVMC(cfg, 32, 'cuda', training=True)
 m.store.initialize(0)
 for k in m.inputs: m.inputs[k].normal_()
 m.train_step(); torch.cuda.synchronize()
+ZERO = os.environ.get('BENCH_ZERO')   # 1: zero activations, 2: zero weights too (clock/power sensitivity)
 enc = m.enc; L = enc.layers[l]; G, Nf = enc.G, enc.Nf
 x = enc.x_in if l == 0 else enc.acts[l - 1]; y = enc.acts[l]; dz = enc.dz[l]
 w, gs_w = (enc.w1p, enc.w1p[0].numel()) if (l == 0 and enc.pad1) else (enc._w(l), enc.gs_p)
@@ -20,6 +21,9 @@ def wgrad():
 def dgrad():
   wt = enc.wt[l]; dx = enc.dz[l - 1]
   ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], ws=enc.dws, w=enc._w(l), gs_w=enc.gs_p)
+if ZERO:
+  x.zero_(); dz.zero_()
+  if ZERO == '2': m.store.params.zero_(); enc.refresh_derived()
 flop = 2.0 * G * Nf * L['Ho'] * L['Wo'] * L['Cout'] * 9 * L['Cin']
 for name, fn in (('fwd', fwd), ('dgrad', dgrad if l > 0 else None), ('wgrad', wgrad)):
   if fn is None: continue

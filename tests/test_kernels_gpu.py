@@ -145,3 +145,61 @@ def test_gemm(dev, M, N, K, ta, tb):
   C = ops.gemm(torch.tensor(A, device=dev), torch.tensor(B, device=dev), ta, tb)
   torch.cuda.synchronize()
   _close(C, ref, 1e-5, 2e-5 * np.sqrt(K), 'gemm')
+
+
+# fc1 + heads + losses (+ gradients): N <= 32 runs the LDS-resident kernel, larger batches the
+# global-memory one; both against the oracle's decoder tail differentiated by autograd in fp64.
+@pytest.mark.parametrize('N,mode', [(1, 'cartesian'), (7, 'cartesian'), (32, 'cartesian'), (33, 'cartesian'),
+                                    (64, 'cartesian'), (32, 'velocity'), (40, 'velocity')])
+def test_heads_loss(dev, N, mode):
+  from geeco_amd import ops
+  H = F = 128
+  g = torch.Generator().manual_seed(100 + N)
+  if mode == 'cartesian':   # (size, kind, weight): graph.py:233-239; lambda_aux = 0.5
+    heads = [(3, 0, 1.0), (3, 1, 1.0), (3, 0, 0.5), (3, 0, 0.5)]
+  else:                     # velocity heads graph.py:240-249, all MSE, unit weights
+    heads = [(7, 0, 1.0), (3, 0, 1.0), (2, 0, 1.0), (3, 0, 1.0), (3, 0, 1.0)]
+  h = torch.randn(N, H, generator=g)
+  w1 = torch.randn(H, F, generator=g) * 0.1
+  b1 = torch.randn(F, generator=g) * 0.1
+  hw = [torch.randn(F, sz, generator=g) * 0.1 for sz, _, _ in heads]
+  hb = [torch.randn(sz, generator=g) * 0.1 for sz, _, _ in heads]
+  tg = [torch.randn(N, sz, generator=g) if kind == 0 else torch.randint(-1, 2, (N, 1), generator=g).float()
+        for sz, kind, _ in heads]
+  # oracle (fp64 autograd)
+  leaves = [t.double().requires_grad_(True) for t in [h, w1, b1] + hw + hb]
+  hd, w1d, b1d = leaves[:3]
+  hwd, hbd = leaves[3:3 + len(heads)], leaves[3 + len(heads):]
+  a1 = torch.relu(hd @ w1d + b1d)
+  total, parts, preds_ref = 0.0, [], []
+  for (sz, kind, wt), w_, b_, t_ in zip(heads, hwd, hbd, tg):
+    pr = a1 @ w_ + b_
+    preds_ref.append(pr)
+    l = O.mse(pr, t_.double()) if kind == 0 else O.softmax_xent(pr, torch.round(t_[:, 0]).long() + 1, sz)
+    parts.append(l)
+    total = total + wt * l
+  total.backward()
+  # HIP
+  d = lambda t: t.to(dev).contiguous()
+  OT = sum(sz for sz, _, _ in heads)
+  preds = torch.empty(N, OT, device=dev)
+  losses = torch.zeros(8, device=dev)
+  ws = torch.empty(ops.heads_ws_bytes(N, H, F) // 4 + 4, device=dev)
+  dh, dw1, db1 = torch.empty(N, H, device=dev), torch.empty(H, F, device=dev), torch.empty(F, device=dev)
+  dhw = [torch.empty(F, sz, device=dev) for sz, _, _ in heads]
+  dhb = [torch.empty(sz, device=dev) for sz, _, _ in heads]
+  tgd = [d(t) for t in tg]
+  ops.heads_loss_into(preds, losses, d(h), d(w1), d(b1), [d(t) for t in hw], [d(t) for t in hb], [sz for sz, _, _ in heads],
+                      [k for _, k, _ in heads], [w for _, _, w in heads], tgd, [t.shape[1] for t in tg], 1.0, N, H, F, ws,
+                      dh=dh, d_fc1_w=dw1, d_fc1_b=db1, d_heads_w=dhw, d_heads_b=dhb)
+  torch.cuda.synchronize()
+  _close(preds, torch.cat(preds_ref, 1), 1e-5, 1e-5, 'preds')
+  _close(losses[0], total, 1e-5, 1e-6, 'loss')
+  _close(losses[1:1 + len(heads)], torch.stack(parts), 1e-5, 1e-6, 'per-head losses')
+  scale = lambda t: float(t.abs().max()) * 2e-5 + 1e-8
+  _close(dh, hd.grad, 0, scale(hd.grad), 'dh')
+  _close(dw1, w1d.grad, 0, scale(w1d.grad), 'd fc1/kernel')
+  _close(db1, b1d.grad, 0, scale(b1d.grad), 'd fc1/bias')
+  for i in range(len(heads)):
+    _close(dhw[i], hwd[i].grad, 0, scale(hwd[i].grad), 'd head kernel %d' % i)
+    _close(dhb[i], hbd[i].grad, 0, scale(hbd[i].grad), 'd head bias %d' % i)
