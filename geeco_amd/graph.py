@@ -114,15 +114,19 @@ class ConvEncoderStack:
       self.wt = [None] + [torch.empty(G, 3, 3, L['Cout'], L['Cin'], **f32) for L in self.layers[1:]]
       if self.pad1:
         self.dw1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
-      wsb = max(ops.conv3x3_wgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
-                for L in self.layers)
-      self.ws = torch.empty(wsb // 4 + 4, **f32)
+      # wgrads of different layers may run concurrently (different streams): one split-K workspace each
+      nside = int(os.environ.get('GEECO_WGRAD_STREAMS', '2'))   # measured: 1 -> 2 streams +1.1 %, 3 slower
+      self.wgrad1_on_main = os.environ.get('GEECO_WGRAD1_SIDE') is None
+      self.ws_l = [torch.empty(ops.conv3x3_wgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) // 4 + 4,
+                               **f32) for L in self.layers]
+      self.ws = self.ws_l[0]
       dsb = max(ops.conv3x3_dgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
                 for L in self.layers[1:])
       self.dws = torch.empty(dsb // 4 + 4, **f32)
-      # wgrad(l) and dgrad(l) only share their input dz[l]: they run on two streams (two branches of
-      # the captured hipGraph) so the small top layers overlap instead of leaving CUs idle in their tails
-      self.side = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+      # wgrad(l) and dgrad(l) only share their input dz[l]: the dgrad chain stays on the main stream and
+      # the wgrads alternate between side streams (branches of the captured hipGraph), so the small top
+      # layers overlap instead of leaving CUs idle in their tails
+      self.sides = [torch.cuda.Stream(device=dev) for _ in range(nside)] if dev.type == 'cuda' else []
     fsb = max(ops.conv3x3_fwd_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) for L in self.layers)
     self.fws = torch.empty(fsb // 4 + 4, **f32)
 
@@ -180,7 +184,7 @@ class ConvEncoderStack:
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied)."""
     G, Nf = self.G, self.Nf
     main = torch.cuda.current_stream()
-    side = self.side if self.two_streams else None
+    sides = self.sides if self.two_streams else []
     for l in range(7, -1, -1):
       L = self.layers[l]
       x = self.x_in if l == 0 else self.acts[l - 1]
@@ -189,11 +193,16 @@ class ConvEncoderStack:
         dw, gs_dw = self.dw1p, self.dw1p[0].numel()
       else:
         dw, gs_dw = self._dw(l), self.gs_p
+      # wgrad(l) is off the critical path (the dgrad chain on `main`): it goes to a side stream, except
+      # conv1's (there is no dgrad left to overlap with, and `main` is idle by then)
+      side = None
+      if sides and not (l == 0 and self.wgrad1_on_main):
+        side = sides[l % len(sides)]
       if side is not None:
         side.wait_stream(main)          # dz[l] is ready
       with torch.cuda.stream(side if side is not None else main):
         ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
-                               L['W'], L['Cin'], L['Cout'], L['stride'], self.ws)
+                               L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l])
         if l == 0 and self.pad1:
           for g in range(G):
             ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
@@ -203,7 +212,7 @@ class ConvEncoderStack:
       dx = self.dz[l - 1]
       ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
                              L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
-    if side is not None:
+    for side in sides:
       main.wait_stream(side)
 
 

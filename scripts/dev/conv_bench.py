@@ -17,7 +17,7 @@ w, gs_w = (enc.w1p, enc.w1p[0].numel()) if (l == 0 and enc.pad1) else (enc._w(l)
 def fwd(): ops.conv3x3_fwd_into(y, x, w, enc._b(l), G, x[0].numel(), gs_w, enc.gs_p, y[0].numel(), Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], relu=True, ws=enc.fws)
 def wgrad():
   dw, gs_dw = (enc.dw1p, enc.dw1p[0].numel()) if (l == 0 and enc.pad1) else (enc._dw(l), enc.gs_p)
-  ops.conv3x3_wgrad_into(dw, enc._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, enc.gs_p, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], enc.ws)
+  ops.conv3x3_wgrad_into(dw, enc._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, enc.gs_p, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], enc.ws_l[l])
 def dgrad():
   wt = enc.wt[l]; dx = enc.dz[l - 1]
   ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], ws=enc.dws, w=enc._w(l), gs_w=enc.gs_p)
