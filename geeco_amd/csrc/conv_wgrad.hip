@@ -22,7 +22,9 @@ struct WgradParams {
   const float* x;
   const float* dz;
   float* part;   // [G][S][Krows*Cout + Cout]
-  long long gs_x, gs_dz;
+  float* dw;     // S == 1: the block's tile is final and goes straight to dw / db (no slab, no reduce launch)
+  float* db;
+  long long gs_x, gs_dz, gs_dw, gs_db;
   int N, H, W, Cin, Ho, Wo, Cout, stride, pt, pl;
   long long M;          // N*Ho*Wo
   long long m_per_split;
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
   // ---- epilogue: lane owns k-row (lane & 15) of its wave's strip, co = 16 i + 4 q .. +3 ---------
   const long long slab = (long long)p.Krows * Cout + Cout;
-  float* __restrict__ part = p.part + ((long long)g * p.S + split) * slab;
+  const bool direct = p.S == 1;
+  float* __restrict__ part = direct ? p.dw + (long long)g * p.gs_dw : p.part + ((long long)g * p.S + split) * slab;
+  float* __restrict__ bpart = direct ? (p.db ? p.db + (long long)g * p.gs_db : nullptr) : part + (long long)p.Krows * Cout;
 #pragma unroll
   for (int j = 0; j < TJW; ++j) {
     const int krow = rt * BR + (wid * TJW + j) * 16 + r;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       }
     }
   }
-  if (rt == 0) {
+  if (rt == 0 && bpart) {
     // bias gradient: per-thread dz sums -> LDS [pixel row][BC] -> fixed-order column sums
     // (the main loop ended with a barrier, so sB is free to reuse)
     float* sT = sB;
@@ -197,43 +201,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       float s = 0.f;
 #pragma unroll
       for (int m = 0; m < MK; ++m) s += sT[m * LDBZ + tid];
-      part[(long long)p.Krows * Cout + co0 + tid] = s;
+      bpart[co0 + tid] = s;
     }
   }
 }
 
-// Sums the S partial slabs in a fixed order.  One thread per element; for large S the slabs of an
-// element are split over the 4 waves of the block and combined through LDS (order still fixed).
+// Sums the S partial slabs in a fixed order (bitwise reproducible).  Streaming float4 kernel: a wave
+// covers 256 consecutive elements; SPLIT (many slabs of a small tensor: conv1 / conv2) deals the slabs
+// to the 4 waves of a block and combines them through LDS as ((w0 + w1) + (w2 + w3)), otherwise every
+// wave sums all S slabs of its own 256 elements.  KC and the slab pitch are multiples of 4.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            float* __restrict__ db, long long gs_dw, long long gs_db,
                                                            int S, long long KC, int Cout) {
-  __shared__ float sred[4][64];
+  __shared__ f32x4 sred[SPLIT ? 4 : 1][64];
   const int g = blockIdx.y;
   const long long slab = KC + Cout;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + lane;
-  float s = 0.f;
+  const long long i = SPLIT ? ((long long)blockIdx.x * 64 + lane) * 4 : ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < slab) {
     const float* src = part + (long long)g * S * slab + i;
-    const int per = (S + 3) / 4;
-    const int k0 = wid * per, k1 = (k0 + per < S) ? k0 + per : S;
-    for (int k = k0; k < k1; ++k) s += src[(long long)k * slab];
+    int k0 = 0, k1 = S;
+    if (SPLIT) {
+      const int per = (S + 3) / 4;
+      k0 = wid * per;
+      k1 = (k0 + per < S) ? k0 + per : S;
+    }
+    for (int k = k0; k < k1; ++k) s += *reinterpret_cast<const f32x4*>(src + (long long)k * slab);
   }
-  sred[wid][lane] = s;
-  __syncthreads();
-  if (wid == 0 && i < slab) {
+  if (SPLIT) {
+    sred[wid][lane] = s;
+    __syncthreads();
+    if (wid != 0) return;
     s = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
-    if (i < KC)
-      dw[(long long)g * gs_dw + i] = s;
-    else if (db)
-      db[(long long)g * gs_db + (i - KC)] = s;
+  }
+  if (i < KC) {
+    *reinterpret_cast<f32x4*>(dw + (long long)g * gs_dw + i) = s;
+  } else if (i < slab && db) {
+    *reinterpret_cast<f32x4*>(db + (long long)g * gs_db + (i - KC)) = s;
   }
 }
 
 void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
                                long long KC, int Cout, int groups, hipStream_t s) {
-  dim3 rgrid((unsigned)cdiv64(KC + Cout, 64), (unsigned)groups);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
+  const long long n4 = (KC + Cout) / 4;
+  // few float4 columns and many slabs: split the slabs over the waves to get enough parallelism
+  if (S >= 16 && n4 * groups < 64 * 1024) {
+    dim3 rgrid((unsigned)cdiv64(n4, 64), (unsigned)groups);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
+  } else {
+    dim3 rgrid((unsigned)cdiv64(n4, 256), (unsigned)groups);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
+  }
 }
 
 int64_t geeco_halo_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
@@ -307,6 +327,7 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   int BC;
   wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &BC);
   p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
+  p.dw = dw; p.db = db; p.gs_dw = gs_dw; p.gs_db = gs_db;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)p.S, (unsigned)(p.row_tiles * p.col_tiles), (unsigned)groups);
   switch (BC) {
@@ -319,10 +340,9 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
     default: hipLaunchKernelGGL((conv_wgrad_kernel<64, 16, 64>), grid, dim3(256), 0, s, p); break;
   }
   GEECO_LAUNCH_CHECK();
-  const long long KC = (long long)p.Krows * Cout;
-  dim3 rgrid((unsigned)cdiv64(KC + Cout, 64), (unsigned)groups);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, s, (const float*)ws, dw, db, (long long)gs_dw,
-                     (long long)gs_db, p.S, KC, Cout);
-  GEECO_LAUNCH_CHECK();
+  if (p.S > 1) {
+    geeco_launch_wgrad_reduce((const float*)ws, dw, db, gs_dw, gs_db, p.S, (long long)p.Krows * Cout, Cout, groups, s);
+    GEECO_LAUNCH_CHECK();
+  }
   return 0;
 }
