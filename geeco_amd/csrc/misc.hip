@@ -56,6 +56,94 @@ extern "C" int geeco_pad_mid(const float* src, float* dst, int64_t A, int B, int
   return 0;
 }
 
+// ---- every derived weight copy of an encoder stack in ONE launch -----------------------------------
+// The per-step derive chain (conv1 kernel padded to 4 input channels + the per-tap transposes of
+// conv2..8 for the dgrad GEMMs) is ~10 launches of a few microseconds each on the critical path of
+// the Adam graph; here a block looks up its job in a small table passed by value.
+#define GEECO_MAX_DERIVE 8
+struct DeriveParams {
+  const float* w[GEECO_MAX_DERIVE];
+  float* wt[GEECO_MAX_DERIVE];
+  long long gs_wt[GEECO_MAX_DERIVE];
+  int A[GEECO_MAX_DERIVE], B[GEECO_MAX_DERIVE];      // [9][A][B] -> [9][B][A]
+  int block0[GEECO_MAX_DERIVE + 2];                    // first block of job l; [n] = first pad block; [n+1] = grid size
+  int n, groups;
+  long long gs_w;
+  const float* pad_src;      // [G][9][Bs][C] at stride gs_w -> pad_dst [G][9][Bd][C] at stride gs_pad
+  float* pad_dst;
+  long long gs_pad;
+  int pad_Bs, pad_Bd, pad_C;
+};
+
+__global__ __launch_bounds__(256) void derive_weights_kernel(const DeriveParams p) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  if (b >= p.block0[p.n]) {      // pad job: one thread per destination element
+    const long long per_g = 9ll * p.pad_Bd * p.pad_C;
+    const long long i = (long long)(b - p.block0[p.n]) * 256 + threadIdx.x;
+    if (i >= per_g * p.groups) return;
+    const int g = (int)(i / per_g);
+    const long long e = i - g * per_g;
+    const int c = (int)(e % p.pad_C);
+    const int bb = (int)((e / p.pad_C) % p.pad_Bd);
+    const int a = (int)(e / ((long long)p.pad_C * p.pad_Bd));
+    p.pad_dst[g * p.gs_pad + e] = bb < p.pad_Bs ? p.pad_src[g * p.gs_w + ((long long)a * p.pad_Bs + bb) * p.pad_C + c] : 0.f;
+    return;
+  }
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < GEECO_MAX_DERIVE; ++k)
+    if (k < p.n && b >= p.block0[k]) l = k;
+  const int A = p.A[l], B = p.B[l];
+  const int tilesB = (B + 31) / 32, tpt = ((A + 31) / 32) * tilesB;
+  const int local = b - p.block0[l];
+  const int gt = local / tpt, t = local - gt * tpt;       // gt = g * 9 + tap
+  const int g = gt / 9, tap = gt - g * 9;
+  const float* src = p.w[l] + (long long)g * p.gs_w + (long long)tap * A * B;
+  float* dst = p.wt[l] + (long long)g * p.gs_wt[l] + (long long)tap * A * B;
+  const int ta = t / tilesB, tb = t - ta * tilesB;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    int a = ta * 32 + ty + i, bb = tb * 32 + tx;
+    if (a < A && bb < B) tile[ty + i][tx] = src[(long long)a * B + bb];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    int bb = tb * 32 + ty + i, a = ta * 32 + tx;
+    if (a < A && bb < B) dst[(long long)bb * A + a] = tile[tx][ty + i];
+  }
+}
+
+extern "C" int geeco_derive_conv_weights(int nlayers, const float* const* w, float* const* wt, const int* Cin,
+                                         const int* Cout, const int64_t* gs_wt, int groups, int64_t gs_w,
+                                         const float* pad_src, float* pad_dst, int pad_Cin, int pad_Cin_padded,
+                                         int pad_Cout, int64_t gs_pad, void* stream) {
+  GEECO_CHECK_ARG(nlayers >= 0 && nlayers <= GEECO_MAX_DERIVE && groups >= 1, "derive_conv_weights: bad arguments");
+  GEECO_CHECK_ARG(nlayers == 0 || (w && wt && Cin && Cout && gs_wt), "derive_conv_weights: null table");
+  DeriveParams p = {};
+  p.n = nlayers; p.groups = groups; p.gs_w = gs_w;
+  int blocks = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    GEECO_CHECK_ARG(w[l] && wt[l] && Cin[l] >= 1 && Cout[l] >= 1, "derive_conv_weights: layer %d", l);
+    p.w[l] = w[l]; p.wt[l] = wt[l]; p.A[l] = Cin[l]; p.B[l] = Cout[l]; p.gs_wt[l] = gs_wt[l];
+    p.block0[l] = blocks;
+    blocks += groups * 9 * cdiv(Cin[l], 32) * cdiv(Cout[l], 32);
+  }
+  p.block0[nlayers] = blocks;
+  if (pad_src && pad_dst) {
+    GEECO_CHECK_ARG(pad_Cin >= 1 && pad_Cin_padded >= pad_Cin && pad_Cout >= 1, "derive_conv_weights: bad pad dims");
+    p.pad_src = pad_src; p.pad_dst = pad_dst; p.gs_pad = gs_pad;
+    p.pad_Bs = pad_Cin; p.pad_Bd = pad_Cin_padded; p.pad_C = pad_Cout;
+    blocks += (int)cdiv64(9ll * pad_Cin_padded * pad_Cout * groups, 256);
+  }
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(derive_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- Adam (tf.train.AdamOptimizer semantics) -------------------------------------------------------
 // scal[0] = lr_t for this step; the step counter lives in device memory so that a captured
 // hipGraph replays with the right bias correction.

@@ -156,14 +156,12 @@ class ConvEncoderStack:
     per-tap transposed kernels of the dgrad GEMMs).  Training calls it right after Adam (inside the
     Adam hipGraph), so the forward / backward graphs contain no pad or transpose launches."""
     G = self.G
-    if self.pad1:
-      L = self.layers[0]
-      for g in range(G):
-        ops.pad_mid_into(self.w1p[g], self._w(0, g), 9, self.Cin, self.Cpad, L['Cout'])
-    if self.training:
-      for l in range(1, 8):
-        L, wt = self.layers[l], self.wt[l]
-        ops.transpose_hwio_into(wt, self._w(l), G, self.gs_p, wt[0].numel(), L['Cin'], L['Cout'])
+    ls = list(range(1, 8)) if self.training else []
+    pad = dict(pad_src=self._w(0), pad_dst=self.w1p, pad_cin=self.Cin, pad_cin_padded=self.Cpad,
+               pad_cout=self.layers[0]['Cout']) if self.pad1 else {}
+    if ls or pad:
+      ops.derive_conv_weights([self._w(l) for l in ls], [self.wt[l] for l in ls], [self.layers[l]['Cin'] for l in ls],
+                              [self.layers[l]['Cout'] for l in ls], G, self.gs_p, **pad)
     self.derived_version = self.store.version
 
   def forward(self):

@@ -140,6 +140,17 @@ def transpose_hwio_into(wt, w, G, gs_w, gs_wt, Cin, Cout):
   check(_lib().geeco_transpose_hwio(_p(w), _p(wt), G, gs_w, gs_wt, Cin, Cout, _stream()), 'geeco_transpose_hwio')
 
 
+def derive_conv_weights(ws, wts, cins, couts, G, gs_w, pad_src=None, pad_dst=None, pad_cin=0, pad_cin_padded=0,
+                        pad_cout=0):
+  """One launch: wts[i] = per-tap transpose of ws[i] (G encoders at stride gs_w) and the zero-padded conv1 kernel."""
+  n = len(ws)
+  larr = (ctypes.c_int64 * max(n, 1))(*[int(t[0].numel()) for t in wts])
+  check(_lib().geeco_derive_conv_weights(
+      n, _parr(ws) if n else None, _parr(wts) if n else None, _iarr(cins) if n else None, _iarr(couts) if n else None,
+      larr, G, gs_w, _p(pad_src), _p(pad_dst), pad_cin, pad_cin_padded, pad_cout,
+      int(pad_dst[0].numel()) if pad_dst is not None else 0, _stream()), 'geeco_derive_conv_weights')
+
+
 def pad_mid_into(dst, src, A, B, Bd, C):
   check(_lib().geeco_pad_mid(_p(src), _p(dst), A, B, Bd, C, _stream()), 'geeco_pad_mid')
 

@@ -94,6 +94,15 @@ int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, i
 int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,
                          int Cout, void* stream);
 
+/* All derived weight copies of an encoder stack in one launch (the per-step chain after Adam):
+ * for l < nlayers: wt[l] = geeco_transpose_hwio(w[l]) with (Cin[l], Cout[l]), group strides gs_w (kernels,
+ * common) and gs_wt[l]; and, if pad_src/pad_dst are given, conv1's kernel [G][9][pad_Cin][pad_Cout]
+ * (stride gs_w) zero-padded to [G][9][pad_Cin_padded][pad_Cout] (stride gs_pad) = geeco_pad_mid per group. */
+int geeco_derive_conv_weights(int nlayers, const float* const* w, float* const* wt, const int* Cin,
+                              const int* Cout, const int64_t* gs_wt, int groups, int64_t gs_w,
+                              const float* pad_src, float* pad_dst, int pad_Cin, int pad_Cin_padded,
+                              int pad_Cout, int64_t gs_pad, void* stream);
+
 /* src [A][B][C] -> dst [A][Bd][C], copying min(B,Bd) middle rows and zero-filling the rest: pads
  * conv1's RGB kernel [9][3][Co] to [9][4][Co] and un-pads its gradient. */
 int geeco_pad_mid(const float* src, float* dst, int64_t A, int B, int Bd, int C, void* stream);

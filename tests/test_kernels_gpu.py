@@ -203,3 +203,27 @@ def test_heads_loss(dev, N, mode):
   for i in range(len(heads)):
     _close(dhw[i], hwd[i].grad, 0, scale(hwd[i].grad), 'd head kernel %d' % i)
     _close(dhb[i], hbd[i].grad, 0, scale(hbd[i].grad), 'd head bias %d' % i)
+
+
+def test_derive_conv_weights(dev):
+  """One-launch derive (per-tap transposes + padded conv1 kernel) vs torch permute / pad, bit-exact copies."""
+  from geeco_amd import ops
+  G = 3
+  shapes = [(32, 48), (48, 64), (64, 128), (20, 36)]     # (Cin, Cout), the last one with ragged 32x32 tiles
+  g = torch.Generator().manual_seed(5)
+  arena = torch.randn(G, 200000, generator=g).to(dev)      # kernels of one encoder at a common group stride
+  gs_w, off, ws = arena.shape[1], 0, []
+  for ci, co in shapes:
+    ws.append(arena[:, off:off + 9 * ci * co])
+    off += 9 * ci * co + 12
+  w1 = arena[:, off:off + 9 * 3 * 32]
+  wts = [torch.empty(G, 9, co, ci, device=dev) for ci, co in shapes]
+  w1p = torch.full((G, 9, 4, 32), 7.0, device=dev)
+  ops.derive_conv_weights([w[0] for w in ws], wts, [s[0] for s in shapes], [s[1] for s in shapes], G, gs_w,
+                          pad_src=w1[0], pad_dst=w1p, pad_cin=3, pad_cin_padded=4, pad_cout=32)
+  torch.cuda.synchronize()
+  for (ci, co), w, wt in zip(shapes, ws, wts):
+    assert torch.equal(wt, w.reshape(G, 9, ci, co).permute(0, 1, 3, 2).contiguous())
+  ref = torch.zeros(G, 9, 4, 32, device=dev)
+  ref[:, :, :3] = w1.reshape(G, 9, 3, 32)
+  assert torch.equal(w1p, ref)
