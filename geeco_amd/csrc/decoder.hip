@@ -518,45 +518,20 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   block_mfma_gemm(N, H, F, p.da1, F, 1, p.fc1_w, 1, F, [&](int n, int k, float v) { p.dh[n * H + k] = v; });
 }
 
-// Same computation with every operand resident in LDS (N <= 32, H <= 128, Hfc <= 128: the shapes of
-// all BASELINE.json configs with batch <= 32).  The phases of heads_loss_kernel hand their results
+// Same computation with every operand resident in LDS (N <= 32, H == Hfc == 128: the shapes of all
+// BASELINE.json configs with batch <= 32; other sizes take heads_loss_kernel).  The phases of heads_loss_kernel hand their results
 // over through global memory (~1-2 us of store->load latency per phase, and an L2 round trip per
 // MFMA operand); here h, fc1/kernel, the packed head matrix and every intermediate live in LDS, so a
 // phase costs LDS latency only.  Gradients and predictions are written straight to their outputs.
-template <class FA, class FB, class FS>
-__device__ __forceinline__ void block_mfma_gemm_f(int M, int N, int K, FA A, FB B, FS st) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int tn = (N + 15) >> 4, nt = ((M + 15) >> 4) * tn;
-  for (int t = wave; t < nt; t += nw) {
-    const int ti = t / tn, tj = t - ti * tn;
-    const int i = ti * 16 + r, j = tj * 16 + r;
-    const bool iv = i < M, jv = j < N;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const bool kv = k0 + q < K;
-      const float av = (iv && kv) ? A(i, k0 + q) : 0.f;
-      const float bv = (jv && kv) ? B(k0 + q, j) : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-    const float e[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int io = ti * 16 + 4 * q + k;
-      if (io < M && jv) st(io, j, e[k]);
-    }
-  }
-}
-
 constexpr int HL_NMAX = 32, HL_DMAX = 128, HL_OMAX = 32;
 constexpr int HL_WP = HL_DMAX + 16;     // row pitch of fc1/kernel: q-th k-row starts 16 banks further
 constexpr int HL_RP = HL_DMAX + 1;      // row pitch of the [n][..] activations: rows on different banks
-constexpr int HL_LDS_FLOATS = HL_DMAX * HL_WP + 3 * HL_NMAX * HL_RP + HL_OMAX * HL_RP + 2 * HL_NMAX * (HL_OMAX + 1);
+constexpr int HL_LDS_FLOATS = HL_DMAX * HL_WP + 3 * HL_NMAX * HL_RP + HL_OMAX * HL_RP + 3 * HL_NMAX * (HL_OMAX + 1);
 
 __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams p) {
   const int tid = threadIdx.x, NT = 1024;
-  const int N = p.N, H = p.H, F = p.Hfc, OT = p.OT;
+  constexpr int H = HL_DMAX, F = HL_DMAX;      // the launcher takes this path only for H == Hfc == 128 (the defaults)
+  const int N = p.N, OT = p.OT;
   extern __shared__ __attribute__((aligned(16))) float hl_smem[];
   float* sW1 = hl_smem;                          // [H][HL_WP]   fc1/kernel [h][f]
   float* sH = sW1 + HL_DMAX * HL_WP;             // [N][HL_RP]   LSTM output
@@ -569,112 +544,242 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
   __shared__ float s_red[16][GEECO_MAX_HEADS];
   __shared__ float s_hb[32], s_b1[HL_DMAX];
   __shared__ int s_hd[32], s_hc[32];
-  if (tid < OT) {
+#ifdef GEECO_STAMPS
+#define HSTAMP(i) do { if (tid == 0) reinterpret_cast<unsigned long long*>(p.dpred)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HSTAMP(i)
+#endif
+  float* sTg = sDp + HL_NMAX * (HL_OMAX + 1);    // [N][HL_OMAX + 1] targets (kind 1: the label in the head's first column)
+  HSTAMP(0);
+  // P0: every global input is fetched up front (independent loads, issued together), then one barrier
+  auto head_of = [&](int o) {
     int hd = 0;
 #pragma unroll
     for (int k = 1; k < GEECO_MAX_HEADS; ++k)
-      if (k < p.nheads && tid >= p.off[k]) hd = k;
+      if (k < p.nheads && o >= p.off[k]) hd = k;
+    return hd;
+  };
+  if (tid < OT) {
+    const int hd = head_of(tid);
     s_hd[tid] = hd;
     s_hc[tid] = tid - sel5(p.off, hd);
     s_hb[tid] = sel5(p.hb, hd)[tid - sel5(p.off, hd)];
   }
   for (int e = tid; e < F; e += NT) s_b1[e] = p.fc1_b[e];
-  for (int e = tid; e < H * F; e += NT) sW1[(e / F) * HL_WP + (e % F)] = p.fc1_w[e];
-  for (int e = tid; e < N * H; e += NT) sH[(e / H) * HL_RP + (e % H)] = p.h[e];
-  __syncthreads();
+  if ((F & 3) == 0 && (H & 3) == 0) {
+    constexpr int WV = HL_DMAX * HL_DMAX / 4 / 1024;      // float4 of fc1/kernel per thread (4)
+    f32x4 wv[WV], hv;
+    const int F4 = F >> 2;
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int e4 = tid + NT * i;
+      wv[i] = e4 < H * F4 ? reinterpret_cast<const f32x4*>(p.fc1_w)[e4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    hv = tid < (N * H >> 2) ? reinterpret_cast<const f32x4*>(p.h)[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int e4 = tid + NT * i;
+      if (e4 < H * F4) *reinterpret_cast<f32x4*>(sW1 + (e4 / F4) * HL_WP + (e4 % F4) * 4) = wv[i];
+    }
+    if (tid < (N * H >> 2)) {
+      const int e = tid * 4;
+      float* d = sH + (e / H) * HL_RP + (e % H);
+      d[0] = hv.x; d[1] = hv.y; d[2] = hv.z; d[3] = hv.w;
+    }
+  } else {
+    for (int e = tid; e < H * F; e += NT) sW1[(e / F) * HL_WP + (e % F)] = p.fc1_w[e];
+    for (int e = tid; e < N * H; e += NT) sH[(e / H) * HL_RP + (e % H)] = p.h[e];
+  }
   for (int e = tid; e < OT * F; e += NT) {
     const int o = e / F, f = e - o * F;
-    const int hd = s_hd[o];
-    sWh[o * HL_RP + f] = sel5(p.hw, hd)[f * sel5(p.size, hd) + s_hc[o]];
+    const int hd = head_of(o);
+    sWh[o * HL_RP + f] = sel5(p.hw, hd)[f * sel5(p.size, hd) + (o - sel5(p.off, hd))];
   }
-  // P1: a1 = relu(h W1 + b1)                                   graph.py:229-230
-  block_mfma_gemm_f(N, F, H, [&](int n, int k) { return sH[n * HL_RP + k]; }, [&](int k, int j) { return sW1[k * HL_WP + j]; },
-                    [&](int n, int j, float v) { sA1[n * HL_RP + j] = fmaxf(v + s_b1[j], 0.f); });
+  for (int e = tid; e < N * OT; e += NT) {
+    const int n = e / OT, o = e - n * OT;
+    const int hd = head_of(o), c = o - sel5(p.off, hd);
+    if (sel5(p.kind, hd) == 0 || c == 0) sTg[n * OP + o] = sel5(p.tgt, hd)[(long long)n * sel5(p.tstride, hd) + c];
+  }
   __syncthreads();
-  // P2: preds                                                   graph.py:233-259
-  block_mfma_gemm_f(N, OT, F, [&](int n, int k) { return sA1[n * HL_RP + k]; }, [&](int k, int o) { return sWh[o * HL_RP + k]; },
-                    [&](int n, int o, float v) {
-                      v += s_hb[o];
-                      sPr[n * OP + o] = v;
-                      p.preds[n * OT + o] = v;
-                    });
-  __syncthreads();
-  // P3: losses and d(loss)/d(pred)           graph.py:430-500, estimator.py:206-239 (as heads_loss_kernel)
-  float lsum[GEECO_MAX_HEADS];
+  HSTAMP(1);
+  HSTAMP(2);
+  // The six small GEMMs run through ONE copy of the MFMA tile loop (operands and results in LDS, or a
+  // global result): the kernel executes once per step from a cold instruction cache, so its run time
+  // follows its code size - six inlined, unrolled GEMMs (47 KB of code) took 3x longer than this loop.
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int nph = p.backward ? 6 : 2;
+#pragma unroll 1
+  for (int ph = 0; ph < nph; ++ph) {
+    // C(i, j) = sum_k A(i, k) B(k, j);  A(i, k) = smem[a + i a_rs + k a_ks], B(k, j) = smem[b + k b_ks + j b_cs],
+    // C -> smem[c + i c_rs + j c_cs] or, if gc, gc[i c_rs + j c_cs]
+    int M, Nn, K, a, a_rs, a_ks, b, b_ks, b_cs, c = 0, c_rs, c_cs;
+    float* gc = nullptr;
+    const int oH = (int)(sH - hl_smem), oW1 = 0, oA1 = (int)(sA1 - hl_smem), oDA = (int)(sDA - hl_smem);
+    const int oWh = (int)(sWh - hl_smem), oPr = (int)(sPr - hl_smem), oDp = (int)(sDp - hl_smem);
+    switch (ph) {
+      case 0:   // P1: fc1 pre-activation = h W1                                  graph.py:229-230
+        M = N; Nn = F; K = H; a = oH; a_rs = HL_RP; a_ks = 1; b = oW1; b_ks = HL_WP; b_cs = 1; c = oA1; c_rs = HL_RP; c_cs = 1;
+        break;
+      case 1:   // P2: preds = a1 Wh                                              graph.py:233-259
+        M = N; Nn = OT; K = F; a = oA1; a_rs = HL_RP; a_ks = 1; b = oWh; b_ks = 1; b_cs = HL_RP; c = oPr; c_rs = OP; c_cs = 1;
+        break;
+      case 2:   // d(a1) = dpred Wh^T (ReluGrad applied after the loop body)
+        M = N; Nn = F; K = OT; a = oDp; a_rs = OP; a_ks = 1; b = oWh; b_ks = HL_RP; b_cs = 1; c = oDA; c_rs = HL_RP; c_cs = 1;
+        break;
+      case 3:   // head kernel gradients [f][o] = a1^T dpred, into the (now free) packed head matrix as [o][f]
+        M = F; Nn = OT; K = N; a = oA1; a_rs = 1; a_ks = HL_RP; b = oDp; b_ks = OP; b_cs = 1; c = oWh; c_rs = 1; c_cs = HL_RP;
+        break;
+      case 4:   // d(h) = d(a1) W1^T
+        M = N; Nn = H; K = F; a = oDA; a_rs = HL_RP; a_ks = 1; b = oW1; b_ks = 1; b_cs = HL_WP; gc = p.dh; c_rs = H; c_cs = 1;
+        break;
+      default:  // d(fc1/kernel) = h^T d(a1)
+        M = H; Nn = F; K = N; a = oH; a_rs = 1; a_ks = HL_RP; b = oDA; b_ks = HL_RP; b_cs = 1; gc = p.d_fc1_w; c_rs = F; c_cs = 1;
+        break;
+    }
+    const int tn = (Nn + 15) >> 4, nt = ((M + 15) >> 4) * tn;
+#pragma unroll 1
+    for (int t = wave; t < nt; t += 16) {
+      const int ti = t / tn, tj = t - ti * tn;
+      const int i = ti * 16 + r, j = tj * 16 + r;
+      const bool iv = i < M, jv = j < Nn;
+      // rows / columns beyond the matrix read row / column 0 (valid data); their results are never stored,
+      // so only the K tail needs masking.  The K loop is pointer bumps: integer multiplies for the operand
+      // addresses (quarter rate) made the VALU, not the MFMA pipe, the limit of these tiny GEMMs.
+      const float* ap = hl_smem + a + (iv ? i : 0) * a_rs + q * a_ks;
+      const float* bp = hl_smem + b + (jv ? j : 0) * b_cs + q * b_ks;
+      const int a4 = 4 * a_ks, b4 = 4 * b_ks;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      int k0 = 0;
+#pragma unroll 1
+      for (; k0 + 16 <= K; k0 += 16) {      // 4 k-steps per pass, two accumulator chains
+        const float a0 = ap[0], a1 = ap[a4], a2 = ap[2 * a4], a3 = ap[3 * a4];
+        const float b0 = bp[0], b1 = bp[b4], b2 = bp[2 * b4], b3 = bp[3 * b4];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+        ap += 4 * a4;
+        bp += 4 * b4;
+      }
+      for (; k0 < K; k0 += 4) {             // tail: clamped address, value zeroed by a 0/1 factor
+        const int k = k0 + q;
+        const float mk = k < K ? 1.f : 0.f;
+        const int back = k < K ? 0 : k - (K - 1);     // steps past the last valid k
+        const float av = ap[-back * a_ks] * mk, bv = bp[-back * b_ks] * mk;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+        ap += a4;
+        bp += b4;
+      }
+      const f32x4 acc = acc0 + acc1;
+      const float e[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-  for (int k = 0; k < GEECO_MAX_HEADS; ++k) lsum[k] = 0.f;
-  const float invn = 1.f / N;
-  for (int n = tid; n < N; n += NT) {
-    const float* pr = sPr + n * OP;
-    float* dp = sDp + n * OP;
-#pragma unroll
-    for (int hd = 0; hd < GEECO_MAX_HEADS; ++hd) {
-      if (hd >= p.nheads) break;
-      const int sz = p.size[hd], of = p.off[hd];
-      const float* tg = p.tgt[hd] + (long long)n * p.tstride[hd];
-      const float wsc = p.weight[hd] * p.loss_scale;
-      if (p.kind[hd] == 0) {
-        const float c2 = 2.f / (float)(N * sz) * wsc;
-        for (int c = 0; c < sz; ++c) {
-          const float d = pr[of + c] - tg[c];
-          lsum[hd] += d * d;
-          dp[of + c] = d * c2;
+      for (int k = 0; k < 4; ++k) {
+        const int io = ti * 16 + 4 * q + k;
+        if (io < M && jv) {
+          if (gc)
+            gc[io * c_rs + j * c_cs] = e[k];
+          else
+            hl_smem[c + io * c_rs + j * c_cs] = e[k];
         }
-      } else {
-        const int label = (int)rintf(tg[0]) + 1;             // estimator.py:213-215
-        float mx = pr[of];
-        for (int c = 1; c < sz; ++c) mx = fmaxf(mx, pr[of + c]);
-        float se = 0.f;
-        for (int c = 0; c < sz; ++c) se += expf(pr[of + c] - mx);
-        const bool lv = label >= 0 && label < sz;
-        if (lv) lsum[hd] += mx + logf(se) - pr[of + label];
-        for (int c = 0; c < sz; ++c)
-          dp[of + c] = lv ? (expf(pr[of + c] - mx) / se - (c == label ? 1.f : 0.f)) * invn * wsc : 0.f;
+      }
+    }
+    __syncthreads();
+    HSTAMP(3 + ph);
+    if (ph == 0) {            // a1 = relu(. + b1)
+      for (int e = tid; e < N * F; e += NT) {
+        const int n = e / F, f = e - n * F;
+        sA1[n * HL_RP + f] = fmaxf(sA1[n * HL_RP + f] + s_b1[f], 0.f);
+      }
+      __syncthreads();
+    } else if (ph == 1) {     // + head biases; predictions out; losses and d(loss)/d(pred)
+      for (int e = tid; e < N * OT; e += NT) {
+        const int n = e / OT, o = e - n * OT;
+        const float v = sPr[n * OP + o] + s_hb[o];
+        sPr[n * OP + o] = v;
+        p.preds[e] = v;
+      }
+      __syncthreads();
+      // P3           graph.py:430-500, estimator.py:206-239 (as heads_loss_kernel)
+      float lsum[GEECO_MAX_HEADS];
+#pragma unroll
+      for (int k = 0; k < GEECO_MAX_HEADS; ++k) lsum[k] = 0.f;
+      const float invn = 1.f / N;
+      for (int n = tid; n < N; n += NT) {
+        const float* pr = sPr + n * OP;
+        float* dp = sDp + n * OP;
+#pragma unroll 1
+        for (int hd = 0; hd < p.nheads; ++hd) {
+          const int sz = sel5(p.size, hd), of = sel5(p.off, hd);
+          const float* tg = sTg + n * OP + of;
+          const float wsc = sel5(p.weight, hd) * p.loss_scale;
+          float l = 0.f;
+          if (sel5(p.kind, hd) == 0) {
+            const float c2 = 2.f / (float)(N * sz) * wsc;
+            for (int cc = 0; cc < sz; ++cc) {
+              const float d = pr[of + cc] - tg[cc];
+              l += d * d;
+              dp[of + cc] = d * c2;
+            }
+          } else {
+            const int label = (int)rintf(tg[0]) + 1;             // estimator.py:213-215
+            float mx = pr[of];
+            for (int cc = 1; cc < sz; ++cc) mx = fmaxf(mx, pr[of + cc]);
+            float se = 0.f;
+            for (int cc = 0; cc < sz; ++cc) se += expf(pr[of + cc] - mx);
+            const bool lv = label >= 0 && label < sz;             // one_hot of an out-of-range label is all-zero
+            if (lv) l = mx + logf(se) - pr[of + label];
+            for (int cc = 0; cc < sz; ++cc)
+              dp[of + cc] = lv ? (expf(pr[of + cc] - mx) / se - (cc == label ? 1.f : 0.f)) * invn * wsc : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < GEECO_MAX_HEADS; ++k)
+            if (k == hd) lsum[k] += l;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GEECO_MAX_HEADS; ++k) {
+        lsum[k] = wave_reduce_sum(lsum[k]);
+        if ((tid & 63) == 0) s_red[tid >> 6][k] = lsum[k];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float total = 0.f;
+        for (int hd = 0; hd < p.nheads; ++hd) {
+          float acc_l = 0.f;
+          for (int w = 0; w < 16; ++w) acc_l += s_red[w][hd];
+          acc_l *= sel5(p.kind, hd) == 0 ? 1.f / (float)(N * sel5(p.size, hd)) : invn;
+          p.losses[1 + hd] = acc_l;
+          total += sel5(p.weight, hd) * acc_l;
+        }
+        p.losses[0] = total;
+      }
+    } else if (ph == 2) {     // ReluGrad of fc1; head bias gradients
+      for (int e = tid; e < N * F; e += NT) {
+        const int n = e / F, f = e - n * F;
+        if (!(sA1[n * HL_RP + f] > 0.f)) sDA[n * HL_RP + f] = 0.f;
+      }
+      for (int o = tid; o < OT; o += NT) {
+        float sum = 0.f;
+        for (int n = 0; n < N; ++n) sum += sDp[n * OP + o];
+        sel5(p.dhb, s_hd[o])[s_hc[o]] = sum;
+      }
+      __syncthreads();
+    } else if (ph == 3) {     // scatter the head kernel gradients to their variables
+      for (int e = tid; e < OT * F; e += NT) {
+        const int o = e / F, f = e - o * F;
+        const int hd = s_hd[o];
+        sel5(p.dhw, hd)[f * sel5(p.size, hd) + s_hc[o]] = sWh[o * HL_RP + f];
+      }
+    } else if (ph == 4) {     // d(fc1/bias)
+      for (int jj = tid; jj < F; jj += NT) {
+        float sum = 0.f;
+        for (int n = 0; n < N; ++n) sum += sDA[n * HL_RP + jj];
+        p.d_fc1_b[jj] = sum;
       }
     }
   }
-#pragma unroll
-  for (int k = 0; k < GEECO_MAX_HEADS; ++k) {
-    lsum[k] = wave_reduce_sum(lsum[k]);
-    if ((tid & 63) == 0) s_red[tid >> 6][k] = lsum[k];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float total = 0.f;
-    for (int hd = 0; hd < p.nheads; ++hd) {
-      float a = 0.f;
-      for (int w = 0; w < 16; ++w) a += s_red[w][hd];
-      a *= p.kind[hd] == 0 ? 1.f / (float)(N * p.size[hd]) : invn;
-      p.losses[1 + hd] = a;
-      total += p.weight[hd] * a;
-    }
-    p.losses[0] = total;
-  }
-  if (!p.backward) return;
-  // P4: head gradients  d_hw[f][o] = sum_n a1[n][f] dpred[n][o];  da1 = (dpred Wh^T) * relu'
-  block_mfma_gemm_f(F, OT, N, [&](int f, int n) { return sA1[n * HL_RP + f]; }, [&](int n, int o) { return sDp[n * OP + o]; },
-                    [&](int f, int o, float v) {
-                      const int hd = s_hd[o];
-                      sel5(p.dhw, hd)[f * sel5(p.size, hd) + s_hc[o]] = v;
-                    });
-  for (int o = tid; o < OT; o += NT) {
-    float sum = 0.f;
-    for (int n = 0; n < N; ++n) sum += sDp[n * OP + o];
-    sel5(p.dhb, s_hd[o])[s_hc[o]] = sum;
-  }
-  block_mfma_gemm_f(N, F, OT, [&](int n, int o) { return sDp[n * OP + o]; }, [&](int o, int f) { return sWh[o * HL_RP + f]; },
-                    [&](int n, int f, float v) { sDA[n * HL_RP + f] = sA1[n * HL_RP + f] > 0.f ? v : 0.f; });
-  __syncthreads();
-  // P5: fc1 gradients and d(h)
-  block_mfma_gemm_f(H, F, N, [&](int k, int n) { return sH[n * HL_RP + k]; }, [&](int n, int j) { return sDA[n * HL_RP + j]; },
-                    [&](int k, int j, float v) { p.d_fc1_w[k * F + j] = v; });
-  for (int j = tid; j < F; j += NT) {
-    float sum = 0.f;
-    for (int n = 0; n < N; ++n) sum += sDA[n * HL_RP + j];
-    p.d_fc1_b[j] = sum;
-  }
-  block_mfma_gemm_f(N, H, F, [&](int n, int f) { return sDA[n * HL_RP + f]; }, [&](int f, int k) { return sW1[k * HL_WP + f]; },
-                    [&](int n, int k, float v) { p.dh[n * H + k] = v; });
+  HSTAMP(10);
 }
 
 extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {
@@ -715,7 +820,7 @@ extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, cons
   p.OT = off;
   p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
   static const int no_lds = getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
-  if (!no_lds && N <= HL_NMAX && H <= HL_DMAX && Hfc <= HL_DMAX) {
+  if (!no_lds && N <= HL_NMAX && H == HL_DMAX && Hfc == HL_DMAX) {
     const size_t lds = (size_t)HL_LDS_FLOATS * 4;
     static bool attr_set = false;
     if (!attr_set) {
