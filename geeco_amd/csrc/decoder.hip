@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void concat_fwd_kernel(const ConcatParams p) {
   p.state[(long long)n * p.state_stride + rem] = v;
 }
 
-__global__ __launch_bounds__(256) void concat_bwd_kernel(const ConcatParams p, int f) {
+// blockIdx.y = feature map (all of them in one launch; maps without a gradient buffer are skipped)
+__global__ __launch_bounds__(256) void concat_bwd_kernel(const ConcatParams p) {
+  const int f = blockIdx.y;
+  if (!p.dfeats[f]) return;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long per = (long long)p.cells * p.ch[f];
   if (i >= per * p.N) return;
@@ -111,13 +114,17 @@ extern "C" int geeco_state_concat_bwd(const float* dstate, int64_t dstate_stride
     p.feats[i] = feats_fwd[i];
     p.dfeats[i] = dfeats[i];
   }
+  long long most = 0;
   for (int f = 0; f < nfeat; ++f) {
     if (!dfeats[f]) continue;
     GEECO_CHECK_ARG(feats_fwd[f], "state_concat_bwd: feats_fwd[%d] is null", f);
     const long long total = (long long)N * cells * p.ch[f];
-    hipLaunchKernelGGL(concat_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, p, f);
-    GEECO_LAUNCH_CHECK();
+    if (total > most) most = total;
   }
+  if (most == 0) return 0;
+  hipLaunchKernelGGL(concat_bwd_kernel, dim3((unsigned)cdiv64(most, 256), (unsigned)nfeat), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  GEECO_LAUNCH_CHECK();
   return 0;
 }
 
@@ -235,7 +242,16 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmParams p) {
   const long long MN = (long long)p.M * p.N;
   if (i >= MN) return;
   float s = 0.f;
-  for (int k = 0; k < p.S; ++k) s += p.part[(long long)k * MN + i];
+  const float* src = p.part + i;
+  int k = 0;
+  for (; k + 8 <= p.S; k += 8) {      // 8 independent loads in flight; the sum keeps the slab order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * MN];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < p.S; ++k) s += src[(long long)k * MN];
   const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
   float* c = p.C + (long long)m * p.ldc + n;
   *c = p.accumulate ? *c + s : s;
