@@ -228,7 +228,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       k0 = wid * per;
       k1 = (k0 + per < S) ? k0 + per : S;
     }
-    for (int k = k0; k < k1; ++k) s += *reinterpret_cast<const f32x4*>(src + (long long)k * slab);
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {       // 4 independent loads in flight; the sum keeps the slab order
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(k + u) * slab);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += t[u];
+    }
+    for (; k < k1; ++k) s += *reinterpret_cast<const f32x4*>(src + (long long)k * slab);
   }
   if (SPLIT) {
     sred[wid][lane] = s;
