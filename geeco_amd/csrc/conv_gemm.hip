@@ -23,6 +23,7 @@
 //       land in different bank halves (conflict free).
 #include "geeco_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 // One parity class of a launch (forward: a single class with all 9 taps; dgrad of a stride-s conv:
 // s*s classes, each with its own subset of taps and its own sub-grid of destination pixels).
@@ -53,6 +54,7 @@ struct ConvGemmParams {
   const float* mask;
   float* out;
   float* part;          // split-K slabs [ksplit][G][N*Hd*Wd][Nout] (ksplit > 1)
+  unsigned long long* stamps;   // -DGEECO_STAMPS builds only: [block][64] s_memtime timeline of thread 0
   long long gs_x, gs_w, gs_b, gs_out;
   int N, Hs, Ws, C;     // source tensor [N][Hs][Ws][C]
   int Hd, Wd, Nout;     // destination tensor [N][Hd][Wd][Nout]
@@ -68,8 +70,23 @@ struct ConvGemmParams {
 // UT ("uniform tap"): C % BK == 0, so every K-step lies inside ONE tap; the per-row validity and the
 // source / kernel pointers are then recomputed only when the tap changes (every C/BK steps) and the
 // K loop itself is pointer bumps + loads: removes most of the gather's address VALU work.
+#ifdef GEECO_STAMPS
+#define STAMP(i)                                                                                  \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && p.stamps && (i) < 64) stamp_base[(i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <int BM, int BN, int BK, int WM, int WN, bool UT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+#ifdef GEECO_STAMPS
+  unsigned long long* stamp_base =
+      p.stamps + ((long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
+  STAMP(0);
+  if (threadIdx.x == 0 && p.stamps) stamp_base[63] = (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+#endif
   constexpr int SPR = BK / 4;     // float4 slots per row per K-step
   constexpr int RPP = 256 / SPR;  // rows staged per pass
   constexpr int PA = BM / RPP;    // A staging passes
@@ -117,6 +134,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     sTap[36 + t] = ok ? cl.wslab[t] * C : 0;
   }
   __syncthreads();
+  STAMP(1);
 
   // ---- per-thread staging state -----------------------------------------------------------
   const int kq = tid % SPR;
@@ -142,6 +160,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       }
     }
   }
+  STAMP(2);
   const int nk_all = (ntaps * C + BK - 1) / BK;
   const int per = (nk_all + p.ksplit - 1) / p.ksplit;
   const int ks_beg = split * per;
@@ -276,20 +295,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = zero4;
 
+  STAMP(3);
   if (nk > 0) {
     load_tiles();
     advance();
+    STAMP(4);
     store_tiles(0);
   }
   __syncthreads();
+  STAMP(5);
 
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
     const bool more = ks + 1 < nk;
+    STAMP(ks < 18 ? 6 + 3 * ks : 64);
     if (more) {
       load_tiles();
       advance();
     }
+    STAMP(ks < 18 ? 7 + 3 * ks : 64);
     const float* a = sA + buf * (BM * BK);
     const float* b = sB + buf * (BK * LDB);
 #pragma unroll
@@ -311,9 +335,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
           for (int j = 0; j < TJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][s], xf[j][s], acc[i][j], 0, 0, 0);
     }
+    STAMP(ks < 18 ? 8 + 3 * ks : 64);
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
   }
+  STAMP(60);
 
   // ---- epilogue: lane owns pixel (lane & 15) of tile j, channels 4*(lane>>4)..+3 of tile i ----
   float* __restrict__ og = p.out + (long long)g * p.gs_out;
@@ -357,6 +383,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       *reinterpret_cast<f32x4*>(og + opix * p.Nout + co) = v;
     }
   }
+#ifdef GEECO_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(61);
+#endif
 }
 
 // Sums the split-K slabs and applies the epilogue (bias, ReLU, mask).  One thread = 4 channels.
@@ -447,7 +477,33 @@ static int64_t conv_ws_bytes(const ConvGemmParams& p, int groups) {
   return (int64_t)pl.ksplit * groups * p.N * p.Hd * p.Wd * p.Nout * 4;
 }
 
+#ifdef GEECO_STAMPS
+// Dev instrumentation: one timeline per block of the LAST conv_gemm launch; geeco_debug_dump_stamps writes it out.
+static unsigned long long* g_stamps = nullptr;
+static const size_t kStampBlocks = 1 << 16;
+static unsigned long long* geeco_stamp_buffer() {
+  if (!g_stamps && hipMalloc(&g_stamps, kStampBlocks * 64 * 8) != hipSuccess) return nullptr;
+  (void)hipMemset(g_stamps, 0, kStampBlocks * 64 * 8);
+  return g_stamps;
+}
+extern "C" int geeco_debug_dump_stamps(const char* path) {
+  if (!g_stamps) return 1;
+  (void)hipDeviceSynchronize();
+  unsigned long long* h = (unsigned long long*)malloc(kStampBlocks * 64 * 8);
+  (void)hipMemcpy(h, g_stamps, kStampBlocks * 64 * 8, hipMemcpyDeviceToHost);
+  FILE* f = fopen(path, "wb");
+  if (!f) return 2;
+  fwrite(h, 8, kStampBlocks * 64, f);
+  fclose(f);
+  free(h);
+  return 0;
+}
+#endif
+
 static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t s) {
+#ifdef GEECO_STAMPS
+  p.stamps = geeco_stamp_buffer();
+#endif
   ConvPlan pl = conv_plan(p, groups);
   if (!ws) pl.ksplit = 1;
   p.ksplit = pl.ksplit;
