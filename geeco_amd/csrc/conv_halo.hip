@@ -9,7 +9,8 @@
 // busy, 1.6-3x HBM over-fetch).  Here a block stages the input HALO of its output tile in LDS once
 // and every tap reads its fragments from there (2.25x fewer bytes for stride 2, 9x for stride 1),
 // the kernel weights stay resident in LDS for the block's lifetime (persistent blocks walk the
-// tiles), and the next tile's halo is prefetched into registers behind the current tile's MFMAs.
+// tiles), and the next tile's halo is fetched behind the current tile's MFMAs (conv2 forward:
+// straight into LDS by LDS-DMA; the gradient kernels: through registers).
 //
 // MFMA: v_mfma_f32_16x16x4_f32, roles as in conv_gemm.hip (row i = output channel, column j =
 // pixel) so every lane owns 4 consecutive NHWC channels of one pixel.
@@ -20,18 +21,14 @@
 // vector-memory counter (vmcnt(0)), which would expose the latency of the epilogue's global stores
 // and of the next tile's prefetch loads once per tile (cdna_hip_programming.md, "Pipelining across
 // barriers").  The "memory" clobber keeps the compiler from moving LDS accesses across it.
-#ifdef GEECO_HALO_SETPRIO
-#define SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define SETPRIO(x)
-#endif
-
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------
-// conv2-type forward: stride 2, CIN % 16 == 0, COUT % 16 == 0, tile = 4 x 16 output pixels.
-// LDS: W as [tap][cq][co][4] (b128 B-fragments), halo as [cq][hy][parity][hx/2] float4 planes
-// (b128 A-fragments: consecutive output columns are consecutive 16-byte slots).
+// conv2-type forward: stride 2, CIN == 32, COUT % 16 == 0, tile = 4 x 16 output pixels.
+// LDS: W as [tap][cq][co][4] (b128 B-fragments); halo (2 buffers, filled by LDS-DMA) as
+// [row][pixel pair][16 float4 = 2 pixels x 8 channel quads, XOR-swizzled by the pair index]:
+// a pixel's 128 bytes are fetched by 8 consecutive lanes and the b128 A-fragments of 16 consecutive
+// output columns (input pixels 2 r + kx) fall on distinct 16-byte slots.
 // ------------------------------------------------------------------------------------------------
 struct HaloFwdParams {
   const float* x;
@@ -44,7 +41,6 @@ struct HaloFwdParams {
   long long ntiles;          // G*N*tiles_y*tiles_x
   int tiles_per_group;       // N*tiles_y*tiles_x
   int relu;
-  int debug;   // ablation switches (GEECO_HALO_DEBUG): 1 = skip MFMAs, 2 = skip halo loads, 4 = skip output stores
 };
 
 __device__ float g_zero_page[64];   // source of LDS-DMA lanes that fall outside the image (TF SAME zero padding)
@@ -276,8 +272,6 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
     p.tiles_per_group = N * p.tiles_x * p.tiles_y;
     p.ntiles = (long long)groups * p.tiles_per_group;
     p.relu = relu;
-    static const int dbg = getenv("GEECO_HALO_DEBUG") ? atoi(getenv("GEECO_HALO_DEBUG")) : 0;
-    p.debug = dbg;
     int rc = launch_s2_halo_fwd<32, 48>(p, stream);
     if (rc) return rc;
     *handled = 1;
