@@ -1,12 +1,12 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE of one conv layer's kernels under GEECO_CONV_DEBUG values. usage: pmc_layer.sh L d1 d2 ...
+# FETCH_SIZE of one conv layer's kernels under env settings. usage: pmc_layer.sh L VAR=val [VAR=val ...]
 R=$GRAFT_REPO_ROOT
 L=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for d in "$@"; do
-  out=$R/gpurun_out/pmcl_$d
+  out=$R/gpurun_out/pmcl_${d//[^A-Za-z0-9_]/_}
   rm -rf $out; mkdir -p $out
-  export GEECO_CONV_DEBUG=$d
+  export $d
   timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o p -- python3 $R/scripts/dev/conv_bench.py $L 3 > $out/log.txt 2>&1 || { echo "rocprof failed"; tail -5 $out/log.txt; exit 1; }
   python3 - $out $d <<'PY'
 import csv, sys, collections, re
