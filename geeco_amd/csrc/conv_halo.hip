@@ -759,12 +759,245 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_dgrad_kernel(const HaloDg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same input gradient with the dz halo cut into 16-channel chunks (conv3: 48 <- 64 channels; any
+// CIN % 16 == 0, COUT % 16 == 0 whose kernel fits LDS).  With 64 output channels the whole halo
+// (5 x 33 pixels x 256 B, twice) no longer fits beside the resident kernel (9 x 48 rows x 256 B), so a
+// tile is processed in COUT / 16 steps: step (tile, chunk) reads the chunk image [hy 5][hx 33][4 quads]
+// (quads XOR-swizzled by (hx >> 1) & 3: the b128 reads of 16 consecutive columns are conflict free), while
+// the next step's image lands in the other buffer by LDS-DMA (4 lanes fetch a pixel's 64 contiguous bytes;
+// no VGPR staging).  Accumulators (4 parity classes x CIN / 16 tiles) live across the chunks of a tile.
+// Why it pays: the gather GEMM re-fetches dz once per tap beyond L2 (PMC: 1.1 GB per conv3 launch for a
+// 100 MB tensor) and runs at the per-CU miss rate of the vector memory path; here dz is read once.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const HaloDgradParams p) {
+  constexpr int NT = 512;
+  constexpr int NCH = COUT / 16;                       // chunks (steps) per tile
+  constexpr int TCI = CIN / 16;                        // ci tiles per wave
+  constexpr int HR = 5, HC = 33;                       // dz halo rows / cols
+  constexpr int IMG_F4 = HR * HC * 4;                  // 660 float4 per chunk image
+  constexpr int NPIECE = (IMG_F4 + 63) / 64;           // 11 DMA pieces
+  constexpr int BUF_F4 = NPIECE * 64;                  // padded: the last piece spills into padding
+  constexpr int NSLOT = (NPIECE + 7) / 8;              // pieces per wave
+  constexpr int WP = COUT / 4 + 1;                     // float4 pitch of a (tap, ci) kernel row (odd)
+  constexpr int W_F4 = 9 * CIN * WP;
+  static_assert(CIN % 16 == 0 && COUT % 16 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sW = reinterpret_cast<f32x4*>(smem);
+  f32x4* sH = sW + W_F4;                               // 2 chunk images
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int row = wid & 3, half = wid >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const long long per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+  long long tile = (long long)blockIdx.x * per;
+  const long long tend = tile + per < p.ntiles ? tile + per : p.ntiles;
+  if (tile >= tend) return;
+  int g, n, ty, tx;
+  {
+    g = (int)(tile / p.tiles_per_group);
+    int rem = (int)(tile - (long long)g * p.tiles_per_group);
+    int per_img = p.tiles_x * p.tiles_y;
+    n = rem / per_img;
+    rem -= n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  auto advance = [&](int& g_, int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        if (++n_ == p.N) {
+          n_ = 0;
+          ++g_;
+        }
+      }
+    }
+  };
+
+  // this wave's DMA pieces: piece k = wid + 8 i covers image slots [64 k, 64 k + 64); lane -> (hy, hx, quad)
+  int d_src[NSLOT];
+  short d_hy[NSLOT], d_hx[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int sl = (wid + 8 * i) * 64 + lane;
+    const int pix = sl >> 2, slot = sl & 3;
+    const int hy = pix / HC, hx = pix - hy * HC;
+    const int quad = slot ^ ((hx >> 1) & 3);
+    d_hy[i] = (short)(sl < IMG_F4 ? hy : 30000);       // out-of-range marker fails the per-tile bounds test
+    d_hx[i] = (short)hx;
+    d_src[i] = (hy * p.Wo + hx) * COUT + quad * 4;
+  }
+  auto dma_chunk = [&](int buf, int g_, int n_, int ty_, int tx_, int chunk) {
+    const int oy0 = ty_ * 4 - 1, ox0 = tx_ * 32 - 1;
+    const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n_ * p.Ho + oy0) * p.Wo + ox0) * COUT + chunk * 16;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      if (wid + 8 * i < NPIECE) {                       // wave-uniform
+        const int oy = oy0 + d_hy[i], ox = ox0 + d_hx[i];
+        const bool v = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+        const float* src = v ? zg + d_src[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * BUF_F4 + (wid + 8 * i) * 64), 16, 0, 0);
+      }
+    }
+  };
+  auto load_weights = [&](int g_) {
+    const f32x4* wg = reinterpret_cast<const f32x4*>(p.w + (long long)g_ * p.gs_w);
+    constexpr int COQ = COUT / 4;
+    for (int e = tid; e < 9 * CIN * COQ; e += NT) {
+      int rowi = e / COQ, c4 = e - rowi * COQ;
+      sW[rowi * WP + c4] = wg[e];
+    }
+  };
+
+  dma_chunk(0, g, n, ty, tx, 0);
+  load_weights(g);
+  int g_w = g;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // lane r = X' column inside the wave's 16-column strip; q selects the co quad of the chunk
+  const int hx_lane = 16 * half + r + 1;                                  // - dx
+  const int b_lane = r * WP + q;                                          // + (tap*CIN + 16 t)*WP + 4 chunk
+  int buf = 0;
+  for (;;) {
+    const bool more = tile + 1 < tend;
+    int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
+    if (more) advance(g2, n2, ty2, tx2);
+    // ReluGrad mask of this wave's 4 x TCI output float4s: issued now, consumed in the epilogue
+    const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + r);
+    f32x4 mk[4][TCI];
+    bool okc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int y = yb + (c >> 1), x = xb + (c & 1);
+      okc[c] = y < p.H && x < p.W;
+#pragma unroll
+      for (int t = 0; t < TCI; ++t) {
+        mk[c][t] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (p.mask && okc[c])
+          mk[c][t] = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_dx +
+                                                     (((long long)n * p.H + y) * p.W + x) * CIN + 16 * t + 4 * q);
+      }
+    }
+    f32x4 acc[4][TCI];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < TCI; ++t) acc[c][t] = zero4;
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      // the next step's image lands in the other buffer while this one is consumed
+      if (chunk + 1 < NCH)
+        dma_chunk(buf ^ 1, g, n, ty, tx, chunk + 1);
+      else if (more)
+        dma_chunk(buf ^ 1, g2, n2, ty2, tx2, 0);
+      const f32x4* hA = sH + buf * BUF_F4;
+      const f32x4* hB = sW + b_lane + 4 * chunk;
+      // static schedule: tap (ky, kx) feeds class (py, px) = (ky & 1, kx & 1) from the dz pixel at
+      // (row + 1 - (ky >> 1), column - (kx >> 1))
+      f32x4 a_cur, b_cur[TCI], a_nxt, b_nxt[TCI];
+      auto frag = [&](int tap, f32x4& a, f32x4 (&b)[TCI]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int hy = row + 1 - (ky >> 1), hx = hx_lane - (kx >> 1);
+        a = hA[(hy * HC + hx) * 4 + (q ^ ((hx >> 1) & 3))];
+#pragma unroll
+        for (int t = 0; t < TCI; ++t) b[t] = hB[(tap * CIN + 16 * t) * WP];
+      };
+      frag(0, a_cur, b_cur);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) frag(tap + 1, a_nxt, b_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int c = (ky & 1) * 2 + (kx & 1);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < TCI; ++t)
+              acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[t][s], a_cur[s], acc[c][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int t = 0; t < TCI; ++t) b_cur[t] = b_nxt[t];
+      }
+      if (chunk + 1 < NCH || more) dma_barrier();   // next image landed; everyone is done with this one
+      buf ^= 1;
+    }
+    // epilogue: class c -> pixel (yb + py, xb + px); lane owns ci = 16 t + 4 q .. +3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (!okc[c]) continue;
+      const int y = yb + (c >> 1), x = xb + (c & 1);
+      float* o = p.dx + (long long)g * p.gs_dx + (((long long)n * p.H + y) * p.W + x) * CIN + 4 * q;
+#pragma unroll
+      for (int t = 0; t < TCI; ++t) {
+        f32x4 v = acc[c][t];
+        const f32x4 m = mk[c][t];
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(o + 16 * t) = v;
+      }
+    }
+    if (!more) break;
+    if (g2 != g_w) {          // (the barrier above already separated everyone from the old kernel)
+      load_weights(g2);
+      g_w = g2;
+      __syncthreads();
+    }
+    g = g2; n = n2; ty = ty2; tx = tx2;
+    ++tile;
+  }
+}
+
+template <int CIN, int COUT>
+static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
+  constexpr int BUF_F4 = ((5 * 33 * 4 + 63) / 64) * 64;
+  const size_t lds = (size_t)(9 * CIN * (COUT / 4 + 1) + 2 * BUF_F4) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  hipLaunchKernelGGL((conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  return 0;
+}
+
 int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,
                          int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
                          int stride, hipStream_t stream, int* handled) {
   *handled = 0;
   static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !w_hwio) return 0;
+  static const int no_chunked = getenv("GEECO_NO_HALO3") ? 1 : 0;
+  if (!no_chunked && stride == 2 && Cin == 48 && Cout == 64 && (H % 2 == 0) && (W % 2 == 0)) {
+    HaloDgradParams p = {};
+    p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx;
+    p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
+    p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+    p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
+    p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+    p.ntiles = (long long)groups * p.tiles_per_group;
+    int rc = launch_dgrad_chunked<48, 64>(p, stream);
+    if (rc) return rc;
+    GEECO_LAUNCH_CHECK();
+    *handled = 1;
+    return 0;
+  }
   if (stride == 2 && Cin == 32 && Cout == 48 && (H % 2 == 0) && (W % 2 == 0)) {
     HaloDgradParams p = {};
     p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx;

@@ -27,6 +27,7 @@ CONV_CASES = [
     (2, 16, 16, 4, 32, 1),      # conv1-like (RGB padded to 4)
     (2, 16, 16, 32, 48, 2),     # conv2-like
     (1, 12, 20, 48, 64, 2),     # conv3-like, non-square
+    (2, 40, 136, 48, 64, 2),    # conv3 chunked-halo dgrad: several 8x64 tiles, ragged last column of tiles
     (3, 8, 8, 64, 128, 2),
     (2, 9, 7, 16, 16, 2),       # odd sizes: SAME pads (1,1)
     (2, 4, 4, 192, 256, 2),     # small-M path
