@@ -255,6 +255,205 @@ static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3-type forward (stride 2, CIN % 16 == 0, COUT % 32 == 0, kernel resident in LDS): the input halo of
+// a 4 x 16 output tile is staged in 16-channel chunks - with 48 input channels the whole halo (twice) does
+// not fit beside the 110 KB kernel.  Step (tile, chunk): 9 taps read their A fragments from the chunk image
+// [row 9][pixel pair 17][8 float4 = 2 pixels x 4 quads, XOR-swizzled by pair & 7] while the next step's
+// image lands in the other buffer by LDS-DMA (4 lanes fetch a pixel's 64 contiguous bytes).  Wave = (output
+// row of the tile, half of the output channels); accumulators live across the chunks of a tile.
+// Why: the gather GEMM fetches every input pixel 2.25 times from beyond L2 (PMC 744 MB for a 302 MB input)
+// and the kernel slab once per block (340 MB), at the per-CU miss rate of the vector memory path.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const HaloFwdParams p) {
+  constexpr int NT = 512;
+  constexpr int TH = 4, TW = 16;
+  constexpr int CQ = CIN / 4;
+  constexpr int NCH = CIN / 16;                       // chunks (steps) per tile
+  constexpr int HY = 2 * TH + 1;
+  constexpr int ROW = 17 * 8;                         // float4 per image row
+  constexpr int IMG_F4 = HY * ROW;                    // 1224
+  constexpr int NPIECE = (IMG_F4 + 63) / 64;          // 20
+  constexpr int BUF_F4 = NPIECE * 64;
+  constexpr int NSLOT = (NPIECE + 7) / 8;
+  constexpr int W_F4 = 9 * CQ * COUT;
+  constexpr int TI = COUT / 32;                       // co tiles per wave (each wave: half of the channels)
+  static_assert(CIN % 16 == 0 && COUT % 32 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sW = reinterpret_cast<f32x4*>(smem);
+  f32x4* sH = sW + W_F4;                              // 2 chunk images
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int strip = wid & 3, cohalf = wid >> 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const long long per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+  long long tile = (long long)blockIdx.x * per;
+  long long tend = tile + per < p.ntiles ? tile + per : p.ntiles;
+  if (tile >= tend) return;
+  int g, n, ty, tx;
+  {
+    g = (int)(tile / p.tiles_per_group);
+    int rem = (int)(tile - (long long)g * p.tiles_per_group);
+    int per_img = p.tiles_x * p.tiles_y;
+    n = rem / per_img;
+    rem -= n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  auto advance = [&](int& g_, int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        if (++n_ == p.N) {
+          n_ = 0;
+          ++g_;
+        }
+      }
+    }
+  };
+
+  int d_src[NSLOT];
+  short d_hy[NSLOT], d_hx[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int sl = (wid + 8 * i) * 64 + lane;
+    const int rw = sl / ROW, rem = sl - rw * ROW;
+    const int pair = rem >> 3, u = (rem & 7) ^ (pair & 7);
+    const int hx = 2 * pair + (u >> 2), cq4 = u & 3;
+    const bool ok = sl < IMG_F4 && hx <= 2 * TW;
+    d_hy[i] = (short)(ok ? rw : 30000);               // out-of-range marker fails the per-tile bounds test
+    d_hx[i] = (short)hx;
+    d_src[i] = (rw * p.W + hx) * CIN + cq4 * 4;
+  }
+  auto dma_chunk = [&](int buf, int g_, int n_, int ty_, int tx_, int chunk) {
+    const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;      // TF SAME, stride 2, even input: pad_before = 0
+    const float* xg = p.x + (long long)g_ * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN + chunk * 16;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      if (wid + 8 * i < NPIECE) {                       // wave-uniform
+        const bool v = iy0 + d_hy[i] < p.H && ix0 + d_hx[i] < p.W;
+        const float* src = v ? xg + d_src[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * BUF_F4 + (wid + 8 * i) * 64), 16, 0, 0);
+      }
+    }
+  };
+  auto load_weights = [&](int g_) {
+    const float* wg = p.w + (long long)g_ * p.gs_w;
+    // HWIO [tap][c][co] -> LDS [tap][c/4][co][c%4]
+    for (int e = tid; e < 9 * CIN * COUT; e += NT) {
+      int co = e % COUT;
+      int tc = e / COUT;               // tap*CIN + c
+      int c = tc % CIN, tap = tc / CIN;
+      smem[((tap * CQ + (c >> 2)) * COUT + co) * 4 + (c & 3)] = wg[e];
+    }
+  };
+
+  dma_chunk(0, g, n, ty, tx, 0);
+  load_weights(g);
+  int g_w = g;
+  f32x4 bias_r[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+    bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + cohalf * (COUT / 2) + i * 16 + 4 * q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const f32x4* hB = sW + q * COUT + cohalf * (COUT / 2) + r;     // + ((tap*CQ + 4 chunk) * COUT + 16 i)
+  int buf = 0;
+  for (;;) {
+    const bool more = tile + 1 < tend;
+    int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
+    if (more) advance(g2, n2, ty2, tx2);
+    f32x4 acc[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[i] = zero4;
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      if (chunk + 1 < NCH)
+        dma_chunk(buf ^ 1, g, n, ty, tx, chunk + 1);
+      else if (more)
+        dma_chunk(buf ^ 1, g2, n2, ty2, tx2, 0);
+      const f32x4* hA = sH + buf * BUF_F4 + (2 * strip) * ROW;
+      const f32x4* hBc = hB + 4 * chunk * COUT;
+      f32x4 a_cur, b_cur[TI], a_nxt, b_nxt[TI];
+      auto frag = [&](int tap, f32x4& a, f32x4 (&b)[TI]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int pair = r + (kx >> 1);
+        a = hA[ky * ROW + pair * 8 + ((((kx & 1) << 2) | q) ^ (pair & 7))];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) b[i] = hBc[tap * CQ * COUT + i * 16];
+      };
+      frag(0, a_cur, b_cur);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) frag(tap + 1, a_nxt, b_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[i][s], a_cur[s], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) b_cur[i] = b_nxt[i];
+      }
+      if (chunk + 1 < NCH || more) dma_barrier();   // next image landed; everyone is done with this one
+      buf ^= 1;
+    }
+    {
+      // epilogue: pixel (oy, ox) = (ty*4 + strip, tx*16 + r); channels cohalf*COUT/2 + 16 i + 4 q .. +3
+      const int oy = ty * TH + strip, ox = tx * TW + r;
+      const bool ok = oy < p.Ho && ox < p.Wo;
+      float* yo = p.y + (long long)g * p.gs_y + (((long long)n * p.Ho + oy) * p.Wo + ox) * COUT + cohalf * (COUT / 2);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        f32x4 v = acc[i] + bias_r[i];
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (ok) *reinterpret_cast<f32x4*>(yo + i * 16 + 4 * q) = v;
+      }
+    }
+    if (!more) break;
+    if (g2 != g_w) {             // the range crosses into the next encoder: refresh the resident kernel
+      load_weights(g2);
+      g_w = g2;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g2 * p.gs_b + cohalf * (COUT / 2) + i * 16 + 4 * q);
+      __syncthreads();
+    }
+    g = g2; n = n2; ty = ty2; tx = tx2;
+    ++tile;
+  }
+}
+
+template <int CIN, int COUT>
+static int launch_s2_halo_fwd_chunked(HaloFwdParams& p, hipStream_t s) {
+  constexpr int BUF_F4 = ((9 * 17 * 8 + 63) / 64) * 64;
+  const size_t lds = (size_t)(9 * (CIN / 4) * COUT + 2 * BUF_F4) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_chunked_kernel<CIN, COUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  hipLaunchKernelGGL((conv_s2_halo_fwd_chunked_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
 // Returns 1 if handled, 0 if the shape is not covered (caller falls back to the gather-GEMM),
 // or an error code < 0 / hipError.
 int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
@@ -263,7 +462,9 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
   *handled = 0;
   static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !b) return 0;
-  if (stride == 2 && Cin == 32 && Cout == 48 && (H % 2 == 0) && (W % 2 == 0)) {
+  static const int no_chunked = getenv("GEECO_NO_HALO3") ? 1 : 0;
+  const bool conv2 = Cin == 32 && Cout == 48, conv3 = Cin == 48 && Cout == 64 && !no_chunked;
+  if (stride == 2 && (conv2 || conv3) && (H % 2 == 0) && (W % 2 == 0)) {
     HaloFwdParams p = {};
     p.x = x; p.w = w; p.bias = b; p.y = y;
     p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
@@ -272,7 +473,7 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
     p.tiles_per_group = N * p.tiles_x * p.tiles_y;
     p.ntiles = (long long)groups * p.tiles_per_group;
     p.relu = relu;
-    int rc = launch_s2_halo_fwd<32, 48>(p, stream);
+    int rc = conv2 ? launch_s2_halo_fwd<32, 48>(p, stream) : launch_s2_halo_fwd_chunked<48, 64>(p, stream);
     if (rc) return rc;
     *handled = 1;
   }
