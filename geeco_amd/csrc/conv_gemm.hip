@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int j = 0; j < PA; ++j) {
       long long m = m0 + tid / SPR + j * RPP;
       if (m < clsM) {
-        long long n = m / HcWc;
+        // 32-bit division (launch_conv_gemm checks M < 2^31): the 64-bit form is a ~150-instruction routine
+        long long n = (unsigned)m / (unsigned)HcWc;
         int rem = (int)(m - n * HcWc);
         int yp = rem / clsWc;
         int xp = rem - yp * clsWc;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   for (int j = 0; j < TJ; ++j) {
     long long m = m0 + pixbase + j * 16 + r;
     if (m >= clsM) continue;
-    long long n = m / HcWc;
+    long long n = (unsigned)m / (unsigned)HcWc;
     int rem = (int)(m - n * HcWc);
     int yp = rem / clsWc;
     int xp = rem - yp * clsWc;
@@ -501,6 +502,11 @@ extern "C" int geeco_debug_dump_stamps(const char* path) {
 #endif
 
 static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t s) {
+  for (int c = 0; c < p.ncls; ++c)
+    if (p.cls[c].M + 256 >= (1ll << 31)) {
+      geeco_set_error("conv3x3: %lld rows per launch exceed the 32-bit row index of the kernel", p.cls[c].M);
+      return (int)hipErrorInvalidValue;
+    }
 #ifdef GEECO_STAMPS
   p.stamps = geeco_stamp_buffer();
 #endif
