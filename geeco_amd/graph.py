@@ -117,6 +117,9 @@ class ConvEncoderStack:
       # wgrads of different layers may run concurrently (different streams): one split-K workspace each
       nside = int(os.environ.get('GEECO_WGRAD_STREAMS', '2'))   # measured: 1 -> 2 streams +1.1 %, 3 slower
       self.wgrad1_on_main = os.environ.get('GEECO_WGRAD1_SIDE') is None
+      # the LDS-halo wgrad kernels of conv1 / conv2 want whole CUs: beside the dgrad chain they only slow it
+      # down (measured: layers below 2 serial +0.8 %, below 3 +0.1 %, below 4 -0.5 %)
+      self.serial_below = int(os.environ.get('GEECO_SERIAL_BELOW', '2'))
       self.ws_l = [torch.empty(ops.conv3x3_wgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) // 4 + 4,
                                **f32) for L in self.layers]
       self.ws = self.ws_l[0]
@@ -191,10 +194,10 @@ class ConvEncoderStack:
         dw, gs_dw = self.dw1p, self.dw1p[0].numel()
       else:
         dw, gs_dw = self._dw(l), self.gs_p
-      # wgrad(l) is off the critical path (the dgrad chain on `main`): it goes to a side stream, except
-      # conv1's (there is no dgrad left to overlap with, and `main` is idle by then)
+      # wgrad(l) of the upper layers is off the critical path (the dgrad chain on `main`): it goes to a side
+      # stream; the bottom layers' (LDS-halo kernels, one or two blocks per CU) stay on `main`
       side = None
-      if sides and not (l == 0 and self.wgrad1_on_main):
+      if sides and not (l == 0 and self.wgrad1_on_main) and l >= self.serial_below:
         side = sides[l % len(sides)]
       if side is not None:
         side.wait_stream(main)          # dz[l] is ready
