@@ -1242,27 +1242,24 @@ struct Conv1FwdParams {
 };
 
 __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParams p) {
+  // Persistent blocks: a block keeps the kernel fragments and bias of its encoder in registers and walks the
+  // tiles t = blockIdx.x, + gridDim.x, ...; the next tile's halo is fetched into registers before the current
+  // tile is computed and lands in the other LDS buffer afterwards.  One block per tile (24 576 blocks of a few
+  // microseconds each) was bound by workgroup dispatch and by the exposed latency of every block's own halo
+  // and kernel loads: load, MFMA and store time simply added up (ablation: 267 = 90 + 52 + 85 + 56 us).
   constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH = TH + 2;
-  __shared__ __attribute__((aligned(16))) float sX[HH * HW_ * 4];
+  constexpr int NPX = HH * HW_;                    // 340 halo pixels
+  constexpr int NLD = (NPX + 255) / 256;           // float4 per thread (2)
+  __shared__ __attribute__((aligned(16))) float sX[2][NPX * 4];
+  __shared__ __attribute__((aligned(16))) float sO[4][16 * 36];   // per wave: [pixel][32 + 4 pad]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  int t = blockIdx.x;
-  const int tx = t % p.tiles_x;
-  t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int n = t / p.tiles_y;
   const int g = blockIdx.y;
-  const int y0 = ty * TH, x0 = tx * TW;
-  const float* xg = p.x + (long long)g * p.gs_x + (long long)n * p.H * p.W * 4;
-  for (int i = tid; i < HH * HW_; i += 256) {
-    const int hy = i / HW_, hx = i - hy * HW_;
-    const int iy = y0 + hy - 1, ix = x0 + hx - 1;        // TF SAME, stride 1: pad 1 on every side
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-      v = *reinterpret_cast<const f32x4*>(xg + ((long long)iy * p.W + ix) * 4);
-    *reinterpret_cast<f32x4*>(sX + i * 4) = v;
-  }
-  // kernel fragments: lane (r = co, q = channel) of tap t, co tile i
+  const int per_img = p.tiles_x * p.tiles_y, ntiles = p.N * per_img;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  const float* xg0 = p.x + (long long)g * p.gs_x;
+  // kernel fragments: lane (r = co, q = channel) of tap tp, co tile i
   const float* wg = p.w + (long long)g * p.gs_w;
   float wf[9][2];
 #pragma unroll
@@ -1272,42 +1269,82 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
   f32x4 bias_r[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + i * 16 + 4 * q);
+
+  f32x4 stage[NLD];
+  auto load_halo = [&](int tt) {
+    const int n = tt / per_img, rem = tt - n * per_img;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* xg = xg0 + (long long)n * p.H * p.W * 4;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 256 * k;
+      const int hy = i / HW_, hx = i - hy * HW_;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;        // TF SAME, stride 1: pad 1 on every side
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < NPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const f32x4*>(xg + ((long long)iy * p.W + ix) * 4);
+      stage[k] = v;
+    }
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 256 * k;
+      if (i < NPX) *reinterpret_cast<f32x4*>(&sX[buf][i * 4]) = stage[k];
+    }
+  };
+  load_halo(t);
+  store_halo(0);
   __syncthreads();
-  // wave w: rows 2w, 2w+1; 2 column halves => 4 strips of 16 pixels.  The 16 x 32 output strip is 2 KB
-  // contiguous in NHWC memory: it is transposed through LDS so that each store instruction writes 1 KB
-  // of consecutive bytes (lane l -> pixel l / 8 (+8), channel quad l % 8) instead of 16 separate 64 B pieces.
-  __shared__ __attribute__((aligned(16))) float sO[4][16 * 36];   // per wave: [pixel][32 + 4 pad]
   float* so = sO[wid];
+  int buf = 0;
+  for (;;) {
+    const int t2 = t + gridDim.x;
+    const bool more = t2 < ntiles;
+    if (more) load_halo(t2);
+    const int n = t / per_img, rem = t - n * per_img;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    float* yg = p.y + (long long)g * p.gs_y + (long long)n * p.H * p.W * 32;
+    // wave w: rows 2w, 2w+1; 2 column halves => 4 strips of 16 pixels.  The 16 x 32 output strip is 2 KB
+    // contiguous in NHWC memory: it is transposed through LDS so that each store instruction writes 1 KB
+    // of consecutive bytes (lane l -> pixel l / 8 (+8), channel quad l % 8) instead of 16 separate 64 B pieces.
 #pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    const int oyl = 2 * wid + (st >> 1), oxl0 = 16 * (st & 1);
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const float* base = sX + ((oyl * HW_ + oxl0 + r) << 2) + q;
+    for (int st = 0; st < 4; ++st) {
+      const int oyl = 2 * wid + (st >> 1), oxl0 = 16 * (st & 1);
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const float* base = &sX[buf][((oyl * HW_ + oxl0 + r) << 2) + q];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int ky = tp / 3, kx = tp - ky * 3;
-      const float xv = base[(ky * HW_ + kx) << 2];
+      for (int tp = 0; tp < 9; ++tp) {
+        const int ky = tp / 3, kx = tp - ky * 3;
+        const float xv = base[(ky * HW_ + kx) << 2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tp][i], xv, acc[i], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f32x4 v = acc[i] + bias_r[i];
-      if (p.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tp][i], xv, acc[i], 0, 0, 0);
       }
-      *reinterpret_cast<f32x4*>(so + r * 36 + i * 16 + 4 * q) = v;      // lane owns pixel r, channels 16 i + 4 q
-    }
-    // same-wave LDS round trip: the compiler's lgkmcnt wait orders the reads behind the writes
-    const int oy = y0 + oyl;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int px = 8 * h + (lane >> 3), c4 = lane & 7;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(so + px * 36 + c4 * 4);
-      const int ox = x0 + oxl0 + px;
-      if (oy < p.H && ox < p.W)
-        *reinterpret_cast<f32x4*>(p.y + (long long)g * p.gs_y + (((long long)n * p.H + oy) * p.W + ox) * 32 + c4 * 4) = v;
+      for (int i = 0; i < 2; ++i) {
+        f32x4 v = acc[i] + bias_r[i];
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(so + r * 36 + i * 16 + 4 * q) = v;      // lane owns pixel r, channels 16 i + 4 q
+      }
+      // same-wave LDS round trip: the compiler's lgkmcnt wait orders the reads behind the writes
+      const int oy = y0 + oyl;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int px = 8 * h + (lane >> 3), c4 = lane & 7;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(so + px * 36 + c4 * 4);
+        const int ox = x0 + oxl0 + px;
+        if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4*>(yg + ((long long)oy * p.W + ox) * 32 + c4 * 4) = v;
+      }
     }
+    if (!more) break;
+    store_halo(buf ^ 1);
+    lds_barrier();      // the other buffer is complete; everyone is done with this one
+    buf ^= 1;
+    t = t2;
   }
 }
 
@@ -1320,7 +1357,9 @@ int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y
   Conv1FwdParams p = {};
   p.x = x; p.w = w; p.bias = b; p.y = y; p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
   p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.relu = relu;
-  dim3 grid((unsigned)(N * p.tiles_x * p.tiles_y), (unsigned)groups);
+  const int ntiles = N * p.tiles_x * p.tiles_y;
+  static const int bpg = getenv("GEECO_C1_BLOCKS") ? atoi(getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)
+  dim3 grid((unsigned)(ntiles < bpg ? ntiles : bpg), (unsigned)groups);
   hipLaunchKernelGGL(conv1_halo_fwd_kernel, grid, dim3(256), 0, stream, p);
   GEECO_LAUNCH_CHECK();
   *handled = 1;
