@@ -228,3 +228,47 @@ def test_derive_conv_weights(dev):
   ref = torch.zeros(G, 9, 4, 32, device=dev)
   ref[:, :, :3] = w1.reshape(G, 9, 3, 32)
   assert torch.equal(w1p, ref)
+
+
+# Grouped launches (G encoders at a stride, as the training step issues them) of the persistent LDS-halo
+# kernels, sized so that some block's tile range CROSSES an encoder boundary: that block has to swap the
+# kernel it keeps resident in LDS mid-flight.  (The single-group cases above never take that path.)
+@pytest.mark.parametrize('Cin,Cout,Nf,Nd', [(32, 48, 7, 5), (48, 64, 7, 5)])
+def test_conv3x3_grouped_halo_kernels(dev, Cin, Cout, Nf, Nd):
+  from geeco_amd import ops
+  G, H, W, stride = 3, 72, 136, 2
+  Ho, Wo = H // 2, W // 2
+  r = np.random.default_rng(21)
+  gs_w = 9 * Cin * Cout + 16           # kernels of the G encoders at a common (padded) stride, like the arena
+  warena = torch.zeros(G, gs_w, device=dev)
+  w = (r.standard_normal([G, 3, 3, Cin, Cout]) / np.sqrt(9 * Cin)).astype(np.float32)
+  warena[:, :9 * Cin * Cout] = torch.tensor(w.reshape(G, -1), device=dev)
+  barena = torch.tensor(r.standard_normal([G, Cout + 16]).astype(np.float32), device=dev)
+  # forward: tiles per encoder (7 x 9 x 5 = 315) are not a multiple of the tiles per block (4)
+  x = r.standard_normal([G, Nf, H, W, Cin]).astype(np.float32)
+  xd = torch.tensor(x, device=dev)
+  y = torch.empty(G, Nf, Ho, Wo, Cout, device=dev)
+  ws = torch.empty(ops.conv3x3_fwd_ws_bytes(G, Nf, H, W, Cin, Cout, stride) // 4 + 4, device=dev)
+  ops.conv3x3_fwd_into(y, xd, warena, barena, G, xd[0].numel(), gs_w, Cout + 16, y[0].numel(), Nf, H, W, Cin, Cout,
+                       stride, relu=True, ws=ws)
+  torch.cuda.synchronize()
+  for g in range(G):
+    ref = O.conv2d_same(torch.tensor(x[g], dtype=torch.float64), torch.tensor(w[g], dtype=torch.float64),
+                        barena[g, :Cout].double().cpu(), stride, relu=True)
+    _close(y[g], ref, 2e-5, 2e-5, 'grouped fwd, encoder %d' % g)
+  # input gradient: 5 x 9 x 3 = 135 tiles per encoder, 2 tiles per block
+  dz = r.standard_normal([G, Nd, Ho, Wo, Cout]).astype(np.float32)
+  mask = r.standard_normal([G, Nd, H, W, Cin]).astype(np.float32)
+  dzd, md = torch.tensor(dz, device=dev), torch.tensor(mask, device=dev)
+  wt = torch.empty(G, 3, 3, Cout, Cin, device=dev)
+  ops.transpose_hwio_into(wt, warena, G, gs_w, wt[0].numel(), Cin, Cout)
+  dx = torch.empty(G, Nd, H, W, Cin, device=dev)
+  dws = torch.empty(ops.conv3x3_dgrad_ws_bytes(G, Nd, H, W, Cin, Cout, stride) // 4 + 4, device=dev)
+  ops.conv3x3_dgrad_into(dx, dzd, wt, md, G, dzd[0].numel(), wt[0].numel(), dx[0].numel(), Nd, H, W, Cin, Cout, stride,
+                         ws=dws, w=warena, gs_w=gs_w)
+  torch.cuda.synchronize()
+  for g in range(G):
+    xg = torch.zeros(Nd, H, W, Cin, dtype=torch.float64, requires_grad=True)
+    yy = O.conv2d_same(xg, torch.tensor(w[g], dtype=torch.float64), torch.zeros(Cout, dtype=torch.float64), stride, relu=False)
+    yy.backward(torch.tensor(dz[g], dtype=torch.float64))
+    _close(dx[g], xg.grad * (torch.tensor(mask[g]) > 0), 2e-5, 2e-5, 'grouped dgrad, encoder %d' % g)
