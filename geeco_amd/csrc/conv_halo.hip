@@ -503,26 +503,33 @@ struct HaloWgradParams {
 };
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWgradParams p) {
+__global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgradParams p) {
   constexpr int NT = 512;
   constexpr int TH = 4, TW = 16;
-  constexpr int CQ = CIN / 4;
-  constexpr int HY = 2 * TH + 1, HX2 = TW + 1;
-  constexpr int PLANE = HY * 2 * HX2;
-  constexpr int HALO_F4 = CQ * PLANE;
-  constexpr int NPIX = HY * (2 * TW + 1);
-  constexpr int NLOAD = (NPIX * CQ + NT - 1) / NT;        // halo float4 per thread
+  constexpr int HY = 2 * TH + 1;
+  // LDS images, both filled by LDS-DMA (no VGPR staging, no ds_write):
+  //   x halo  [row 9][pixel pair 17][16 float4 = 2 pixels x 8 channel quads]; the quad slot is XOR-swizzled by
+  //           (pair & 3) << 2 so that the ds_read_b32 of a k-group (4 consecutive pixel pairs x 16 channels of one
+  //           16-channel half) covers all 64 banks: bank = 4 ((half << 3 | cq) ^ swz) + (c % 4);
+  //   dz tile [64 pixels][COUT] row-major (pitch COUT = 16 mod 32: the 4 pixels of a k-group use different banks).
+  constexpr int ROW = 17 * 16;
+  constexpr int HALO_USED = HY * ROW;                   // 2448 float4
+  constexpr int NHP = (HALO_USED + 63) / 64;            // 39 pieces of 1 KiB
+  constexpr int HALO_F4 = NHP * 64;
   constexpr int C4 = COUT / 4;
-  constexpr int DZ_F4 = TH * TW * C4;                     // dz tile float4
+  constexpr int DZ_F4 = TH * TW * C4;                   // 768 float4 = 12 pieces
+  constexpr int NZP = DZ_F4 / 64;
   constexpr int NDZ = (DZ_F4 + NT - 1) / NT;
+  constexpr int NSLOT = (NHP + NZP + 7) / 8;            // DMA pieces per wave (halo pieces first, then dz)
   constexpr int TI = COUT / 16;
-  static_assert(CIN == 32, "two ci halves <-> two wave groups");
-  static_assert(COUT % 32 == 16, "dz row pitch must be 16 (mod 32) floats");
+  static_assert(CIN == 32, "two ci halves <-> two wave groups; 8 quads per pixel");
+  static_assert(COUT % 32 == 16 && DZ_F4 % 64 == 0, "dz row pitch must be 16 (mod 32) floats");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sH = reinterpret_cast<f32x4*>(smem);            // 2 halo buffers
   f32x4* sZ = sH + 2 * HALO_F4;                           // 2 dz tiles
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int strip = wid & 3, cit = wid >> 2;
   const int g = blockIdx.y, split = blockIdx.x;
@@ -552,68 +559,69 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWg
     }
   };
 
-  int l_off[NLOAD], l_src[NLOAD];
-  short l_hy[NLOAD], l_hx[NLOAD];
+  // this wave's DMA pieces k = wid + 8 i: k < NHP -> halo slots [64 k, +64), else dz float4 [64 (k - NHP), +64)
+  int d_src[NSLOT];
+  short d_a[NSLOT], d_b[NSLOT];       // halo: (row, hx); dz: (tile row, tile column)
 #pragma unroll
-  for (int i = 0; i < NLOAD; ++i) {
-    int idx = tid + NT * i;
-    int pix = idx / CQ, cq = idx - pix * CQ;
-    int hy = pix / (2 * TW + 1), hx = pix - hy * (2 * TW + 1);
-    l_hy[i] = (short)hy; l_hx[i] = (short)hx;
-    l_off[i] = (pix < NPIX) ? cq * PLANE + (hy * 2 + (hx & 1)) * HX2 + (hx >> 1) : -1;
-    l_src[i] = (hy * p.W + hx) * CIN + cq * 4;
+  for (int i = 0; i < NSLOT; ++i) {
+    const int k = wid + 8 * i;
+    if (k < NHP) {
+      const int sl = k * 64 + lane;
+      const int rw = sl / ROW, rem = sl - rw * ROW;
+      const int pair = rem >> 4, u = (rem & 15) ^ ((pair & 3) << 2);
+      const int hx = 2 * pair + (u >> 3), cq = u & 7;
+      const bool ok = sl < HALO_USED && hx <= 2 * TW;
+      d_a[i] = (short)(ok ? rw : 30000);                 // out-of-range marker fails the per-tile bounds test
+      d_b[i] = (short)hx;
+      d_src[i] = (rw * p.W + hx) * CIN + cq * 4;
+    } else {
+      const int f = (k - NHP) * 64 + lane;
+      const int px = f / C4, c4 = f - px * C4;
+      d_a[i] = (short)(k < NHP + NZP ? (px >> 4) : 30000);
+      d_b[i] = (short)(px & 15);
+      d_src[i] = ((px >> 4) * p.Wo + (px & 15)) * COUT + c4 * 4;
+    }
   }
-  int z_px[NDZ], z_c4[NDZ];
-#pragma unroll
-  for (int i = 0; i < NDZ; ++i) {
-    int idx = tid + NT * i;
-    z_px[i] = idx < DZ_F4 ? idx / C4 : -1;
-    z_c4[i] = idx % C4;
-  }
-  f32x4 stage[NLOAD], zst[NDZ], dbsum[NDZ];
-#pragma unroll
-  for (int i = 0; i < NDZ; ++i) dbsum[i] = zero4;
-
-  auto load_tile = [&](int n_, int ty_, int tx_) {
+  auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
     const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
     const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN;
+    const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * COUT;
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      bool v = l_off[i] >= 0 && iy0 + l_hy[i] < p.H && ix0 + l_hx[i] < p.W;
-      stage[i] = v ? *reinterpret_cast<const f32x4*>(xg + l_src[i]) : zero4;
-    }
-    const float* zg = p.dz + (long long)g * p.gs_dz;
-#pragma unroll
-    for (int i = 0; i < NDZ; ++i) {
-      int oy = ty_ * TH + (z_px[i] >> 4), ox = tx_ * TW + (z_px[i] & 15);
-      bool v = z_px[i] >= 0 && oy < p.Ho && ox < p.Wo;
-      zst[i] = v ? *reinterpret_cast<const f32x4*>(zg + (((long long)n_ * p.Ho + oy) * p.Wo + ox) * COUT + z_c4[i] * 4)
-                 : zero4;
+    for (int i = 0; i < NSLOT; ++i) {
+      const int k = wid + 8 * i;                          // wave-uniform
+      if (k < NHP) {
+        const bool v = iy0 + d_a[i] < p.H && ix0 + d_b[i] < p.W;
+        const float* src = v ? xg + d_src[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * HALO_F4 + k * 64), 16, 0, 0);
+      } else if (k < NHP + NZP) {
+        const bool v = ty_ * TH + d_a[i] < p.Ho && tx_ * TW + d_b[i] < p.Wo;
+        const float* src = v ? zg + d_src[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * DZ_F4 + (k - NHP) * 64), 16, 0, 0);
+      }
     }
   };
 
+  f32x4 dbsum[NDZ];
+#pragma unroll
+  for (int i = 0; i < NDZ; ++i) dbsum[i] = zero4;
   f32x4 acc[9][TI];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < TI; ++i) acc[t][i] = zero4;
 
-  if (tile < tend) {
-    load_tile(n, ty, tx);
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i)
-      if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
-#pragma unroll
-    for (int i = 0; i < NDZ; ++i)
-      if (z_px[i] >= 0) {
-        sZ[z_px[i] * C4 + z_c4[i]] = zst[i];
-        dbsum[i] += zst[i];
-      }
-  }
+  if (tile < tend) dma_tile(0, n, ty, tx);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // B-operand (x) float index of lane: plane cq = 4 cit + r/4, component r%4; A-operand (dz): co = r
-  const int xb_lane = (((cit * 4 + (r >> 2)) * PLANE + (4 * strip) * HX2 + q) << 2) + (r & 3);
+  // B-operand (x) of lane: channel 16 cit + r, pixel pair 4 s + q (+1 for kx = 2); A-operand (dz): co = r
+  const int cq_lane = cit * 4 + (r >> 2);
+  int xe[3];                                              // float offset of (pair q + (kx >> 1), half kx & 1, cq, c % 4)
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int pr = q + (kx >> 1);
+    xe[kx] = ((pr * 16 + ((((kx & 1) << 3) | cq_lane) ^ ((pr & 3) << 2))) << 2) + (r & 3);
+  }
   const int za_lane = (16 * strip + q) * COUT + r;
   int buf = 0;
   for (; tile < tend; ++tile) {
@@ -621,12 +629,14 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWg
     int n2 = n, ty2 = ty, tx2 = tx;
     if (more) {
       advance(n2, ty2, tx2);
-      load_tile(n2, ty2, tx2);
+      dma_tile(buf ^ 1, n2, ty2, tx2);                    // lands behind this tile's MFMAs
     }
-    const float* hx = reinterpret_cast<const float*>(sH + buf * HALO_F4) + xb_lane;
+    // bias gradient: every thread adds its share of the dz tile (NDZ float4 reads per tile)
+#pragma unroll
+    for (int i = 0; i < NDZ; ++i)
+      if (tid + NT * i < DZ_F4) dbsum[i] += sZ[buf * DZ_F4 + tid + NT * i];
+    const float* hx = reinterpret_cast<const float*>(sH + buf * HALO_F4) + (2 * strip) * ROW * 4;
     const float* hz = reinterpret_cast<const float*>(sZ + buf * DZ_F4) + za_lane;
-    f32x4* hN = sH + (buf ^ 1) * HALO_F4;
-    f32x4* zN = sZ + (buf ^ 1) * DZ_F4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float a[TI], b[9];
@@ -635,25 +645,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWg
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ky = t / 3, kx = t - ky * 3;
-        b[t] = hx[(((ky * 2 + (kx & 1)) * HX2 + 4 * s + (kx >> 1)) << 2)];
-      }
-      if (more) {      // stage the next tile into the other LDS buffers behind this group's MFMAs
-        if (s == 1) {
-#pragma unroll
-          for (int i = 0; i < NLOAD; ++i)
-            if (i < 3 && l_off[i] >= 0) hN[l_off[i]] = stage[i];
-        } else if (s == 2) {
-#pragma unroll
-          for (int i = 3; i < NLOAD; ++i)
-            if (l_off[i] >= 0) hN[l_off[i]] = stage[i];
-        } else if (s == 3) {
-#pragma unroll
-          for (int i = 0; i < NDZ; ++i)
-            if (z_px[i] >= 0) {
-              zN[z_px[i] * C4 + z_c4[i]] = zst[i];
-              dbsum[i] += zst[i];
-            }
-        }
+        b[t] = hx[(ky * ROW + 4 * s * 16) * 4 + xe[kx]];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -662,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWg
         for (int i = 0; i < TI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t], acc[t][i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    lds_barrier();
+    dma_barrier();
     n = n2; ty = ty2; tx = tx2;
     buf ^= 1;
   }
@@ -693,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_wgrad_kernel(const HaloWg
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NDZ; ++i)
-    if (z_px[i] >= 0) sZ[z_px[i] * C4 + z_c4[i]] = dbsum[i];
+    if (tid + NT * i < DZ_F4) sZ[tid + NT * i] = dbsum[i];
   __syncthreads();
   if (tid < COUT) {
     const float* zf = reinterpret_cast<const float*>(sZ);
@@ -730,8 +722,8 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
     p.tiles_x = cdiv(p.Wo, 16); p.tiles_y = cdiv(p.Ho, 4);
     p.tiles_per_group = N * p.tiles_x * p.tiles_y;
     p.S = halo_wgrad_S(groups);
-    constexpr int CQ = 8, PLANE = 9 * 2 * 17;
-    const size_t lds = (size_t)(2 * CQ * PLANE + 2 * 4 * 16 * 12) * 16;
+    constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
+    const size_t lds = (size_t)(2 * HALO_F4 + 2 * 4 * 16 * 12) * 16;
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_wgrad_kernel<32, 48>),
