@@ -410,7 +410,7 @@ __device__ __forceinline__ void block_mfma_gemm(int M, int N, int K, const float
     const float* ap = a + (long long)(iv ? i : 0) * a_rs + q * a_ks;
     const float* bp = b + (long long)(jv ? j : 0) * b_cs + q * b_ks;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+
     for (int k0 = 0; k0 < K; k0 += 4) {
       const bool kv = k0 + q < K;
       const float av = (iv && kv) ? ap[(long long)k0 * a_ks] : 0.f;
