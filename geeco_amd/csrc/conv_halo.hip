@@ -51,8 +51,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Barrier that also retires this wave's LDS-DMA (global_load_lds) writes before anyone reads them.
 __device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdParams p) {
+// RW: the wave's kernel fragments (9 taps x COUT / 16 float4 = 108 registers) stay in VGPRs for the block's
+// lifetime, so the K loop reads ONE ds_read_b128 per 12 MFMAs instead of four; costs the second block per CU.
+template <int CIN, int COUT, bool RW>
+__global__ __launch_bounds__(512, RW ? 1 : 2) void conv_s2_halo_fwd_kernel(const HaloFwdParams p) {
   constexpr int NT = 512;                             // 8 waves = 4 output rows x 2 halves of the channel (K) range
   constexpr int TH = 4, TW = 16;
   constexpr int CQ = CIN / 4;
@@ -162,6 +164,18 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
   // lane r = output column of row `strip`; this wave sums channels [khalf*CIN/2, (khalf+1)*CIN/2)
   const int cq_lane = khalf * KBW * 4 + q;
   const f32x4* hB = sW + cq_lane * COUT + r;
+  f32x4 wreg[RW ? NIT : 1][TI];
+  auto load_wreg = [&]() {
+    if constexpr (RW) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int tap = it / KBW, kb = it - tap * KBW;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) wreg[it][i] = hB[(tap * CQ + kb * 4) * COUT + i * 16];
+      }
+    }
+  };
+  load_wreg();
   int buf = 0;
   for (;;) {
     const bool more = tile + 1 < tend;
@@ -181,8 +195,10 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
       const int ky = tap / 3, kx = tap - ky * 3;
       const int pair = r + (kx >> 1);
       a = hA[ky * ROW + pair * 16 + (((((kx & 1) << 3) | (cq_lane + 4 * kb))) ^ (pair & 15))];
+      if constexpr (!RW) {
 #pragma unroll
-      for (int i = 0; i < TI; ++i) b[i] = hB[(tap * CQ + kb * 4) * COUT + i * 16];
+        for (int i = 0; i < TI; ++i) b[i] = hB[(tap * CQ + kb * 4) * COUT + i * 16];
+      }
     };
     frag(0, a_cur, b_cur);
 #pragma unroll
@@ -193,11 +209,13 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[i][s], a_cur[s], acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(RW ? wreg[RW ? it : 0][i][s] : b_cur[i][s], a_cur[s], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       a_cur = a_nxt;
+      if constexpr (!RW) {
 #pragma unroll
-      for (int i = 0; i < TI; ++i) b_cur[i] = b_nxt[i];
+        for (int i = 0; i < TI; ++i) b_cur[i] = b_nxt[i];
+      }
     }
     f32x4* red = sR + (int)(tile & 1) * RED_F4;
     if (khalf == 1) {
@@ -227,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
       for (int i = 0; i < TI; ++i)
         bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g2 * p.gs_b + i * 16 + 4 * q);
       __syncthreads();
+      load_wreg();
     }
     g = g2; n = n2; ty = ty2; tx = tx2;
     buf ^= 1;
@@ -234,14 +253,14 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_fwd_kernel(const HaloFwdP
   }
 }
 
-template <int CIN, int COUT>
-static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
+template <int CIN, int COUT, bool RW>
+static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
   constexpr int CQ = CIN / 4;
   constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
   const size_t lds = (size_t)(9 * CQ * COUT + 2 * HALO_F4 + 2 * 4 * (COUT / 16) * 64) * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_kernel<CIN, COUT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_kernel<CIN, COUT, RW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -250,9 +269,15 @@ static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
     attr_set = true;
   }
   long long blocks = p.ntiles < 256 ? p.ntiles : 256;
-  hipLaunchKernelGGL((conv_s2_halo_fwd_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((conv_s2_halo_fwd_kernel<CIN, COUT, RW>), dim3((unsigned)blocks), dim3(512), lds, s, p);
   GEECO_LAUNCH_CHECK();
   return 0;
+}
+
+template <int CIN, int COUT>
+static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
+  static const int rw = getenv("GEECO_HALO_RW") ? atoi(getenv("GEECO_HALO_RW")) : 1;   // measured +2.4..3.6 % on the launch
+  return rw ? launch_s2_halo_fwd_v<CIN, COUT, true>(p, s) : launch_s2_halo_fwd_v<CIN, COUT, false>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------
