@@ -106,8 +106,8 @@ def roofline_conv2(model, iters):
   macs = enc.G * enc.Nf * L['Ho'] * L['Wo'] * L['Cout'] * 9 * L['Cin']
   achieved = 2.0 * macs / (ms * 1e-3) / 1e12
   halo = os.environ.get('GEECO_NO_HALO') is None and L['H'] % 2 == 0 and L['W'] % 2 == 0
-  rw = os.environ.get('GEECO_HALO_RW', '1') != '0'       # rocprof name: conv_s2_halo_fwd_kernel<32, 48, true|false>
-  kname = ('conv_s2_halo_fwd_kernel<32,48,%s>' % ('true' if rw else 'false')) if halo else 'conv_gemm_kernel<128,48,16,4,1,true>'
+  ws = os.environ.get('GEECO_HALO_WS', '4') != '0'       # rocprof name: conv_s2_halo_fwd_ws_kernel<32, 48, 4>
+  kname = ('conv_s2_halo_fwd_ws_kernel<32,48,4>' if ws else 'conv_s2_halo_fwd_kernel<32,48,true>') if halo else 'conv_gemm_kernel<128,48,16,4,1,true>'
   return {'bound': 'mfma', 'kernel': '%s (conv2 forward, %d frames)' % (kname, enc.G * enc.Nf),
           'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
           'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': recorded_traffic(kname),

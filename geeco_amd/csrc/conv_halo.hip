@@ -16,6 +16,7 @@
 // pixel) so every lane owns 4 consecutive NHWC channels of one pixel.
 #include "geeco_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter (vmcnt(0)), which would expose the latency of the epilogue's global stores
@@ -41,7 +42,33 @@ struct HaloFwdParams {
   long long ntiles;          // G*N*tiles_y*tiles_x
   int tiles_per_group;       // N*tiles_y*tiles_x
   int relu;
+  unsigned long long* stamps;   // -DGEECO_STAMPS builds only: [block][2 waves][64] s_memtime timeline
 };
+
+#ifdef GEECO_STAMPS
+// Dev instrumentation (scripts/dev/halo_stamps.py): per-tile timeline of wave 0 (K half 0) and wave 4 (K half 1).
+static unsigned long long* g_hstamps = nullptr;
+extern "C" int geeco_debug_dump_halo_stamps(const char* path) {
+  if (!g_hstamps) return 1;
+  (void)hipDeviceSynchronize();
+  const size_t n = 256 * 2 * 64;
+  unsigned long long* h = (unsigned long long*)malloc(n * 8);
+  (void)hipMemcpy(h, g_hstamps, n * 8, hipMemcpyDeviceToHost);
+  FILE* f = fopen(path, "wb");
+  if (!f) return 2;
+  fwrite(h, 8, n, f);
+  fclose(f);
+  free(h);
+  return 0;
+}
+#define HSTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    if (lane == 0 && wid < 8 && (wid & 3) == 0 && p.stamps && (i) < 64)                                  \
+      p.stamps[((long long)blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define HSTAMP(i)
+#endif
 
 __device__ float g_zero_page[64];   // source of LDS-DMA lanes that fall outside the image (TF SAME zero padding)
 
@@ -253,6 +280,272 @@ __global__ __launch_bounds__(512, RW ? 1 : 2) void conv_s2_halo_fwd_kernel(const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Warp-specialised conv2 forward (the default): 8 compute waves (4 output rows x 2 K halves, kernel fragments
+// in registers, loaded straight from the HWIO kernel) + LW loader waves that do nothing but issue the LDS-DMA of
+// the halos TWO tiles ahead into a ring of three buffers; the output strip is transposed through LDS so that
+// every store instruction writes 1 KiB of consecutive bytes.
+// Why (in-kernel timelines, scripts/dev/halo_stamps.py): in the variant above an LDS-DMA instruction holds the
+// issuing wave for ~300-600 cycles, ~3k cycles per tile on the compute waves that issue the 39 pieces; they reach
+// the tile barrier late and their partners idle (tile period 9.6k cycles for 6.9k cycles of MFMA work per SIMD).
+// With loaders the compute waves' MFMA phase is 3.7k cycles (3.5k ideal); what remains is the CU's vector
+// memory pipe: 39 KB in + 12 KB out per tile pass through it at ~5.5 B/clk whoever issues them (the epilogue's
+// three store instructions wait ~3-4k cycles behind the loaders' pieces).  Measured: +3.5 % on the launch.
+// All waves meet at ONE barrier per tile: loaders arrive once the halo of the NEXT tile has landed (`vmcnt`
+// leaves the tile after it in flight), compute waves after their last fragment read of the current one.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vm_imm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CIN, int COUT, int LW>
+__global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(const HaloFwdParams p) {
+  constexpr int NT = 512 + 64 * LW;
+  constexpr int TH = 4, TW = 16;
+  constexpr int CQ = CIN / 4;
+  static_assert(CQ == 8 && CIN == 32, "pair-swizzled halo image is laid out for 8 channel quads; 2 K halves of 16");
+  constexpr int HY = 2 * TH + 1;
+  constexpr int ROW = 17 * 16;
+  constexpr int HALO_USED = HY * ROW;
+  constexpr int NDMA = (HALO_USED + 63) / 64;         // 39 pieces of 1 KiB per tile
+  constexpr int HALO_F4 = NDMA * 64;
+  constexpr int NSLOT = (NDMA + LW - 1) / LW;         // pieces per loader wave
+  constexpr int TI = COUT / 16;
+  constexpr int RED_F4 = 4 * TI * 64;
+  constexpr int NBUF = 3;                             // halo ring: the DMA runs two tiles ahead of the MFMAs
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sH = reinterpret_cast<f32x4*>(smem);         // NBUF halo buffers
+  f32x4* sR = sH + NBUF * HALO_F4;                    // 2 reduction buffers
+  constexpr int OP = COUT / 4 + 1;                    // float4 pitch of an output pixel in the store staging (odd)
+  f32x4* sO = sR + 2 * RED_F4;                        // 4 strips x [16 pixels][OP]: output transposed for full-line stores
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wid >= 8;
+  const int r = lane & 15, q = lane >> 4;
+  const int strip = wid & 3, khalf = (wid >> 2) & 1;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const long long per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+  long long tile = (long long)blockIdx.x * per;
+  long long tend = tile + per < p.ntiles ? tile + per : p.ntiles;
+  if (tile >= tend) return;
+  int g, n, ty, tx;
+  {
+    g = (int)(tile / p.tiles_per_group);
+    int rem = (int)(tile - (long long)g * p.tiles_per_group);
+    int per_img = p.tiles_x * p.tiles_y;
+    n = rem / per_img;
+    rem -= n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  auto advance = [&](int& g_, int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        if (++n_ == p.N) {
+          n_ = 0;
+          ++g_;
+        }
+      }
+    }
+  };
+  if (loader) {
+    // ===== loader waves ===================================================================================
+    const int lw = wid - 8;
+    int d_src[NSLOT];
+    short d_hy[NSLOT], d_hx[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int sl = (lw + LW * i) * 64 + lane;
+      const int row = sl / ROW, rem = sl - row * ROW;
+      const int pair = rem >> 4, u = (rem & 15) ^ (pair & 15);
+      const int hx = 2 * pair + (u >> 3), cq = u & 7;
+      const bool ok = sl < HALO_USED && hx <= 2 * TW;
+      d_hy[i] = (short)(ok ? row : 30000);              // out-of-range marker fails the per-tile bounds test
+      d_hx[i] = (short)hx;
+      d_src[i] = (row * p.W + hx) * CIN + cq * 4;
+    }
+    auto dma_halo = [&](int buf, int g_, int n_, int ty_, int tx_) {
+      const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;      // TF SAME, stride 2, even input: pad_before = 0
+      const float* xg = p.x + (long long)g_ * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN;
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        if (lw + LW * i < NDMA) {                         // wave-uniform
+          const bool v = iy0 + d_hy[i] < p.H && ix0 + d_hx[i] < p.W;
+          const float* src = v ? xg + d_src[i] : g_zero_page;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (lw + LW * i) * 64 + buf * HALO_F4), 16, 0, 0);
+        }
+      }
+    };
+    {
+      // LDS-DMA ring: tiles t+1, t+2 are in flight ahead of the compute waves
+      const int npieces = (NDMA - lw + LW - 1) / LW;       // 10 or 9 (wave-uniform)
+      int g1 = g, n1 = n, ty1 = ty, tx1 = tx;              // tile + 1
+      dma_halo(0, g, n, ty, tx);
+      const bool has1 = tile + 1 < tend;
+      if (has1) {
+        advance(g1, n1, ty1, tx1);
+        dma_halo(1, g1, n1, ty1, tx1);
+      }
+      if (has1) {
+        if (npieces == NSLOT) wait_vm_imm<NSLOT>(); else wait_vm_imm<NSLOT - 1>();
+      } else {
+        wait_vm_imm<0>();
+      }
+      asm volatile("s_barrier" ::: "memory");             // (A) halo 0 landed
+      int g2 = g1, n2 = n1, ty2 = ty1, tx2 = tx1;          // tile + 2
+      int slot = 2;                                        // ring slot of tile + 2
+      for (;;) {
+        const bool more1 = tile + 1 < tend, more2 = tile + 2 < tend;
+        if (more2) {
+          advance(g2, n2, ty2, tx2);
+          dma_halo(slot, g2, n2, ty2, tx2);
+          slot = slot + 1 == NBUF ? 0 : slot + 1;
+        }
+        // tile barrier: the halo of tile + 1 must have landed (tile + 2 may stay in flight)
+        if (more2) {
+          if (npieces == NSLOT) wait_vm_imm<NSLOT>(); else wait_vm_imm<NSLOT - 1>();
+        } else {
+          wait_vm_imm<0>();
+        }
+        asm volatile("s_barrier" ::: "memory");
+        if (!more1) break;
+        ++tile;
+      }
+    }
+    return;
+  }
+
+  // ===== compute waves ======================================================================================
+  int g_w = g;
+  f32x4 bias_r[TI];
+  const int cq_lane = khalf * 4 + q;       // this wave sums channels [16 khalf, 16 khalf + 16)
+  f32x4 wreg[9][TI];
+  // kernel fragments straight from the HWIO kernel (no LDS staging): lane (r, q) of co tile i holds
+  // w[tap][4 cq_lane + s][16 i + r], s = 0..3; 16 lanes read 64 consecutive bytes
+  auto load_wreg = [&](int g_) {
+    const float* wg = p.w + (long long)g_ * p.gs_w + (4 * cq_lane) * COUT + r;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const float* w0 = wg + tap * CIN * COUT + 16 * i;
+        wreg[tap][i] = f32x4{w0[0], w0[COUT], w0[2 * COUT], w0[3 * COUT]};
+      }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g_ * p.gs_b + i * 16 + 4 * q);
+  };
+  load_wreg(g);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");               // (A)
+  int buf = 0;
+  int tcount = 0;
+  for (;;) {
+    const bool more = tile + 1 < tend;
+    int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
+    HSTAMP(tcount < 10 ? 6 * tcount + 0 : 64);
+    if (more) advance(g2, n2, ty2, tx2);
+    HSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
+    f32x4 acc[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[i] = zero4;
+    const f32x4* hA = sH + buf * HALO_F4 + (2 * strip) * ROW;
+    f32x4 a_cur, a_nxt;
+    auto frag = [&](int tap, f32x4& a) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int pair = r + (kx >> 1);
+      a = hA[ky * ROW + pair * 16 + ((((kx & 1) << 3) | cq_lane) ^ (pair & 15))];
+    };
+    frag(0, a_cur);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) frag(tap + 1, a_nxt);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch read ABOVE this group's MFMAs
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][i][s], a_cur[s], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+    }
+    HSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
+    f32x4* red = sR + (int)(tile & 1) * RED_F4;
+    if (khalf == 1) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) red[(strip * TI + i) * 64 + lane] = acc[i];
+    }
+    HSTAMP(tcount < 10 ? 6 * tcount + 3 : 64);
+    lds_barrier();
+    HSTAMP(tcount < 10 ? 6 * tcount + 4 : 64);   // tile barrier: partial sums visible; everyone is done with buf; the loaders' next halo landed
+    if (khalf == 0) {
+      // epilogue: lane owns pixel (ty*4 + strip, tx*16 + r), channels 16 i + 4 q .. +3.  The strip's 16 x COUT
+      // outputs are 3 KB of consecutive NHWC bytes: they are transposed through LDS so that every store instruction
+      // writes 1 KiB of consecutive bytes instead of 16 separate 64-byte pieces (in-kernel timeline: the three
+      // piecewise stores held the wave ~3.6k cycles per tile - the kernel's critical path).
+      f32x4* so = sO + strip * 16 * OP;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        f32x4 v = acc[i] + red[(strip * TI + i) * 64 + lane] + bias_r[i];
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        so[r * OP + 4 * i + q] = v;
+      }
+      // same-wave LDS round trip: the compiler's lgkmcnt wait orders the reads behind the writes
+      const int oy = ty * TH + strip;
+      float* yo = p.y + (long long)g * p.gs_y + (((long long)n * p.Ho + oy) * p.Wo + tx * TW) * COUT;
+      constexpr int C4 = COUT / 4;
+#pragma unroll
+      for (int jj = 0; jj < TI; ++jj) {          // 16 * C4 float4 = TI x 64 lanes
+        const int m = lane + 64 * jj;
+        const int px = m / C4, c4 = m - px * C4;
+        const f32x4 v = so[px * OP + c4];
+        if (oy < p.Ho && tx * TW + px < p.Wo) *reinterpret_cast<f32x4*>(yo + m * 4) = v;
+      }
+    }
+    HSTAMP(tcount < 10 ? 6 * tcount + 5 : 64);
+    ++tcount;
+    if (!more) break;
+    if (g2 != g_w) {             // the range crosses into the next encoder: new kernel fragments
+      load_wreg(g2);
+      g_w = g2;
+    }
+    g = g2; n = n2; ty = ty2; tx = tx2;
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    ++tile;
+  }
+}
+
+template <int CIN, int COUT, int LW>
+static int launch_s2_halo_fwd_ws(HaloFwdParams& p, hipStream_t s) {
+  constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
+  const size_t lds = (size_t)(3 * HALO_F4 + 2 * 4 * (COUT / 16) * 64 + 4 * 16 * (COUT / 4 + 1)) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_ws_kernel<CIN, COUT, LW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+#ifdef GEECO_STAMPS
+  if (!g_hstamps) (void)hipMalloc(&g_hstamps, 256 * 2 * 64 * 8);
+  (void)hipMemset(g_hstamps, 0, 256 * 2 * 64 * 8);
+  p.stamps = g_hstamps;
+#endif
+  long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  hipLaunchKernelGGL((conv_s2_halo_fwd_ws_kernel<CIN, COUT, LW>), dim3((unsigned)blocks), dim3(512 + 64 * LW), lds, s, p);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int CIN, int COUT, bool RW>
 static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
   constexpr int CQ = CIN / 4;
@@ -277,6 +570,10 @@ static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
 template <int CIN, int COUT>
 static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
   static const int rw = getenv("GEECO_HALO_RW") ? atoi(getenv("GEECO_HALO_RW")) : 1;   // measured +2.4..3.6 % on the launch
+  // loader waves (0 = the kernels above): 4 measured +3.5 % on the launch, 2 are too few (-5 %)
+  static const int ws = getenv("GEECO_HALO_WS") ? atoi(getenv("GEECO_HALO_WS")) : 4;
+  if (ws == 4) return launch_s2_halo_fwd_ws<CIN, COUT, 4>(p, s);
+  if (ws == 2) return launch_s2_halo_fwd_ws<CIN, COUT, 2>(p, s);
   return rw ? launch_s2_halo_fwd_v<CIN, COUT, true>(p, s) : launch_s2_halo_fwd_v<CIN, COUT, false>(p, s);
 }
 
