@@ -20,7 +20,7 @@ def wgrad():
   ops.conv3x3_wgrad_into(dw, enc._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, enc.gs_p, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], enc.ws_l[l])
 def dgrad():
   wt = enc.wt[l]; dx = enc.dz[l - 1]
-  ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], ws=enc.dws, w=enc._w(l), gs_w=enc.gs_p)
+  ops.conv3x3_dgrad_into(dx, dz, wt, None if os.environ.get('BENCH_NOMASK') else x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], ws=enc.dws, w=enc._w(l), gs_w=enc.gs_p)
 if ZERO:
   x.zero_(); dz.zero_()
   if ZERO == '2': m.store.params.zero_(); enc.refresh_derived()
