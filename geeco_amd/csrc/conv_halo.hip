@@ -301,7 +301,6 @@ __device__ __forceinline__ void wait_vm_imm() {
 
 template <int CIN, int COUT, int LW>
 __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(const HaloFwdParams p) {
-  constexpr int NT = 512 + 64 * LW;
   constexpr int TH = 4, TW = 16;
   constexpr int CQ = CIN / 4;
   static_assert(CQ == 8 && CIN == 32, "pair-swizzled halo image is laid out for 8 channel quads; 2 K halves of 16");
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");               // (A)
   int buf = 0;
-  int tcount = 0;
+  [[maybe_unused]] int tcount = 0;        // tile ordinal, for the dev stamps only
   for (;;) {
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
