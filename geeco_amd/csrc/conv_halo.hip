@@ -1491,6 +1491,364 @@ static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv2 input gradient FUSED with conv1's filter/bias gradient (encoder bottom: conv1 4->32 s1, conv2 32->48 s2).
+//   dz1 = (y1 > 0) * conv2_dgrad(dz2)          dw1[(tap, c)][co] = sum_p x[p + tap][c] dz1[p][co]     db1 = sum_p dz1[p]
+// conv1 has no input gradient (its input is data), so dz1 has exactly one consumer; produced and consumed inside one
+// kernel it never goes to HBM: the unfused pair writes and re-reads 805 MB per step and needs a second launch.
+// Built on conv_s2_halo_dgrad_kernel (same tiles, resident kernel, dz2 halo, MFMA schedule).  Per tile the block
+// also stages the 10 x 66 halo of conv1's input x (RGB padded to 4 channels) by LDS-DMA; in the epilogue each wave
+// takes its 64 masked pixels class by class: 16 pixels x 32 channels go through a private LDS staging [ch][17]
+// (transposition: the MFMA needs the pixel on the k index) and feed 4 k-groups x 4 MFMAs (2 co tiles x 2 tiles of
+// the 27 (tap, RGB) columns) into 4 accumulator tiles that live for the block's whole tile range; at the end the 8
+// waves are summed through LDS into one slab per block (wgrad_reduce_kernel adds the slabs in a fixed order).
+// ------------------------------------------------------------------------------------------------
+struct FusedBottomParams {
+  const float* dz;      // dz2 [G][N][Ho][Wo][48]
+  const float* w;       // conv2 kernel HWIO [G][9][32][48]
+  const float* mask;    // y1 [G][N][H][W][32]
+  const float* x;       // conv1 input [G][N][H][W][4]
+  float* part;          // [G][S][9*4*32 + 32]
+  float* dx;            // optional: also store dz1 (null in training)
+  long long gs_dz, gs_w, gs_y, gs_x;
+  int N, H, W, Ho, Wo;
+  int tiles_x, tiles_y, tiles_per_group, S;
+};
+
+__global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const FusedBottomParams p) {
+  constexpr int CIN = 32, COUT = 48;
+  constexpr int NT = 512;
+  constexpr int COQ = COUT / 4;
+  constexpr int KB = COUT / 16;
+  constexpr int HR = 5, HC = 33;                       // dz2 halo rows / cols
+  constexpr int PLANE = HR * HC;
+  constexpr int HALO_F4 = COQ * PLANE;                 // 1980
+  constexpr int NLOAD = (HALO_F4 + NT - 1) / NT;
+  constexpr int WP = 15;
+  constexpr int W_F4 = 9 * CIN * WP;                   // 4320
+  constexpr int XH = 10, XW = 66;                      // x halo of the 8 x 64 pixel tile (conv1: stride 1, pad 1)
+  constexpr int X_F4 = XH * XW;                        // 660 float4 (one pixel = RGB0)
+  constexpr int NXP = (X_F4 + 63) / 64;                // 11 DMA pieces
+  constexpr int SX_F4 = NXP * 64;                      // 704 (padded)
+  constexpr int TP = 17;                               // staging pitch: [channel][16 pixels + 1]
+  constexpr int ST_F = CIN * TP;                       // 544 floats per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sW = reinterpret_cast<f32x4*>(smem);
+  f32x4* sH = sW + W_F4;                               // 2 dz2 halo buffers
+  f32x4* sX = sH + 2 * HALO_F4;                        // x halo of the current tile
+  float* sT = reinterpret_cast<float*>(sX + SX_F4);    // 8 private transposition stagings
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int row = wid & 3, half = wid >> 2;
+  const int g = blockIdx.y, split = blockIdx.x;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int per = (p.tiles_per_group + p.S - 1) / p.S;
+  int tile = split * per;
+  const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
+  const long long slab = 9 * 4 * 32 + 32;
+  float* part = p.part + ((long long)g * p.S + split) * slab;
+  int n, ty, tx;
+  {
+    int per_img = p.tiles_x * p.tiles_y;
+    n = tile / per_img;
+    int rem = tile - n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        ++n_;
+      }
+    }
+  };
+
+  // dz2 halo staging (register staged, as conv_s2_halo_dgrad_kernel)
+  int l_off[NLOAD], l_src[NLOAD];
+  short l_hy[NLOAD], l_hx[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    int idx = tid + NT * i;
+    int pix = idx / COQ, cq = idx - pix * COQ;
+    int hy = pix / HC, hx = pix - hy * HC;
+    l_hy[i] = (short)hy; l_hx[i] = (short)hx;
+    l_off[i] = (idx < HALO_F4) ? cq * PLANE + hy * HC + hx : -1;
+    l_src[i] = (hy * p.Wo + hx) * COUT + cq * 4;
+  }
+  f32x4 stage[NLOAD];
+  auto load_halo = [&](int n_, int ty_, int tx_) {
+    const int oy0 = ty_ * 4 - 1, ox0 = tx_ * 32 - 1;
+    const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + oy0) * p.Wo + ox0) * COUT;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      int oy = oy0 + l_hy[i], ox = ox0 + l_hx[i];
+      bool v = l_off[i] >= 0 && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+      stage[i] = v ? *reinterpret_cast<const f32x4*>(zg + l_src[i]) : zero4;
+    }
+  };
+  // x halo: LDS-DMA, pieces wid and wid + 8 (11 pieces): lane -> halo pixel (hy, hx), row-major
+  auto dma_x = [&](int n_, int ty_, int tx_) {
+    const int y0 = ty_ * 8 - 1, x0 = tx_ * 64 - 1;
+    const float* xg = p.x + (long long)g * p.gs_x + (long long)n_ * p.H * p.W * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = wid + 8 * i;                       // wave-uniform
+      if (k < NXP) {
+        const int idx = k * 64 + lane;
+        const int hy = idx / XW, hx = idx - hy * XW;
+        const int iy = y0 + hy, ix = x0 + hx;
+        const bool v = idx < X_F4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* src = v ? xg + ((long long)iy * p.W + ix) * 4 : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + k * 64), 16, 0, 0);
+      }
+    }
+  };
+  {
+    const f32x4* wg = reinterpret_cast<const f32x4*>(p.w + (long long)g * p.gs_w);
+    for (int e = tid; e < 9 * CIN * COQ; e += NT) {
+      int rowi = e / COQ, c4 = e - rowi * COQ;
+      sW[rowi * WP + c4] = wg[e];
+    }
+  }
+  if (tile < tend) {
+    load_halo(n, ty, tx);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i)
+      if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
+  }
+
+  // conv1 wgrad: only the 27 real (tap, RGB) columns are computed (the 4th input channel is padding): lane's two
+  // columns jj = 16 tj + r = 3 tap + c and their offsets inside the x halo
+  constexpr int NJ = 2;
+  int xoff[NJ];
+  float xkeep[NJ];
+#pragma unroll
+  for (int tj = 0; tj < NJ; ++tj) {
+    const int jj = 16 * tj + r;
+    const int tap = jj / 3, c = jj - tap * 3;
+    const bool v = jj < 27;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    xoff[tj] = v ? ((ky * XW + kx) << 2) + c : 0;
+    xkeep[tj] = v ? 1.f : 0.f;
+  }
+  f32x4 accw[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accw[i][j] = zero4;
+  f32x4 dbl[2] = {zero4, zero4};
+  float* st = sT + wid * ST_F;
+
+  __syncthreads();
+  const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;
+  const int b_lane = r * WP + q;
+  int buf = 0;
+  for (; tile < tend; ++tile) {
+    const bool more = tile + 1 < tend;
+    int n2 = n, ty2 = ty, tx2 = tx;
+    dma_x(n, ty, tx);                      // this tile's x halo: needed in the epilogue (published by the mid barrier)
+    if (more) {
+      advance(n2, ty2, tx2);
+      load_halo(n2, ty2, tx2);
+    }
+    // ReluGrad mask of this wave's 4 x 2 output float4s: issued now, consumed in the epilogue
+    const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + r);
+    f32x4 mk[4][2];
+    bool okc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int y = yb + (c >> 1), x = xb + (c & 1);
+      okc[c] = y < p.H && x < p.W;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        mk[c][t] = zero4;                  // pixels outside the image contribute nothing to dw1
+        if (okc[c])
+          mk[c][t] = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_y +
+                                                     (((long long)n * p.H + y) * p.W + x) * CIN + 16 * t + 4 * q);
+      }
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[c][t] = zero4;
+    const f32x4* hA = sH + buf * HALO_F4 + a_lane;
+    const f32x4* hB = sW + b_lane;
+    f32x4* hN = sH + (buf ^ 1) * HALO_F4;
+    f32x4 a_cur, b_cur[2], a_nxt, b_nxt[2];
+    auto frag = [&](int it, f32x4& a, f32x4 (&b)[2]) {
+      const int tap = it / KB, kb = it - tap * KB;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      a = hA[kb * 4 * PLANE - (ky >> 1) * HC - (kx >> 1)];
+      b[0] = hB[(tap * CIN) * WP + 4 * kb];
+      b[1] = hB[(tap * CIN + 16) * WP + 4 * kb];
+    };
+    constexpr int NIT = 9 * KB;
+    frag(0, a_cur, b_cur);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it + 1 < NIT) frag(it + 1, a_nxt, b_nxt);
+      if (more && it >= NIT - NLOAD - 4 && it < NIT - 4) {
+        const int j = it - (NIT - NLOAD - 4);
+        if (l_off[j] >= 0) hN[l_off[j]] = stage[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int tap = it / KB;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int c = (ky & 1) * 2 + (kx & 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[t][s], a_cur[s], acc[c][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+      b_cur[0] = b_nxt[0];
+      b_cur[1] = b_nxt[1];
+    }
+    dma_barrier();      // mid barrier: the x halo has landed (every wave waited for its own pieces)
+    // ---- epilogue: ReluGrad, then conv1's filter gradient class by class ------------------------------------
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // this wave's 16 pixels of class c = (py, px): (yb + py, 2 (tx*32 + 16 half + j) + px), j = 0..15 (lane r = j)
+      const int py = c >> 1, px = c & 1;
+      f32x4 v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        v[t] = acc[c][t];
+        const f32x4 m = mk[c][t];
+        v[t].x = m.x > 0.f ? v[t].x : 0.f; v[t].y = m.y > 0.f ? v[t].y : 0.f;
+        v[t].z = m.z > 0.f ? v[t].z : 0.f; v[t].w = m.w > 0.f ? v[t].w : 0.f;
+        dbl[t] += v[t];
+        float* d = st + (16 * t + 4 * q) * TP + r;        // [channel][pixel]
+        d[0] = v[t].x; d[TP] = v[t].y; d[2 * TP] = v[t].z; d[3 * TP] = v[t].w;
+      }
+      if (p.dx && okc[c]) {
+        float* o = p.dx + (long long)g * p.gs_y + (((long long)n * p.H + yb + py) * p.W + xb + px) * CIN + 4 * q;
+        *reinterpret_cast<f32x4*>(o) = v[0];
+        *reinterpret_cast<f32x4*>(o + 16) = v[1];
+      }
+      // same-wave LDS round trip (the compiler's lgkmcnt wait orders the reads behind the writes)
+      // k-group s: pixels j = 4 s + q;  A(i = co, k = pixel) from the staging, B(k = pixel, j = (tap, c)) from the x halo
+      const float* xs = reinterpret_cast<const float*>(sX) + (((2 * row + py) * XW + 2 * (16 * half + q) + px) << 2);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a[2], b[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = st[(16 * i + r) * TP + 4 * s + q];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = xs[((2 * 4 * s) << 2) + xoff[j]] * xkeep[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) accw[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], accw[i][j], 0, 0, 0);
+      }
+    }
+    lds_barrier();      // end of tile: next dz2 halo complete; everyone is done with this buffer and with the x halo
+    n = n2; ty = ty2; tx = tx2;
+    buf ^= 1;
+  }
+
+  // ---- block reduction of conv1's gradient: [wave 8][4 tiles][64 lanes] float4 = 32 KB in the dz2 halo area --------
+  __syncthreads();
+  f32x4* sR = sH;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sR[(wid * 4 + i * NJ + j) * 64 + lane] = accw[i][j];
+  // bias gradient: lane holds sums over its pixels for channels 16 t + 4 q .. +3; fold the 16 pixel lanes
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      dbl[t].x += __shfl_xor(dbl[t].x, off);
+      dbl[t].y += __shfl_xor(dbl[t].y, off);
+      dbl[t].z += __shfl_xor(dbl[t].z, off);
+      dbl[t].w += __shfl_xor(dbl[t].w, off);
+    }
+  }
+  float* sD = sT;       // [wave 8][32 channels]
+  __syncthreads();      // (stagings are free; sR writes done)
+  if (r == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float* d = sD + wid * 32 + 16 * t + 4 * q;
+      d[0] = dbl[t].x; d[1] = dbl[t].y; d[2] = dbl[t].z; d[3] = dbl[t].w;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * 64; e += NT) {
+    const int ln = e & 63, k = e >> 6;
+    f32x4 s4 = sR[(0 * 4 + k) * 64 + ln];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) s4 += sR[(w * 4 + k) * 64 + ln];
+    const int i = k / NJ, j = k - i * NJ;
+    const int jj = 16 * j + (ln & 15), co = 16 * i + 4 * (ln >> 4);
+    if (jj < 27) {                         // slab layout [tap][4][32]: row tap * 4 + c
+      const int tap = jj / 3, c = jj - tap * 3;
+      *reinterpret_cast<f32x4*>(part + (tap * 4 + c) * 32 + co) = s4;
+    }
+  }
+  if (tid < 9 * 8) {                       // the padding channel's rows of the slab: zeros
+    const int tap = tid >> 3, c4 = tid & 7;
+    *reinterpret_cast<f32x4*>(part + (tap * 4 + 3) * 32 + c4 * 4) = zero4;
+  }
+  if (tid < 32) {
+    float s1 = 0.f;
+    for (int w = 0; w < 8; ++w) s1 += sD[w * 32 + tid];
+    part[9 * 4 * 32 + tid] = s1;
+  }
+}
+
+static int fused_bottom_S(int groups) {
+  int S = 256 / groups;
+  return S < 1 ? 1 : S;
+}
+
+extern "C" int64_t geeco_conv2_dgrad_conv1_wgrad_ws_bytes(int groups) {
+  return (int64_t)groups * fused_bottom_S(groups) * (9 * 4 * 32 + 32) * 4;
+}
+
+extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float* y1, const float* x,
+                                             float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
+                                             int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
+                                             int64_t gs_db1, int N, int H, int W, void* ws, void* stream) {
+  GEECO_CHECK_ARG(dz2 && w2 && y1 && x && dw1 && db1 && ws, "conv2_dgrad_conv1_wgrad: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                  "conv2_dgrad_conv1_wgrad: H = %d, W = %d must be even", H, W);
+  FusedBottomParams p = {};
+  p.dz = dz2; p.w = w2; p.mask = y1; p.x = x; p.part = (float*)ws; p.dx = dz1;
+  p.gs_dz = gs_dz2; p.gs_w = gs_w2; p.gs_y = gs_y1; p.gs_x = gs_x;
+  p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+  p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
+  p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+  p.S = fused_bottom_S(groups);
+  const size_t lds = (size_t)(9 * 32 * 15 + 2 * 12 * 165 + 11 * 64) * 16 + (size_t)8 * 32 * 17 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
+  GEECO_LAUNCH_CHECK();
+  geeco_launch_wgrad_reduce((const float*)ws, dw1, db1, gs_dw1, gs_db1, p.S, 9 * 4 * 32, 32, groups, s);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
 int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,
                          int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
                          int stride, hipStream_t stream, int* handled) {

@@ -110,7 +110,13 @@ class ConvEncoderStack:
     if self.pad1:
       self.w1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
     if training:
-      self.dz = [torch.empty_like(a) for a in self.acts]
+      # encoder bottom fused backward (conv2 dgrad + conv1 wgrad): the reference encoder's shapes, even sizes
+      L0, L1 = self.layers[0], self.layers[1]
+      self.fused_bottom = (os.environ.get('GEECO_NO_FUSED_BOTTOM') is None and os.environ.get('GEECO_NO_HALO') is None
+                           and self.pad1 and self.Cpad == 4 and L0['Cout'] == 32 and L0['stride'] == 1
+                           and L1['Cout'] == 48 and L1['stride'] == 2 and L1['H'] % 2 == 0 and L1['W'] % 2 == 0)
+      # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
+      self.dz = [None if (i == 0 and self.fused_bottom) else torch.empty_like(a) for i, a in enumerate(self.acts)]
       self.wt = [None] + [torch.empty(G, 3, 3, L['Cout'], L['Cin'], **f32) for L in self.layers[1:]]
       if self.pad1:
         self.dw1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
@@ -130,6 +136,8 @@ class ConvEncoderStack:
       # the wgrads alternate between side streams (branches of the captured hipGraph), so the small top
       # layers overlap instead of leaving CUs idle in their tails
       self.sides = [torch.cuda.Stream(device=dev) for _ in range(nside)] if dev.type == 'cuda' else []
+      if self.fused_bottom:
+        self.fws_fused = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, **f32)
     fsb = max(ops.conv3x3_fwd_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) for L in self.layers)
     self.fws = torch.empty(fsb // 4 + 4, **f32)
 
@@ -209,6 +217,16 @@ class ConvEncoderStack:
             ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
       if l == 0:
         break   # conv1's input is data: no dgrad
+      if l == 1 and self.fused_bottom:
+        # conv2's input gradient and conv1's filter gradient in one kernel: dz1 has no other consumer and stays
+        # on chip (805 MB less written and read again per step, one big launch less)
+        L0 = self.layers[0]
+        ops.conv2_dgrad_conv1_wgrad_into(self.dw1p, self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
+                                         x[0].numel(), self.x_in[0].numel(), self.dw1p[0].numel(), self.gs_p, Nf, L['H'],
+                                         L['W'], self.fws_fused)
+        for g in range(G):
+          ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L0['Cout'])
+        break
       wt = self.wt[l]
       dx = self.dz[l - 1]
       ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],

@@ -272,3 +272,45 @@ def test_conv3x3_grouped_halo_kernels(dev, Cin, Cout, Nf, Nd):
     yy = O.conv2d_same(xg, torch.tensor(w[g], dtype=torch.float64), torch.zeros(Cout, dtype=torch.float64), stride, relu=False)
     yy.backward(torch.tensor(dz[g], dtype=torch.float64))
     _close(dx[g], xg.grad * (torch.tensor(mask[g]) > 0), 2e-5, 2e-5, 'grouped dgrad, encoder %d' % g)
+
+
+# Fused encoder bottom backward (conv2 dgrad + conv1 wgrad, dz1 on chip) vs the oracle's conv1 -> ReLU -> conv2
+# differentiated by autograd in fp64; grouped, ragged tiles (H = 24 -> 3 tile rows, W = 72 -> 2 tile columns, the
+# second one partial) and a block whose tile range crosses an image boundary.
+@pytest.mark.parametrize('G,N,H,W', [(1, 2, 16, 64), (3, 3, 24, 72), (2, 40, 32, 64)])
+def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W):
+  from geeco_amd import ops
+  r = np.random.default_rng(31)
+  x3 = r.standard_normal([G, N, H, W, 3]).astype(np.float32)
+  x4 = np.concatenate([x3, np.zeros([G, N, H, W, 1], np.float32)], -1)
+  w1 = (r.standard_normal([G, 3, 3, 3, 32]) / np.sqrt(27)).astype(np.float32)
+  b1 = (0.1 * r.standard_normal([G, 32])).astype(np.float32)
+  w2 = (r.standard_normal([G, 3, 3, 32, 48]) / np.sqrt(288)).astype(np.float32)
+  dz2 = r.standard_normal([G, N, H // 2, W // 2, 48]).astype(np.float32)
+  dw_ref, db_ref, y1s, dz1_ref = [], [], [], []
+  for g in range(G):
+    w1t = torch.tensor(w1[g], dtype=torch.float64, requires_grad=True)
+    b1t = torch.tensor(b1[g], dtype=torch.float64, requires_grad=True)
+    y1 = O.conv2d_same(torch.tensor(x3[g], dtype=torch.float64), w1t, b1t, 1, relu=True)
+    y1.retain_grad()
+    z2 = O.conv2d_same(y1, torch.tensor(w2[g], dtype=torch.float64), torch.zeros(48, dtype=torch.float64), 2, relu=False)
+    z2.backward(torch.tensor(dz2[g], dtype=torch.float64))
+    dw_ref.append(w1t.grad); db_ref.append(b1t.grad); y1s.append(y1.detach().float().numpy())
+    dz1_ref.append((y1.grad * (y1.detach() > 0)))
+  y1d = torch.tensor(np.stack(y1s), device=dev)
+  dw1p = torch.full((G, 9, 4, 32), 3.0, device=dev)
+  db1 = torch.full((G, 32), 3.0, device=dev)
+  dz1 = torch.empty(G, N, H, W, 32, device=dev)
+  ws = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, device=dev)
+  xd, w2d, dz2d = torch.tensor(x4, device=dev), torch.tensor(w2, device=dev), torch.tensor(dz2, device=dev)
+  for with_dz1 in (True, False):
+    ops.conv2_dgrad_conv1_wgrad_into(dw1p, db1, dz2d, w2d, y1d, xd, G, dz2d[0].numel(), w2d[0].numel(), y1d[0].numel(),
+                                     xd[0].numel(), dw1p[0].numel(), 32, N, H, W, ws, dz1=dz1 if with_dz1 else None)
+    torch.cuda.synchronize()
+    scale = np.sqrt(N * H * W)
+    for g in range(G):
+      _close(dw1p[g, :, :3], dw_ref[g].reshape(9, 3, 32), 2e-5, 2e-5 * scale, 'fused dw1, encoder %d' % g)
+      assert float(dw1p[g, :, 3].abs().max()) == 0.0        # the padded input channel is zero
+      _close(db1[g], db_ref[g], 2e-5, 2e-5 * scale, 'fused db1, encoder %d' % g)
+      if with_dz1:
+        _close(dz1[g], dz1_ref[g], 2e-5, 2e-5, 'fused dz1, encoder %d' % g)
