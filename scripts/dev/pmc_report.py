@@ -22,7 +22,7 @@ print('%-34s %8s %6s %6s %6s %6s %7s %8s %8s %6s %6s' % ('kernel', 'us', 'mfma%'
 for i in ids:
   if not (lo < i <= hi): continue
   a = P[0][i]
-  if not (a['name'].startswith('conv_') or a['name'].startswith('dynimg') or a['name'].startswith('heads')): continue
+  if not (a['name'].startswith('conv') or a['name'].startswith('dynimg') or a['name'].startswith('heads')): continue
   us = D.get(i, 0)
   wc = a.get('SQ_WAVE_CYCLES', 1)
   busy = a.get('SQ_BUSY_CYCLES', 1)
