@@ -38,7 +38,7 @@ SIGNATURES = {
     'geeco_conv3x3_wgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_wgrad': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv2_dgrad_conv1_wgrad_ws_bytes': (_L, [_I]),
-    'geeco_conv2_dgrad_conv1_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
+    'geeco_conv2_dgrad_conv1_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     'geeco_transpose_hwio': (_I, [_P, _P, _I, _L, _L, _I, _I, _P]),
     'geeco_derive_conv_weights': (_I, [_I, _PP, _PP, POINTER(_I), POINTER(_I), POINTER(_L), _I, _L, _P, _P, _I, _I, _I, _L,
                                        _P]),

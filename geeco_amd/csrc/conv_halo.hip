@@ -1515,6 +1515,8 @@ struct FusedBottomParams {
   int tiles_x, tiles_y, tiles_per_group, S;
 };
 
+// CREAL = real input channels of conv1 (3: RGB padded to 4, the pad column is skipped; 4: RGB-D)
+template <int CREAL>
 __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const FusedBottomParams p) {
   constexpr int CIN = 32, COUT = 48;
   constexpr int NT = 512;
@@ -1622,16 +1624,17 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
       if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
   }
 
-  // conv1 wgrad: only the 27 real (tap, RGB) columns are computed (the 4th input channel is padding): lane's two
-  // columns jj = 16 tj + r = 3 tap + c and their offsets inside the x halo
-  constexpr int NJ = 2;
+  // conv1 wgrad: only the 9 * CREAL real (tap, channel) columns are computed (RGB: the 4th input channel is
+  // padding): lane's columns jj = 16 tj + r = CREAL tap + c and their offsets inside the x halo
+  constexpr int NCOL = 9 * CREAL;
+  constexpr int NJ = (NCOL + 15) / 16;
   int xoff[NJ];
   float xkeep[NJ];
 #pragma unroll
   for (int tj = 0; tj < NJ; ++tj) {
     const int jj = 16 * tj + r;
-    const int tap = jj / 3, c = jj - tap * 3;
-    const bool v = jj < 27;
+    const int tap = jj / CREAL, c = jj - tap * CREAL;
+    const bool v = jj < NCOL;
     const int ky = tap / 3, kx = tap - ky * 3;
     xoff[tj] = v ? ((ky * XW + kx) << 2) + c : 0;
     xkeep[tj] = v ? 1.f : 0.f;
@@ -1756,13 +1759,14 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     buf ^= 1;
   }
 
-  // ---- block reduction of conv1's gradient: [wave 8][4 tiles][64 lanes] float4 = 32 KB in the dz2 halo area --------
+  // ---- block reduction of conv1's gradient: [wave 8][2 NJ tiles][64 lanes] float4 (<= 48 KB) in the dz2 halo area ----
   __syncthreads();
   f32x4* sR = sH;
+  constexpr int NTL = 2 * NJ;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) sR[(wid * 4 + i * NJ + j) * 64 + lane] = accw[i][j];
+    for (int j = 0; j < NJ; ++j) sR[(wid * NTL + i * NJ + j) * 64 + lane] = accw[i][j];
   // bias gradient: lane holds sums over its pixels for channels 16 t + 4 q .. +3; fold the 16 pixel lanes
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -1784,19 +1788,19 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     }
   }
   __syncthreads();
-  for (int e = tid; e < 4 * 64; e += NT) {
+  for (int e = tid; e < NTL * 64; e += NT) {
     const int ln = e & 63, k = e >> 6;
-    f32x4 s4 = sR[(0 * 4 + k) * 64 + ln];
+    f32x4 s4 = sR[(0 * NTL + k) * 64 + ln];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) s4 += sR[(w * 4 + k) * 64 + ln];
+    for (int w = 1; w < 8; ++w) s4 += sR[(w * NTL + k) * 64 + ln];
     const int i = k / NJ, j = k - i * NJ;
     const int jj = 16 * j + (ln & 15), co = 16 * i + 4 * (ln >> 4);
-    if (jj < 27) {                         // slab layout [tap][4][32]: row tap * 4 + c
-      const int tap = jj / 3, c = jj - tap * 3;
+    if (jj < NCOL) {                       // slab layout [tap][4][32]: row tap * 4 + c
+      const int tap = jj / CREAL, c = jj - tap * CREAL;
       *reinterpret_cast<f32x4*>(part + (tap * 4 + c) * 32 + co) = s4;
     }
   }
-  if (tid < 9 * 8) {                       // the padding channel's rows of the slab: zeros
+  if (CREAL == 3 && tid < 9 * 8) {         // the padding channel's rows of the slab: zeros
     const int tap = tid >> 3, c4 = tid & 7;
     *reinterpret_cast<f32x4*>(part + (tap * 4 + 3) * 32 + c4 * 4) = zero4;
   }
@@ -1819,8 +1823,11 @@ extern "C" int64_t geeco_conv2_dgrad_conv1_wgrad_ws_bytes(int groups) {
 extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float* y1, const float* x,
                                              float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
                                              int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
-                                             int64_t gs_db1, int N, int H, int W, void* ws, void* stream) {
+                                             int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
+                                             void* stream) {
   GEECO_CHECK_ARG(dz2 && w2 && y1 && x && dw1 && db1 && ws, "conv2_dgrad_conv1_wgrad: null pointer");
+  GEECO_CHECK_ARG(real_channels == 3 || real_channels == 4, "conv2_dgrad_conv1_wgrad: real_channels = %d (3 or 4)",
+                  real_channels);
   GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
                   "conv2_dgrad_conv1_wgrad: H = %d, W = %d must be even", H, W);
   FusedBottomParams p = {};
@@ -1833,8 +1840,11 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
   const size_t lds = (size_t)(9 * 32 * 15 + 2 * 12 * 165 + 11 * 64) * 16 + (size_t)8 * 32 * 17 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
       return (int)e;
@@ -1842,7 +1852,10 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
+  if (real_channels == 3)
+    hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel<3>, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
+  else
+    hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel<4>, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
   GEECO_LAUNCH_CHECK();
   geeco_launch_wgrad_reduce((const float*)ws, dw1, db1, gs_dw1, gs_db1, p.S, 9 * 4 * 32, 32, groups, s);
   GEECO_LAUNCH_CHECK();

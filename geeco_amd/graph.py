@@ -113,7 +113,7 @@ class ConvEncoderStack:
       # encoder bottom fused backward (conv2 dgrad + conv1 wgrad): the reference encoder's shapes, even sizes
       L0, L1 = self.layers[0], self.layers[1]
       self.fused_bottom = (os.environ.get('GEECO_NO_FUSED_BOTTOM') is None and os.environ.get('GEECO_NO_HALO') is None
-                           and self.pad1 and self.Cpad == 4 and L0['Cout'] == 32 and L0['stride'] == 1
+                           and self.Cpad == 4 and self.Cin in (3, 4) and L0['Cout'] == 32 and L0['stride'] == 1
                            and L1['Cout'] == 48 and L1['stride'] == 2 and L1['H'] % 2 == 0 and L1['W'] % 2 == 0)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
       self.dz = [None if (i == 0 and self.fused_bottom) else torch.empty_like(a) for i, a in enumerate(self.acts)]
@@ -221,11 +221,13 @@ class ConvEncoderStack:
         # conv2's input gradient and conv1's filter gradient in one kernel: dz1 has no other consumer and stays
         # on chip (805 MB less written and read again per step, one big launch less)
         L0 = self.layers[0]
-        ops.conv2_dgrad_conv1_wgrad_into(self.dw1p, self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
-                                         x[0].numel(), self.x_in[0].numel(), self.dw1p[0].numel(), self.gs_p, Nf, L['H'],
-                                         L['W'], self.fws_fused)
-        for g in range(G):
-          ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L0['Cout'])
+        dw1, gs_dw1 = (self.dw1p, self.dw1p[0].numel()) if self.pad1 else (self._dw(0), self.gs_p)
+        ops.conv2_dgrad_conv1_wgrad_into(dw1, self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
+                                         x[0].numel(), self.x_in[0].numel(), gs_dw1, self.gs_p, Nf, L['H'], L['W'],
+                                         self.fws_fused, real_channels=self.Cin)
+        if self.pad1:
+          for g in range(G):
+            ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L0['Cout'])
         break
       wt = self.wt[l]
       dx = self.dz[l - 1]

@@ -141,10 +141,10 @@ def conv2_dgrad_conv1_wgrad_ws_bytes(G):
 
 
 def conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x, G, gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, ws,
-                                 dz1=None):
+                                 dz1=None, real_channels=3):
   """Fused encoder bottom backward: conv2's input gradient + conv1's filter/bias gradient (dz1 stays on chip)."""
   check(_lib().geeco_conv2_dgrad_conv1_wgrad(_p(dz2), _p(w2), _p(y1), _p(x), _p(dw1), _p(db1), _p(dz1), G, gs_dz2, gs_w2,
-                                             gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, _p(ws), _stream()),
+                                             gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, real_channels, _p(ws), _stream()),
         'geeco_conv2_dgrad_conv1_wgrad')
 
 

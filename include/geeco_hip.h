@@ -93,7 +93,9 @@ int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, i
 /* Encoder bottom, backward, fused (autodiff of graph.py:76-85 via estimator.py:243-244): conv2's input gradient and
  * conv1's filter/bias gradient in one kernel - conv1's input is data, so dz1 = (y1 > 0) * conv2_dgrad(dz2) has a
  * single consumer and never has to reach HBM:
- *   dw1[g][3][3][4][32], db1[g][32]  <-  x [G][N][H][W][4] (RGB zero-padded to 4 channels), dz1
+ *   dw1[g][3][3][4][32], db1[g][32]  <-  x [G][N][H][W][4], dz1
+ * real_channels = 3: x is RGB zero-padded to 4 channels (the pad channel's rows of dw1 are written as zeros);
+ * real_channels = 4: RGB-D, all four input channels are real.
  * dz2 [G][N][H/2][W/2][48], w2 [G][3][3][32][48] (HWIO), y1 [G][N][H][W][32] (conv1's output: the ReLU mask).
  * dz1 (optional, may be NULL): if given, dz1 is ALSO written ([G][N][H][W][32], group stride gs_y1).
  * Shapes are fixed to the reference encoder's conv1 (4 -> 32, stride 1) / conv2 (32 -> 48, stride 2); H, W even.
@@ -102,7 +104,8 @@ int64_t geeco_conv2_dgrad_conv1_wgrad_ws_bytes(int groups);
 int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float* y1, const float* x,
                                   float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
                                   int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
-                                  int64_t gs_db1, int N, int H, int W, void* ws, void* stream);
+                                  int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
+                                  void* stream);
 
 /* [G][9][A][B] -> [G][9][B][A] per-tap transpose (HWIO -> HWOI) feeding geeco_conv3x3_dgrad. */
 int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,

@@ -277,13 +277,13 @@ def test_conv3x3_grouped_halo_kernels(dev, Cin, Cout, Nf, Nd):
 # Fused encoder bottom backward (conv2 dgrad + conv1 wgrad, dz1 on chip) vs the oracle's conv1 -> ReLU -> conv2
 # differentiated by autograd in fp64; grouped, ragged tiles (H = 24 -> 3 tile rows, W = 72 -> 2 tile columns, the
 # second one partial) and a block whose tile range crosses an image boundary.
-@pytest.mark.parametrize('G,N,H,W', [(1, 2, 16, 64), (3, 3, 24, 72), (2, 40, 32, 64)])
-def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W):
+@pytest.mark.parametrize('G,N,H,W,C', [(1, 2, 16, 64, 3), (3, 3, 24, 72, 3), (2, 40, 32, 64, 3), (2, 3, 24, 72, 4)])
+def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W, C):
   from geeco_amd import ops
   r = np.random.default_rng(31)
-  x3 = r.standard_normal([G, N, H, W, 3]).astype(np.float32)
-  x4 = np.concatenate([x3, np.zeros([G, N, H, W, 1], np.float32)], -1)
-  w1 = (r.standard_normal([G, 3, 3, 3, 32]) / np.sqrt(27)).astype(np.float32)
+  x3 = r.standard_normal([G, N, H, W, C]).astype(np.float32)      # C real input channels (3: RGB, 4: RGB-D)
+  x4 = np.concatenate([x3, np.zeros([G, N, H, W, 4 - C], np.float32)], -1)
+  w1 = (r.standard_normal([G, 3, 3, C, 32]) / np.sqrt(9 * C)).astype(np.float32)
   b1 = (0.1 * r.standard_normal([G, 32])).astype(np.float32)
   w2 = (r.standard_normal([G, 3, 3, 32, 48]) / np.sqrt(288)).astype(np.float32)
   dz2 = r.standard_normal([G, N, H // 2, W // 2, 48]).astype(np.float32)
@@ -305,12 +305,14 @@ def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W):
   xd, w2d, dz2d = torch.tensor(x4, device=dev), torch.tensor(w2, device=dev), torch.tensor(dz2, device=dev)
   for with_dz1 in (True, False):
     ops.conv2_dgrad_conv1_wgrad_into(dw1p, db1, dz2d, w2d, y1d, xd, G, dz2d[0].numel(), w2d[0].numel(), y1d[0].numel(),
-                                     xd[0].numel(), dw1p[0].numel(), 32, N, H, W, ws, dz1=dz1 if with_dz1 else None)
+                                     xd[0].numel(), dw1p[0].numel(), 32, N, H, W, ws, dz1=dz1 if with_dz1 else None,
+                                     real_channels=C)
     torch.cuda.synchronize()
     scale = np.sqrt(N * H * W)
     for g in range(G):
-      _close(dw1p[g, :, :3], dw_ref[g].reshape(9, 3, 32), 2e-5, 2e-5 * scale, 'fused dw1, encoder %d' % g)
-      assert float(dw1p[g, :, 3].abs().max()) == 0.0        # the padded input channel is zero
+      _close(dw1p[g, :, :C], dw_ref[g].reshape(9, C, 32), 2e-5, 2e-5 * scale, 'fused dw1, encoder %d' % g)
+      if C == 3:
+        assert float(dw1p[g, :, 3].abs().max()) == 0.0      # the padded input channel is zero
       _close(db1[g], db_ref[g], 2e-5, 2e-5 * scale, 'fused db1, encoder %d' % g)
       if with_dz1:
         _close(dz1[g], dz1_ref[g], 2e-5, 2e-5, 'fused dz1, encoder %d' % g)
