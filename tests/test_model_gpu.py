@@ -125,3 +125,29 @@ def test_train_step_parity(dev, name, cfg_kw, goal, N, H):
   moved = Pn[k0] - P[k0]
   agree = np.mean(np.sign(moved) == np.sign(moved_ref))
   assert agree > 0.995, agree
+
+
+def test_loss_trajectory_graph_replay(dev):
+  """Ten optimiser steps through the production step runner (captured hipGraphs, multi-stream backward, fused
+  kernels) on a FRESH batch every step vs the fp64 oracle trainer fed the same batches: per-step loss to 1e-4
+  relative (BASELINE.json north_star).  Guards the replay path: device-resident Adam step counter, derived weight
+  copies refreshed inside the Adam graph, input buffers rewritten between replays."""
+  from geeco_amd.runtime import TrainStepRunner
+  cfg_kw = dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=4, lr=1e-3)
+  ocfg, P, feats, labels = _mk(cfg_kw, True, 2, 160)
+  model = _build(ocfg, True, P, feats, labels, dev)
+  oracle = O.OracleTrainer(ocfg, True, P, dtype=torch.float64)
+  runner = TrainStepRunner(model, use_graph=True, warmup=2)
+  losses = []
+  for step in range(10):
+    feats, labels = O.synthetic_batch(ocfg, True, 2, seed=100 + step, H=160, W=160)
+    model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+    runner.step()
+    torch.cuda.synchronize()
+    l_ref, _ = oracle.train_step(feats, labels)
+    l_hip = float(model.loss)
+    losses.append((l_hip, l_ref))
+    assert abs(l_hip - l_ref) <= 1e-4 * abs(l_ref), (step, l_hip, l_ref)
+  assert runner._ga is not None                      # the last steps were graph replays
+  assert int(model.store.global_step.item()) == 10
+  print('loss trajectory (hip, oracle):', ['%.5f/%.5f' % p for p in losses])
