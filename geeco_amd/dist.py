@@ -10,6 +10,10 @@ from __future__ import annotations
 
 import os
 
+# The host driver of this pool only supports dmabuf IPC: without this RCCL / cross-process device memory fails with
+# `hipIpcGetMemHandle: invalid argument`.  Already exported on the GPU boxes; kept here for any other launcher.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 import torch.distributed as dist
 
