@@ -1,42 +1,49 @@
 #!/usr/bin/env python
 """bench.py -- train-step frames/s of geeco-f (goal_e2evmc, rgb/dynimg/dyndiff) on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched with
-``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0 prints
-ONE JSON line.  A "step" = forward + backward + gradient all-reduce + Adam on one batch of
-synthetic 256x256 RGB x 16-frame windows (BASELINE.json configs[1]: batch 32 per GPU), inputs
-resident in HBM before the timed region.  ``value`` = global_batch * seq_len * steps / time.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  With N > 1 and no WORLD_SIZE in
+the environment this process NEVER touches the GPU: it starts ``python -m torch.distributed.run
+--nproc-per-node N bench.py ...`` as a child (one rank per GPU, RCCL over xGMI), relays its output and
+exits with its code; launched by the driver under torch.distributed.run it is one of the N ranks.
+Rank 0 prints ONE JSON line.  A "step" = forward + backward + gradient all-reduce + Adam on one batch
+of synthetic 256x256 RGB x 16-frame windows (BASELINE.json configs[1]: batch 32 per GPU), inputs
+resident in HBM before the timed region.  ``value`` = global_batch * seq_len * steps / wall time of the
+timed region (barrier + synchronize on both sides, max over ranks).
 
-Extra objects: ``roofline`` (dominant forward kernel: the conv2 launch of the three encoders,
-fp32 MFMA bound) and ``cpu_baseline`` (the CPU restatement in oracle/, timed on the host cores).
+Extra objects (N = 1): ``layers`` (every conv launch of the step timed alone with HIP events: FLOP, us,
+TFLOP/s, fraction of the fp32 MFMA peak), ``roofline`` (the kernel with the largest share of the step,
+taken from that table), ``hbm`` (dynimg calls and Adam against the HBM peak), ``encoder_forward`` and
+``cpu_baseline`` (the CPU restatement in oracle/, timed on the host cores).  N > 1 adds the measured
+all-reduce time and its exposed part.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip table
+PEAK_HBM_TBS = 8.0                # spec; 6.29 TB/s is what a float4 copy achieves (same guide)
 ENC_FWD_FLOP_PER_FRAME = {3: 1137180672, 4: 1174929408}
-CONV2_MACS_PER_FRAME = 226492416                           # 128*128*48*288
 
 
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=30)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--batch', type=int, default=32, help='windows per GPU (weak scaling)')
   ap.add_argument('--seq-len', type=int, default=16)
   ap.add_argument('--channels', type=int, default=3)
   ap.add_argument('--model', default='geeco-f', choices=['geeco-f', 'e2e_vmc'])
   ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying hipGraphs')
   ap.add_argument('--skip-cpu', action='store_true', help='skip the cpu_baseline leg')
+  ap.add_argument('--skip-layers', action='store_true', help='skip the per-layer / roofline / hbm legs (profiling runs)')
   ap.add_argument('--cpu-steps', type=int, default=6)
   ap.add_argument('--cpu-batch', type=int, default=4)
   return ap.parse_args()
@@ -46,9 +53,47 @@ def log(msg):
   print('[bench] ' + msg, file=sys.stderr, flush=True)
 
 
+# ======================================================================================================
+# N > 1 without a launcher: start the ranks ourselves (before any GPU call in this process)
+# ======================================================================================================
+def spawn_ranks(args):
+  import torch
+  have = torch.cuda.device_count()        # counting devices does not initialise the GPU
+  if have < args.gpus:
+    log('--gpus %d requested but only %d GPU(s) are visible' % (args.gpus, have))
+    return 2
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  log('launching %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+  proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  line = None
+  for ln in proc.stdout.splitlines():
+    if ln.startswith('{') and '"metric"' in ln:
+      line = ln
+    else:
+      print(ln, file=sys.stderr)
+  if proc.returncode != 0 or line is None:
+    log('child launcher failed (rc %d)' % proc.returncode)
+    return proc.returncode or 3
+  if json.loads(line).get('n_gpus') != args.gpus:
+    log('the process group formed with %s ranks, not %d' % (json.loads(line).get('n_gpus'), args.gpus))
+    return 3
+  print(line, flush=True)
+  return 0
+
+
+# ======================================================================================================
+# helpers
+# ======================================================================================================
 def host_cores():
-  """Threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota when one is set."""
-  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  """(threads the CPU leg uses, cores of the box): affinity mask capped by the cgroup CPU quota, then by GEECO_CPU_THREADS."""
+  box = os.cpu_count() or 1
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else box
   try:
     with open('/sys/fs/cgroup/cpu.max') as f:
       quota, period = f.read().split()
@@ -56,11 +101,12 @@ def host_cores():
       n = min(n, max(1, int(int(quota) / int(period))))
   except (OSError, ValueError):
     pass
-  return max(1, min(n, int(os.environ.get('GEECO_CPU_THREADS', '16'))))
+  return max(1, min(n, int(os.environ.get('GEECO_CPU_THREADS', '16')))), box, n
 
 
 def synthetic_batch(model, seed):
   """seeded inputs generated on the device."""
+  import torch
   g = torch.Generator(device=model.device)
   g.manual_seed(seed)
   for k, buf in model.inputs.items():
@@ -78,7 +124,8 @@ def synthetic_batch(model, seed):
 
 
 def time_region(fn, iters):
-  """Average milliseconds per call, HIP events on the current (launch) stream."""
+  """Average milliseconds per call, HIP events on the current stream (the stream our kernels are launched on)."""
+  import torch
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
   for _ in range(iters):
@@ -88,44 +135,111 @@ def time_region(fn, iters):
   return e0.elapsed_time(e1) / iters
 
 
-def roofline_conv2(model, iters):
-  """Dominant forward kernel: conv2 (3x3, stride 2, 32 -> 48, 256^2 -> 128^2) over all encoders'
-  frames in one launch.  achieved = algorithmic FLOP (2 * MACs, bias/ReLU excluded) / avg duration."""
+def percentile(sorted_vals, q):
+  if not sorted_vals:
+    return None
+  i = min(len(sorted_vals) - 1, max(0, int(round(q * (len(sorted_vals) - 1)))))
+  return sorted_vals[i]
+
+
+# ======================================================================================================
+# per-layer table, dominant-kernel roofline, HBM-bound pieces
+# ======================================================================================================
+def layer_table(model, iters):
+  """Every conv launch of one step, timed ALONE (HIP events over `iters` back-to-back launches): forward,
+  input gradient and filter gradient of conv1..conv8 over all encoder frames.  FLOP = 2 * MACs of the layer
+  (bias / ReLU / mask excluded).  A call that also runs a small reduce / epilogue kernel is timed
+  as a whole (its names are listed)."""
   from geeco_amd import ops
   enc = model.enc
-  L = enc.layers[1]
-  x, y = enc.acts[0], enc.acts[1]
-  w, b = enc._w(1), enc._b(1)
+  rows = []
+  frames = enc.G * enc.Nf
+  for l, L in enumerate(enc.layers):
+    cin_real = enc.Cin if l == 0 else L['Cin']
+    flop = 2.0 * frames * L['Ho'] * L['Wo'] * L['Cout'] * 9 * cin_real
+    todo = [('fwd', lambda l=l: enc.launch_fwd(l), flop)]
+    if l >= 1:
+      if l == 1 and enc.fused_bottom:
+        L0 = enc.layers[0]
+        flop0 = 2.0 * frames * L0['Ho'] * L0['Wo'] * L0['Cout'] * 9 * enc.Cin
+        todo.append(('dgrad+conv1_wgrad', lambda l=l: enc.launch_dgrad(l), flop + flop0))
+      else:
+        todo.append(('dgrad', lambda l=l: enc.launch_dgrad(l), flop))
+    if not (l == 0 and enc.fused_bottom):
+      todo.append(('wgrad', lambda l=l: enc.launch_wgrad(l), flop))
+    for what, fn, fl in todo:
+      names = ops.kernel_trace(fn)
+      fn()
+      ms = time_region(fn, iters)
+      tf = fl / (ms * 1e-3) / 1e12
+      rows.append({'layer': 'conv%d' % (l + 1), 'op': what, 'kernel': names[0] if names else '?', 'kernels': names,
+                   'flop': int(fl), 'us': round(ms * 1e3, 1), 'tflops': round(tf, 2),
+                   'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+  return rows
 
-  def launch():
-    ops.conv3x3_fwd_into(y, x, w, b, enc.G, x[0].numel(), enc.gs_p, enc.gs_p, y[0].numel(), enc.Nf, L['H'], L['W'],
-                         L['Cin'], L['Cout'], L['stride'], relu=True, ws=enc.fws)
-  for _ in range(3):
-    launch()
-  ms = time_region(launch, iters)
-  macs = enc.G * enc.Nf * L['Ho'] * L['Wo'] * L['Cout'] * 9 * L['Cin']
-  achieved = 2.0 * macs / (ms * 1e-3) / 1e12
-  halo = os.environ.get('GEECO_NO_HALO') is None and L['H'] % 2 == 0 and L['W'] % 2 == 0
-  ws = os.environ.get('GEECO_HALO_WS', '4') != '0'       # rocprof name: conv_s2_halo_fwd_ws_kernel<32, 48, 4>
-  kname = ('conv_s2_halo_fwd_ws_kernel<32,48,4>' if ws else 'conv_s2_halo_fwd_kernel<32,48,true>') if halo else 'conv_gemm_kernel<128,48,16,4,1,true>'
-  return {'bound': 'mfma', 'kernel': '%s (conv2 forward, %d frames)' % (kname, enc.G * enc.Nf),
-          'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-          'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': recorded_traffic(kname),
-          'avg_launch_ms': round(ms, 4), 'flop_per_launch': 2 * macs}
+
+def dominant_roofline(rows):
+  """The kernel (by name) whose launches take the largest share of a step; achieved = sum of the algorithmic FLOP
+  of those launches / sum of their durations (= FLOP per launch / average launch duration)."""
+  by = {}
+  for r in rows:
+    d = by.setdefault(r['kernel'], {'us': 0.0, 'flop': 0.0, 'launches': []})
+    d['us'] += r['us']
+    d['flop'] += r['flop']
+    d['launches'].append('%s %s' % (r['layer'], r['op']))
+  name, d = max(by.items(), key=lambda kv: kv[1]['us'])
+  achieved = d['flop'] / (d['us'] * 1e-6) / 1e12
+  n = len(d['launches'])
+  return {'bound': 'mfma', 'kernel': name, 'launches_per_step': d['launches'], 'achieved': round(achieved, 2),
+          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+          'traffic': recorded_traffic(name), 'avg_launch_ms': round(d['us'] / n * 1e-3, 4),
+          'flop_per_launch': int(d['flop'] / n),
+          'share_of_conv_time': round(d['us'] / sum(r['us'] for r in rows), 4)}
 
 
 def recorded_traffic(kname):
-  """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-  (profiles/r01/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on
-  gfx950, + WRITE_SIZE; separate --pmc passes).  PMC counters cannot be read from inside this process,
-  so this is the recorded measurement of the same kernel and shape, or null when there is none."""
-  path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_roofline_kernel.json')
-  try:
-    with open(path) as f:
-      rec = json.load(f)
-    return rec['traffic_bytes'] if rec.get('kernel') == kname else None
-  except (OSError, ValueError, KeyError):
-    return None
+  """HBM bytes per launch (average over the kernel's launches in a step) from the committed rocprofv3 PMC passes
+  (profiles/r02/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on
+  gfx950, + WRITE_SIZE; separate --pmc passes).  PMC counters cannot be read from inside this process, so this is
+  the recorded measurement of the same kernel and shapes, or null when there is none."""
+  for rnd in ('r02', 'r01'):
+    path = os.path.join(ROOT, 'profiles', rnd, 'pmc_roofline_kernel.json')
+    try:
+      with open(path) as f:
+        rec = json.load(f)
+      if rec.get('kernel', '').replace(' ', '') == kname.replace(' ', ''):
+        return rec['traffic_bytes']
+    except (OSError, ValueError, KeyError):
+      pass
+  return None
+
+
+def hbm_table(model, args, iters):
+  """HBM-bound pieces against the 8.0 TB/s peak, algorithmic bytes per SURVEY.md 8(d)."""
+  from geeco_amd import ops
+  rows = []
+  N, K, C = model.N, model.K, model.C
+  HW = model.H * model.W
+
+  def add(name, nbytes, fn):
+    fn()
+    ms = time_region(fn, iters)
+    tbs = nbytes / (ms * 1e-3) / 1e12
+    rows.append({'piece': name, 'bytes': int(nbytes), 'us': round(ms * 1e3, 1), 'TB/s': round(tbs, 3),
+                 'frac': round(tbs / PEAK_HBM_TBS, 4)})
+  if args.model == 'geeco-f':
+    frames, tgt = model._frames()
+    x_in = model.enc.x_in
+    cur = frames[:, K - 1]
+    add('dynimg buffer image (K=%d)' % K, 4.0 * N * HW * C * (K + 1),
+        lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C))
+    add('dynimg diff image (K=2)', 4.0 * N * HW * C * 3,
+        lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
+  s = model.store
+  P = s.count_parameters()
+  add('adam (7 x 4 B x params)', 28.0 * P,
+      lambda: ops.adam_tf(s.params, s.grads, s.adam_m, s.adam_v, s.size, model.scal, grad_scale=1.0, l2=0.0))
+  return rows
 
 
 def encoder_forward_tflops(model, iters, channels):
@@ -140,10 +254,11 @@ def encoder_forward_tflops(model, iters, channels):
 def cpu_baseline(args):
   """CPU restatement (oracle/) of the same step on a bounded sample: BASELINE.json configs[0]
   (geeco-f rgb, batch 4, seq_len 16, 256x256), fwd + bwd + Adam, all host cores."""
+  import torch
   from oracle import geeco_oracle as O
-  cores = host_cores()
-  torch.set_num_threads(cores)
-  log('cpu_baseline: %d threads' % cores)
+  threads, box, usable = host_cores()
+  torch.set_num_threads(threads)
+  log('cpu_baseline: %d threads (box has %d cores, %d usable by this process)' % (threads, box, usable))
   if args.model == 'geeco-f':
     cfg = O.make_config(proc_obs='dynimg', proc_tgt='dyndiff', window_size=args.seq_len, img_channels=args.channels,
                         batch_size=args.cpu_batch)
@@ -161,19 +276,50 @@ def cpu_baseline(args):
   steps = max(1, min(args.cpu_steps, int(25.0 / max(warm, 1e-3))))   # keep the leg to ~25 s of CPU work
   t0 = time.perf_counter()
   for i in range(steps):
-    loss, _ = tr.train_step(feats, labels)
+    tr.train_step(feats, labels)
     log('cpu_baseline: step %d/%d' % (i + 1, steps))
   dt = (time.perf_counter() - t0) / steps
-  args.cpu_steps = steps
   return {'value': round(args.cpu_batch * args.seq_len / dt, 2), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
-          'kind': 'port',
+          'box_cores': box, 'usable_cores': usable, 'kind': 'port',
           'sample': '%d timed train steps (fwd+bwd+Adam, torch-CPU fp32 restatement in oracle/) of %s rgb%s batch=%d '
                     'seq_len=%d 256x256; %.3f s/step; NOT TF1.15 (not installable here)' %
-                    (args.cpu_steps, args.model, 'd' if args.channels == 4 else '', args.cpu_batch, args.seq_len, dt)}
+                    (steps, args.model, 'd' if args.channels == 4 else '', args.cpu_batch, args.seq_len, dt)}
 
 
+def check_losses(args, first_loss, final_loss, total_steps):
+  """Regression guard: the loss of the FIRST optimiser step (seed-0 weights, batch seed 1234) must equal the
+  committed value the fp64 oracle gives on the same inputs (tests/golden/bench_losses.json, written by
+  tests/golden/make_bench_losses.py) to 1e-4 relative; the loss after the run's last step is compared with the
+  recorded HIP value for the same step count when there is one."""
+  key = '%s c%d b%d k%d' % (args.model, args.channels, args.batch, args.seq_len)
+  try:
+    with open(os.path.join(ROOT, 'tests', 'golden', 'bench_losses.json')) as f:
+      ref = json.load(f).get(key)
+  except (OSError, ValueError):
+    ref = None
+  out = {'first_step_loss': round(first_loss, 6), 'config_key': key}
+  if not ref:
+    out['status'] = 'no committed value for this config'
+    return out, True
+  rel = abs(first_loss - ref['first_step_loss_oracle_fp64']) / abs(ref['first_step_loss_oracle_fp64'])
+  out.update({'first_step_loss_oracle': ref['first_step_loss_oracle_fp64'], 'first_step_rel_err': float('%.3g' % rel)})
+  ok = rel <= 1e-4
+  fin = (ref.get('final_loss_hip') or {}).get(str(total_steps))
+  if fin is not None:
+    rel2 = abs(final_loss - fin) / abs(fin)
+    out.update({'final_loss_recorded': fin, 'final_rel_err': float('%.3g' % rel2)})
+    ok = ok and rel2 <= 2e-2      # ~30 steps of a chaotic trajectory: rounding-order changes move it by ~1e-3
+  out['status'] = 'ok' if ok else 'MISMATCH'
+  return out, ok
+
+
+# ======================================================================================================
 def main():
   args = parse_args()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(spawn_ranks(args))
+
+  import torch
   from geeco_amd import dist as gdist
   from geeco_amd import graph
   from geeco_amd.params import create_e2evmc_config
@@ -181,8 +327,9 @@ def main():
 
   world = gdist.init_from_env('nccl')
   rank = gdist.rank()
-  if world != args.gpus and rank == 0:
-    print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+  if world != args.gpus:
+    log('--gpus %d but the process group has %d rank(s): refusing to report a number for the wrong N' % (args.gpus, world))
+    sys.exit(3)
   local = int(os.environ.get('LOCAL_RANK', '0'))
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
@@ -200,7 +347,10 @@ def main():
 
   log('model built: %d parameters, batch %d/GPU, world %d' % (model.store.count_parameters(), args.batch, world))
   runner = TrainStepRunner(model, use_graph=not args.no_graph, warmup=2)
-  runner.prepare()     # 2 eager steps + hipGraph capture, outside warm-up and timed region
+  runner.step()                       # first optimiser step, eager: its loss is checked against the oracle's
+  torch.cuda.synchronize()
+  first_loss = float(model.loss)
+  runner.prepare()     # second eager step + hipGraph capture, outside warm-up and timed region
   torch.cuda.synchronize()
   log('graphs captured' if not args.no_graph else 'eager mode')
   for i in range(args.warmup):
@@ -209,12 +359,15 @@ def main():
       torch.cuda.synchronize()
       log('warm-up step %d done' % (i + 1))
   torch.cuda.synchronize()
+  evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   if world > 1:
     torch.distributed.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  evs[0].record()
+  for i in range(args.steps):
     runner.step()
+    evs[i + 1].record()
   torch.cuda.synchronize()
   if world > 1:
     torch.distributed.barrier()
@@ -222,8 +375,34 @@ def main():
   dt = time.perf_counter() - t0
   dt = gdist.max_over_ranks(dt, dev)
   loss = float(model.loss)
+  total_steps = runner._calls
+  per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
   log('timed region: %d steps in %.3f s' % (args.steps, dt))
 
+  comm = None
+  if world > 1:      # every rank takes part; rank 0 reports
+    iters = max(5, min(args.steps, 20))
+    g = model.store.grads
+    def exchange():
+      for w in runner._exchange_early() + runner._exchange_late():
+        w.wait()
+    exchange()
+    ar_ms = time_region(exchange, iters)
+    torch.distributed.barrier()
+    runner.skip_allreduce = True
+    for _ in range(3):
+      runner.step()
+    nocomm_ms = time_region(runner.step, iters)
+    runner.skip_allreduce = False
+    ar_ms = gdist.max_over_ranks(ar_ms, dev)
+    nocomm_ms = gdist.max_over_ranks(nocomm_ms, dev)
+    step_ms = dt / args.steps * 1e3
+    comm = {'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
+            'bus_GB/s': round(2.0 * (world - 1) / world * g.numel() * 4 / (ar_ms * 1e-3) / 1e9, 1),
+            'step_ms_without_allreduce': round(nocomm_ms, 4),
+            'allreduce_exposed_ms': round(max(step_ms - nocomm_ms, 0.0), 4), 'buckets': runner.bucket_info()}
+
+  rc = 0
   if rank == 0:
     ms_step = dt / args.steps * 1e3
     frames = world * args.batch * args.seq_len
@@ -236,20 +415,35 @@ def main():
                                (args.model, 'rgb' if args.channels == 3 else 'rgbd', cfg.img_height, cfg.img_width,
                                 args.seq_len, args.batch, world * args.batch),
                    'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, 'params': model.store.count_parameters()},
+        'step_ms': {'median': round(percentile(per_step, 0.5), 4), 'p10': round(percentile(per_step, 0.1), 4),
+                    'p90': round(percentile(per_step, 0.9), 4), 'timer': 'HIP events per step, rank 0'},
         'final_loss': round(loss, 6),
     }
-    if world == 1:
-      iters = max(10, min(args.steps, 50))
-      if args.model == 'geeco-f':
-        out['roofline'] = roofline_conv2(model, iters)
+    out['loss_check'], ok = check_losses(args, first_loss, loss, total_steps)
+    if not ok:
+      rc = 4
+    if comm:
+      out['comm'] = comm
+    if world == 1 and not args.skip_layers:
+      iters = max(10, min(args.steps, 30))
+      rows = layer_table(model, iters)
+      out['roofline'] = dominant_roofline(rows)
+      for r in rows:
+        del r['kernels']
+      out['layers'] = rows
+      out['hbm'] = hbm_table(model, args, iters)
       tf_, ms_enc = encoder_forward_tflops(model, iters, args.channels)
       out['encoder_forward'] = {'tflops': round(tf_, 2), 'frac_of_f32_mfma_peak': round(tf_ / PEAK_F32_MFMA_TFLOPS, 4),
                                 'ms': round(ms_enc, 3), 'frames': model.enc.G * model.enc.Nf}
-      if not args.skip_cpu:
-        out['cpu_baseline'] = cpu_baseline(args)
+      out['step_frac_of_f32_mfma_peak'] = round(
+          (3 * ENC_FWD_FLOP_PER_FRAME[args.channels] - 2 * 56623104 * (args.channels / 3.0)) * model.enc.G * model.enc.Nf
+          / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    if world == 1 and not args.skip_cpu:
+      out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)
   if torch.distributed.is_available() and torch.distributed.is_initialized():
     torch.distributed.destroy_process_group()
+  sys.exit(rc)
 
 
 if __name__ == '__main__':

@@ -26,6 +26,8 @@ _I, _L, _F = c_int, c_int64, c_float
 SIGNATURES = {
     'geeco_abi_version': (_I, []),
     'geeco_last_error': (c_char_p, []),
+    'geeco_debug_kernel_trace_begin': (None, []),
+    'geeco_debug_kernel_trace_end': (c_char_p, []),
     'geeco_dynimg_alpha': (None, [_I, _P]),
     'geeco_dynimg_ws_bytes': (_L, [_I, _L]),
     'geeco_dynimg_fwd': (_I, [_P, _P, _L, _L, _P, _I, _I, _L, _I, _I, _P, _P, _P]),

@@ -432,6 +432,7 @@ static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
   }
   dim3 grid((unsigned)tiles, (unsigned)(cdiv(p.Nout, BN) * p.ksplit), (unsigned)groups);
   static const int no_ut = getenv("GEECO_CONV_NO_UT") ? 1 : 0;
+  geeco_note_kernel("conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, BK, WM, WN, (p.C % BK == 0 && !no_ut) ? "true" : "false");
   if (p.C % BK == 0 && !no_ut)
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, true>), grid, dim3(256), 0, s, p);
   else
@@ -547,6 +548,7 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
   if (p.ksplit > 1) {
     const long long total4 = (long long)p.N * p.Hd * p.Wd * p.Nout / 4;
     dim3 grid((unsigned)cdiv64(total4, 256), (unsigned)groups);
+    geeco_note_kernel("conv_splitk_epilogue_kernel");
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, grid, dim3(256), 0, s, p);
     GEECO_LAUNCH_CHECK();
   }

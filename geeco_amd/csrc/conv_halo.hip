@@ -540,6 +540,7 @@ static int launch_s2_halo_fwd_ws(HaloFwdParams& p, hipStream_t s) {
   p.stamps = g_hstamps;
 #endif
   long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  geeco_note_kernel("conv_s2_halo_fwd_ws_kernel<%d, %d, %d>", CIN, COUT, LW);
   hipLaunchKernelGGL((conv_s2_halo_fwd_ws_kernel<CIN, COUT, LW>), dim3((unsigned)blocks), dim3(512 + 64 * LW), lds, s, p);
   GEECO_LAUNCH_CHECK();
   return 0;
@@ -561,6 +562,7 @@ static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
     attr_set = true;
   }
   long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  geeco_note_kernel("conv_s2_halo_fwd_kernel<%d, %d, %s>", CIN, COUT, RW ? "true" : "false");
   hipLaunchKernelGGL((conv_s2_halo_fwd_kernel<CIN, COUT, RW>), dim3((unsigned)blocks), dim3(512), lds, s, p);
   GEECO_LAUNCH_CHECK();
   return 0;
@@ -770,6 +772,7 @@ static int launch_s2_halo_fwd_chunked(HaloFwdParams& p, hipStream_t s) {
     attr_set = true;
   }
   long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  geeco_note_kernel("conv_s2_halo_fwd_chunked_kernel<%d, %d>", CIN, COUT);
   hipLaunchKernelGGL((conv_s2_halo_fwd_chunked_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(512), lds, s, p);
   GEECO_LAUNCH_CHECK();
   return 0;
@@ -1055,6 +1058,7 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
       }
       attr_set = true;
     }
+    geeco_note_kernel("conv_s2_halo_wgrad_kernel<32, 48>");
     hipLaunchKernelGGL((conv_s2_halo_wgrad_kernel<32, 48>), dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds,
                        stream, p);
     GEECO_LAUNCH_CHECK();
@@ -1487,6 +1491,7 @@ static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
     attr_set = true;
   }
   long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  geeco_note_kernel("conv_s2_halo_dgrad_chunked_kernel<%d, %d>", CIN, COUT);
   hipLaunchKernelGGL((conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   return 0;
 }
@@ -1852,6 +1857,7 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
+  geeco_note_kernel("conv2_dgrad_conv1_wgrad_kernel<%d>", real_channels == 3 ? 3 : 4);
   if (real_channels == 3)
     hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel<3>, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
   else
@@ -1903,6 +1909,7 @@ int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymas
       attr_set = true;
     }
     long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+    geeco_note_kernel("conv_s2_halo_dgrad_kernel<32, 48>");
     hipLaunchKernelGGL((conv_s2_halo_dgrad_kernel<32, 48>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
     GEECO_LAUNCH_CHECK();
     *handled = 1;
@@ -2044,6 +2051,7 @@ int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y
   const int ntiles = N * p.tiles_x * p.tiles_y;
   static const int bpg = getenv("GEECO_C1_BLOCKS") ? atoi(getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)
   dim3 grid((unsigned)(ntiles < bpg ? ntiles : bpg), (unsigned)groups);
+  geeco_note_kernel("conv1_halo_fwd_kernel");
   hipLaunchKernelGGL(conv1_halo_fwd_kernel, grid, dim3(256), 0, stream, p);
   GEECO_LAUNCH_CHECK();
   *handled = 1;
@@ -2227,6 +2235,7 @@ int geeco_try_conv1_wgrad(const float* x, const float* dz, float* dw, float* db,
   p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 4);
   p.tiles_per_group = N * p.tiles_x * p.tiles_y;
   p.S = conv1_wgrad_S(groups);
+  geeco_note_kernel("conv1_halo_wgrad_kernel");
   hipLaunchKernelGGL(conv1_halo_wgrad_kernel, dim3((unsigned)p.S, (unsigned)groups), dim3(256), 0, stream, p);
   GEECO_LAUNCH_CHECK();
   geeco_launch_wgrad_reduce((const float*)ws, dw, db, gs_dw, gs_db, p.S, 9 * 4 * 32, 32, groups, stream);

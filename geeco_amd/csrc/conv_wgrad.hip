@@ -257,9 +257,11 @@ void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long lon
   // few float4 columns and many slabs: split the slabs over the waves to get enough parallelism
   if (S >= 16 && n4 * groups < 64 * 1024) {
     dim3 rgrid((unsigned)cdiv64(n4, 64), (unsigned)groups);
+    geeco_note_kernel("wgrad_reduce_kernel<true>");
     hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
   } else {
     dim3 rgrid((unsigned)cdiv64(n4, 256), (unsigned)groups);
+    geeco_note_kernel("wgrad_reduce_kernel<false>");
     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
   }
 }
@@ -339,13 +341,13 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)p.S, (unsigned)(p.row_tiles * p.col_tiles), (unsigned)groups);
   switch (BC) {
-    case 128128: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 16>), grid, dim3(256), 0, s, p); break;
-    case 128064: hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 16>), grid, dim3(256), 0, s, p); break;
-    case 64128: hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 16>), grid, dim3(256), 0, s, p); break;
-    case 64064: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32>), grid, dim3(256), 0, s, p); break;
-    case 64048: hipLaunchKernelGGL((conv_wgrad_kernel<64, 48, 32>), grid, dim3(256), 0, s, p); break;
-    case 64032: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64>), grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((conv_wgrad_kernel<64, 16, 64>), grid, dim3(256), 0, s, p); break;
+    case 128128: geeco_note_kernel("conv_wgrad_kernel<128, 128, 16>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 16>), grid, dim3(256), 0, s, p); break;
+    case 128064: geeco_note_kernel("conv_wgrad_kernel<128, 64, 16>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 16>), grid, dim3(256), 0, s, p); break;
+    case 64128: geeco_note_kernel("conv_wgrad_kernel<64, 128, 16>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 16>), grid, dim3(256), 0, s, p); break;
+    case 64064: geeco_note_kernel("conv_wgrad_kernel<64, 64, 32>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32>), grid, dim3(256), 0, s, p); break;
+    case 64048: geeco_note_kernel("conv_wgrad_kernel<64, 48, 32>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 48, 32>), grid, dim3(256), 0, s, p); break;
+    case 64032: geeco_note_kernel("conv_wgrad_kernel<64, 32, 64>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64>), grid, dim3(256), 0, s, p); break;
+    default: geeco_note_kernel("conv_wgrad_kernel<64, 16, 64>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 16, 64>), grid, dim3(256), 0, s, p); break;
   }
   GEECO_LAUNCH_CHECK();
   if (p.S > 1) {

@@ -12,3 +12,27 @@ void geeco_set_error(const char* fmt, ...) {
 
 extern "C" const char* geeco_last_error(void) { return g_err; }
 extern "C" int geeco_abi_version(void) { return GEECO_ABI_VERSION; }
+
+// ---- dispatch trace (diagnostics for bench.py / tests): which kernels a call launched ----------------
+static thread_local bool g_trace_on = false;
+static thread_local char g_trace[1024] = "";
+
+void geeco_note_kernel(const char* fmt, ...) {
+  if (!g_trace_on) return;
+  size_t n = strlen(g_trace);
+  if (n + 2 >= sizeof(g_trace)) return;
+  if (n) g_trace[n++] = ';';
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_trace + n, sizeof(g_trace) - n, fmt, ap);
+  va_end(ap);
+}
+
+extern "C" void geeco_debug_kernel_trace_begin(void) {
+  g_trace_on = true;
+  g_trace[0] = 0;
+}
+extern "C" const char* geeco_debug_kernel_trace_end(void) {
+  g_trace_on = false;
+  return g_trace;
+}

@@ -10,6 +10,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void geeco_set_error(const char* fmt, ...);
+// records the name of the kernel a dispatcher is about to launch (no-op unless a trace was begun on this thread)
+void geeco_note_kernel(const char* fmt, ...);
 
 #define GEECO_CHECK_ARG(cond, ...)              \
   do {                                          \

@@ -59,6 +59,20 @@ def allreduce_gradients(grads: torch.Tensor):
   dist.all_reduce(grads, op=dist.ReduceOp.SUM)
 
 
+class _Done:
+  def wait(self):
+    return True
+
+
+def allreduce_async(t: torch.Tensor):
+  """SUM over ranks of one gradient bucket, in place.  With RCCL the collective runs on the communicator's own
+  stream, ordered behind the work already enqueued on the current stream; ``.wait()`` on the returned handle makes
+  the current stream wait for it (the host does not block), so kernels enqueued in between overlap it."""
+  if world_size() == 1:
+    return _Done()
+  return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def shard_bounds(n_items: int, r=None, w=None):
   """Contiguous equal shards; requires n_items % world == 0 so that mean-of-means == global mean."""
   r = rank() if r is None else r
@@ -67,6 +81,15 @@ def shard_bounds(n_items: int, r=None, w=None):
     raise ValueError('global batch %d is not divisible by world size %d' % (n_items, w))
   per = n_items // w
   return r * per, (r + 1) * per
+
+
+def broadcast_int(value: int, device='cpu', src=0) -> int:
+  """Rank `src`'s integer on every rank (e.g. the epoch's shuffle seed: all ranks must agree on the episode order)."""
+  if world_size() == 1:
+    return int(value)
+  t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+  dist.broadcast(t, src=src)
+  return int(t.item())
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -235,18 +235,47 @@ class Estimator:
 
   @staticmethod
   def _shard(batch, world, rank):
+    """Slice of a GLOBAL batch for this rank (synthetic inputs / unsharded input_fns): contiguous, sizes differing by
+    at most one, so a ragged global batch is kept (geeco_gym.py:471 has no drop_remainder).  Returns
+    (features, labels, n_local, n_global); n_local may be 0."""
     feats, labels = batch
     n = int(feats['step'].shape[0]) if 'step' in feats else int(next(iter(feats.values())).shape[0])
     if world == 1:
-      return feats, labels, n
-    if n % world:
-      return None, None, 0       # ragged global batch: dropped under data parallelism
-    lo, hi = gdist.shard_bounds(n, rank, world)
+      return feats, labels, n, n
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    if hi == lo:
+      return None, None, 0, n
     sl = lambda d: {k: v[lo:hi] for k, v in d.items()} if d is not None else None
-    return sl(feats), sl(labels), hi - lo
+    return sl(feats), sl(labels), hi - lo, n
 
-  def _get_spec(self, mode, feats, labels, n):
-    key = (mode, n)
+  def _local_batches(self, it, world, rank):
+    """Yields (features, labels, n_local, n_global) per optimiser step.  An input_fn that already sharded the
+    episodes over the ranks (pickplace_input_fn(shard=...)) carries ``dp_schedule`` = every rank's window count per
+    step; otherwise each rank slices the same global batch."""
+    sched = getattr(it, 'dp_schedule', None) if world > 1 else None
+    if sched is None:
+      for batch in it:
+        yield self._shard(batch, world, rank)
+      return
+    src = iter(it)
+    for counts in sched:
+      if counts[rank] > 0:
+        feats, labels = next(src)
+        n = int(feats['step'].shape[0])
+        if n != counts[rank]:
+          raise RuntimeError('data-parallel schedule expected %d windows on rank %d, the input pipeline delivered %d'
+                             % (counts[rank], rank, n))
+        yield feats, labels, n, sum(counts)
+      else:
+        yield None, None, 0, sum(counts)
+
+  def _get_spec(self, mode, feats, labels, n, loss_scale=1.0):
+    """One model (+ captured graphs) per (mode, local batch size, loss scale).  ``loss_scale`` = n_local * world /
+    n_global weights this rank's batch-mean loss so that the SUM all-reduce followed by 1/world is the mean over the
+    GLOBAL batch also when the ranks hold different numbers of windows (ragged final batch); 1 for equal shards."""
+    key = (mode, n) if loss_scale == 1.0 else (mode, n, round(float(loss_scale), 9))
     if key in self._specs:
       return self._specs[key]
     dev = self._device()
@@ -265,6 +294,7 @@ class Estimator:
     params['_variable_store'] = self._store
     params.setdefault('use_hipgraph', self.config.use_hipgraph)
     spec = self._model_fn(fbuf, lbuf, mode, params)
+    spec.model.decoder.loss_scale = float(loss_scale)
     if self._store is None:
       self._store = spec.model.store
       self._store.initialize(seed=self.config.init_seed)
@@ -310,18 +340,25 @@ class Estimator:
   def train(self, input_fn, steps=None, max_steps=None):
     world, rank = gdist.world_size(), gdist.rank()
     t0, nsteps, step = time.time(), 0, None
-    for batch in input_fn():
-      feats, labels, n = self._shard(batch, world, rank)
+    last_runner = None
+    for feats, labels, n, n_global in self._local_batches(input_fn(), world, rank):
       if n == 0:
-        continue
-      spec, fbuf, lbuf = self._get_spec(ModeKeys.TRAIN, feats, labels, n)
-      self._feed(fbuf, feats)
-      self._feed(lbuf, labels)
-      spec.train_op()
+        # this rank has no window in this step (ragged end of the epoch): it still takes part in the gradient
+        # exchange, with zeros, and applies the same update as the others
+        if last_runner is None:
+          raise RuntimeError('rank %d has no data in its first training step' % rank)
+        last_runner.null_step()
+        spec = None
+      else:
+        spec, fbuf, lbuf = self._get_spec(ModeKeys.TRAIN, feats, labels, n, loss_scale=n * world / float(n_global))
+        self._feed(fbuf, feats)
+        self._feed(lbuf, labels)
+        spec.train_op()
+        last_runner = spec.train_op.__self__
       nsteps += 1
-      if spec.training_hooks or self.config.save_checkpoints_steps:
+      if (spec is not None and spec.training_hooks) or self.config.save_checkpoints_steps:
         step = int(self._store.global_step.item()) if (nsteps == 1 or step is None) else step + 1
-        for h in spec.training_hooks or []:
+        for h in (spec.training_hooks if spec is not None else None) or []:
           h.after_run(step, self.model_dir)
         if (self.config.save_checkpoints_steps and step % self.config.save_checkpoints_steps == 0 and rank == 0
             and self.model_dir):
@@ -341,8 +378,7 @@ class Estimator:
     """Streams the eval metrics of estimator.py:246-254; 'loss' = mean of per-batch losses [TF1.15]."""
     world, rank = gdist.world_size(), gdist.rank()
     sums, nb, loss_sum = {}, 0, None
-    for batch in input_fn():
-      feats, labels, n = self._shard(batch, world, rank)
+    for feats, labels, n, _ in self._local_batches(input_fn(), world, rank):
       if n == 0:
         continue
       spec, fbuf, lbuf = self._get_spec(ModeKeys.EVAL, feats, labels, n)

@@ -175,33 +175,69 @@ class ConvEncoderStack:
                               [self.layers[l]['Cout'] for l in ls], G, self.gs_p, **pad)
     self.derived_version = self.store.version
 
+  # -- single launches (also timed one by one by bench.py's per-layer table) ---------------------------
+  def launch_fwd(self, l):
+    G, Nf, L = self.G, self.Nf, self.layers[l]
+    x = self.x_in if l == 0 else self.acts[l - 1]
+    y = self.acts[l]
+    if l == 0 and self.pad1:
+      w, gs_w = self.w1p, self.w1p[0].numel()
+    else:
+      w, gs_w = self._w(l), self.gs_p
+    ops.conv3x3_fwd_into(y, x, w, self._b(l), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(), Nf, L['H'], L['W'],
+                         L['Cin'], L['Cout'], L['stride'], relu=True, ws=self.fws)
+
+  def launch_wgrad(self, l):
+    """Filter + bias gradient of layer l (skipped for conv1 when the encoder bottom is fused: launch_dgrad(1) does it)."""
+    G, Nf, L = self.G, self.Nf, self.layers[l]
+    if l == 0 and self.fused_bottom:
+      return
+    x = self.x_in if l == 0 else self.acts[l - 1]
+    dz = self.dz[l]
+    if l == 0 and self.pad1:
+      dw, gs_dw = self.dw1p, self.dw1p[0].numel()
+    else:
+      dw, gs_dw = self._dw(l), self.gs_p
+    ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
+                           L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l])
+    if l == 0 and self.pad1:
+      for g in range(G):
+        ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
+
+  def launch_dgrad(self, l):
+    """Input gradient of layer l >= 1 into dz[l-1] (ReluGrad of the layer below fused).  With the fused encoder
+    bottom, l == 1 also produces conv1's filter / bias gradient: dz1 has no other consumer and stays on chip
+    (805 MB less written and read again per step, one big launch less)."""
+    G, Nf, L = self.G, self.Nf, self.layers[l]
+    x = self.acts[l - 1]
+    dz = self.dz[l]
+    if l == 1 and self.fused_bottom:
+      L0 = self.layers[0]
+      dw1, gs_dw1 = (self.dw1p, self.dw1p[0].numel()) if self.pad1 else (self._dw(0), self.gs_p)
+      ops.conv2_dgrad_conv1_wgrad_into(dw1, self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
+                                       x[0].numel(), self.x_in[0].numel(), gs_dw1, self.gs_p, Nf, L['H'], L['W'],
+                                       self.fws_fused, real_channels=self.Cin)
+      if self.pad1:
+        for g in range(G):
+          ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L0['Cout'])
+      return
+    wt = self.wt[l]
+    dx = self.dz[l - 1]
+    ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
+                           L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
+
   def forward(self):
-    G, Nf = self.G, self.Nf
     if not self.lazy_refresh or self.derived_version != self.store.version:
       self.refresh_derived()
-    for l, L in enumerate(self.layers):
-      x = self.x_in if l == 0 else self.acts[l - 1]
-      y = self.acts[l]
-      if l == 0 and self.pad1:
-        w, gs_w = self.w1p, self.w1p[0].numel()
-      else:
-        w, gs_w = self._w(l), self.gs_p
-      ops.conv3x3_fwd_into(y, x, w, self._b(l), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(), Nf, L['H'], L['W'],
-                           L['Cin'], L['Cout'], L['stride'], relu=True, ws=self.fws)
+    for l in range(len(self.layers)):
+      self.launch_fwd(l)
 
-  def backward(self):
-    """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied)."""
-    G, Nf = self.G, self.Nf
+  def backward(self, hi=7, lo=0):
+    """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied).  Runs layers
+    hi..lo (the data-parallel runner splits the chain at conv3 / conv2 to start the gradient exchange early)."""
     main = torch.cuda.current_stream()
     sides = self.sides if self.two_streams else []
-    for l in range(7, -1, -1):
-      L = self.layers[l]
-      x = self.x_in if l == 0 else self.acts[l - 1]
-      dz = self.dz[l]
-      if l == 0 and self.pad1:
-        dw, gs_dw = self.dw1p, self.dw1p[0].numel()
-      else:
-        dw, gs_dw = self._dw(l), self.gs_p
+    for l in range(hi, lo - 1, -1):
       # wgrad(l) of the upper layers is off the critical path (the dgrad chain on `main`): it goes to a side
       # stream; the bottom layers' (LDS-halo kernels, one or two blocks per CU) stay on `main`
       side = None
@@ -210,31 +246,16 @@ class ConvEncoderStack:
       if side is not None:
         side.wait_stream(main)          # dz[l] is ready
       with torch.cuda.stream(side if side is not None else main):
-        ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
-                               L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l])
-        if l == 0 and self.pad1:
-          for g in range(G):
-            ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
+        self.launch_wgrad(l)
       if l == 0:
         break   # conv1's input is data: no dgrad
+      self.launch_dgrad(l)
       if l == 1 and self.fused_bottom:
-        # conv2's input gradient and conv1's filter gradient in one kernel: dz1 has no other consumer and stays
-        # on chip (805 MB less written and read again per step, one big launch less)
-        L0 = self.layers[0]
-        dw1, gs_dw1 = (self.dw1p, self.dw1p[0].numel()) if self.pad1 else (self._dw(0), self.gs_p)
-        ops.conv2_dgrad_conv1_wgrad_into(dw1, self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
-                                         x[0].numel(), self.x_in[0].numel(), gs_dw1, self.gs_p, Nf, L['H'], L['W'],
-                                         self.fws_fused, real_channels=self.Cin)
-        if self.pad1:
-          for g in range(G):
-            ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L0['Cout'])
         break
-      wt = self.wt[l]
-      dx = self.dz[l - 1]
-      ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
-                             L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
     for side in sides:
       main.wait_stream(side)
+
+  SPLIT = 2   # backward(part='upper') = layers 7..SPLIT, 'bottom' = SPLIT-1..0
 
 
 # ================================================================================================
@@ -422,8 +443,13 @@ class _ModelBase:
     ops.adam_tf(s.params, s.grads, s.adam_m, s.adam_v, s.size, self.scal, grad_scale=1.0 / self.world,
                 l2=float(cfg.l2_regularizer))
     # weights changed: re-derive the padded / transposed copies now (the version stamp is unchanged, so
-    # the next forward, eager or replayed, launches no pad / transpose kernels)
+    # the next forward, eager or replayed, launches no pad / transpose kernels).  A model that shares the store
+    # with the primary training stack (the one built for a ragged final batch) must refresh THAT stack's copies
+    # too: the primary relies on its own post-Adam refresh and would otherwise run one step on stale copies.
     self.enc.refresh_derived()
+    primary = getattr(s, 'primary_stack', None)
+    if primary is not None and primary is not self.enc:
+      primary.refresh_derived()
 
   def predictions(self):
     """estimator.py:48-61 / 183-197."""
@@ -538,7 +564,12 @@ class GoalE2EVMC(_ModelBase):
     d.forward(backward_too)
     self._finish_forward()
 
-  def backward(self):
+  def backward(self, part=None):
+    """part None = whole backward; 'upper' / 'bottom' = the two halves the data-parallel runner captures
+    separately (runtime.py): everything down to conv3, then the encoder bottom (conv2 / conv1)."""
+    if part == 'bottom':
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0)
+      return
     N, K, jn = self.N, self.K, self.cfg.dim_jnt_state
     d = self.decoder
     d.backward()
@@ -566,7 +597,7 @@ class GoalE2EVMC(_ModelBase):
       for t in range(K):
         ops.state_concat_bwd_into([dfe[0][t], dfe[1][t]], d.dstates[t], d.D, [feats[0][t], feats[1][t]], self.feat_ch,
                                   1, jn, N, _CELLS)
-    self.enc.backward()
+    self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0)
 
   def endpoints(self):
     """dynbuff / dyndiff debug endpoints (graph.py:377,393,401): the LAST computed images."""
@@ -609,7 +640,10 @@ class E2EVMC(_ModelBase):
     d.forward(backward_too)
     self._finish_forward()
 
-  def backward(self):
+  def backward(self, part=None):
+    if part == 'bottom':
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0)
+      return
     N, K = self.N, self.K
     d = self.decoder
     d.backward()
@@ -617,7 +651,7 @@ class E2EVMC(_ModelBase):
     dfe = self.enc.dfeatures[0].view(K, N, _CELLS, 256)
     for t in range(K):
       ops.state_concat_bwd_into([dfe[t]], d.dstates[t], d.D, [feats[t]], [256], 1, self.cfg.dim_jnt_state, N, _CELLS)
-    self.enc.backward()
+    self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0)
 
   def endpoints(self):
     return {'conv8': self.enc.features}

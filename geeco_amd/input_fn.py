@@ -135,6 +135,9 @@ class DeviceWindows:
     off = 0
     for frames_dev, starts in self.segments:
       n = len(starts)
+      if frames_dev.device != out.device:
+        raise RuntimeError('DeviceWindows: episode frames live on %s but the batch buffer on %s (each rank must '
+                           'upload to its own GPU)' % (frames_dev.device, out.device))
       st = torch.as_tensor(starts, device=out.device)
       ops.gather_windows_into(out[off:off + n], frames_dev, st, n, self.K, fe, self.divisor)
       off += n
@@ -160,20 +163,37 @@ def episode_to_device(ex, device):
   """Uploads the image streams of one episode: RGB as uint8 when the recorded values are integral
   (they are: the recorder stores uint8 frames as float lists), depth as float32."""
   import torch
+  from .runtime import CAPTURE_LOCK
+  device = resolve_device(device)
   T = ex['rgb'].shape[0]
   dev = {}
   rgb = ex['rgb'].reshape(T, -1)
   as_u8 = bool(np.all(rgb == np.rint(rgb)) and rgb.min() >= 0 and rgb.max() <= 255)
-  dev['rgb'] = torch.as_tensor(rgb.astype(np.uint8) if as_u8 else rgb / np.float32(255.0)).to(device)
+  host = {'rgb': torch.as_tensor(rgb.astype(np.uint8) if as_u8 else rgb / np.float32(255.0)),
+          'depth': torch.as_tensor(np.ascontiguousarray(ex['depth'].reshape(T, -1)))}
   dev['rgb_div'] = 255.0 if as_u8 else 1.0
-  dev['depth'] = torch.as_tensor(np.ascontiguousarray(ex['depth'].reshape(T, -1))).to(device)
   if 'target_rgb' in ex:
     t = ex['target_rgb'].reshape(1, -1)
     t_u8 = bool(np.all(t == np.rint(t)) and t.min() >= 0 and t.max() <= 255)
-    dev['target_rgb'] = torch.as_tensor(t.astype(np.uint8) if t_u8 else t / np.float32(255.0)).to(device)
+    host['target_rgb'] = torch.as_tensor(t.astype(np.uint8) if t_u8 else t / np.float32(255.0))
     dev['target_rgb_div'] = 255.0 if t_u8 else 1.0
-    dev['target_depth'] = torch.as_tensor(np.ascontiguousarray(ex['target_depth'].reshape(1, -1))).to(device)
+    host['target_depth'] = torch.as_tensor(np.ascontiguousarray(ex['target_depth'].reshape(1, -1)))
+  # allocations / synchronous copies from this (prefetch) thread must not fall into a hipGraph capture window of
+  # the training thread (runtime.CAPTURE_LOCK)
+  with CAPTURE_LOCK:
+    for k, v in host.items():
+      dev[k] = v.to(device)
   return dev
+
+
+def resolve_device(device):
+  """An explicit (type, index) device.  A bare 'cuda' means the CALLING thread's current device: resolve it
+  before handing work to another thread (the current HIP device is thread-local and starts at 0 there)."""
+  import torch
+  d = torch.device(device)
+  if d.type == 'cuda' and d.index is None:
+    d = torch.device('cuda', torch.cuda.current_device())
+  return d
 
 
 def episode_windows(ex, window_size, starts, dev=None):
@@ -208,13 +228,17 @@ def episode_windows(ex, window_size, starts, dev=None):
 class _Prefetcher:
   """Runs an iterator factory in background threads (tf.data's num_parallel_calls / prefetch)."""
 
-  def __init__(self, make_iter, depth):
+  def __init__(self, make_iter, depth, device=None):
     self._q = queue.Queue(maxsize=max(int(depth), 1))
+    self._device = device
     self._t = threading.Thread(target=self._run, args=(make_iter,), daemon=True)
     self._t.start()
 
   def _run(self, make_iter):
     try:
+      if self._device is not None and self._device.type == 'cuda':
+        import torch
+        torch.cuda.set_device(self._device)     # thread-local: a new thread starts on device 0 whatever LOCAL_RANK is
       for item in make_iter():
         self._q.put(('item', item))
       self._q.put(('end', None))
@@ -247,11 +271,24 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
   meta = get_meta_v4(dataset_dir)
   paths = collect_tfrecords(dataset_dir, split_name, mode)
   if mode == 'train':   # record-level shuffle only (:436-437)
+    if shard is not None and seed is None:
+      raise ValueError('sharded training input needs one seed shared by all ranks (they must agree on the episode order)')
     np.random.default_rng(seed).shuffle(paths)
-  if shard is not None:
-    paths = paths[shard[0]::shard[1]]
-  print('[pickplace_input_fn_v4] #tfrecords: %d' % len(paths))
   K = window_size
+  dp_schedule = None
+  if shard is not None:
+    # every rank reads its own rank-strided subset of the episodes.  Episodes have the fixed length
+    # of the meta file (pickplace.py:157), so each rank can work out how many windows EVERY rank contributes to
+    # each step without talking to the others: dp_schedule[s][r] = windows of rank r in step s.
+    rank, world = shard
+    nwin = (meta.episode_length - 1) - K + 1
+    per_rank = [len(paths[r::world]) * nwin * num_epochs for r in range(world)]
+    steps = max(-(-w // batch_size) for w in per_rank) if per_rank else 0
+    dp_schedule = [tuple(max(0, min(batch_size, w - s * batch_size)) for w in per_rank) for s in range(steps)]
+    paths = paths[rank::world]
+  if device is not None:
+    device = resolve_device(device)
+  print('[pickplace_input_fn_v4] #tfrecords: %d' % len(paths))
 
   def batches():
     carry_f, carry_l = None, None   # windows left over from the previous episode (batch() spans episodes)
@@ -260,6 +297,9 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
         ex = load_episode(path, meta, fetch_target, raw_rgb=device is not None)
         dev = episode_to_device(ex, device) if device is not None else None
         T = ex['step'].shape[0]
+        if shard is not None and T != meta.episode_length - 1:
+          raise ValueError('%s holds %d frames, meta_info.json says %d: the data-parallel batch schedule assumes '
+                           'fixed-length episodes' % (path, T + 1, meta.episode_length))
         nwin = T - K + 1
         pos = 0
         while pos < nwin:
@@ -278,7 +318,9 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
     if carry_f is not None:   # ragged final batch (dataset.batch without drop_remainder, :471)
       yield carry_f, carry_l
 
-  return _Prefetcher(batches, prefetch_size)
+  it = _Prefetcher(batches, prefetch_size, device)
+  it.dp_schedule = dp_schedule
+  return it
 
 
 # ------------------------------------------------------------------------------------------------

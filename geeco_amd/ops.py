@@ -97,6 +97,9 @@ def pack_pixels_into(dst, src, src_sample_stride, N, HW, C1, Cpad, src2=None, sr
 def gather_windows_into(out, src, starts_dev, N, K, frame_elems, divisor=1.0):
   """out[n][k] <- src[starts[n] + k] / divisor for an episode resident in HBM (uint8 or float32 frames)."""
   assert src.is_cuda and src.dtype in (torch.uint8, torch.float32) and starts_dev.dtype == torch.int32
+  if not (src.device == out.device == starts_dev.device):
+    raise RuntimeError('gather_windows: source %s, starts %s and output %s must be on one device' %
+                       (src.device, starts_dev.device, out.device))
   check(_lib().geeco_gather_windows(ctypes.c_void_p(src.data_ptr()), 1 if src.dtype == torch.uint8 else 0,
                                     ctypes.c_void_p(starts_dev.data_ptr()), N, K, frame_elems, float(divisor), _p(out),
                                     _stream()), 'geeco_gather_windows')
@@ -285,3 +288,17 @@ def adam_tf(p, g, m, v, n, scal, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
 
 def sumsq_into(out, p, n):
   check(_lib().geeco_sumsq(_p(p), n, _p(out), _stream()), 'geeco_sumsq')
+
+
+# --------------------------------------------------------------------------------------------
+# diagnostics
+# --------------------------------------------------------------------------------------------
+def kernel_trace(fn):
+  """Runs ``fn()`` and returns the names of the conv kernels its calls dispatched (in launch order)."""
+  lib = _lib()
+  lib.geeco_debug_kernel_trace_begin()
+  try:
+    fn()
+  finally:
+    names = lib.geeco_debug_kernel_trace_end()
+  return [n for n in (names.decode() if names else '').split(';') if n]

@@ -1,17 +1,60 @@
 """Step runner: replays one training step as captured hipGraphs, with the data-parallel exchange.
 
 The reference's hot loop is ``session.run(train_op)`` once per batch.  All shapes
-are static, so the ~150 kernel launches of a step are captured once (HIP stream capture through
-``torch.cuda.CUDAGraph``, our kernels are launched on torch's current stream) and replayed:
-  graph A = forward + backward  ->  [RCCL all-reduce of the gradient arena, world > 1]  ->
-  graph B = Adam.
+are static, so the ~110 kernel launches of a step are captured once (HIP stream capture through
+``torch.cuda.CUDAGraph``, our kernels are launched on torch's current stream) and replayed.
+
+One GPU:      graph A (forward + backward)  ->  graph B (Adam + re-derived weight copies).
+Data parallel (buckets in reverse-layer order, overlapped with the backward):
+  graph A1 = forward + decoder backward + encoder backward down to conv3 (every gradient except the
+             encoders' conv1 / conv2 is final: 99.4 % of the bytes)
+  -> EARLY bucket: asynchronous RCCL all-reduce of those arena ranges on the communicator's stream
+  graph A2 = conv2's filter gradient + the fused encoder bottom (conv2 dgrad + conv1 wgrad, ~0.9 ms)
+             + pack of the conv1 / conv2 gradients into one small staging buffer
+  -> LATE bucket: all-reduce of the staging buffer (177 KB)
+  graph B  = wait for both, unpack the staging buffer, Adam (grad_scale = 1 / world).
+The early bucket therefore runs beside A2's kernels; only the small late bucket is exposed.
 The Adam step counter and lr_t live in device memory, so replays advance them correctly.
 """
 from __future__ import annotations
 
+import re
+import threading
+
 import torch
 
 from . import dist as gdist
+
+# hipGraph capture in the default ("global") mode is invalidated by a hipMalloc / synchronous copy issued by ANOTHER
+# thread during the capture window (the input prefetcher uploads episodes in a background thread): both sides take
+# this lock (geeco_amd/input_fn.py: episode_to_device).
+CAPTURE_LOCK = threading.RLock()
+
+_LATE = re.compile(r'/conv[12]/(kernel|bias)$')
+
+
+def gradient_buckets(store):
+  """(early ranges, late ranges) of the flat gradient arena as (offset, length) in floats.  late = the encoders'
+  conv1 / conv2 variables (their gradients come out of the last two launches of the backward); early = the rest,
+  merged into maximal contiguous ranges (alignment pads included)."""
+  late = []
+  names = list(store.shapes.keys())
+  for i, n in enumerate(names):
+    if _LATE.search(n):
+      lo = store.offsets[n]
+      hi = store.offsets[names[i + 1]] if i + 1 < len(names) else store.size
+      if late and late[-1][1] == lo:
+        late[-1][1] = hi
+      else:
+        late.append([lo, hi])
+  early, pos = [], 0
+  for lo, hi in late:
+    if lo > pos:
+      early.append((pos, lo - pos))
+    pos = hi
+  if store.size > pos:
+    early.append((pos, store.size - pos))
+  return early, [(lo, hi - lo) for lo, hi in late]
 
 
 class TrainStepRunner:
@@ -21,43 +64,104 @@ class TrainStepRunner:
     self.world = gdist.world_size()
     model.world = self.world
     self.use_graph = bool(use_graph) and torch.cuda.is_available()
-    self._ga = self._gb = None
+    self._graphs = None
     self._warm = warmup
     self._calls = 0
+    self.skip_allreduce = False          # bench.py: measure the step without the exchange
+    self.early, self.late = gradient_buckets(model.store)
+    self.staging = None
+    if self.world > 1 and self.late:
+      self.staging = torch.zeros(sum(n for _, n in self.late), dtype=torch.float32, device=model.store.grads.device)
 
-  def _fwd_bwd(self):
+  def bucket_info(self):
+    return {'early_bytes': 4 * sum(n for _, n in self.early), 'early_ranges': len(self.early),
+            'late_bytes': 4 * sum(n for _, n in self.late), 'late_ranges': len(self.late)}
+
+  # -- pieces of a step ----------------------------------------------------------------------------------
+  def _part1(self):
     self.model.forward(backward_too=True)
-    self.model.backward()
+    if self.world > 1:
+      self.model.backward(part='upper')
+    else:
+      self.model.backward()
+
+  def _part2(self):
+    self.model.backward(part='bottom')
+    g, pos = self.model.store.grads, 0
+    for off, n in self.late:
+      self.staging[pos:pos + n].copy_(g[off:off + n])
+      pos += n
+
+  def _part3(self):
+    if self.world > 1:
+      g, pos = self.model.store.grads, 0
+      for off, n in self.late:
+        g[off:off + n].copy_(self.staging[pos:pos + n])
+        pos += n
+    self.model.apply_gradients()
+
+  def _exchange_early(self):
+    if self.skip_allreduce:
+      return []
+    g = self.model.store.grads
+    return [gdist.allreduce_async(g[off:off + n]) for off, n in self.early]
+
+  def _exchange_late(self):
+    if self.skip_allreduce or self.staging is None:
+      return []
+    return [gdist.allreduce_async(self.staging)]
 
   def _capture(self):
-    # capture on a side stream; the warm-up steps before this call already ran eagerly
-    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(ga):
-      self._fwd_bwd()
-    with torch.cuda.graph(gb):
-      self.model.apply_gradients()
-    self._ga, self._gb = ga, gb
+    # the warm-up steps before this call already ran eagerly
+    parts = [self._part1, self._part3] if self.world == 1 else [self._part1, self._part2, self._part3]
+    graphs = []
+    with CAPTURE_LOCK:
+      for fn in parts:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+          fn()
+        graphs.append(g.replay)
+    self._graphs = graphs
 
   def prepare(self):
     """Untimed set-up for benchmarks: run the eager warm-up steps and capture the graphs now, so that
     no later call pays for the capture."""
-    while self.use_graph and self._ga is None:
+    while self.use_graph and self._graphs is None:
       self.step()
 
   def step(self):
     """One optimiser step on the batch currently in ``model.inputs``."""
-    if self.use_graph and self._ga is None and self._calls >= self._warm:
+    if self.use_graph and self._graphs is None and self._calls >= self._warm:
       # NB capture itself does not execute the step; fall through to replay
       self._capture()
     self._calls += 1
-    if self._ga is not None:
-      self._ga.replay()
-      gdist.allreduce_gradients(self.model.store.grads)
-      self._gb.replay()
+    if self._graphs is not None:
+      run = self._graphs
     else:
-      self._fwd_bwd()
-      gdist.allreduce_gradients(self.model.store.grads)
-      self.model.apply_gradients()
+      run = [self._part1, self._part3] if self.world == 1 else [self._part1, self._part2, self._part3]
+    if self.world == 1:
+      run[0]()
+      run[1]()
+      return
+    run[0]()
+    works = self._exchange_early()         # on the communicator's stream, behind part 1, beside part 2
+    run[1]()
+    works += self._exchange_late()
+    for w in works:
+      w.wait()                             # the compute stream waits; the host does not (RCCL)
+    run[2]()
+
+
+  def null_step(self):
+    """A step of a rank that holds no sample (ragged end of an epoch under data parallelism): zero gradients into
+    the exchange, then the same Adam update as every other rank."""
+    self._calls += 1
+    self.model.store.grads.zero_()
+    if self.staging is not None:
+      self.staging.zero_()
+    for w in self._exchange_early() + self._exchange_late():
+      w.wait()
+    self._part3()
 
 
 class EvalStepRunner:
@@ -73,8 +177,9 @@ class EvalStepRunner:
   def step(self):
     if self.use_graph and self._g is None and self._calls >= self._warm:
       g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g):
-        self.model.forward(backward_too=False)
+      with CAPTURE_LOCK:
+        with torch.cuda.graph(g):
+          self.model.forward(backward_too=False)
       self._g = g
     self._calls += 1
     if self._g is not None:

@@ -32,6 +32,12 @@ extern "C" {
 int geeco_abi_version(void);
 const char* geeco_last_error(void);
 
+/* Diagnostics (bench.py's per-layer table): between _begin and _end on one host thread every
+ * conv entry point records the names of the kernels it dispatched; _end returns them ';'-separated
+ * (thread-local buffer, valid until the next _begin on that thread). */
+void geeco_debug_kernel_trace_begin(void);
+const char* geeco_debug_kernel_trace_end(void);
+
 /* ---- dynamic image: src/models/e2evmc/graph.py:30-55 (dynimg), :17-28 (_H/_alpha) -------------
  * frames [N][K][H][W][C] (or, when frame_stride/sample_stride are given, any strided stack of
  * HWC frames) -> out [N][H][W][Cpad] = (D - min_n) / (max_n - min_n + 1e-6), D = sum_t alpha_t X_t.

@@ -477,3 +477,85 @@ def synthetic_batch(cfg: Config, goal: bool, N: int, seed=1234, H=None, W=None):
        'ee_target': r.random([N, 7], dtype=np.float32),
        'grp_target': r.random([N, 2], dtype=np.float32)}
   return f, l
+
+
+# --------------------------------------------------------------------------------------
+# chunked evaluation for the full BASELINE shapes (same mathematics, bounded memory)
+# --------------------------------------------------------------------------------------
+def _encoder_jobs(features, cfg: Config, goal: bool, dtype):
+  """(scope, frames [F,H,W,C]) per encoder pass of model_forward, in the order whose features
+  feed the decoder.  e2e_vmc: time-major frames (graph.py:310-313); goal/dynimg: graph.py:386-402."""
+  if cfg.img_channels == 3:
+    obs = features['rgb']
+    tgt = features.get('target_rgb') if goal else None
+  else:
+    obs = torch.cat([features['rgb'], features['depth']], dim=-1)
+    tgt = torch.cat([features['target_rgb'], features['target_depth']], dim=-1) if goal else None
+  N, K = obs.shape[0], obs.shape[1]
+  if not goal:
+    return [('VMC/ConvEncoder', obs.transpose(0, 1).reshape((K * N,) + tuple(obs.shape[2:])))], {}
+  if cfg.proc_obs != 'dynimg':
+    raise NotImplementedError('chunked oracle: goal model only for proc_obs=dynimg')
+  cur = obs[:, -1]
+  db = dynimg(obs)
+  dd = dynimg(torch.stack([cur, tgt], dim=1))
+  return ([('GoalVMC/ConvEncoder', cur), ('GoalVMC/DynBuffEncoder', db), ('GoalVMC/DynDiffEncoder', dd)],
+          {'dynbuff': db, 'dyndiff': dd})
+
+
+def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16, enc_dtype=None):
+  """Same result as ``OracleTrainer.loss_and_grads`` (up to summation order) without holding the
+  autograd graph of every frame at once: (1) encoder forward per chunk without graph -> conv8
+  features; (2) decoder + loss with autograd on the features; (3) per chunk, encoder forward
+  again WITH graph and backward from d(loss)/d(features).  ``enc_dtype`` lets the encoder run
+  in float32 while decoder/loss stay in the trainer's dtype (1024-frame case)."""
+  cfg, goal, dt = trainer.cfg, trainer.goal, trainer.dtype
+  edt = enc_dtype or dt
+  features, labels = trainer._cast(features), trainer._cast(labels)
+  P = trainer.P
+  jobs, ep = _encoder_jobs(features, cfg, goal, dt)
+  Pe = {k: v.detach().to(edt) for k, v in P.items() if '/conv' in k}
+  feats = []
+  with torch.no_grad():
+    for scope, x in jobs:
+      outs = [conv_encoder(x[i:i + chunk].to(edt), Pe, scope) for i in range(0, x.shape[0], chunk)]
+      feats.append(torch.cat(outs, dim=0).to(dt))
+  first_last = {scope: (f[0].clone(), f[-1].clone()) for (scope, _), f in zip(jobs, feats)}
+  for f in feats:
+    f.requires_grad_(True)
+  dec = {k: v for k, v in P.items() if '/conv' not in k}
+  for p in dec.values():
+    p.requires_grad_(True); p.grad = None
+  jnt = features['jnt_state']
+  N, K = jnt.shape[0], jnt.shape[1]
+  if goal:
+    st = [representation_concatenation_v2(feats[0], feats[1], jnt[:, -1], feats[2])]
+    dep = lstm_decoder(st, P, 'GoalVMC/LSTMDecoder', cfg)
+  else:
+    f = feats[0].reshape((K, N) + tuple(feats[0].shape[1:]))
+    st = [state_concatenation(f[k], jnt[:, k]) for k in range(K)]
+    dep = lstm_decoder(st, P, 'VMC/LSTMDecoder', cfg)
+  if cfg.control_mode == 'cartesian':
+    pred = {'cmd_ee': dep['pred_cmd_ee'], 'logits_cmd_grp': dep['logits_cmd_grp'],
+            'pos_ee': dep['pred_aux_ee'], 'pos_obj': dep['pred_aux_obj']}
+  else:
+    pred = {'cmd_vel': dep['pred_cmd_vel'], 'cmd_ee': dep['pred_cmd_ee'], 'cmd_grp': dep['pred_cmd_grp'],
+            'pos_ee': dep['pred_aux_ee'], 'pos_obj': dep['pred_aux_obj']}
+  if cfg.l2_regularizer > 0.0:
+    raise NotImplementedError('chunked oracle: l2_regularizer must be 0')
+  loss, parts = model_loss(pred, build_targets(features, labels, cfg), P, cfg)
+  loss.backward()
+  grads = {k: p.grad.detach().clone() for k, p in dec.items()}
+  for p in dec.values():
+    p.requires_grad_(False)
+  for (scope, x), f in zip(jobs, feats):
+    names = [k for k in P if k.startswith(scope + '/')]
+    Pg = {k: P[k].detach().to(edt).requires_grad_(True) for k in names}
+    for i in range(0, x.shape[0], chunk):
+      out = conv_encoder(x[i:i + chunk].to(edt), Pg, scope)
+      out.backward(f.grad[i:i + chunk].to(edt))
+    for k in names:
+      grads[k] = Pg[k].grad.detach().to(dt)
+  ep = dict(ep)
+  ep['conv8_first_last'] = first_last
+  return (loss.detach(), {k: v.detach() for k, v in parts.items()}, grads, {k: v.detach() for k, v in pred.items()}, ep)

@@ -8,7 +8,8 @@ over the CLI on restart :229-232, ``model.ckpt-<step>*`` + ``checkpoint``, best-
 (:288-291).  Only the imports differ: ``geeco_amd.estimator`` instead of ``tf.estimator``.
 
 Data parallel: launch with ``python -m torch.distributed.run --nproc-per-node N scripts/train_e2evmc.py ...``;
-``--batch_size`` stays the GLOBAL batch (each rank takes its slice).
+``--batch_size`` stays the GLOBAL batch: each rank reads its own rank-strided share of the episodes in batches of
+batch_size / world windows (geeco_amd.input_fn.pickplace_input_fn(shard=...)).
 ``--dataset_dir synthetic:<num_batches>`` trains on seeded synthetic windows (no dataset on disk).
 """
 import argparse
@@ -152,14 +153,29 @@ def main(args):
   model_fn, _scope = _GOAL_CONDITION_TO_MODEL[args.goal_condition]
   estimator = est.Estimator(model_fn=model_fn, model_dir=args.model_dir, config=run_config, params=estimator_params)
 
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  synthetic = args.dataset_dir.startswith('synthetic:')
+  if world > 1 and not synthetic and args.batch_size % world:
+    raise ValueError('--batch_size %d (the GLOBAL batch) must be divisible by the %d ranks' % (args.batch_size, world))
+
   def input_fn(estimator_mode):
+    import torch
+    dev = torch.device('cuda', local_rank)
+    kw = {}
+    if world > 1 and not synthetic:
+      # every rank reads its own rank-strided subset of the episodes (one shuffle order agreed through rank 0's
+      # seed) in batches of batch_size / world windows; ragged ends are handled by the Estimator (dp_schedule)
+      seed = gdist.broadcast_int(int.from_bytes(os.urandom(4), 'little'), dev) if estimator_mode == 'train' else None
+      kw = dict(shard=(rank, world), batch_size=args.batch_size // world, seed=seed)
+    else:
+      kw = dict(batch_size=args.batch_size, seed=None)
     return pickplace_input_fn(
         dataset_dir=args.dataset_dir, split_name=args.split_name, mode=estimator_mode, encoding=args.data_encoding,
         window_size=e2evmc_config.window_size, fetch_target=(args.goal_condition == 'target'),
-        shuffle_buffer=args.shuffle_buffer, batch_size=args.batch_size, num_epochs=1, num_threads=args.num_threads,
-        prefetch_size=args.prefetch_size, seed=None,
-        # episodes are uploaded once and windows are gathered in HBM unless GEECO_HOST_WINDOWS is set
-        device=None if os.environ.get('GEECO_HOST_WINDOWS') else 'cuda')
+        shuffle_buffer=args.shuffle_buffer, num_epochs=1, num_threads=args.num_threads,
+        prefetch_size=args.prefetch_size,
+        # episodes are uploaded once (to THIS rank's GPU) and windows are gathered in HBM unless GEECO_HOST_WINDOWS is set
+        device=None if os.environ.get('GEECO_HOST_WINDOWS') else dev, **kw)
   train_input = lambda: input_fn(estimator_mode='train')
   eval_input = lambda: input_fn(estimator_mode='eval')
 

@@ -88,3 +88,80 @@ def test_shard_bounds_errors():
   assert gdist.shard_bounds(8, 1, 4) == (2, 4)
   with pytest.raises(ValueError):
     gdist.shard_bounds(7, 0, 2)
+
+
+# ----------------------------------------------------------------------------------------------------
+# bucketed exchange of the step runner (early ranges beside the bottom of the backward, late staging)
+# ----------------------------------------------------------------------------------------------------
+class _FakeModel:
+  """Stands in for a graph.* model on the CPU: 'backward' writes rank-dependent gradients, the upper part into
+  the early ranges only, the bottom part into the late (conv1 / conv2) ranges only."""
+
+  def __init__(self, store, rank, early, late):
+    self.store, self.rank, self.early, self.late = store, rank, early, late
+    self.world = 1
+    self.applied = None
+
+  def forward(self, backward_too=False):
+    self.store.grads.fill_(float('nan'))            # every element must be rewritten by the two backward parts
+
+  def backward(self, part=None):
+    g = self.store.grads
+    idx = torch.arange(g.numel(), dtype=torch.float32)
+    val = (self.rank + 1) * (1.0 + 0.001 * (idx % 97))
+    for rngs, on in ((self.early, part in (None, 'upper')), (self.late, part in (None, 'bottom'))):
+      if on:
+        for off, n in rngs:
+          g[off:off + n] = val[off:off + n]
+
+  def apply_gradients(self):
+    self.applied = self.store.grads.clone() / self.world
+
+
+def _bucket_worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.set_num_threads(1)
+  from geeco_amd import dist as gdist
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import TrainStepRunner, gradient_buckets
+  from geeco_amd.variables import VariableStore
+  gdist.init_from_env('gloo')
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2))
+  store = VariableStore(model_variable_shapes(cfg, True), 'cpu')
+  early, late = gradient_buckets(store)
+  model = _FakeModel(store, rank, early, late)
+  runner = TrainStepRunner(model, use_graph=False)
+  assert runner.world == world and model.world == world
+  runner.step()
+  q.put((rank, model.applied.numpy(), early, late, runner.bucket_info()))
+  dist.destroy_process_group()
+
+
+def test_bucketed_exchange_covers_the_arena():
+  sys.path.insert(0, ROOT)
+  world, port = 2, 31500 + (os.getpid() % 2000)
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  g0, early, late, info = res[0][1], res[0][2], res[0][3], res[0][4]
+  # the ranges partition the arena
+  cover = np.zeros(g0.size, np.int32)
+  for off, n in early + late:
+    cover[off:off + n] += 1
+  assert (cover == 1).all()
+  # geeco-f: conv1 + conv2 of three encoders = 3 x (3*3*3*32 + 32 + 3*3*32*48 + 48) floats
+  assert info['late_bytes'] == 4 * 3 * (864 + 32 + 13824 + 48) and info['late_ranges'] == 3
+  assert info['early_bytes'] + info['late_bytes'] == 4 * g0.size
+  # every element = mean over ranks of (rank + 1) * pattern = 1.5 * pattern, identical on both ranks
+  idx = np.arange(g0.size, dtype=np.float32)
+  want = 1.5 * (1.0 + 0.001 * (idx % 97))
+  np.testing.assert_allclose(g0, want, rtol=1e-6)
+  np.testing.assert_array_equal(res[0][1], res[1][1])

@@ -78,3 +78,55 @@ def test_two_ranks_equal_single_process(dev):
   # global loss = mean of the two shard losses
   for s in range(3):
     assert abs(0.5 * (res[0][2][s] + res[1][2][s]) - ref_losses[s]) < 2e-4 * abs(ref_losses[s]) + 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------
+# Estimator under data parallelism with ragged global batches: 4 -> 2+2, 3 -> 2+1 (loss scales 4/3 and 2/3),
+# 1 -> 1+0 (rank 1 takes a null step: zeros into the exchange, same Adam update)
+# ----------------------------------------------------------------------------------------------------
+def _global_batches():
+  sys.path.insert(0, ROOT)
+  from geeco_amd.input_fn import synthetic_batches
+  full = list(synthetic_batches(4, 3, 3, (136, 136), 3, True, seed=17)())
+  cut = lambda b, n: ({k: v[:n] for k, v in b[0].items()}, {k: v[:n] for k, v in b[1].items()})
+  return [full[0], cut(full[1], 3), cut(full[2], 1)]
+
+
+def _est_worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from geeco_amd import dist as gdist
+  from geeco_amd import estimator as est
+  from geeco_amd.params import create_e2evmc_config
+  torch.cuda.set_device(0)
+  gdist.init_from_env('gloo')
+  params = {'e2evmc_config': create_e2evmc_config(KW), 'log_steps': 100, 'debug': False}
+  e = est.Estimator(est.goal_e2evmc_model_fn, None, est.RunConfig(init_seed=4), params)
+  e.train(input_fn=lambda: iter(_global_batches()))
+  torch.cuda.synchronize()
+  q.put((rank, e._store.params.detach().cpu().numpy(), int(e._store.global_step.item())))
+  torch.distributed.destroy_process_group()
+
+
+def test_estimator_ragged_batches_two_ranks(dev):
+  from geeco_amd import estimator as est
+  from geeco_amd.params import create_e2evmc_config
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 30700 + os.getpid() % 1000
+  procs = [ctx.Process(target=_est_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  params = {'e2evmc_config': create_e2evmc_config(KW), 'log_steps': 100, 'debug': False}
+  e = est.Estimator(est.goal_e2evmc_model_fn, None, est.RunConfig(init_seed=4), params)
+  e.train(input_fn=lambda: iter(_global_batches()))
+  torch.cuda.synchronize()
+  ref = e._store.params.detach().cpu().numpy()
+  assert res[0][2] == res[1][2] == 3                                               # the null step advanced rank 1 too
+  np.testing.assert_array_equal(res[0][1], res[1][1])                               # replicas stay identical
+  np.testing.assert_allclose(res[0][1], ref, rtol=0, atol=3e-4)                     # == single process on the global batches
+  assert np.mean(np.abs(res[0][1] - ref) < 2e-5) > 0.99

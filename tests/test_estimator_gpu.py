@@ -109,6 +109,8 @@ def test_device_windows_match_host_pipeline(dev, tmp_path):
     for k in fh:
       got = fd[k].numpy() if isinstance(fd[k], DeviceWindows) else fd[k]
       assert isinstance(fd[k], DeviceWindows) == (k in ('rgb', 'depth', 'target_rgb', 'target_depth')), k
+      if isinstance(fd[k], DeviceWindows):     # uploaded from the prefetch THREAD to the explicit device of the caller
+        assert fd[k].segments[0][0].device == torch.device('cuda', torch.cuda.current_device()), k
       np.testing.assert_array_equal(got, fh[k], err_msg=k)          # incl. the /255.0 of geeco_gym.py:312
     for k in lh:
       np.testing.assert_array_equal(ld[k], lh[k])
@@ -127,7 +129,7 @@ def test_device_windows_match_host_pipeline(dev, tmp_path):
 
 def test_ragged_final_batch_and_shared_store(dev, tmp_path):
   """dataset.batch() keeps a ragged final batch (geeco_gym.py:471); the Estimator builds a second graph for
-  it on the SAME variables.  A 4+4+2 epoch must equal the same three steps taken through one-off models."""
+  it on the SAME variables.  A 4+4+2 epoch followed by a full batch must equal the same four steps taken through one-off models."""
   from geeco_amd import estimator as est
   from geeco_amd import graph
   from geeco_amd.input_fn import synthetic_batches
@@ -135,9 +137,12 @@ def test_ragged_final_batch_and_shared_store(dev, tmp_path):
   full = list(synthetic_batches(4, 2, 3, (136, 136), 3, True, seed=8)())
   f3, l3 = full[2]
   ragged = full[:2] + [({k: v[:2] for k, v in f3.items()}, {k: v[:2] for k, v in l3.items()})]
+  # ... followed by a full batch again (the next epoch's first step runs on the PRIMARY model, whose derived weight
+  # copies must have been refreshed by the ragged model's Adam step)
+  ragged = ragged + [full[0]]
   e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path / 'a'), est.RunConfig(use_hipgraph=True), params)
   e.train(input_fn=lambda: iter(ragged))
-  assert int(e._store.global_step.item()) == 3 and len(e._specs) == 2
+  assert int(e._store.global_step.item()) == 4 and len(e._specs) == 2
   got = e._store.to_numpy('params')
   # reference: the same three steps, eager, fresh model objects sharing one store
   cfg = params['e2evmc_config']

@@ -1,0 +1,102 @@
+"""Parity at the FULL single-GPU shapes of BASELINE.json (not only at the reduced test shapes):
+
+  config 2  geeco-f rgb   256x256  N=32 K=16   (the bench workload)
+  config 4  e2e_vmc rgb   256x256  N=64 K=16   (1024 frame passes; conv1's output is exactly 2^31 floats)
+  config 5  geeco-f rgbd  256x256  N=32 K=32   (per-GPU shape of the 8-GPU rgbd config)
+
+One forward + backward of the HIP path vs the CPU oracle evaluated in chunks
+(``oracle.loss_and_grads_chunked``: identical mathematics, bounded memory; checked against the
+plain oracle in tests/test_oracle_kat.py).  Compared: loss and loss parts (1e-4 relative,
+BASELINE.json north_star), predictions, every variable's gradient, and conv8's features of the
+FIRST and the LAST frame of every encoder -- the last frame is where a 32-bit offset overflow
+would corrupt data silently.  Oracle precision: fp64 throughout for configs 2 and 5; for the
+1024-frame config 4 the encoder runs in fp32 on the CPU (fp64 would take minutes), decoder and
+loss in fp64, and the gradient bound is correspondingly looser.
+
+Gradient tolerance (fraction of the variable's max |g|) is a FIXED cap per case, asserted, and the
+achieved worst error is printed.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geeco_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+#        name               cfg overrides                                                     goal  N   enc dtype      grad cap
+FULL = [
+    ('config2 geeco-f rgb N=32 K=16', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 32, torch.float64, 1e-3),
+    ('config4 e2e_vmc rgb N=64 K=16', dict(window_size=16), False, 64, torch.float32, 3e-3),
+    ('config5 geeco-f rgbd N=32 K=32', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=32, img_channels=4), True, 32,
+     torch.float64, 1e-3),
+]
+
+
+def _rel_max(a, b):
+  a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+  return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize('name,cfg_kw,goal,N,enc_dtype,gcap', FULL, ids=[c[0].split()[0] for c in FULL])
+def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype, gcap):
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  cfg_kw = dict(cfg_kw, batch_size=N)
+  ocfg = O.make_config(**cfg_kw)
+  P = O.init_params(O.model_param_shapes(ocfg, goal), seed=21)
+  r = np.random.default_rng(22)
+  for k in P:
+    if k.endswith('/bias'):
+      P[k] = (0.05 * r.standard_normal(P[k].shape)).astype(np.float32)
+  feats, labels = O.synthetic_batch(ocfg, goal, N, seed=23)
+
+  t0 = time.time()
+  model = (graph.GoalE2EVMC if goal else graph.E2EVMC)(create_e2evmc_config(ocfg._asdict()), N, dev, training=True)
+  model.store.load_numpy(P)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  model.forward(backward_too=True)
+  model.backward()
+  torch.cuda.synchronize()
+  t_hip = time.time() - t0
+
+  t0 = time.time()
+  tr = O.OracleTrainer(ocfg, goal, P, dtype=torch.float64)
+  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(tr, feats, labels, chunk=16, enc_dtype=enc_dtype)
+  t_ora = time.time() - t0
+
+  # ---- conv8 features of the first and the last frame of every encoder ------------------------------
+  f8 = model.enc.features.cpu().numpy()                       # [G][Nf][2][2][C]
+  for g, scope in enumerate(model.enc.scopes):
+    first, last = ep_ref['conv8_first_last'][scope]
+    scale = max(float(first.abs().max()), float(last.abs().max()), 1e-30)
+    assert np.abs(f8[g, 0] - first.numpy()).max() <= 2e-4 * scale, (scope, 'first frame')
+    assert np.abs(f8[g, -1] - last.numpy()).max() <= 2e-4 * scale, (scope, 'last frame')
+  if goal:
+    ep = model.endpoints()
+    for k in ('dynbuff', 'dyndiff'):
+      assert _rel_max(ep[k].cpu().numpy(), ep_ref[k].numpy()) < 2e-5, k
+
+  # ---- predictions, loss ------------------------------------------------------------------------------
+  preds = {k: v.cpu().numpy() for k, v in model.predictions().items()}
+  for k, v in pred_ref.items():
+    np.testing.assert_allclose(preds[k], v.numpy(), rtol=2e-4, atol=5e-5, err_msg=k)
+  parts = {k: float(v) for k, v in model.loss_parts().items()}
+  assert abs(parts['loss'] - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (parts['loss'], float(loss_ref))
+  for k, v in parts_ref.items():
+    if k != 'loss_reg':
+      assert abs(parts[k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-7, (k, parts[k], float(v))
+
+  # ---- every variable's gradient ----------------------------------------------------------------------
+  grads = model.store.to_numpy('grads')
+  worst = ('', 0.0)
+  for k, g in grads_ref.items():
+    e = _rel_max(grads[k], g.numpy())
+    assert np.isfinite(grads[k]).all(), k
+    assert e <= gcap, (k, e, gcap)
+    if e > worst[1]:
+      worst = (k, e)
+  print('%s: loss %.6f (oracle %.6f); worst gradient error %.2e of max|g| at %s (cap %.0e); hip %.1f s, oracle %.1f s'
+        % (name, parts['loss'], float(loss_ref), worst[1], worst[0], gcap, t_hip, t_ora))

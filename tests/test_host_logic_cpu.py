@@ -212,3 +212,31 @@ def test_tf_checkpoint_bundle_roundtrip(tmp_path):
   with pytest.raises(KeyError):
     C.write_checkpoint(str(tmp_path / 'small'), {'a': np.zeros([2, 2], np.float32)})
     C.import_checkpoint(st2, str(tmp_path / 'small'))
+
+
+def test_dp_sharded_input_schedule(tmp_path):
+  """pickplace_input_fn(shard=(rank, world)): disjoint rank-strided episodes, one shuffle order for all ranks, and a
+  dp_schedule that tells every rank how many windows EVERY rank holds per step (ragged ends included)."""
+  from geeco_amd.estimator import Estimator
+  from geeco_amd.input_fn import pickplace_input_fn
+  T, K, B, world = 9, 3, 4, 2
+  _make_dataset(str(tmp_path), n_eps=3, T=T)         # 3 episodes x 6 windows: rank 0 gets 2 episodes, rank 1 gets 1
+  its = [pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=K, batch_size=B, shard=(r, world), seed=7)
+         for r in range(world)]
+  assert its[0].dp_schedule == its[1].dp_schedule == [(4, 4), (4, 2), (4, 0)]
+  got = [list(it) for it in its]
+  assert [len(f['step']) for f, _ in got[0]] == [4, 4, 4] and [len(f['step']) for f, _ in got[1]] == [4, 2]
+  # the two ranks together see every window of the split exactly once
+  full = list(pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=K, batch_size=100, seed=7))[0][0]
+  key = lambda f: sorted(map(tuple, np.concatenate([f['cmd'].reshape(len(f['cmd']), -1)], 0).tolist()))
+  seen = sorted(sum([key(f) for r in range(world) for f, _ in got[r]], []))
+  assert seen == key(full)
+  with pytest.raises(ValueError):    # every rank must use the same shuffle seed
+    pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=K, batch_size=B, shard=(0, 2), seed=None)
+  # slicing of an unsharded (global) batch: contiguous, sizes differ by at most one, nothing dropped
+  batch = ({'step': np.arange(7)[:, None], 'x': np.arange(7)}, {'cmd': np.arange(7)})
+  parts = [Estimator._shard(batch, 3, r) for r in range(3)]
+  assert [p[2] for p in parts] == [3, 2, 2] and all(p[3] == 7 for p in parts)
+  assert np.concatenate([p[0]['x'] for p in parts]).tolist() == list(range(7))
+  f, l, n, ng = Estimator._shard(({'step': np.arange(1)[:, None]}, None), 2, 1)
+  assert f is None and n == 0 and ng == 1

@@ -5,7 +5,7 @@ Tolerances (fp32 HIP vs fp64 oracle): loss 1e-4 relative (BASELINE.json north_st
 max(2e-4, 4 x the error of the SAME oracle run in fp32 on the CPU) of the variable's max |g|: on
 noise-like inputs (the K=16 dynamic image of random frames) fp32 rounding of the input flips a few
 ReLU masks in conv1-4, which moves those layers' gradients by ~1e-3 in ANY fp32 implementation, the
-CPU restatement included, so the fp32 CPU run is the yardstick there; Adam step 1 moves
+CPU restatement included, so the fp32 CPU run is the yardstick there, capped at GRAD_TOL_CAP; Adam step 1 moves
 every weight by ~lr * sign(g) so weights are compared with atol = 2.5 * lr ("Adam step-1
 sign sensitivity").
 """
@@ -16,6 +16,10 @@ import torch
 from oracle import geeco_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+# hard ceiling of the floating gradient bound below (fraction of the variable's max |g|); the worst achieved
+# error of every case is printed and stays under it
+GRAD_TOL_CAP = 5e-3
 
 
 def _mk(cfg_kw, goal, N, H, seed=1):
@@ -99,7 +103,7 @@ def test_train_step_parity(dev, name, cfg_kw, goal, N, H):
   worst = ('', 0.0)
   for k, g in grads_ref.items():
     e = _rel_max(grads[k], g.numpy())
-    tol = max(2e-4, 4.0 * _rel_max(grads_ref32[k].numpy(), g.numpy()))
+    tol = min(max(2e-4, 4.0 * _rel_max(grads_ref32[k].numpy(), g.numpy())), GRAD_TOL_CAP)
     assert e <= tol, (k, e, tol)
     if e > worst[1]:
       worst = (k, e)
@@ -148,6 +152,6 @@ def test_loss_trajectory_graph_replay(dev):
     l_hip = float(model.loss)
     losses.append((l_hip, l_ref))
     assert abs(l_hip - l_ref) <= 1e-4 * abs(l_ref), (step, l_hip, l_ref)
-  assert runner._ga is not None                      # the last steps were graph replays
+  assert runner._graphs is not None                      # the last steps were graph replays
   assert int(model.store.global_step.item()) == 10
   print('loss trajectory (hip, oracle):', ['%.5f/%.5f' % p for p in losses])

@@ -120,3 +120,28 @@ def test_error_surface():
   with pytest.raises(ValueError):
     O.decoder_param_shapes('s', 10, O.make_config(control_mode='nope'))
   assert O.make_config(bogus_key=3) == O.make_config()                        # unknown keys silently dropped
+
+
+def test_chunked_evaluation_matches_plain():
+  """loss_and_grads_chunked (used by the full-size GPU parity tests) is the same mathematics as
+  loss_and_grads: loss, predictions and every gradient agree in fp64 for both model kinds."""
+  for goal, kw, N in ((True, dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3), 3),
+                      (True, dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2, img_channels=4), 2),
+                      (False, dict(window_size=3), 3)):
+    cfg = O.make_config(img_height=136, img_width=136, batch_size=N, **kw)
+    P = O.init_params(O.model_param_shapes(cfg, goal), seed=3)
+    r = np.random.default_rng(4)
+    for k in P:
+      if k.endswith('/bias'):
+        P[k] = (0.05 * r.standard_normal(P[k].shape)).astype(np.float32)
+    feats, labels = O.synthetic_batch(cfg, goal, N, seed=5, H=136, W=136)
+    tr = O.OracleTrainer(cfg, goal, P, dtype=torch.float64)
+    loss, parts, grads, pred, _ = tr.loss_and_grads(feats, labels)
+    loss2, parts2, grads2, pred2, ep2 = O.loss_and_grads_chunked(tr, feats, labels, chunk=2)
+    assert abs(float(loss) - float(loss2)) < 1e-12 * abs(float(loss))
+    for k in pred:
+      torch.testing.assert_close(pred2[k], pred[k], rtol=1e-11, atol=1e-13)
+    for k in grads:
+      torch.testing.assert_close(grads2[k], grads[k], rtol=1e-9, atol=1e-14, msg=k)
+    assert set(grads2) == set(grads)
+    assert len(ep2['conv8_first_last']) == (3 if goal else 1)
