@@ -276,6 +276,11 @@ int geeco_try_conv1_wgrad(const float* x, const float* dz, float* dw, float* db,
                           int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout,
                           int stride, void* ws, hipStream_t stream, int* handled);
 
+int64_t geeco_wgrad_lds_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
+int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, int groups, int64_t gs_x, int64_t gs_dz,
+                        int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
+                        hipStream_t stream, int* handled);
+
 static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride, WgradParams* p, int* bc) {
   int Ho, Wo, pt, pl;
   same_pad(H, 3, stride, &Ho, &pt);
@@ -313,7 +318,9 @@ extern "C" int64_t geeco_conv3x3_wgrad_ws_bytes(int groups, int N, int H, int W,
   int64_t a = (int64_t)groups * p.S * ((int64_t)p.Krows * Cout + Cout) * 4;
   int64_t b = geeco_halo_wgrad_ws_bytes(groups, N, H, W, Cin, Cout, stride);
   int64_t c = geeco_conv1_wgrad_ws_bytes(groups, Cin, Cout, stride);
+  int64_t d = geeco_wgrad_lds_ws_bytes(groups, N, H, W, Cin, Cout, stride);
   a = a > b ? a : b;
+  a = a > d ? a : d;
   return a > c ? a : c;
 }
 
@@ -331,6 +338,9 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
     if (rc || handled) return rc;
     rc = geeco_try_conv1_wgrad(x, dz, dw, db, groups, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws,
                                (hipStream_t)stream, &handled);
+    if (rc || handled) return rc;
+    rc = geeco_try_wgrad_lds(x, dz, dw, db, groups, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws,
+                             (hipStream_t)stream, &handled);
     if (rc || handled) return rc;
   }
   WgradParams p = {};

@@ -1,0 +1,341 @@
+// Filter/bias gradient of the stride-2 middle layers (conv3 .. conv6 of the encoder) with the input halo and
+// the dz tile staged ONCE per block in LDS.
+//
+// Autodiff of reference src/models/e2evmc/graph.py:86-105 (conv3..conv6: 3x3, stride 2, TF SAME) taken by
+// tf.train.AdamOptimizer.minimize (src/models/e2evmc/estimator.py:243-244):
+//
+//   dw[tap][ci][co] = sum_pixels x[2 oy + ky][2 ox + kx][ci] * dz[oy][ox][co]          db[co] = sum dz
+//
+// Why: the generic kernel of conv_wgrad.hip gathers the x rows of every (tap, 64 k-rows) tile again from L2
+// (conv3: 1.38 GB L2->LDS for 403 MB of operands; PMC FETCH 1.6-4.8x the algorithmic bytes; 47 % of the MFMA
+// peak).  Here a block owns a (CIB input channels) x (64 output channels) block of dw for ALL nine taps and walks a
+// contiguous range of TH x TW output-pixel tiles: per tile the (2 TH + 1) x (2 TW + 1) input halo of its CIB
+// channels and the TH x TW x 64 dz tile land in LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no
+// ds_write), double buffered behind the previous tile's MFMAs, and all nine taps read their fragments from there:
+// x is fetched once per co block, dz once per ci block, 47 FLOP per staged byte instead of 16.
+//
+// Wave roles: wave = (ci tile of 16, COT co tiles of 16); all waves walk the same pixels, so there is no
+// intra-block reduction: 9 x COT accumulator tiles per wave live in registers for the block's whole tile range and
+// are written once, to the block's part of split slab `s` ([G][S][9*Cin*Cout + Cout], summed in a fixed order by
+// wgrad_reduce_kernel: bitwise reproducible).  MFMA v_mfma_f32_16x16x4_f32: k = 4 consecutive output pixels of a
+// row, A = dz fragment (row i = co), B = x fragment (column j = ci) => each lane owns 4 consecutive co of one
+// (tap, ci) row = one 16-byte store into the HWIO slab.
+//
+// LDS images (float4 granules, each DMA piece = 64 consecutive granules = 1 KiB):
+//   x   [row][halo column][XPQ granules]: XPQ = 16 with the granule index XOR-ed by ((column >> 1) & 1) << 2 for
+//       CIB = 64, XPQ = 14 (pitch 56 floats = 8 mod 16) unswizzled for CIB = 48: the ds_read_b32 of a B fragment
+//       (16 channels x the 4 columns 2 (4 s + q) + kx) then covers 2 x 16 distinct banks per 32-lane group;
+//   dz  [pixel][16 granules], granule index XOR-ed by (pixel & 1) << 2 (A fragment: 16 channels x 4 pixels).
+#include "geeco_common.h"
+#include <stdlib.h>
+
+static __device__ float g_zero_page[64];   // source of the DMA lanes that fall outside the image (TF SAME zero padding) or on pad granules
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct WgradHaloParams {
+  const float* x;
+  const float* dz;
+  float* part;               // [G][S][9*Cin*Cout + Cout]
+  long long gs_x, gs_dz;
+  int N, H, W, Ho, Wo, Cin, Cout;
+  int tiles_x, tiles_y, tiles_per_group;
+  int S;                     // pixel slices (slabs) per group
+  int n_cib, n_cob;          // ci / co blocks
+  int n_sigma;               // G * n_cib * S  (slices dealt round-robin to the XCDs)
+};
+
+void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
+                               long long KC, int Cout, int groups, hipStream_t s);
+
+// CIB = 16 NCI input channels per block; 64 = 16 NCO COT output channels per block; NW = NCI * NCO waves.
+template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ>
+__global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const WgradHaloParams p) {
+  constexpr int NW = NCI * NCO, NT = 64 * NW;
+  constexpr int CIB = 16 * NCI, CQ = CIB / 4;
+  constexpr int HY = 2 * TH + 1, HX = 2 * TW + 1;
+  constexpr int X_USED = HY * HX * XPQ;                  // float4 granules of the halo image
+  constexpr int NXP = (X_USED + 63) / 64;                // its 1 KiB DMA pieces
+  constexpr int X_F4 = NXP * 64;
+  constexpr int Z_F4 = TH * TW * 16;                     // dz tile: [pixel][16 granules]
+  constexpr int NZP = Z_F4 / 64;
+  constexpr int NSLOT = (NXP + NZP + NW - 1) / NW;       // DMA pieces per wave and tile
+  constexpr int KG = TW / 4;                             // k-groups (4 consecutive pixels) per tile row
+  static_assert(NCO * COT == 4 && TW % 4 == 0 && Z_F4 % 64 == 0, "co block = 64 channels");
+  static_assert(XPQ >= CQ && (SWZ ? (XPQ == 16 && CQ == 16) : (XPQ % 4 == 2)), "x pixel pitch must be 8 (mod 16) floats or swizzled");
+  static_assert(Z_F4 <= NT, "one dz granule per thread for the bias gradient");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sX = reinterpret_cast<f32x4*>(smem);            // 2 halo buffers
+  f32x4* sZ = sX + 2 * X_F4;                             // 2 dz tiles
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int cit = wid % NCI, cog = wid / NCI;            // this wave's ci tile and group of COT co tiles
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- which (group, ci block, pixel slice, co block) is this block?  Slices sigma = (g, cib, s) are dealt
+  // round-robin to the 8 XCDs (blocks b and b + 8 share an XCD) and the co blocks of one slice are neighbours on
+  // ITS XCD, so the x halo they all read is served by one L2. ---------------------------------------------------------
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int cob = j % p.n_cob;
+  const int sigma = (j / p.n_cob) * 8 + xcd;
+  if (sigma >= p.n_sigma) return;                         // whole block leaves together (before any barrier)
+  const int split = sigma % p.S;
+  const int cib = (sigma / p.S) % p.n_cib;
+  const int g = sigma / (p.S * p.n_cib);
+  const int ci0 = cib * CIB, co0 = cob * 64;
+  const int Cin = p.Cin, Cout = p.Cout;
+
+  const int per = (p.tiles_per_group + p.S - 1) / p.S;
+  int tile = split * per;
+  const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
+  const long long slab = 9ll * Cin * Cout + Cout;
+  float* part = p.part + ((long long)g * p.S + split) * slab;
+
+  int n, ty, tx;
+  {
+    const int per_img = p.tiles_x * p.tiles_y;
+    n = tile / per_img;
+    const int rem = tile - n * per_img;
+    ty = rem / p.tiles_x;
+    tx = rem - ty * p.tiles_x;
+  }
+
+  // ---- this wave's DMA pieces k = wid + NW i: k < NXP -> halo granules [64 k, +64), else dz granules --------------
+  int d_src[NSLOT];
+  short d_a[NSLOT], d_b[NSLOT];       // halo: (row, column); dz: (tile row, tile column); 30000 = never valid
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int k = wid + NW * i;
+    if (k < NXP) {
+      const int sl = k * 64 + lane;
+      const int rw = sl / (HX * XPQ), rem = sl - rw * (HX * XPQ);
+      const int hx = rem / XPQ, qs = rem - hx * XPQ;
+      const int quad = SWZ ? (qs ^ (((hx >> 1) & 1) << 2)) : qs;
+      const bool ok = sl < X_USED && quad < CQ;
+      d_a[i] = (short)(ok ? rw : 30000);
+      d_b[i] = (short)hx;
+      d_src[i] = (rw * p.W + hx) * Cin + ci0 + quad * 4;
+    } else {
+      const int f = (k - NXP) * 64 + lane;
+      const int px = f >> 4, qs = f & 15;
+      const int zr = px / TW, zc = px - zr * TW;
+      const int quad = qs ^ ((zc & 1) << 2);
+      d_a[i] = (short)(k < NXP + NZP ? zr : 30000);
+      d_b[i] = (short)zc;
+      d_src[i] = (zr * p.Wo + zc) * Cout + co0 + quad * 4;
+    }
+  }
+  auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
+    const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
+    const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * Cin;
+    const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * Cout;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int k = wid + NW * i;                          // wave-uniform
+      if (k < NXP) {
+        const bool v = iy0 + d_a[i] < p.H && ix0 + d_b[i] < p.W;
+        const float* src = v ? xg + d_src[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + buf * X_F4 + k * 64), 16, 0, 0);
+      } else if (k < NXP + NZP) {
+        const bool v = ty_ * TH + d_a[i] < p.Ho && tx_ * TW + d_b[i] < p.Wo;
+        const float* src = v ? zg + d_src[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * Z_F4 + (k - NXP) * 64), 16, 0, 0);
+      }
+    }
+  };
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    if (++tx_ == p.tiles_x) {
+      tx_ = 0;
+      if (++ty_ == p.tiles_y) {
+        ty_ = 0;
+        ++n_;
+      }
+    }
+  };
+
+  f32x4 dbsum = zero4;
+  f32x4 acc[9][COT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < COT; ++i) acc[t][i] = zero4;
+
+  if (tile < tend) dma_tile(0, n, ty, tx);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- per-lane fragment offsets (floats) ------------------------------------------------------------------------
+  // B (x): channel ci0 + 16 cit + r of halo column 2 (4 s + q) + kx;  A (dz): channel co0 + 16 (COT cog + i) + r of pixel 4 s + q
+  int xe[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int col = 2 * q + kx;
+    const int quad = cit * 4 + (r >> 2);
+    const int slot = SWZ ? (quad ^ (((col >> 1) & 1) << 2)) : quad;    // (8 s + col) >> 1 has the parity of col >> 1
+    xe[kx] = (col * XPQ + slot) * 4 + (r & 3);
+  }
+  int ze[COT];
+#pragma unroll
+  for (int i = 0; i < COT; ++i) {
+    const int quad = (cog * COT + i) * 4 + (r >> 2);
+    ze[i] = (q * 16 + (quad ^ ((q & 1) << 2))) * 4 + (r & 3);           // pixel 4 s + q has the parity of q
+  }
+
+  int buf = 0;
+  for (; tile < tend; ++tile) {
+    const bool more = tile + 1 < tend;
+    int n2 = n, ty2 = ty, tx2 = tx;
+    if (more) {
+      advance(n2, ty2, tx2);
+      dma_tile(buf ^ 1, n2, ty2, tx2);                    // lands behind this tile's MFMAs
+    }
+    if (tid < Z_F4) dbsum += sZ[buf * Z_F4 + tid];        // bias gradient: one dz granule per thread and tile
+    const float* hx = reinterpret_cast<const float*>(sX + buf * X_F4);
+    const float* hz = reinterpret_cast<const float*>(sZ + buf * Z_F4);
+    // software pipeline over the TH * KG k-groups: the fragments of group u + 1 are read while group u's MFMAs run
+    float a[2][COT], b[2][9];
+    auto load_frags = [&](int u, int set) {
+      const int oyl = u / KG, s = u - oyl * KG;
+#pragma unroll
+      for (int i = 0; i < COT; ++i) a[set][i] = hz[(oyl * TW + 4 * s) * 64 + ze[i]];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        b[set][t] = hx[((2 * oyl + ky) * HX + 8 * s) * XPQ * 4 + xe[kx]];
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int u = 0; u < TH * KG; ++u) {
+      if (u + 1 < TH * KG) load_frags(u + 1, (u + 1) & 1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < COT; ++i)
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u & 1][i], b[u & 1][t], acc[t][i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    n = n2; ty = ty2; tx = tx2;
+    buf ^= 1;
+  }
+
+  // ---- epilogue: lane owns row (tap, ci = ci0 + 16 cit + r), co = co0 + 16 (COT cog + i) + 4 q .. +3 ------------------
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+      *reinterpret_cast<f32x4*>(part + ((long long)t * Cin + ci0 + 16 * cit + r) * Cout + co0 + 16 * (cog * COT + i) + 4 * q) =
+          acc[t][i];
+  // ---- bias gradient (blocks of the first ci block only): per-thread granule sums -> LDS -> fixed-order column sums -----
+  if (cib == 0) {
+    f32x4* sB = sX;                                       // the main loop ended with a barrier: LDS is free
+    if (tid < Z_F4) sB[tid] = dbsum;
+    __syncthreads();
+    if (tid < 64) {
+      const float* bf = reinterpret_cast<const float*>(sB);
+      float s1 = 0.f;
+#pragma unroll 4
+      for (int px = 0; px < TH * TW; ++px)
+        s1 += bf[(px * 16 + ((tid >> 2) ^ (((px % TW) & 1) << 2))) * 4 + (tid & 3)];
+      part[9ll * Cin * Cout + co0 + tid] = s1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradHaloPlan {
+  int variant;       // 0 = not handled; 1 = CIB 48 (conv3 type); 2 = CIB 64, TW 16; 3 = CIB 64, TW 8
+  int TH, TW, n_cib, n_cob, S;
+};
+
+static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
+  WgradHaloPlan pl = {};
+  static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_WGRAD_LDS")) ? 1 : 0;
+  if (disabled || stride != 2 || (H & 1) || (W & 1) || Cout % 64 != 0) return pl;
+  const int Ho = H / 2, Wo = W / 2;
+  if (Wo < 8 || Ho < 2) return pl;                        // the tiny top layers stay with the gather kernel
+  if (Cin == 48 && Wo >= 16) {
+    pl.variant = 1; pl.TH = 2; pl.TW = 16; pl.n_cib = 1;
+  } else if (Cin % 64 == 0) {
+    pl.variant = Wo >= 16 ? 2 : 3;
+    pl.TH = Wo >= 16 ? 2 : 4; pl.TW = Wo >= 16 ? 16 : 8;
+    pl.n_cib = Cin / 64;
+  } else {
+    return pl;
+  }
+  pl.n_cob = Cout / 64;
+  const long long tiles = (long long)N * cdiv(Ho, pl.TH) * cdiv(Wo, pl.TW);
+  if (tiles >= (1ll << 30) || (long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31)) {
+    pl.variant = 0;                                       // 32-bit tile counters / in-frame offsets
+    return pl;
+  }
+  // One block per CU (its LDS images take > 80 KB).  Blocks are dealt round-robin to the 8 XCDs and the n_cob co
+  // blocks of a slice sit on one XCD: a launch must not put more than 32 blocks on any XCD, or that XCD runs two
+  // rounds while the others idle (measured on conv5: 33 blocks on four XCDs took 200 us instead of 100).
+  int S = (8 * (32 / pl.n_cob)) / (groups * pl.n_cib);
+  if (S < 1) S = 1;
+  if (S > tiles) S = (int)tiles;
+  pl.S = S;
+  return pl;
+}
+
+int64_t geeco_wgrad_lds_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
+  const WgradHaloPlan pl = wgrad_halo_plan(groups, N, H, W, Cin, Cout, stride);
+  if (!pl.variant) return 0;
+  return (int64_t)groups * pl.S * (9ll * Cin * Cout + Cout) * 4;
+}
+
+template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ>
+static int launch_wgrad_lds(const WgradHaloParams& p, int blocks, hipStream_t stream) {
+  constexpr int X_F4 = ((2 * TH + 1) * (2 * TW + 1) * XPQ + 63) / 64 * 64;
+  constexpr size_t lds = (size_t)(2 * X_F4 + 2 * TH * TW * 16) * 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static int attr_state = 0;          // 0 = not set; set once (idempotent: racing threads set the same value)
+  if (__atomic_load_n(&attr_state, __ATOMIC_ACQUIRE) == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_wgrad_lds_kernel<NCI, NCO, COT, TH, TW, XPQ, SWZ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    __atomic_store_n(&attr_state, 1, __ATOMIC_RELEASE);
+  }
+  geeco_note_kernel("conv_s2_wgrad_lds_kernel<%d, %d, %d, %d, %d, %d, %s>", NCI, NCO, COT, TH, TW, XPQ, SWZ ? "true" : "false");
+  hipLaunchKernelGGL((conv_s2_wgrad_lds_kernel<NCI, NCO, COT, TH, TW, XPQ, SWZ>), dim3((unsigned)blocks), dim3(64 * NCI * NCO), lds,
+                     stream, p);
+  return 0;
+}
+
+int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, int groups, int64_t gs_x, int64_t gs_dz,
+                        int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
+                        hipStream_t stream, int* handled) {
+  *handled = 0;
+  const WgradHaloPlan pl = wgrad_halo_plan(groups, N, H, W, Cin, Cout, stride);
+  if (!pl.variant) return 0;
+  WgradHaloParams p = {};
+  p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
+  p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2; p.Cin = Cin; p.Cout = Cout;
+  p.tiles_x = cdiv(p.Wo, pl.TW); p.tiles_y = cdiv(p.Ho, pl.TH);
+  p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+  p.S = pl.S; p.n_cib = pl.n_cib; p.n_cob = pl.n_cob;
+  p.n_sigma = groups * pl.n_cib * pl.S;
+  const int blocks = 8 * cdiv(p.n_sigma, 8) * pl.n_cob;
+  int rc = 0;
+  switch (pl.variant) {
+    case 1: rc = launch_wgrad_lds<3, 4, 1, 2, 16, 14, false>(p, blocks, stream); break;
+    case 2: rc = launch_wgrad_lds<4, 2, 2, 2, 16, 16, true>(p, blocks, stream); break;
+    default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true>(p, blocks, stream); break;
+  }
+  if (rc) return rc;
+  GEECO_LAUNCH_CHECK();
+  geeco_launch_wgrad_reduce((const float*)ws, dw, db, gs_dw, gs_db, pl.S, 9ll * Cin * Cout, Cout, groups, stream);
+  GEECO_LAUNCH_CHECK();
+  *handled = 1;
+  return 0;
+}

@@ -74,7 +74,20 @@ def test_conv3x3_dgrad(dev, N, H, W, Cin, Cout, stride):
   _close(dx, ref, 2e-5, 2e-5, 'conv dgrad')
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', CONV_CASES + [(2, 64, 64, 4, 32, 1), (3, 32, 32, 32, 48, 2), (5, 128, 128, 32, 48, 2)])
+# LDS-staged filter gradient of the middle layers (conv_wgrad_halo.hip): every tile variant, ragged tile rows / columns,
+# several ci / co blocks, more slices than tiles
+WGRAD_LDS_CASES = [
+    (2, 64, 64, 48, 64, 2),     # conv3 type (CIB 48, 2x16 tiles), exact tiles
+    (3, 36, 72, 48, 64, 2),     # conv3 type, Ho = 18, Wo = 36: ragged last tile column
+    (5, 20, 24, 64, 64, 2),     # CIB 64, 4x8 tiles: Ho = 10, Wo = 12 ragged in both directions
+    (4, 16, 16, 192, 256, 2),   # conv6 type: 3 ci blocks x 4 co blocks, 4x8 tiles
+    (1, 4, 32, 64, 128, 2),     # 2x16 tiles with fewer tiles (1) than slices
+    (2, 34, 66, 128, 64, 2),    # Ho = 17 (odd): last tile row half empty; Wo = 33
+]
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', CONV_CASES + WGRAD_LDS_CASES +
+                         [(2, 64, 64, 4, 32, 1), (3, 32, 32, 32, 48, 2), (5, 128, 128, 32, 48, 2)])
 def test_conv3x3_wgrad(dev, N, H, W, Cin, Cout, stride):
   from geeco_amd import ops
   r = np.random.default_rng(9)
@@ -316,3 +329,33 @@ def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W, C):
       _close(db1[g], db_ref[g], 2e-5, 2e-5 * scale, 'fused db1, encoder %d' % g)
       if with_dz1:
         _close(dz1[g], dz1_ref[g], 2e-5, 2e-5, 'fused dz1, encoder %d' % g)
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W', [(48, 64, 40, 72), (64, 128, 24, 40), (128, 192, 16, 16)])
+def test_conv3x3_wgrad_grouped_lds(dev, Cin, Cout, H, W):
+  """Grouped launch (G encoders at padded arena strides) of the LDS-staged filter gradient: every encoder's dw / db
+  against the fp64 oracle; also checks the dispatch really took the new kernel."""
+  from geeco_amd import ops
+  G, Nf, stride = 3, 5, 2
+  Ho, Wo = H // 2, W // 2
+  r = np.random.default_rng(33)
+  x = r.standard_normal([G, Nf, H, W, Cin]).astype(np.float32)
+  dz = r.standard_normal([G, Nf, Ho, Wo, Cout]).astype(np.float32)
+  xd, dzd = torch.tensor(x, device=dev), torch.tensor(dz, device=dev)
+  gs_w, gs_b = 9 * Cin * Cout + 32, Cout + 16
+  dw = torch.full((G, gs_w), float('nan'), device=dev)
+  db = torch.full((G, gs_b), float('nan'), device=dev)
+  ws = torch.empty(ops.conv3x3_wgrad_ws_bytes(G, Nf, H, W, Cin, Cout, stride) // 4 + 4, device=dev)
+  names = ops.kernel_trace(lambda: ops.conv3x3_wgrad_into(dw, db, xd, dzd, G, xd[0].numel(), dzd[0].numel(), gs_w, gs_b, Nf,
+                                                          H, W, Cin, Cout, stride, ws))
+  torch.cuda.synchronize()
+  assert names and names[0].startswith('conv_s2_wgrad_lds_kernel'), names
+  scale = np.sqrt(Nf * Ho * Wo)
+  for g in range(G):
+    wt = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = O.conv2d_same(torch.tensor(x[g], dtype=torch.float64), wt, bt, stride, relu=False)
+    y.backward(torch.tensor(dz[g], dtype=torch.float64))
+    _close(dw[g, :9 * Cin * Cout].reshape(3, 3, Cin, Cout), wt.grad, 2e-5, 2e-5 * scale, 'grouped wgrad, encoder %d' % g)
+    _close(db[g, :Cout], bt.grad, 2e-5, 2e-5 * scale, 'grouped bias grad, encoder %d' % g)
+  assert torch.isnan(dw[:, 9 * Cin * Cout:]).all() and torch.isnan(db[:, Cout:]).all()     # pads untouched
