@@ -231,10 +231,18 @@ def hbm_table(model, args, iters):
     frames, tgt = model._frames()
     x_in = model.enc.x_in
     cur = frames[:, K - 1]
-    add('dynimg buffer image (K=%d)' % K, 4.0 * N * HW * C * (K + 1),
-        lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C))
-    add('dynimg diff image (K=2)', 4.0 * N * HW * C * 3,
-        lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
+    if getattr(model, 'fused_inputs', False):
+      # one launch = both dynamic images + the current-frame copy; algorithmic bytes = SURVEY 8(d)'s two dynimg
+      # figures (buffer image: K frames in + 1 out; diff image: 2 in + 1 out).  The launch really moves
+      # (K + 1) frames in and 3 channel-padded frames out.
+      add('goal inputs: dynimg buffer (K=%d) + diff (K=2) + current frame, one launch' % K, 4.0 * N * HW * C * (K + 1 + 3),
+          lambda: ops.goal_inputs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, C, model.gin_ws, K * HW * C, HW * C))
+      rows[-1]['moved_bytes'] = int(4.0 * N * HW * (C * (K + 1) + 3 * 4))
+    else:
+      add('dynimg buffer image (K=%d)' % K, 4.0 * N * HW * C * (K + 1),
+          lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C))
+      add('dynimg diff image (K=2)', 4.0 * N * HW * C * 3,
+          lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
   s = model.store
   P = s.count_parameters()
   add('adam (7 x 4 B x params)', 28.0 * P,

@@ -52,6 +52,19 @@ int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_s
                      int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW,
                      int C, int Cpad, float* out, void* ws, void* stream);
 
+/* Fused input stage of goal_e2evmc's dynimg branch (graph.py:386-402): ONE launch reads a batch of K-frame windows
+ * (frames [N][K][HW][C], element strides given; C = 3 or 4 with 16-byte aligned frames) and the target frames
+ * (tgt [N][HW][C]) once and writes the three conv1 inputs [N][HW][4]:
+ *   out_obs = frames[:, K-1] (:387), out_dyn = dynimg(frames) (:392), out_diff = dynimg([frames[:, K-1], tgt]) (:397-400).
+ * Replaces pack_pixels + 2 x (dynimg weighted sum + normalisation pass).  `ws`: geeco_goal_inputs_ws_bytes(N) bytes that
+ * must be ZERO before the first call (the kernel leaves them zero: safe to reuse and to replay in a hipGraph).
+ * geeco_goal_inputs_supported() tells whether the shape is served (else use the separate entry points). */
+int64_t geeco_goal_inputs_ws_bytes(int N);
+int geeco_goal_inputs_supported(int N, int K, int64_t HW, int C);
+int geeco_goal_inputs_fwd(const float* frames, int64_t sample_stride, int64_t frame_stride, const float* tgt,
+                          int64_t tgt_stride, const float* alpha_host, int N, int K, int64_t HW, int C,
+                          float* out_obs, float* out_dyn, float* out_diff, void* ws, void* stream);
+
 /* Copy [npix][C] -> [npix][Cpad] (zero-filled tail).  Used for the "current frame" view
  * rgb[:, -1] (graph.py:387) and for RGB||depth concat (estimator.py:169,172) via src2. */
 int geeco_pack_pixels(const float* src, int64_t src_sample_stride, const float* src2,
