@@ -65,8 +65,14 @@ class ConvEncoderStack:
   """``conv_encoder`` for G weight sets with identical shapes, Nf frames each."""
 
   def __init__(self, store: VariableStore, scopes, Nf, H, W, Cin, dim_out, training):
+    """``dim_out``: conv8's output channels, one int or one per encoder (dim_s_obs / dim_s_dyn / dim_s_diff,
+    graph.py:390,394,402).  With unequal values conv1..conv7 still run as grouped launches and conv8 (the only layer
+    whose shape differs) runs once per encoder (``split_top``)."""
     self.store, self.scopes, self.G, self.Nf = store, list(scopes), len(scopes), Nf
     self.H, self.W, self.Cin = H, W, Cin
+    self.dim_outs = [int(d) for d in dim_out] if isinstance(dim_out, (list, tuple)) else [int(dim_out)] * len(self.scopes)
+    self.split_top = len(set(self.dim_outs)) > 1
+    dim_out = max(self.dim_outs)
     self.two_streams = os.environ.get('GEECO_ONE_STREAM') is None
     self.derived_version = -1
     # Only the FIRST training stack built on a store may rely on the post-Adam refresh of its derived
@@ -84,7 +90,7 @@ class ConvEncoderStack:
     if G > 1:
       gs = store.offsets[self.scopes[1] + '/conv1/kernel'] - store.offsets[self.scopes[0] + '/conv1/kernel']
       for g in range(G):
-        for l in range(1, 9):
+        for l in range(1, 8 if self.split_top else 9):
           for kind in ('kernel', 'bias'):
             a = store.offsets['%s/conv%d/%s' % (self.scopes[g], l, kind)]
             b = store.offsets['%s/conv%d/%s' % (self.scopes[0], l, kind)]
@@ -106,6 +112,9 @@ class ConvEncoderStack:
     f32 = dict(dtype=torch.float32, device=dev)
     self.x_in = torch.zeros(G, Nf, H, W, self.Cpad, **f32)
     self.acts = [torch.empty(G, Nf, L['Ho'], L['Wo'], L['Cout'], **f32) for L in self.layers]
+    if self.split_top:      # per-encoder conv8 outputs of different widths
+      L7 = self.layers[7]
+      self.acts[7] = [torch.empty(Nf, L7['Ho'], L7['Wo'], d, **f32) for d in self.dim_outs]
     self.pad1 = self.Cpad != Cin
     if self.pad1:
       self.w1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
@@ -116,8 +125,11 @@ class ConvEncoderStack:
                            and self.Cpad == 4 and self.Cin in (3, 4) and L0['Cout'] == 32 and L0['stride'] == 1
                            and L1['Cout'] == 48 and L1['stride'] == 2 and L1['H'] % 2 == 0 and L1['W'] % 2 == 0)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
-      self.dz = [None if (i == 0 and self.fused_bottom) else torch.empty_like(a) for i, a in enumerate(self.acts)]
+      self.dz = [None if (i == 0 and self.fused_bottom) else
+                 ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]
       self.wt = [None] + [torch.empty(G, 3, 3, L['Cout'], L['Cin'], **f32) for L in self.layers[1:]]
+      if self.split_top:
+        self.wt[7] = [torch.empty(3, 3, d, self.layers[7]['Cin'], **f32) for d in self.dim_outs]
       if self.pad1:
         self.dw1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
       # wgrads of different layers may run concurrently (different streams): one split-K workspace each
@@ -167,7 +179,11 @@ class ConvEncoderStack:
     per-tap transposed kernels of the dgrad GEMMs).  Training calls it right after Adam (inside the
     Adam hipGraph), so the forward / backward graphs contain no pad or transpose launches."""
     G = self.G
-    ls = list(range(1, 8)) if self.training else []
+    ls = list(range(1, 7 if self.split_top else 8)) if self.training else []
+    if self.training and self.split_top:
+      L7 = self.layers[7]
+      for g in range(G):
+        ops.derive_conv_weights([self._w(7, g)], [self.wt[7][g].unsqueeze(0)], [L7['Cin']], [self.dim_outs[g]], 1, 0)
     pad = dict(pad_src=self._w(0), pad_dst=self.w1p, pad_cin=self.Cin, pad_cin_padded=self.Cpad,
                pad_cout=self.layers[0]['Cout']) if self.pad1 else {}
     if ls or pad:
@@ -178,6 +194,11 @@ class ConvEncoderStack:
   # -- single launches (also timed one by one by bench.py's per-layer table) ---------------------------
   def launch_fwd(self, l):
     G, Nf, L = self.G, self.Nf, self.layers[l]
+    if l == 7 and self.split_top:
+      for g in range(G):
+        ops.conv3x3_fwd_into(self.acts[7][g], self.acts[6][g], self._w(7, g), self._b(7, g), 1, 0, 0, 0, 0, Nf, L['H'], L['W'],
+                             L['Cin'], self.dim_outs[g], L['stride'], relu=True, ws=self.fws)
+      return
     x = self.x_in if l == 0 else self.acts[l - 1]
     y = self.acts[l]
     if l == 0 and self.pad1:
@@ -191,6 +212,11 @@ class ConvEncoderStack:
     """Filter + bias gradient of layer l (skipped for conv1 when the encoder bottom is fused: launch_dgrad(1) does it)."""
     G, Nf, L = self.G, self.Nf, self.layers[l]
     if l == 0 and self.fused_bottom:
+      return
+    if l == 7 and self.split_top:
+      for g in range(G):
+        ops.conv3x3_wgrad_into(self._dw(7, g), self._db(7, g), self.acts[6][g], self.dz[7][g], 1, 0, 0, 0, 0, Nf, L['H'],
+                               L['W'], L['Cin'], self.dim_outs[g], L['stride'], self.ws_l[7])
       return
     x = self.x_in if l == 0 else self.acts[l - 1]
     dz = self.dz[l]
@@ -209,6 +235,11 @@ class ConvEncoderStack:
     bottom, l == 1 also produces conv1's filter / bias gradient: dz1 has no other consumer and stays on chip
     (805 MB less written and read again per step, one big launch less)."""
     G, Nf, L = self.G, self.Nf, self.layers[l]
+    if l == 7 and self.split_top:
+      for g in range(G):
+        ops.conv3x3_dgrad_into(self.dz[6][g], self.dz[7][g], self.wt[7][g], self.acts[6][g], 1, 0, 0, 0, Nf, L['H'], L['W'],
+                               L['Cin'], self.dim_outs[g], L['stride'], ws=self.dws, w=self._w(7, g), gs_w=0)
+      return
     x = self.acts[l - 1]
     dz = self.dz[l]
     if l == 1 and self.fused_bottom:
@@ -368,7 +399,9 @@ class _ModelBase:
     if (ops.same_out(self.H, 128), ops.same_out(self.W, 128)) != (2, 2):
       # seven stride-2 layers must end on the hard-coded 2x2 grid (graph.py:139)
       raise ValueError('the 2x2 state tiling needs 129..256 pixel inputs, got %dx%d' % (self.H, self.W))
-    self.store = store or VariableStore(model_variable_shapes(cfg, goal), self.device)
+    shapes = model_variable_shapes(cfg, goal)
+    encoder_scopes = sorted({n.split('/conv')[0] for n in shapes if '/conv' in n}, key=lambda sc: list(shapes).index(sc + '/conv1/kernel'))
+    self.store = store or VariableStore(shapes, self.device, uniform_scopes=encoder_scopes)
     f32 = dict(dtype=torch.float32, device=self.device)
     N, K, H, W = self.N, self.K, self.H, self.W
     self.inputs = {
@@ -500,19 +533,18 @@ class GoalE2EVMC(_ModelBase):
     jn = cfg.dim_jnt_state
     self.mode = cfg.proc_obs if cfg.proc_obs == 'dynimg' else 'seq_' + cfg.proc_tgt
     if self.mode == 'dynimg':             # geeco-f (:386-407); proc_tgt is ignored by this branch
-      if not (cfg.dim_s_obs == cfg.dim_s_dyn == cfg.dim_s_diff):
-        raise NotImplementedError('dim_s_obs, dim_s_dyn and dim_s_diff must be equal (grouped encoders)')
       scopes, Nf, T = [root + '/ConvEncoder', root + '/DynBuffEncoder', root + '/DynDiffEncoder'], N, 1
       self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_dyn, cfg.dim_s_diff]
+      dims = self.feat_ch
     elif self.mode in ('seq_constant', 'seq_residual'):   # target goes through the SAME ConvEncoder (:354, 364)
       scopes, Nf, T = [root + '/ConvEncoder'], (K + 1) * N, K
       self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_obs] if self.mode == 'seq_constant' else [cfg.dim_s_obs]
+      dims = [cfg.dim_s_obs]
     else:                                  # seq_dyndiff (:371-381)
-      if cfg.dim_s_obs != cfg.dim_s_diff:
-        raise NotImplementedError('dim_s_obs and dim_s_diff must be equal (grouped encoders)')
       scopes, Nf, T = [root + '/ConvEncoder', root + '/DynDiffEncoder'], K * N, K
       self.feat_ch = [cfg.dim_s_obs, cfg.dim_s_diff]
-    self.enc = ConvEncoderStack(self.store, scopes, Nf, H, W, C, cfg.dim_s_obs, training)
+      dims = self.feat_ch
+    self.enc = ConvEncoderStack(self.store, scopes, Nf, H, W, C, dims, training)
     D = _CELLS * (sum(self.feat_ch) + jn)
     self.decoder = LSTMDecoder(self.store, root + '/LSTMDecoder', cfg, N, T, D, training)
     self._bind_labels()
@@ -567,10 +599,10 @@ class GoalE2EVMC(_ModelBase):
         ops.pack_pixels_into(xs[0][t], frames[:, t], K * HW * C, N, HW, C, 4)
         ops.dynimg_into(xs[1][t], frames[:, t], 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)   # :373-376
       self.enc.forward()
-      feats = self.enc.features.view(2, K, N, _CELLS, self.feat_ch[0])
+      f0 = self.enc.features[0].view(K, N, _CELLS, self.feat_ch[0])
+      f1 = self.enc.features[1].view(K, N, _CELLS, self.feat_ch[1])
       for t in range(K):                  # representation_concatenation(feat, tgt_feat, jnt) (:381)
-        ops.state_concat_fwd_into(d.states[t], [feats[0][t], feats[1][t]], self.feat_ch, 1, jnts[:, t], K * jn, jn, N,
-                                  _CELLS, d.D)
+        ops.state_concat_fwd_into(d.states[t], [f0[t], f1[t]], self.feat_ch, 1, jnts[:, t], K * jn, jn, N, _CELLS, d.D)
     d.forward(backward_too)
     self._finish_forward()
 
@@ -601,12 +633,10 @@ class GoalE2EVMC(_ModelBase):
           ops.state_concat_bwd_into([dfe[K]], d.dstates[t], d.D, [feats[K]], self.feat_ch, 1, jn, N, _CELLS,
                                     accumulate=t > 0, scale=1.0)
     else:
-      ch = self.feat_ch[0]
-      feats = self.enc.features.view(2, K, N, _CELLS, ch)
-      dfe = self.enc.dfeatures.view(2, K, N, _CELLS, ch)
+      f = [self.enc.features[g].view(K, N, _CELLS, self.feat_ch[g]) for g in range(2)]
+      df = [self.enc.dfeatures[g].view(K, N, _CELLS, self.feat_ch[g]) for g in range(2)]
       for t in range(K):
-        ops.state_concat_bwd_into([dfe[0][t], dfe[1][t]], d.dstates[t], d.D, [feats[0][t], feats[1][t]], self.feat_ch,
-                                  1, jn, N, _CELLS)
+        ops.state_concat_bwd_into([df[0][t], df[1][t]], d.dstates[t], d.D, [f[0][t], f[1][t]], self.feat_ch, 1, jn, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0)
 
   def endpoints(self):

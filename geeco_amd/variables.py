@@ -56,13 +56,28 @@ class VariableStore:
 
   ALIGN = 4   # floats
 
-  def __init__(self, shapes, device):
+  def __init__(self, shapes, device, uniform_scopes=None):
+    """``uniform_scopes``: scope prefixes (the encoders of one model) whose variable blocks must start at a COMMON
+    stride, so that one grouped launch can address encoder g at base + g * stride.  Blocks of equal size (the default
+    dim_s_obs == dim_s_dyn == dim_s_diff) already do; a shorter block (smaller conv8) is followed by zero pad floats."""
     self.shapes = collections.OrderedDict(shapes)
     self.device = torch.device(device)
     self.offsets = collections.OrderedDict()
-    off = 0
+    al = lambda v: -(-v // self.ALIGN) * self.ALIGN
+    stride, first = 0, {}
+    if uniform_scopes and len(uniform_scopes) > 1:
+      for g, sc in enumerate(uniform_scopes):
+        names = [n for n in self.shapes if n.startswith(sc + '/')]
+        first[names[0]] = g
+        stride = max(stride, sum(al(int(np.prod(self.shapes[n]))) for n in names))
+    off, start0 = 0, None
     for name, shp in self.shapes.items():
-      off = -(-off // self.ALIGN) * self.ALIGN
+      off = al(off)
+      if name in first:
+        if first[name] == 0:
+          start0 = off
+        else:
+          off = max(off, start0 + first[name] * stride)
       self.offsets[name] = off
       off += int(np.prod(shp))
     self.size = -(-off // self.ALIGN) * self.ALIGN

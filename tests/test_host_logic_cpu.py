@@ -240,3 +240,26 @@ def test_dp_sharded_input_schedule(tmp_path):
   assert np.concatenate([p[0]['x'] for p in parts]).tolist() == list(range(7))
   f, l, n, ng = Estimator._shard(({'step': np.arange(1)[:, None]}, None), 2, 1)
   assert f is None and n == 0 and ng == 1
+
+
+def test_variable_store_uniform_encoder_stride():
+  """Unequal dim_s_*: the encoders' variable blocks still start at one common stride (grouped launches address
+  encoder g at base + g * stride); equal dims keep the packed layout of the default model."""
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.variables import VariableStore
+  scopes = ['GoalVMC/ConvEncoder', 'GoalVMC/DynBuffEncoder', 'GoalVMC/DynDiffEncoder']
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', dim_s_obs=64, dim_s_dyn=256, dim_s_diff=128))
+  shapes = model_variable_shapes(cfg, True)
+  st = VariableStore(shapes, 'cpu', uniform_scopes=scopes)
+  for l in range(1, 8):
+    for kind in ('kernel', 'bias'):
+      o = [st.offsets['%s/conv%d/%s' % (sc, l, kind)] for sc in scopes]
+      assert o[1] - o[0] == o[2] - o[1] > 0
+  assert st.count_parameters() == O.count_parameters(O.model_param_shapes(O.make_config(**cfg._asdict()), True))
+  ends = sorted((o, o + int(np.prod(shapes[n]))) for n, o in st.offsets.items())
+  assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:]))                     # no overlap
+  dflt = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff'))
+  a = VariableStore(model_variable_shapes(dflt, True), 'cpu', uniform_scopes=scopes)
+  b = VariableStore(model_variable_shapes(dflt, True), 'cpu')
+  assert a.offsets == b.offsets and a.size == b.size

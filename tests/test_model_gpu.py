@@ -64,6 +64,11 @@ CASES = [
     ('goal seq dyndiff', dict(proc_obs='sequence', proc_tgt='dyndiff', window_size=2), True, 2, 136),
     ('e2e_vmc velocity', dict(window_size=2, control_mode='velocity'), False, 3, 136),
     ('geeco-f l2', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, l2_regularizer=1e-3), True, 2, 136),
+    # unequal dim_s_obs / dim_s_dyn / dim_s_diff (train_e2evmc.py:55-61; graph.py:390,394,402): conv1-7 grouped, conv8 per encoder
+    ('geeco-f dims 256/128/64', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, dim_s_obs=256, dim_s_dyn=128,
+                                     dim_s_diff=64), True, 2, 136),
+    ('goal seq dyndiff dims 128/64', dict(proc_obs='sequence', proc_tgt='dyndiff', window_size=2, dim_s_obs=128, dim_s_diff=64),
+     True, 2, 136),
     # degenerate sizes: one sample, one-frame window (alpha = [0] => the buffer image is identically 0)
     ('geeco-f N=1 K=1', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=1), True, 1, 136),
     ('e2e_vmc N=1 K=1', dict(window_size=1), False, 1, 136),
