@@ -52,13 +52,17 @@ class RunConfig:
   """tf.estimator.RunConfig(session_config, save_checkpoints_steps, keep_checkpoint_max) (train_e2evmc.py:221-224)."""
 
   def __init__(self, session_config=None, save_checkpoints_steps=None, keep_checkpoint_max=5, device=None,
-               use_hipgraph=True, init_seed=0):
+               use_hipgraph=True, init_seed=0, save_tf_bundle=False):
     self.session_config = session_config or ConfigProto()
     self.save_checkpoints_steps = save_checkpoints_steps
     self.keep_checkpoint_max = keep_checkpoint_max
     self.device = device
     self.use_hipgraph = use_hipgraph
     self.init_seed = init_seed
+    # also write every checkpoint as a TF-1.15 tensor bundle (model.ckpt-<step>.index / .data-00000-of-00001 with the
+    # reference's variable names, Adam slots and global_step): what tf.train.Saver consumers such as the reference's
+    # predictor (predictor.py:85-95) and _export_snapshot (train_e2evmc.py:160-181) expect to find
+    self.save_tf_bundle = save_tf_bundle
 
 
 EstimatorSpec = collections.namedtuple(
@@ -70,8 +74,12 @@ EstimatorSpec.__new__.__defaults__ = (None,) * 7
 # ================================================================================================
 # checkpoints (TF-style names so that _export_snapshot-like tooling works unchanged)
 # ================================================================================================
+_BUNDLE_SUFFIXES = ('.index', '.data-00000-of-00001')
+
+
 def latest_checkpoint(model_dir):
-  """tf.train.latest_checkpoint: '<model_dir>/model.ckpt-<step>' or None (train_e2evmc.py:160)."""
+  """tf.train.latest_checkpoint: '<model_dir>/model.ckpt-<step>' or None (train_e2evmc.py:160).  The prefix counts
+  when its native file (.pt) or its TF tensor bundle (.index) exists."""
   index = os.path.join(model_dir, 'checkpoint')
   if not os.path.exists(index):
     return None
@@ -80,20 +88,28 @@ def latest_checkpoint(model_dir):
   if not m:
     return None
   path = os.path.join(model_dir, os.path.basename(m.group(1)))
-  return path if os.path.exists(path + '.pt') else None
+  return path if (os.path.exists(path + '.pt') or os.path.exists(path + '.index')) else None
 
 
-def save_checkpoint(store, model_dir, keep_max):
+def save_checkpoint(store, model_dir, keep_max, tf_bundle=False, lstm_batch=None):
   step = int(store.global_step.item())
   name = 'model.ckpt-%d' % step
   tmp = os.path.join(model_dir, name + '.pt.tmp')
   torch.save(store.state_dict(), tmp)
   os.replace(tmp, os.path.join(model_dir, name + '.pt'))
+  if tf_bundle:
+    from . import tf_checkpoint
+    mem = [n.rsplit('/', 2)[0] + '/lstm_memory' for n in store.shapes if n.endswith('/lstm_cell/kernel')]
+    tf_checkpoint.export_checkpoint(store, os.path.join(model_dir, name), lstm_memory_name=mem[0] if mem else None,
+                                    batch_size=lstm_batch)
   existing = sorted((int(re.match(r'model\.ckpt-(\d+)\.pt$', fn).group(1)) for fn in os.listdir(model_dir)
                      if re.match(r'model\.ckpt-(\d+)\.pt$', fn)))
   if keep_max and len(existing) > keep_max:
     for s in existing[:-keep_max]:
-      os.remove(os.path.join(model_dir, 'model.ckpt-%d.pt' % s))
+      for suffix in ('.pt',) + _BUNDLE_SUFFIXES:
+        fn = os.path.join(model_dir, 'model.ckpt-%d%s' % (s, suffix))
+        if os.path.exists(fn):
+          os.remove(fn)
     existing = existing[-keep_max:]
   with open(os.path.join(model_dir, 'checkpoint'), 'w') as f:
     f.write('model_checkpoint_path: "%s"\n' % name)
@@ -103,7 +119,12 @@ def save_checkpoint(store, model_dir, keep_max):
 
 
 def load_checkpoint(store, prefix):
-  store.load_state_dict(torch.load(prefix + '.pt', map_location='cpu'))
+  """Native .pt file when present, else the TF-1.15 tensor bundle of the same prefix (parameters, Adam slots, step)."""
+  if os.path.exists(prefix + '.pt'):
+    store.load_state_dict(torch.load(prefix + '.pt', map_location='cpu'))
+  else:
+    from . import tf_checkpoint
+    tf_checkpoint.import_checkpoint(store, prefix, load_optimizer=True)
 
 
 # ================================================================================================
@@ -362,7 +383,8 @@ class Estimator:
           h.after_run(step, self.model_dir)
         if (self.config.save_checkpoints_steps and step % self.config.save_checkpoints_steps == 0 and rank == 0
             and self.model_dir):
-          save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max)
+          save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max, self.config.save_tf_bundle,
+                          self.params['e2evmc_config'].batch_size if 'e2evmc_config' in self.params else None)
       if steps is not None and nsteps >= steps:
         break
       if max_steps is not None and step is not None and step >= max_steps:
@@ -370,7 +392,8 @@ class Estimator:
     if nsteps and torch.cuda.is_available():
       torch.cuda.synchronize()
     if nsteps and rank == 0 and self.model_dir:
-      path = save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max)
+      path = save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max, self.config.save_tf_bundle,
+                          self.params['e2evmc_config'].batch_size if 'e2evmc_config' in self.params else None)
       print('INFO: saved %s after %d steps (%.1f steps/s)' % (path, nsteps, nsteps / max(time.time() - t0, 1e-9)))
     return self
 

@@ -18,8 +18,10 @@ Variable names: the model variables of SURVEY.md 8b, their Adam slots ``<var>/Ad
 ``<var>/Adam_1`` (v), ``beta1_power`` / ``beta2_power``, ``global_step`` (int64) and the unused
 ``.../LSTMDecoder/lstm_memory`` (skipped on import exactly as predictor.py:87 does).
 
-NOT VERIFIED AGAINST A TF-WRITTEN FILE: no TensorFlow and no checkpoint exist in this environment; the
-tests cover writer -> reader round trips and the table structure only.
+NOT VERIFIED AGAINST A TF-WRITTEN FILE: no TensorFlow and no checkpoint exist in this environment.  The tests cover
+writer -> reader round trips, a bundle assembled by hand from the documented table / proto layouts with an independent
+CRC-32C (tests/test_host_logic_cpu.py::test_tf_bundle_hand_assembled_golden: reader and writer against a third party)
+and the GPU end-to-end path Estimator -> bundle -> predictor (tests/test_predictor_gpu.py::test_tf_bundle_end_to_end).
 """
 from __future__ import annotations
 
@@ -177,11 +179,11 @@ def write_checkpoint(prefix, tensors: dict):
   offset = 0
   with open(prefix + '.data-00000-of-00001', 'wb') as fdata:
     for name in names:
-      arr = np.ascontiguousarray(tensors[name])
+      arr = np.asarray(tensors[name])          # NB np.ascontiguousarray would turn a scalar (global_step) into shape [1]
       dt = arr.dtype.newbyteorder('<') if arr.dtype.byteorder == '>' else arr.dtype
       if np.dtype(dt) not in _DTYPE_ENUM:
         raise TypeError('%s: unsupported dtype %s' % (name, arr.dtype))
-      raw = arr.astype(dt, copy=False).tobytes()
+      raw = arr.astype(dt, order='C', copy=False).tobytes()
       shape = b''.join(_len_field(2, _var_field(1, int(d))) for d in arr.shape)
       entry = _var_field(1, _DTYPE_ENUM[np.dtype(dt)]) + _len_field(2, shape)
       if offset:

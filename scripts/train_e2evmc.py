@@ -129,7 +129,10 @@ def main(args):
     save_run_command(argparser=ARGPARSER, run_dir=args.model_dir)
   gpu_options = est.GPUOptions(allow_growth=True, per_process_gpu_memory_fraction=args.memcap)
   run_config = est.RunConfig(session_config=est.ConfigProto(gpu_options=gpu_options),
-                             save_checkpoints_steps=args.ckpt_steps, keep_checkpoint_max=args.num_last_ckpt)
+                             save_checkpoints_steps=args.ckpt_steps, keep_checkpoint_max=args.num_last_ckpt,
+                             # checkpoints are also written as TF-1.15 tensor bundles (model.ckpt-<step>.index / .data-*),
+                             # the files the reference's predictor and snapshot tooling read
+                             save_tf_bundle=os.environ.get('GEECO_NO_TF_BUNDLE') is None)
   config_name = 'e2evmc_config'
   config_path = os.path.join(args.model_dir, '%s.json' % config_name)
   if os.path.exists(config_path):    # a previous run's config wins over the CLI (train_e2evmc.py:229-232)

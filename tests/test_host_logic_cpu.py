@@ -263,3 +263,98 @@ def test_variable_store_uniform_encoder_stride():
   a = VariableStore(model_variable_shapes(dflt, True), 'cpu', uniform_scopes=scopes)
   b = VariableStore(model_variable_shapes(dflt, True), 'cpu')
   assert a.offsets == b.offsets and a.size == b.size
+
+
+def _crc32c_bitwise(data):
+  """Independent CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), bit by bit: not the product's table code."""
+  crc = 0xFFFFFFFF
+  for b in data:
+    crc ^= b
+    for _ in range(8):
+      crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+  return crc ^ 0xFFFFFFFF
+
+
+def _masked(data):
+  c = _crc32c_bitwise(data)
+  return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
+def test_tf_bundle_hand_assembled_golden(tmp_path):
+  """A tensor bundle assembled BY HAND in this test from the documented layouts (LevelDB table format: prefix-compressed
+  entries, restart array, 5-byte block trailer with masked CRC-32C, metaindex + index blocks, 48-byte footer with the
+  magic; tensor_bundle.proto field numbers), with its own bit-wise CRC-32C, so that reader and writer are not only
+  checked against each other.  The index keys are SHORTENED separators as TF's table builder emits them
+  (FindShortestSeparator / FindShortSuccessor), which the product's writer does not produce."""
+  import struct
+  from geeco_amd import tf_checkpoint as T
+  assert _crc32c_bitwise(b'123456789') == 0xe3069283
+  a = np.arange(6, dtype='<f4').reshape(2, 3) * 0.5
+  g = np.asarray(77, dtype='<i8')
+  data = a.tobytes() + g.tobytes()
+  open(str(tmp_path / 'm.data-00000-of-00001'), 'wb').write(data)
+
+  def varint(v):
+    out = bytearray()
+    while True:
+      b = v & 0x7f
+      v >>= 7
+      out.append(b | (0x80 if v else 0))
+      if not v:
+        return bytes(out)
+  def shape_proto(dims):        # TensorShapeProto: repeated Dim dim = 2 { int64 size = 1 }
+    return b''.join(b'\x12' + varint(len(b'\x08' + varint(d))) + b'\x08' + varint(d) for d in dims)
+  def entry(dtype, dims, offset, size, payload):      # BundleEntryProto: dtype=1 shape=2 shard_id=3 offset=4 size=5 crc32c=6 (fixed32)
+    sp = shape_proto(dims)
+    e = b'\x08' + varint(dtype) + b'\x12' + varint(len(sp)) + sp
+    if offset:
+      e += b'\x20' + varint(offset)
+    return e + b'\x28' + varint(size) + b'\x35' + struct.pack('<I', _masked(payload))
+  header = b'\x08\x01' + b'\x10\x00' + b'\x1a\x02\x08\x01'     # BundleHeaderProto: num_shards=1, endianness=LITTLE, version{producer=1}
+  kv = [(b'', header), (b'enc/a', entry(1, [2, 3], 0, 24, a.tobytes())), (b'enc/global_step', entry(9, [], 24, 8, g.tobytes()))]
+
+  def block(items, restart_every=16):
+    out, restarts, prev = bytearray(), [], b''
+    for i, (k, v) in enumerate(items):
+      shared = 0
+      if i % restart_every == 0:
+        restarts.append(len(out))
+      else:
+        while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+          shared += 1
+      out += varint(shared) + varint(len(k) - shared) + varint(len(v)) + k[shared:] + v
+      prev = k
+    for r in restarts or [0]:
+      out += struct.pack('<I', r)
+    return bytes(out + struct.pack('<I', len(restarts or [0])))
+  def with_trailer(b):
+    return b + b'\x00' + struct.pack('<I', _masked(b + b'\x00'))
+  # two data blocks (split after the second key) so that the index has two entries with shortened separator keys
+  b0, b1 = block(kv[:2]), block(kv[2:])
+  f = bytearray()
+  h0 = (len(f), len(b0)); f += with_trailer(b0)
+  h1 = (len(f), len(b1)); f += with_trailer(b1)
+  meta = block([])
+  hm = (len(f), len(meta)); f += with_trailer(meta)
+  idx = block([(b'enc/b', varint(h0[0]) + varint(h0[1])),       # 'enc/a' < 'enc/b' <= 'enc/global_step': shortest separator
+               (b'f', varint(h1[0]) + varint(h1[1]))])          # short successor of 'enc/global_step'
+  hi = (len(f), len(idx)); f += with_trailer(idx)
+  footer = varint(hm[0]) + varint(hm[1]) + varint(hi[0]) + varint(hi[1])
+  f += footer + b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57)
+  open(str(tmp_path / 'm.index'), 'wb').write(bytes(f))
+
+  t = T.read_checkpoint(str(tmp_path / 'm'))
+  assert set(t) == {'enc/a', 'enc/global_step'}
+  np.testing.assert_array_equal(t['enc/a'], a)
+  assert t['enc/global_step'].dtype == np.int64 and int(t['enc/global_step']) == 77
+  # the product's writer, given the same tensors, produces the same data file, per-tensor entries and header bytes
+  T.write_checkpoint(str(tmp_path / 'w'), {'enc/a': a, 'enc/global_step': g})
+  assert open(str(tmp_path / 'w.data-00000-of-00001'), 'rb').read() == data
+  got = dict(T._read_table(str(tmp_path / 'w.index')))
+  assert {k: bytes(v) for k, v in got.items()} == dict(kv)
+  # corrupting one byte of a data block is caught by the trailer CRC
+  bad = bytearray(f); bad[3] ^= 0x40
+  open(str(tmp_path / 'bad.index'), 'wb').write(bytes(bad))
+  open(str(tmp_path / 'bad.data-00000-of-00001'), 'wb').write(data)
+  with pytest.raises(IOError):
+    T.read_checkpoint(str(tmp_path / 'bad'))
