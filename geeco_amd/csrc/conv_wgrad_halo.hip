@@ -50,8 +50,10 @@ void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long lon
                                long long KC, int Cout, int groups, hipStream_t s);
 
 // CIB = 16 NCI input channels per block; 64 = 16 NCO COT output channels per block; NW = NCI * NCO waves.
-template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ>
-__global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const WgradHaloParams p) {
+// NBUF = 2: halo / dz double buffered, one block per CU;  NBUF = 1: single buffers (half the LDS), the host launches
+// TWO blocks per CU (MINW waves per SIMD in total) which fill each other's DMA waits and barrier stalls.
+template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ, int NBUF, int MINW>
+__global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel(const WgradHaloParams p) {
   constexpr int NW = NCI * NCO, NT = 64 * NW;
   constexpr int CIB = 16 * NCI, CQ = CIB / 4;
   constexpr int HY = 2 * TH + 1, HX = 2 * TW + 1;
@@ -66,8 +68,8 @@ __global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const
   static_assert(XPQ >= CQ && (SWZ ? (XPQ == 16 && CQ == 16) : (XPQ % 4 == 2)), "x pixel pitch must be 8 (mod 16) floats or swizzled");
   static_assert(Z_F4 <= NT, "one dz granule per thread for the bias gradient");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4* sX = reinterpret_cast<f32x4*>(smem);            // 2 halo buffers
-  f32x4* sZ = sX + 2 * X_F4;                             // 2 dz tiles
+  f32x4* sX = reinterpret_cast<f32x4*>(smem);            // NBUF halo buffers
+  f32x4* sZ = sX + NBUF * X_F4;                          // NBUF dz tiles
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,23 +131,25 @@ __global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const
       d_src[i] = (zr * p.Wo + zc) * Cout + co0 + quad * 4;
     }
   }
-  auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
+  // one DMA piece (slot i of this wave) of tile (n_, ty_, tx_) into buffer buf
+  auto dma_piece = [&](int i, int buf, int n_, int ty_, int tx_) {
     const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
-    const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * Cin;
-    const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * Cout;
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const int k = wid + NW * i;                          // wave-uniform
-      if (k < NXP) {
-        const bool v = iy0 + d_a[i] < p.H && ix0 + d_b[i] < p.W;
-        const float* src = v ? xg + d_src[i] : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + buf * X_F4 + k * 64), 16, 0, 0);
-      } else if (k < NXP + NZP) {
-        const bool v = ty_ * TH + d_a[i] < p.Ho && tx_ * TW + d_b[i] < p.Wo;
-        const float* src = v ? zg + d_src[i] : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * Z_F4 + (k - NXP) * 64), 16, 0, 0);
-      }
+    const int k = wid + NW * i;                            // wave-uniform
+    if (k < NXP) {
+      const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * Cin;
+      const bool v = iy0 + d_a[i] < p.H && ix0 + d_b[i] < p.W;
+      const float* src = v ? xg + d_src[i] : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + buf * X_F4 + k * 64), 16, 0, 0);
+    } else if (k < NXP + NZP) {
+      const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * Cout;
+      const bool v = ty_ * TH + d_a[i] < p.Ho && tx_ * TW + d_b[i] < p.Wo;
+      const float* src = v ? zg + d_src[i] : g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * Z_F4 + (k - NXP) * 64), 16, 0, 0);
     }
+  };
+  auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) dma_piece(i, buf, n_, ty_, tx_);
   };
   auto advance = [&](int& n_, int& ty_, int& tx_) {
     if (++tx_ == p.tiles_x) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const
     int n2 = n, ty2 = ty, tx2 = tx;
     if (more) {
       advance(n2, ty2, tx2);
-      dma_tile(buf ^ 1, n2, ty2, tx2);                    // lands behind this tile's MFMAs
+      if (NBUF == 2) dma_tile(buf ^ 1, n2, ty2, tx2);     // lands behind this tile's MFMAs
     }
     if (tid < Z_F4) dbsum += sZ[buf * Z_F4 + tid];        // bias gradient: one dz granule per thread and tile
     const float* hx = reinterpret_cast<const float*>(sX + buf * X_F4);
@@ -211,6 +215,8 @@ __global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const
     load_frags(0, 0);
 #pragma unroll
     for (int u = 0; u < TH * KG; ++u) {
+      // NB pinning this order with sched_barrier (reads of group u + 1 strictly before the MFMAs of group u) was
+      // measured 5 % SLOWER: the compiler then waits with lgkmcnt(0) in front of every MFMA group anyway
       if (u + 1 < TH * KG) load_frags(u + 1, (u + 1) & 1);
 #pragma unroll
       for (int t = 0; t < 9; ++t)
@@ -218,9 +224,17 @@ __global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const
         for (int i = 0; i < COT; ++i)
           acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u & 1][i], b[u & 1][t], acc[t][i], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NBUF == 2) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      buf ^= 1;
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the images
+      if (more) {
+        dma_tile(0, n2, ty2, tx2);                        // the CU's other block computes meanwhile
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
     n = n2; ty = ty2; tx = tx2;
-    buf ^= 1;
   }
 
   // ---- epilogue: lane owns row (tap, ci = ci0 + 16 cit + r), co = co0 + 16 (COT cog + i) + 4 q .. +3 ------------------
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(64 * NCI * NCO) void conv_s2_wgrad_lds_kernel(const
 struct WgradHaloPlan {
   int variant;       // 0 = not handled; 1 = CIB 48 (conv3 type); 2 = CIB 64, TW 16; 3 = CIB 64, TW 8
   int TH, TW, n_cib, n_cob, S;
+  int bpc;           // blocks per CU: 1 = double-buffered images, 2 = single-buffered
 };
 
 static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
@@ -278,7 +293,9 @@ static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, i
   // One block per CU (its LDS images take > 80 KB).  Blocks are dealt round-robin to the 8 XCDs and the n_cob co
   // blocks of a slice sit on one XCD: a launch must not put more than 32 blocks on any XCD, or that XCD runs two
   // rounds while the others idle (measured on conv5: 33 blocks on four XCDs took 200 us instead of 100).
-  int S = (8 * (32 / pl.n_cob)) / (groups * pl.n_cib);
+  static const int bpc_env = getenv("GEECO_WGRAD_BPC") ? atoi(getenv("GEECO_WGRAD_BPC")) : 0;
+  pl.bpc = bpc_env == 1 || bpc_env == 2 ? bpc_env : 1;
+  int S = (8 * (32 * pl.bpc / pl.n_cob)) / (groups * pl.n_cib);
   if (S < 1) S = 1;
   if (S > tiles) S = (int)tiles;
   pl.S = S;
@@ -291,14 +308,14 @@ int64_t geeco_wgrad_lds_ws_bytes(int groups, int N, int H, int W, int Cin, int C
   return (int64_t)groups * pl.S * (9ll * Cin * Cout + Cout) * 4;
 }
 
-template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ>
+template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ, int NBUF, int MINW>
 static int launch_wgrad_lds(const WgradHaloParams& p, int blocks, hipStream_t stream) {
   constexpr int X_F4 = ((2 * TH + 1) * (2 * TW + 1) * XPQ + 63) / 64 * 64;
-  constexpr size_t lds = (size_t)(2 * X_F4 + 2 * TH * TW * 16) * 16;
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr size_t lds = (size_t)(NBUF * X_F4 + NBUF * TH * TW * 16) * 16;
+  static_assert(lds * (3 - NBUF) <= 160 * 1024, "LDS budget (two blocks per CU when single-buffered)");
   static int attr_state = 0;          // 0 = not set; set once (idempotent: racing threads set the same value)
   if (__atomic_load_n(&attr_state, __ATOMIC_ACQUIRE) == 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_wgrad_lds_kernel<NCI, NCO, COT, TH, TW, XPQ, SWZ>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_wgrad_lds_kernel<NCI, NCO, COT, TH, TW, XPQ, SWZ, NBUF, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -306,8 +323,8 @@ static int launch_wgrad_lds(const WgradHaloParams& p, int blocks, hipStream_t st
     }
     __atomic_store_n(&attr_state, 1, __ATOMIC_RELEASE);
   }
-  geeco_note_kernel("conv_s2_wgrad_lds_kernel<%d, %d, %d, %d, %d, %d, %s>", NCI, NCO, COT, TH, TW, XPQ, SWZ ? "true" : "false");
-  hipLaunchKernelGGL((conv_s2_wgrad_lds_kernel<NCI, NCO, COT, TH, TW, XPQ, SWZ>), dim3((unsigned)blocks), dim3(64 * NCI * NCO), lds,
+  geeco_note_kernel("conv_s2_wgrad_lds_kernel<%d, %d, %d, %d, %d, %d, %s, %d, %d>", NCI, NCO, COT, TH, TW, XPQ, SWZ ? "true" : "false", NBUF, MINW);
+  hipLaunchKernelGGL((conv_s2_wgrad_lds_kernel<NCI, NCO, COT, TH, TW, XPQ, SWZ, NBUF, MINW>), dim3((unsigned)blocks), dim3(64 * NCI * NCO), lds,
                      stream, p);
   return 0;
 }
@@ -327,10 +344,18 @@ int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, i
   p.n_sigma = groups * pl.n_cib * pl.S;
   const int blocks = 8 * cdiv(p.n_sigma, 8) * pl.n_cob;
   int rc = 0;
-  switch (pl.variant) {
-    case 1: rc = launch_wgrad_lds<3, 4, 1, 2, 16, 14, false>(p, blocks, stream); break;
-    case 2: rc = launch_wgrad_lds<4, 2, 2, 2, 16, 16, true>(p, blocks, stream); break;
-    default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true>(p, blocks, stream); break;
+  if (pl.bpc == 1) {
+    switch (pl.variant) {
+      case 1: rc = launch_wgrad_lds<3, 4, 1, 2, 16, 14, false, 2, 3>(p, blocks, stream); break;
+      case 2: rc = launch_wgrad_lds<4, 2, 2, 2, 16, 16, true, 2, 2>(p, blocks, stream); break;
+      default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true, 2, 2>(p, blocks, stream); break;
+    }
+  } else {
+    switch (pl.variant) {
+      case 1: rc = launch_wgrad_lds<3, 4, 1, 2, 16, 14, false, 1, 6>(p, blocks, stream); break;
+      case 2: rc = launch_wgrad_lds<4, 2, 2, 2, 16, 16, true, 1, 4>(p, blocks, stream); break;
+      default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true, 1, 4>(p, blocks, stream); break;
+    }
   }
   if (rc) return rc;
   GEECO_LAUNCH_CHECK();
