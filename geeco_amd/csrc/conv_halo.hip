@@ -15,6 +15,7 @@
 // MFMA: v_mfma_f32_16x16x4_f32, roles as in conv_gemm.hip (row i = output channel, column j =
 // pixel) so every lane owns 4 consecutive NHWC channels of one pixel.
 #include "geeco_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -524,7 +525,7 @@ template <int CIN, int COUT, int LW>
 static int launch_s2_halo_fwd_ws(HaloFwdParams& p, hipStream_t s) {
   constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
   const size_t lds = (size_t)(3 * HALO_F4 + 2 * 4 * (COUT / 16) * 64 + 4 * 16 * (COUT / 4 + 1)) * 16;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_ws_kernel<CIN, COUT, LW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -551,7 +552,7 @@ static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
   constexpr int CQ = CIN / 4;
   constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
   const size_t lds = (size_t)(9 * CQ * COUT + 2 * HALO_F4 + 2 * 4 * (COUT / 16) * 64) * 16;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_kernel<CIN, COUT, RW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -761,7 +762,7 @@ template <int CIN, int COUT>
 static int launch_s2_halo_fwd_chunked(HaloFwdParams& p, hipStream_t s) {
   constexpr int BUF_F4 = ((9 * 17 * 8 + 63) / 64) * 64;
   const size_t lds = (size_t)(9 * (CIN / 4) * COUT + 2 * BUF_F4) * 16;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_fwd_chunked_kernel<CIN, COUT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1048,7 +1049,7 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
     p.S = halo_wgrad_S(groups);
     constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
     const size_t lds = (size_t)(2 * HALO_F4 + 2 * 4 * 16 * 12) * 16;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_wgrad_kernel<32, 48>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1480,7 +1481,7 @@ template <int CIN, int COUT>
 static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
   constexpr int BUF_F4 = ((5 * 33 * 4 + 63) / 64) * 64;
   const size_t lds = (size_t)(9 * CIN * (COUT / 4 + 1) + 2 * BUF_F4) * 16;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1843,7 +1844,7 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
   p.tiles_per_group = N * p.tiles_x * p.tiles_y;
   p.S = fused_bottom_S(groups);
   const size_t lds = (size_t)(9 * 32 * 15 + 2 * 12 * 165 + 11 * 64) * 16 + (size_t)8 * 32 * 17 * 4;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1898,7 +1899,7 @@ int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymas
     p.tiles_per_group = N * p.tiles_x * p.tiles_y;
     p.ntiles = (long long)groups * p.tiles_per_group;
     const size_t lds = (size_t)(9 * 32 * 15 + 2 * 12 * 165) * 16;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_kernel<32, 48>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -3,6 +3,7 @@
 // Replaces reference src/models/e2evmc/graph.py:123-192 (concats), :198-260 (lstm_decoder),
 // :452-500 (losses) and the loss composition of src/models/e2evmc/estimator.py:206-239.
 #include "geeco_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 // =====================================================================================================
@@ -838,7 +839,7 @@ extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, cons
   static const int no_lds = getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
   if (!no_lds && N <= HL_NMAX && H == HL_DMAX && Hfc == HL_DMAX) {
     const size_t lds = (size_t)HL_LDS_FLOATS * 4;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&heads_loss_lds_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -131,11 +131,21 @@ def load_checkpoint(store, prefix):
 # model_fn (estimator.py:14-141 and 144-279)
 # ================================================================================================
 class _SummarySaverHook:
-  """Counterpart of the per-loss-term SummarySaverHooks (estimator.py:305-313): one JSON line per
-  ``log_steps`` steps in <model_dir>/events.jsonl."""
+  """Counterpart of the per-loss-term SummarySaverHooks (estimator.py:305-313): every ``log_steps`` steps the loss
+  terms go to a TensorBoard event file (<model_dir>/events.out.tfevents.*, tags ``loss`` and ``loss_<term>`` like the
+  reference's tf.summary.scalar names) and as one JSON line to <model_dir>/events.jsonl."""
+
+  _writers = {}     # one event file per model_dir and process
 
   def __init__(self, model, every):
     self.model, self.every = model, max(int(every), 1)
+
+  @classmethod
+  def _writer(cls, model_dir):
+    if model_dir not in cls._writers:
+      from .summary import EventFileWriter
+      cls._writers[model_dir] = EventFileWriter(model_dir)
+    return cls._writers[model_dir]
 
   def after_run(self, step, model_dir):
     if step % self.every or gdist.rank() != 0:
@@ -146,6 +156,7 @@ class _SummarySaverHook:
     if model_dir:
       with open(os.path.join(model_dir, 'events.jsonl'), 'a') as f:
         f.write(json.dumps(parts) + '\n')
+      self._writer(model_dir).add_scalars({k: v for k, v in parts.items() if k.startswith('loss')}, step, parts['wall_time'])
     print('INFO: loss = %.6f, step = %d' % (parts['loss'], step), flush=True)
 
 
