@@ -59,7 +59,7 @@ def log(msg):
 def spawn_ranks(args):
   import torch
   have = torch.cuda.device_count()        # counting devices does not initialise the GPU
-  if have < args.gpus:
+  if have < args.gpus and not os.environ.get('GEECO_BENCH_SHARE_GPU'):
     log('--gpus %d requested but only %d GPU(s) are visible' % (args.gpus, have))
     return 2
   with socket.socket() as s:
@@ -333,7 +333,13 @@ def main():
   from geeco_amd.params import create_e2evmc_config
   from geeco_amd.runtime import TrainStepRunner
 
-  world = gdist.init_from_env('nccl')
+  # Rehearsal of the N > 1 path on a one-GPU box: GEECO_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+  # GEECO_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Such a run exercises the launcher, the
+  # three-graph step and the bucketed exchange; its numbers mean nothing.
+  share = os.environ.get('GEECO_BENCH_SHARE_GPU') is not None
+  if share:
+    os.environ['LOCAL_RANK'] = '0'
+  world = gdist.init_from_env(os.environ.get('GEECO_DIST_BACKEND', 'nccl'))
   rank = gdist.rank()
   if world != args.gpus:
     log('--gpus %d but the process group has %d rank(s): refusing to report a number for the wrong N' % (args.gpus, world))
@@ -418,7 +424,7 @@ def main():
         'metric': 'train-step frames/sec (256x256 RGB, seq_len=%d)' % args.seq_len,
         'value': round(frames * args.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not share else 'synthetic (REHEARSAL: ranks share one GPU)',
         'config': {'workload': '%s %s %dx%d seq_len=%d batch=%d/GPU (global %d), fwd+bwd+allreduce+Adam' %
                                (args.model, 'rgb' if args.channels == 3 else 'rgbd', cfg.img_height, cfg.img_width,
                                 args.seq_len, args.batch, world * args.batch),

@@ -73,7 +73,11 @@ class ConvEncoderStack:
     self.dim_outs = [int(d) for d in dim_out] if isinstance(dim_out, (list, tuple)) else [int(dim_out)] * len(self.scopes)
     self.split_top = len(set(self.dim_outs)) > 1
     dim_out = max(self.dim_outs)
-    self.two_streams = os.environ.get('GEECO_ONE_STREAM') is None
+    # Backward schedule: ONE stream by default.  Round 1 ran the filter-gradient launches of the upper layers on two side
+    # streams beside the input-gradient chain (+1-2 % then: the gather wgrad kernel left MFMA slack for its neighbour);
+    # with the LDS-staged wgrad kernels every big launch fills the chip by itself and the two schedules measure the same
+    # (3.717 vs 3.719 ms), so the simpler one is the default.  GEECO_MULTI_STREAM=1 restores the side streams.
+    self.two_streams = os.environ.get('GEECO_MULTI_STREAM') is not None
     self.derived_version = -1
     # Only the FIRST training stack built on a store may rely on the post-Adam refresh of its derived
     # weight copies; eval / predict stacks and any later training stack (e.g. the model built for a
