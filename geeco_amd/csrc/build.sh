@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
 rm -rf build && mkdir -p build
 pids=()
-for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo dynimg decoder misc; do
+for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
   $HIPCC $FLAGS -c $f.hip -o build/$f.o &
   pids+=($!)
 done

@@ -1,0 +1,274 @@
+// Input gradient of the stride-2 middle layers (conv4 .. conv6 of the encoder) with the weights and the dz halo streamed
+// through LDS by LDS-DMA in 16-output-channel chunks, fused with the ReluGrad of the layer below.
+//
+// Autodiff of reference src/models/e2evmc/graph.py:91-105 (3x3, stride 2, TF SAME, even sizes => pad_before = 0) taken
+// by tf.train.AdamOptimizer.minimize (src/models/e2evmc/estimator.py:243-244):
+//
+//   dx[2Y+py][2X+px][ci] = (y[2Y+py][2X+px][ci] > 0) * sum_{taps of class (py,px)} sum_co dz[Y+dy][X+dx][co] w[ky][kx][ci][co]
+//   py = 0: (ky = 0, dy = 0), (ky = 2, dy = -1);   py = 1: (ky = 1, dy = 0)     (same in x): classes with 4 / 2 / 2 / 1 taps.
+//
+// Why: the gather GEMM (conv_gemm.hip) serves these layers at 46-61 % (conv6: 33 %) of the MFMA peak: every block gathers
+// its dz rows again per tap from L2, the four parity classes have short, unequal K loops and blocks are prologue
+// dominated.  Here a 512-thread block owns 8 groups of 16 class pixels (a 16 x 32 input-pixel tile for wide images, two
+// whole 16 x 16 frames for conv6) x 64 input channels and loops over Cout in chunks of 16: per chunk the 9 x 64 x 16
+// weight slab (read straight from the HWIO kernel: 64 contiguous bytes per (tap, ci) row) and the dz halo of the tile
+// land in LDS by LDS-DMA, double buffered behind the previous chunk's MFMAs; the stream of (tile, chunk) steps is
+// prefetched across tile boundaries.  All four classes of a pixel group are accumulated by ONE wave (16 accumulator
+// tiles), so the nine taps share four dz fragments and the class imbalance disappears.
+//
+// MFMA v_mfma_f32_16x16x4_f32, row i = ci, column j = pixel, k = 4 consecutive co: both operands are ds_read_b128 of
+// naturally contiguous data (weights: 16 ci rows x 64 B; dz: 16 pixels x 64 B), each feeding 4 MFMAs; a lane ends up
+// with 4 consecutive NHWC channels of one pixel = one 16-byte masked store.
+#include "geeco_common.h"
+#include <atomic>
+#include <stdlib.h>
+
+static __device__ float g_zero_page[64];   // source of the DMA lanes that fall outside the image
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct DgradLdsParams {
+  const float* dz;       // [G][N][Ho][Wo][Cout]
+  const float* w;        // HWIO [G][9][Cin][Cout]
+  const float* mask;     // y of the layer below [G][N][H][W][Cin] (ReluGrad) or null
+  float* dx;             // [G][N][H][W][Cin]
+  long long gs_dz, gs_w, gs_dx;
+  int N, H, W, Ho, Wo, Cin, Cout;
+  int n_cib;             // Cin / 64
+  int tiles_y, tiles_x;  // tiles per frame (wide images) -- 1 x 1 for the two-frame tiles
+  int tiles_per_group;   // tiles of one encoder
+  int items;             // G * n_cib * tiles_per_group
+  int per;               // items per block
+};
+
+// A group = PR x PC = 16 class pixels; a tile = 8 groups stacked in y (FR frames per tile: 1 for wide images, 2 when a
+// frame holds only 4 groups).
+template <int PR, int PC, int FR>
+__global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsParams p) {
+  static_assert(PR * PC == 16, "16 pixels per MFMA column group");
+  constexpr int GPF = 8 / FR;                       // groups per frame of the tile
+  constexpr int IR = GPF * PR + 1, IC = PC + 1;     // dz halo image of one frame: rows -1 .. GPF*PR-1, cols -1 .. PC-1
+  constexpr int Z_F4 = FR * IR * IC * 4;            // [pixel][4 granules of 4 co]
+  constexpr int NZP = (Z_F4 + 63) / 64;
+  constexpr int ZP_F4 = NZP * 64;
+  constexpr int W_F4 = 9 * 64 * 4;                  // [tap][ci 64][4 granules]
+  constexpr int NWP = W_F4 / 64;                    // 36 pieces
+  constexpr int NSLOT = (NWP + NZP + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* sW = reinterpret_cast<f32x4*>(smem);       // 2 weight chunks
+  f32x4* sZ = sW + 2 * W_F4;                        // 2 dz halo chunks
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int Cin = p.Cin, Cout = p.Cout;
+  const int nch = Cout >> 4;
+
+  int item = blockIdx.x * p.per;
+  const int item_end = item + p.per < p.items ? item + p.per : p.items;
+  if (item >= item_end) return;
+
+  // ---- DMA pieces of this wave: k = wid + 8 i; k < NWP: weight granules [64 k, +64), else dz granules ---------------
+  int d_off[NSLOT];
+  short d_a[NSLOT], d_b[NSLOT];      // dz pieces: frame-local row / col (-1 based) ; d_f: frame of the tile
+  signed char d_f[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int k = wid + 8 * i;
+    if (k < NWP) {
+      const int row = k * 16 + (lane >> 2);         // (tap, ci) row of the slab
+      const int tap = row >> 6, ci = row & 63;
+      d_off[i] = (tap * Cin + ci) * Cout + (lane & 3) * 4;
+      d_a[i] = 0; d_b[i] = 0; d_f[i] = 0;
+    } else {
+      const int sl = (k - NWP) * 64 + lane;
+      const int px = sl >> 2;
+      const int f = px / (IR * IC), rem = px - f * (IR * IC);
+      const int ir = rem / IC, ic = rem - ir * IC;
+      const bool ok = k < NWP + NZP && sl < Z_F4;
+      d_f[i] = (signed char)(ok ? f : 100);
+      d_a[i] = (short)(ir - 1);
+      d_b[i] = (short)(ic - 1);
+      d_off[i] = ((ir - 1) * p.Wo + (ic - 1)) * Cout + (sl & 3) * 4;
+    }
+  }
+  // item -> (encoder g, ci block, frame n0, class-pixel origin Y0, X0)
+  auto decode = [&](int it, int& g_, int& cib_, int& n0_, int& y0_, int& x0_) {
+    const int per_g = p.n_cib * p.tiles_per_group;
+    g_ = it / per_g;
+    int rem = it - g_ * per_g;
+    cib_ = rem / p.tiles_per_group;
+    const int t = rem - cib_ * p.tiles_per_group;
+    const int tpf = p.tiles_y * p.tiles_x;
+    const int fi = t / tpf, tt = t - fi * tpf;
+    n0_ = fi * FR;
+    const int ty = tt / p.tiles_x;
+    y0_ = ty * (GPF * PR);
+    x0_ = (tt - ty * p.tiles_x) * PC;
+  };
+  auto dma_chunk = [&](int buf, int g_, int cib_, int n0_, int y0_, int x0_, int ch) {
+    const float* wg = p.w + (long long)g_ * p.gs_w + (long long)cib_ * 64 * Cout + ch * 16;
+    const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n0_ * p.Ho + y0_) * p.Wo + x0_) * Cout + ch * 16;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int k = wid + 8 * i;                    // wave-uniform
+      if (k < NWP) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(wg + d_off[i]), (lptr_t)(sW + buf * W_F4 + k * 64), 16, 0, 0);
+      } else if (k < NWP + NZP) {
+        const int f = d_f[i];
+        const bool v = n0_ + f < p.N && (unsigned)(y0_ + d_a[i]) < (unsigned)p.Ho && (unsigned)(x0_ + d_b[i]) < (unsigned)p.Wo;
+        const float* src = v ? zg + (long long)f * p.Ho * p.Wo * Cout + d_off[i] : g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * ZP_F4 + (k - NWP) * 64), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- this wave's pixel group and fragment offsets (in float4 granules) ----------------------------------------------
+  const int gf = wid / GPF, gyl = wid - gf * GPF;   // frame of the tile, group row inside the frame
+  const int pr = r / PC, pc = r - pr * PC;
+  const int zpix = (gf * IR + gyl * PR + pr + 1) * IC + pc + 1;       // image pixel of lane r at shift (0, 0)
+  int zoff[4];                                      // shifts (dy, dx) = (0,0), (0,-1), (-1,0), (-1,-1)
+  zoff[0] = zpix * 4 + q; zoff[1] = (zpix - 1) * 4 + q; zoff[2] = (zpix - IC) * 4 + q; zoff[3] = (zpix - IC - 1) * 4 + q;
+  const int woff = r * 4 + q;                       // + (tap * 64 + cit * 16) * 4
+
+  int g, cib, n0, y0, x0;
+  decode(item, g, cib, n0, y0, x0);
+  dma_chunk(0, g, cib, n0, y0, x0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][4];                                  // [class py * 2 + px][ci tile]
+  int buf = 0;
+  while (true) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[c][t] = zero4;
+    int gn = g, cibn = cib, n0n = n0, y0n = y0, x0n = x0;
+    const bool more_items = item + 1 < item_end;
+    if (more_items) decode(item + 1, gn, cibn, n0n, y0n, x0n);
+    for (int ch = 0; ch < nch; ++ch) {
+      // prefetch the next (item, chunk) step: the stream crosses tile boundaries
+      if (ch + 1 < nch) dma_chunk(buf ^ 1, g, cib, n0, y0, x0, ch + 1);
+      else if (more_items) dma_chunk(buf ^ 1, gn, cibn, n0n, y0n, x0n, 0);
+      const f32x4* zb = sZ + buf * ZP_F4;
+      const f32x4* wb = sW + buf * W_F4 + woff;
+      f32x4 bz[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bz[s] = zb[zoff[s]];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int cls = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+          const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
+          const int tap = ky * 3 + kx;
+          f32x4 a[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a[t] = wb[(tap * 64 + t * 16) * 4];
+          // k component outer, ci tile inner: an accumulator is touched again only after 3 other MFMAs (the dependent
+          // latency of v_mfma_f32_16x16x4_f32 is 40 cycles against 32 of issue)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, bz[sh].x, acc[cls][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, bz[sh].y, acc[cls][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, bz[sh].z, acc[cls][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, bz[sh].w, acc[cls][t], 0, 0, 0);
+        }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      buf ^= 1;
+    }
+    // ---- epilogue: ReluGrad mask + 16-byte stores; lane = pixel r of the group, channels ci0 + 16 t + 4 q .. +3 -----
+    {
+      const int n = n0 + gf;
+      if (n < p.N) {
+        const int Y = y0 + gyl * PR + pr, X = x0 + pc;
+        const long long gbase = (long long)g * p.gs_dx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int py = c >> 1, px = c & 1;
+          const long long pix = ((long long)n * p.H + 2 * Y + py) * p.W + 2 * X + px;
+          const long long o = gbase + pix * Cin + cib * 64 + 4 * q;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            f32x4 v = acc[c][t];
+            if (p.mask) {
+              const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + o + 16 * t);
+              v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+              v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.dx + o + 16 * t) = v;
+          }
+        }
+      }
+    }
+    if (!more_items) break;
+    ++item;
+    g = gn; cib = cibn; n0 = n0n; y0 = y0n; x0 = x0n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int PR, int PC, int FR>
+static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t stream) {
+  constexpr int IR = (8 / FR) * PR + 1, IC = PC + 1;
+  constexpr int ZP_F4 = (FR * IR * IC * 4 + 63) / 64 * 64;
+  constexpr size_t lds = (size_t)(2 * 9 * 64 * 4 + 2 * ZP_F4) * 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_dgrad_lds_kernel<PR, PC, FR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  geeco_note_kernel("conv_s2_dgrad_lds_kernel<%d, %d, %d>", PR, PC, FR);
+  hipLaunchKernelGGL((conv_s2_dgrad_lds_kernel<PR, PC, FR>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  return 0;
+}
+
+int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups, int64_t gs_dz,
+                        int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride,
+                        hipStream_t stream, int* handled) {
+  *handled = 0;
+  static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
+  if (disabled || !w_hwio || stride != 2 || (H & 1) || (W & 1) || Cin % 64 != 0 || Cout % 16 != 0 || Cout < 32) return 0;
+  const int Ho = H / 2, Wo = W / 2;
+  int variant = 0;
+  if (Ho % 8 == 0 && Wo % 16 == 0) variant = 1;          // 8 groups of 1 x 16 class pixels: a 16 x 32 input-pixel tile
+  else if (Ho == 8 && Wo == 8) variant = 2;               // 2 x 8 groups: a tile = two whole frames
+  if (!variant) return 0;
+  if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 31)) return 0;
+  DgradLdsParams p = {};
+  p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
+  p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout;
+  p.n_cib = Cin / 64;
+  long long tiles;
+  if (variant == 1) {
+    p.tiles_y = Ho / 8; p.tiles_x = Wo / 16;
+    tiles = (long long)N * p.tiles_y * p.tiles_x;
+  } else {
+    p.tiles_y = 1; p.tiles_x = 1;
+    tiles = (N + 1) / 2;
+  }
+  const long long items = (long long)groups * p.n_cib * tiles;
+  if (items >= (1ll << 30)) return 0;
+  p.tiles_per_group = (int)tiles;
+  p.items = (int)items;
+  // one block per CU (94 KB of LDS): equal item counts per block, as many blocks as fit one round
+  const int rounds = (int)((items + 255) / 256);
+  p.per = rounds;
+  const int blocks = (int)((items + rounds - 1) / rounds);
+  int rc = variant == 1 ? launch_dgrad_lds<1, 16, 1>(p, blocks, stream) : launch_dgrad_lds<2, 8, 2>(p, blocks, stream);
+  if (rc) return rc;
+  GEECO_LAUNCH_CHECK();
+  *handled = 1;
+  return 0;
+}

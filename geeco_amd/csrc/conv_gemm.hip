@@ -34,6 +34,9 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
 int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
                         int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                         int relu, hipStream_t stream, int* handled);
+int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups, int64_t gs_dz,
+                        int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride,
+                        hipStream_t stream, int* handled);
 int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,
                          int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
                          int stride, hipStream_t stream, int* handled);
@@ -661,6 +664,9 @@ extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* w, const float*
     int handled = 0;
     int rc = geeco_try_halo_dgrad(dz, w, ymask, dx, groups, gs_dz, gs_w, gs_dx, N, H, W, Cin, Cout, stride,
                                   (hipStream_t)stream, &handled);
+    if (rc || handled) return rc;
+    rc = geeco_try_dgrad_lds(dz, w, ymask, dx, groups, gs_dz, gs_w, gs_dx, N, H, W, Cin, Cout, stride,
+                             (hipStream_t)stream, &handled);
     if (rc || handled) return rc;
   }
   ConvGemmParams p = {};

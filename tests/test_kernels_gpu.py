@@ -56,7 +56,19 @@ def test_conv3x3_fwd(dev, N, H, W, Cin, Cout, stride):
   _close(y, ref, 2e-5, 2e-5, 'conv fwd')
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [c for c in CONV_CASES if c[3] % 16 == 0] + [(3, 128, 192, 32, 48, 2)])
+# LDS-staged input gradient of the middle layers (conv_dgrad_lds.hip): both tile variants, several ci blocks, odd frame
+# counts for the two-frame tiles, more items than one round of blocks
+DGRAD_LDS_CASES = [
+    (3, 32, 64, 64, 128, 2),    # 1x16 groups: Ho = 16, Wo = 32 -> 2 x 2 tiles per frame
+    (2, 16, 32, 128, 64, 2),    # two ci blocks, one tile per frame
+    (5, 16, 16, 192, 256, 2),   # conv6 type: two-frame tiles, odd frame count, three ci blocks
+    (4, 16, 16, 64, 32, 2),     # two-frame tiles, two co chunks only
+    (40, 32, 32, 64, 128, 2),   # 80 tiles x ... enough items for several per block
+]
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [c for c in CONV_CASES if c[3] % 16 == 0] + DGRAD_LDS_CASES +
+                         [(3, 128, 192, 32, 48, 2)])
 def test_conv3x3_dgrad(dev, N, H, W, Cin, Cout, stride):
   from geeco_amd import ops
   r = np.random.default_rng(8)
@@ -388,3 +400,35 @@ def test_goal_inputs_fused(dev, N, K, H, W, C):
     if C == 3:
       for o in outs:
         assert float(o[..., 3].abs().max()) == 0.0        # pad channel
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W,Nd', [(64, 128, 32, 32, 5), (128, 192, 16, 32, 4), (192, 256, 16, 16, 7)])
+def test_conv3x3_dgrad_grouped_lds(dev, Cin, Cout, H, W, Nd):
+  """Grouped launch (G encoders, padded arena strides) of the LDS-staged input gradient with the fused ReluGrad mask and
+  WITHOUT a mask, against the fp64 oracle; also checks that the dispatch took the new kernel."""
+  from geeco_amd import ops
+  G, stride = 3, 2
+  Ho, Wo = H // 2, W // 2
+  r = np.random.default_rng(51)
+  gs_w = 9 * Cin * Cout + 48
+  warena = torch.zeros(G, gs_w, device=dev)
+  w = (r.standard_normal([G, 3, 3, Cin, Cout]) / np.sqrt(9 * Cout)).astype(np.float32)
+  warena[:, :9 * Cin * Cout] = torch.tensor(w.reshape(G, -1), device=dev)
+  dz = r.standard_normal([G, Nd, Ho, Wo, Cout]).astype(np.float32)
+  mask = r.standard_normal([G, Nd, H, W, Cin]).astype(np.float32)
+  dzd, md = torch.tensor(dz, device=dev), torch.tensor(mask, device=dev)
+  wt = torch.empty(G, 3, 3, Cout, Cin, device=dev)
+  ops.transpose_hwio_into(wt, warena, G, gs_w, wt[0].numel(), Cin, Cout)
+  dws = torch.empty(ops.conv3x3_dgrad_ws_bytes(G, Nd, H, W, Cin, Cout, stride) // 4 + 4, device=dev)
+  for use_mask in (True, False):
+    dx = torch.full((G, Nd, H, W, Cin), float('nan'), device=dev)
+    names = ops.kernel_trace(lambda: ops.conv3x3_dgrad_into(dx, dzd, wt, md if use_mask else None, G, dzd[0].numel(), wt[0].numel(),
+                                                            dx[0].numel(), Nd, H, W, Cin, Cout, stride, ws=dws, w=warena, gs_w=gs_w))
+    torch.cuda.synchronize()
+    assert names and names[0].startswith('conv_s2_dgrad_lds_kernel'), names
+    for g in range(G):
+      xg = torch.zeros(Nd, H, W, Cin, dtype=torch.float64, requires_grad=True)
+      yy = O.conv2d_same(xg, torch.tensor(w[g], dtype=torch.float64), torch.zeros(Cout, dtype=torch.float64), stride, relu=False)
+      yy.backward(torch.tensor(dz[g], dtype=torch.float64))
+      ref = xg.grad * (torch.tensor(mask[g]) > 0) if use_mask else xg.grad
+      _close(dx[g], ref, 2e-5, 2e-5, 'grouped dgrad (mask %s), encoder %d' % (use_mask, g))
