@@ -40,7 +40,10 @@ struct DgradLdsParams {
   int tiles_per_group;   // tiles of one encoder
   int items;             // G * n_cib * tiles_per_group
   int per;               // items per block
+  int stagger;           // waves 4-7 issue their DMA pieces mid-chunk
 };
+
+__device__ __forceinline__ bool getenv_stagger(const DgradLdsParams& p) { return p.stagger != 0; }
 
 // A group = PR x PC = 16 class pixels; a tile = 8 groups stacked in y (FR frames per tile: 1 for wide images, 2 when a
 // frame holds only 4 groups).
@@ -49,10 +52,17 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
   static_assert(PR * PC == 16, "16 pixels per MFMA column group");
   constexpr int GPF = 8 / FR;                       // groups per frame of the tile
   constexpr int IR = GPF * PR + 1, IC = PC + 1;     // dz halo image of one frame: rows -1 .. GPF*PR-1, cols -1 .. PC-1
-  constexpr int Z_F4 = FR * IR * IC * 4;            // [pixel][4 granules of 4 co]
+  // LDS images in 16-byte granules (4 co).  A ds_read_b128 is served in four groups of 16 lanes, each holding every
+  // r = lane & 15 exactly once (from two different q = lane >> 4): the 16 lanes hit 16 distinct bank quads iff the granule
+  // index is  (multiple of 16) * q + r-dependent part with 16 consecutive values.  Hence q-major images:
+  //   weights [tap][ci tile][q][16 ci rows],  dz [q][pixel] planes of NPIXP (multiple of 16) pixels.
+  // (The natural [row][q] order gives a 2-way conflict on every read: measured SQ_LDS_BANK_CONFLICT 50 %.)
+  constexpr int NPIX = FR * IR * IC;
+  constexpr int NPIXP = (NPIX + 15) / 16 * 16;
+  constexpr int Z_F4 = 4 * NPIXP;
   constexpr int NZP = (Z_F4 + 63) / 64;
   constexpr int ZP_F4 = NZP * 64;
-  constexpr int W_F4 = 9 * 64 * 4;                  // [tap][ci 64][4 granules]
+  constexpr int W_F4 = 9 * 64 * 4;                  // [tap][ci tile 4][q 4][ci row 16]
   constexpr int NWP = W_F4 / 64;                    // 36 pieces
   constexpr int NSLOT = (NWP + NZP + 7) / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,20 +87,20 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
   for (int i = 0; i < NSLOT; ++i) {
     const int k = wid + 8 * i;
     if (k < NWP) {
-      const int row = k * 16 + (lane >> 2);         // (tap, ci) row of the slab
-      const int tap = row >> 6, ci = row & 63;
-      d_off[i] = (tap * Cin + ci) * Cout + (lane & 3) * 4;
+      // piece k = (tap, ci tile): lane = q * 16 + ci row
+      const int tap = k >> 2, cit = k & 3;
+      d_off[i] = (tap * Cin + cit * 16 + (lane & 15)) * Cout + (lane >> 4) * 4;
       d_a[i] = 0; d_b[i] = 0; d_f[i] = 0;
     } else {
-      const int sl = (k - NWP) * 64 + lane;
-      const int px = sl >> 2;
+      const int sl = (k - NWP) * 64 + lane;         // granule index inside the dz image: q * NPIXP + pixel
+      const int qq = sl / NPIXP, px = sl - qq * NPIXP;
       const int f = px / (IR * IC), rem = px - f * (IR * IC);
       const int ir = rem / IC, ic = rem - ir * IC;
-      const bool ok = k < NWP + NZP && sl < Z_F4;
+      const bool ok = k < NWP + NZP && sl < Z_F4 && px < NPIX;
       d_f[i] = (signed char)(ok ? f : 100);
       d_a[i] = (short)(ir - 1);
       d_b[i] = (short)(ic - 1);
-      d_off[i] = ((ir - 1) * p.Wo + (ic - 1)) * Cout + (sl & 3) * 4;
+      d_off[i] = ((ir - 1) * p.Wo + (ic - 1)) * Cout + qq * 4;
     }
   }
   // item -> (encoder g, ci block, frame n0, class-pixel origin Y0, X0)
@@ -129,8 +139,8 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
   const int pr = r / PC, pc = r - pr * PC;
   const int zpix = (gf * IR + gyl * PR + pr + 1) * IC + pc + 1;       // image pixel of lane r at shift (0, 0)
   int zoff[4];                                      // shifts (dy, dx) = (0,0), (0,-1), (-1,0), (-1,-1)
-  zoff[0] = zpix * 4 + q; zoff[1] = (zpix - 1) * 4 + q; zoff[2] = (zpix - IC) * 4 + q; zoff[3] = (zpix - IC - 1) * 4 + q;
-  const int woff = r * 4 + q;                       // + (tap * 64 + cit * 16) * 4
+  zoff[0] = q * NPIXP + zpix; zoff[1] = zoff[0] - 1; zoff[2] = zoff[0] - IC; zoff[3] = zoff[0] - IC - 1;
+  const int woff = q * 16 + r;                      // + (tap * 4 + cit) * 64
 
   int g, cib, n0, y0, x0;
   decode(item, g, cib, n0, y0, x0);
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  const bool late = wid >= 4 && getenv_stagger(p);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][4];                                  // [class py * 2 + px][ci tile]
   int buf = 0;
@@ -150,9 +161,14 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
     const bool more_items = item + 1 < item_end;
     if (more_items) decode(item + 1, gn, cibn, n0n, y0n, x0n);
     for (int ch = 0; ch < nch; ++ch) {
-      // prefetch the next (item, chunk) step: the stream crosses tile boundaries
-      if (ch + 1 < nch) dma_chunk(buf ^ 1, g, cib, n0, y0, x0, ch + 1);
-      else if (more_items) dma_chunk(buf ^ 1, gn, cibn, n0n, y0n, x0n, 0);
+      // prefetch the next (item, chunk) step: the stream crosses tile boundaries.  Waves 0-3 issue their DMA pieces at
+      // the head of the chunk, waves 4-7 (their SIMD partners) in the middle of the tap loop: an LDS-DMA instruction
+      // holds its wave for 100-200 cycles, and partners that stall at the same time leave the SIMD's MFMA pipe idle.
+      auto prefetch = [&]() {
+        if (ch + 1 < nch) dma_chunk(buf ^ 1, g, cib, n0, y0, x0, ch + 1);
+        else if (more_items) dma_chunk(buf ^ 1, gn, cibn, n0n, y0n, x0n, 0);
+      };
+      if (!late) prefetch();
       const f32x4* zb = sZ + buf * ZP_F4;
       const f32x4* wb = sW + buf * W_F4 + woff;
       f32x4 bz[4];
@@ -165,9 +181,10 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
           const int cls = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
           const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
           const int tap = ky * 3 + kx;
+          if (tap == 4 && late) prefetch();
           f32x4 a[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) a[t] = wb[(tap * 64 + t * 16) * 4];
+          for (int t = 0; t < 4; ++t) a[t] = wb[(tap * 4 + t) * 64];
           // k component outer, ci tile inner: an accumulator is touched again only after 3 other MFMAs (the dependent
           // latency of v_mfma_f32_16x16x4_f32 is 40 cycles against 32 of issue)
 #pragma unroll
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
 template <int PR, int PC, int FR>
 static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t stream) {
   constexpr int IR = (8 / FR) * PR + 1, IC = PC + 1;
-  constexpr int ZP_F4 = (FR * IR * IC * 4 + 63) / 64 * 64;
+  constexpr int ZP_F4 = (4 * ((FR * IR * IC + 15) / 16 * 16) + 63) / 64 * 64;
   constexpr size_t lds = (size_t)(2 * 9 * 64 * 4 + 2 * ZP_F4) * 16;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
@@ -250,6 +267,8 @@ int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask
   p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout;
   p.n_cib = Cin / 64;
+  static const int no_stagger = getenv("GEECO_DGRAD_NO_STAGGER") ? 1 : 0;
+  p.stagger = !no_stagger;
   long long tiles;
   if (variant == 1) {
     p.tiles_y = Ho / 8; p.tiles_x = Wo / 16;

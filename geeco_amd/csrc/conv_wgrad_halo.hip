@@ -193,6 +193,8 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
   for (; tile < tend; ++tile) {
     const bool more = tile + 1 < tend;
     int n2 = n, ty2 = ty, tx2 = tx;
+    // (Issuing the DMA of half of the waves mid-tile, which pays on the input-gradient twin of this kernel, measured
+    // 0.4 % slower here.)
     if (more) {
       advance(n2, ty2, tx2);
       if (NBUF == 2) dma_tile(buf ^ 1, n2, ty2, tx2);     // lands behind this tile's MFMAs
