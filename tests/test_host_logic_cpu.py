@@ -398,3 +398,17 @@ def test_tensorboard_event_file(tmp_path):
   assert e0['file_version'] == 'brain.Event:2'
   assert e1 == {'wall_time': 123.5, 'step': 7, 'scalars': {'loss': 1.5, 'loss_cmd_ee': 0.25}}
   assert e2['step'] == 300 and e2['scalars'] == {'loss': 1.25}
+
+
+def test_bench_refuses_missing_gpus():
+  """`python bench.py --gpus N` without a launcher must start N ranks itself or fail loudly: with fewer visible GPUs than
+  ranks it exits non-zero BEFORE touching a GPU and prints no JSON line (a driver must never record a 1-GPU number as
+  the N-GPU result)."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+  out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=300)
+  assert out.returncode == 2, (out.returncode, out.stderr[-500:])
+  assert '"metric"' not in out.stdout
+  assert 'only' in out.stderr and 'GPU' in out.stderr
