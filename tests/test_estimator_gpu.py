@@ -159,3 +159,29 @@ def test_ragged_final_batch_and_shared_store(dev, tmp_path):
   want = store.to_numpy('params')
   for k in want:
     np.testing.assert_allclose(got[k], want[k], rtol=0, atol=1e-7, err_msg=k)
+
+
+def test_prefetch_uploads_during_graph_capture(dev, tmp_path):
+  """The input prefetch thread keeps uploading episodes (hipMalloc + synchronous H2D copies) while the training thread
+  captures its hipGraphs at step 3 and replays them afterwards: both sides take runtime.CAPTURE_LOCK, so neither the
+  capture nor an upload is invalidated.  Eight episodes behind a prefetch depth of one batch keep the producer busy for
+  the whole run."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_host_logic_cpu import _make_dataset
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import pickplace_input_fn
+  from geeco_amd.params import create_e2evmc_config
+  root = str(tmp_path / 'ds')
+  os.makedirs(root)
+  _make_dataset(root, n_eps=8, T=12, H=136, W=136)
+  params = {'e2evmc_config': create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136,
+                                                       img_width=136, batch_size=4)), 'log_steps': 100, 'debug': False}
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path / 'm'), est.RunConfig(use_hipgraph=True), params)
+  e.train(input_fn=lambda: pickplace_input_fn(root, 'default', 'train', window_size=3, fetch_target=True, batch_size=4,
+                                              prefetch_size=1, seed=1, device='cuda'))
+  # 8 episodes x (11 - 3 + 1) windows = 72 windows = 18 steps, all but the first two replayed
+  assert int(e._store.global_step.item()) == 18
+  r = e.evaluate(input_fn=lambda: pickplace_input_fn(root, 'default', 'eval', window_size=3, fetch_target=True, batch_size=4,
+                                                     prefetch_size=1, device='cuda'))
+  assert np.isfinite(r['loss']) and r['global_step'] == 18
