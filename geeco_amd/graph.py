@@ -432,10 +432,15 @@ class _ModelBase:
         self.inputs['target_depth'] = torch.zeros(N, H, W, 1, **f32)
     self.scal = torch.zeros(4, **f32)          # [0] = Adam lr_t, [1] = sum of squares of the arena
     self.world = 1
-    if self.C == 4:
-      self.obs4 = torch.empty(N, K, H, W, 4, **f32)      # rgb || depth (estimator.py:36,169)
+    # RGB-D: rgb || depth (estimator.py:36,169,172).  The dynimg branch of the goal model forms the concat inside its
+    # input kernels (no packed copy of all N * K frames: 1.07 GB read + 1.43 GB written per step at K = 32); the other
+    # graphs pack once per step.
+    self.split_rgbd = (self.C == 4 and goal and cfg.proc_obs == 'dynimg' and (H * W) % 4 == 0 and
+                       os.environ.get('GEECO_PACK_RGBD') is None and os.environ.get('GEECO_FUSED_INPUTS') is None)
+    if self.C == 4 and not self.split_rgbd:
+      self.obs4 = torch.empty(N, K, H, W, 4, **f32)
       if goal:
-        self.tgt4 = torch.empty(N, H, W, 4, **f32)       # target_rgb || target_depth (estimator.py:172)
+        self.tgt4 = torch.empty(N, H, W, 4, **f32)
 
   def load_batch(self, features, labels=None):
     """Copies one batch into the static input buffers (H2D or D2D; torch is plumbing here)."""
@@ -565,10 +570,25 @@ class GoalE2EVMC(_ModelBase):
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
     HW = H * W
     x_in = self.enc.x_in
-    frames, tgt = self._frames()
     jn = self.cfg.dim_jnt_state
     jnts = self.inputs['jnt_state']
     d = self.decoder
+    if self.mode == 'dynimg' and self.split_rgbd:
+      inp = self.inputs
+      rgb, dep = inp['rgb'], inp['depth']
+      cur_rgb, cur_dep = rgb[:, K - 1], dep[:, K - 1]
+      ops.pack_pixels_into(x_in[0], cur_rgb, K * HW * 3, N, HW, 3, 4, cur_dep, K * HW, 1)
+      ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
+      ops.dynimg_rgbd_into(x_in[2], cur_rgb, cur_dep, 2, N, HW, self.dyn_ws, K * HW * 3, 0, K * HW, 0,
+                           rgb2=inp['target_rgb'], depth2=inp['target_depth'])
+      self.enc.forward()
+      feats = self.enc.features
+      ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], self.feat_ch, 2, jnts[:, K - 1], K * jn,
+                                jn, N, _CELLS, d.D)
+      d.forward(backward_too)
+      self._finish_forward()
+      return
+    frames, tgt = self._frames()
     if self.mode == 'dynimg':
       cur = frames[:, K - 1]                                  # rgb_frame_list[-1] (graph.py:387)
       # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)

@@ -79,6 +79,14 @@ def dynimg_into(out, frames, K, N, HW, C, Cpad, ws, sample_stride, frame_stride,
                                 _stream()), 'geeco_dynimg_fwd')
 
 
+def dynimg_rgbd_into(out, rgb, depth, K, N, HW, ws, sample_stride, frame_stride, dsample_stride, dframe_stride, rgb2=None,
+                     depth2=None):
+  """out [N][HW][4] <- normalised dynamic image of K RGB-D frames whose rgb / depth live in separate tensors."""
+  check(_lib().geeco_dynimg_rgbd_fwd(_p(rgb), _p(rgb2), sample_stride, frame_stride, _p(depth), _p(depth2), dsample_stride,
+                                     dframe_stride, ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N, K, HW, _p(out), _p(ws),
+                                     _stream()), 'geeco_dynimg_rgbd_fwd')
+
+
 def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
   """frames [N,K,H,W,C] contiguous -> [N,H,W,Cpad]."""
   N, K, H, W, C = frames.shape

@@ -52,6 +52,14 @@ int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_s
                      int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW,
                      int C, int Cpad, float* out, void* ws, void* stream);
 
+/* RGB-D form of geeco_dynimg_fwd without packing: `rgb` [N][K][HW][3] and `depth` [N][K][HW] stay separate tensors
+ * (each with its own sample / frame strides, 16-byte aligned, HW % 4 == 0) and tf.concat([rgb, depth], -1)
+ * (estimator.py:169,172) happens in registers; out [N][HW][4] normalised over all four channels (graph.py:47-54).
+ * Two-frame form: K = 2, rgb2 / depth2 = the second frame ([N][HW][3], [N][HW]). */
+int geeco_dynimg_rgbd_fwd(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
+                          const float* depth, const float* depth2, int64_t dsample_stride, int64_t dframe_stride,
+                          const float* alpha_host, int N, int K, int64_t HW, float* out, void* ws, void* stream);
+
 /* Fused input stage of goal_e2evmc's dynimg branch (graph.py:386-402): ONE launch reads a batch of K-frame windows
  * (frames [N][K][HW][C], element strides given; C = 3 or 4 with 16-byte aligned frames) and the target frames
  * (tgt [N][HW][C]) once and writes the three conv1 inputs [N][HW][4]:

@@ -147,6 +147,30 @@ def test_dynimg(dev, N, K, H, W, C, Cpad):
     assert float(out[..., C:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('N,K,H,W', [(2, 5, 40, 52), (3, 32, 136, 136), (2, 2, 64, 64)])
+def test_dynimg_rgbd_unpacked(dev, N, K, H, W):
+  """RGB-D dynamic image with rgb and depth in separate tensors (concat in registers) == the oracle on the packed frames;
+  also the two-frame form used for the diff image."""
+  from geeco_amd import ops
+  r = np.random.default_rng(12)
+  rgb = r.random([N, K, H, W, 3], dtype=np.float32)
+  dep = (0.5 + 2.5 * r.random([N, K, H, W, 1], dtype=np.float32))
+  ws = ops.dynimg_ws(N, H * W * 4, dev)
+  out = torch.full((N, H, W, 4), float('nan'), device=dev)
+  rd, dd = torch.tensor(rgb, device=dev), torch.tensor(dep, device=dev)
+  ops.dynimg_rgbd_into(out, rd, dd, K, N, H * W, ws, K * H * W * 3, H * W * 3, K * H * W, H * W)
+  torch.cuda.synchronize()
+  ref = O.dynimg(torch.tensor(np.concatenate([rgb, dep], -1), dtype=torch.float64))
+  _close(out, ref, 0, 5e-6, 'rgbd buffer image')
+  tr, td = r.random([N, H, W, 3], dtype=np.float32), (0.5 + 2.5 * r.random([N, H, W, 1], dtype=np.float32))
+  ops.dynimg_rgbd_into(out, rd[:, K - 1], dd[:, K - 1], 2, N, H * W, ws, K * H * W * 3, 0, K * H * W, 0,
+                       rgb2=torch.tensor(tr, device=dev), depth2=torch.tensor(td, device=dev))
+  torch.cuda.synchronize()
+  cur = np.concatenate([rgb[:, K - 1], dep[:, K - 1]], -1)
+  ref2 = O.dynimg(torch.tensor(np.stack([cur, np.concatenate([tr, td], -1)], 1), dtype=torch.float64))
+  _close(out, ref2, 0, 5e-6, 'rgbd diff image')
+
+
 def test_dynimg_known_answers(dev):
   """Constant sequence -> D == 0 -> normalised image == 0 (sum alpha = 0); dyndiff(cur == tgt) == 0."""
   from geeco_amd import ops
