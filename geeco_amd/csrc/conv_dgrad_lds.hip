@@ -35,20 +35,22 @@ struct DgradLdsParams {
   float* dx;             // [G][N][H][W][Cin]
   long long gs_dz, gs_w, gs_dx;
   int N, H, W, Ho, Wo, Cin, Cout;
-  int n_cib;             // Cin / 64
+  int n_cib;             // Cin / (16 NCIT)
   int tiles_y, tiles_x;  // tiles per frame (wide images) -- 1 x 1 for the two-frame tiles
   int tiles_per_group;   // tiles of one encoder
   int items;             // G * n_cib * tiles_per_group
-  int per;               // items per block
   int stagger;           // waves 4-7 issue their DMA pieces mid-chunk
 };
 
 __device__ __forceinline__ bool getenv_stagger(const DgradLdsParams& p) { return p.stagger != 0; }
 
 // A group = PR x PC = 16 class pixels; a tile = 8 groups stacked in y (FR frames per tile: 1 for wide images, 2 when a
-// frame holds only 4 groups).
-template <int PR, int PC, int FR>
-__global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsParams p) {
+// frame holds only 4 groups).  NCIT = ci tiles of 16 per block: 4 (64 channels, 94 KB of LDS, one block per CU) or 2 (32
+// channels, 57 KB, TWO blocks per CU: twice as many, half as heavy items when 64-channel items cannot fill the chip evenly).
+// Blocks take items blockIdx.x, blockIdx.x + gridDim.x, ...: with two blocks per CU, blocks b and b + 256 tend to share a
+// CU, so a CU's total stays balanced when the item count is not a multiple of the grid.
+template <int PR, int PC, int FR, int NCIT>
+__global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kernel(const DgradLdsParams p) {
   static_assert(PR * PC == 16, "16 pixels per MFMA column group");
   constexpr int GPF = 8 / FR;                       // groups per frame of the tile
   constexpr int IR = GPF * PR + 1, IC = PC + 1;     // dz halo image of one frame: rows -1 .. GPF*PR-1, cols -1 .. PC-1
@@ -62,8 +64,9 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
   constexpr int Z_F4 = 4 * NPIXP;
   constexpr int NZP = (Z_F4 + 63) / 64;
   constexpr int ZP_F4 = NZP * 64;
-  constexpr int W_F4 = 9 * 64 * 4;                  // [tap][ci tile 4][q 4][ci row 16]
-  constexpr int NWP = W_F4 / 64;                    // 36 pieces
+  constexpr int CIB = 16 * NCIT;
+  constexpr int W_F4 = 9 * NCIT * 64;               // [tap][ci tile][q 4][ci row 16]
+  constexpr int NWP = 9 * NCIT;                     // one piece per (tap, ci tile)
   constexpr int NSLOT = (NWP + NZP + 7) / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sW = reinterpret_cast<f32x4*>(smem);       // 2 weight chunks
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
   const int Cin = p.Cin, Cout = p.Cout;
   const int nch = Cout >> 4;
 
-  int item = blockIdx.x * p.per;
-  const int item_end = item + p.per < p.items ? item + p.per : p.items;
-  if (item >= item_end) return;
+  int item = blockIdx.x;
+  const int item_step = gridDim.x;
+  if (item >= p.items) return;
 
   // ---- DMA pieces of this wave: k = wid + 8 i; k < NWP: weight granules [64 k, +64), else dz granules ---------------
   int d_off[NSLOT];
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
     const int k = wid + 8 * i;
     if (k < NWP) {
       // piece k = (tap, ci tile): lane = q * 16 + ci row
-      const int tap = k >> 2, cit = k & 3;
+      const int tap = k / NCIT, cit = k - tap * NCIT;
       d_off[i] = (tap * Cin + cit * 16 + (lane & 15)) * Cout + (lane >> 4) * 4;
       d_a[i] = 0; d_b[i] = 0; d_f[i] = 0;
     } else {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
     x0_ = (tt - ty * p.tiles_x) * PC;
   };
   auto dma_chunk = [&](int buf, int g_, int cib_, int n0_, int y0_, int x0_, int ch) {
-    const float* wg = p.w + (long long)g_ * p.gs_w + (long long)cib_ * 64 * Cout + ch * 16;
+    const float* wg = p.w + (long long)g_ * p.gs_w + (long long)cib_ * CIB * Cout + ch * 16;
     const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n0_ * p.Ho + y0_) * p.Wo + x0_) * Cout + ch * 16;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
@@ -150,16 +153,16 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
 
   const bool late = wid >= 4 && getenv_stagger(p);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[4][4];                                  // [class py * 2 + px][ci tile]
+  f32x4 acc[4][NCIT];                               // [class py * 2 + px][ci tile]
   int buf = 0;
   while (true) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[c][t] = zero4;
+      for (int t = 0; t < NCIT; ++t) acc[c][t] = zero4;
     int gn = g, cibn = cib, n0n = n0, y0n = y0, x0n = x0;
-    const bool more_items = item + 1 < item_end;
-    if (more_items) decode(item + 1, gn, cibn, n0n, y0n, x0n);
+    const bool more_items = item + item_step < p.items;
+    if (more_items) decode(item + item_step, gn, cibn, n0n, y0n, x0n);
     for (int ch = 0; ch < nch; ++ch) {
       // prefetch the next (item, chunk) step: the stream crosses tile boundaries.  Waves 0-3 issue their DMA pieces at
       // the head of the chunk, waves 4-7 (their SIMD partners) in the middle of the tap loop: an LDS-DMA instruction
@@ -182,19 +185,19 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
           const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
           const int tap = ky * 3 + kx;
           if (tap == 4 && late) prefetch();
-          f32x4 a[4];
+          f32x4 a[NCIT];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) a[t] = wb[(tap * 4 + t) * 64];
+          for (int t = 0; t < NCIT; ++t) a[t] = wb[(tap * NCIT + t) * 64];
           // k component outer, ci tile inner: an accumulator is touched again only after 3 other MFMAs (the dependent
           // latency of v_mfma_f32_16x16x4_f32 is 40 cycles against 32 of issue)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, bz[sh].x, acc[cls][t], 0, 0, 0);
+          for (int t = 0; t < NCIT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, bz[sh].x, acc[cls][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, bz[sh].y, acc[cls][t], 0, 0, 0);
+          for (int t = 0; t < NCIT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, bz[sh].y, acc[cls][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, bz[sh].z, acc[cls][t], 0, 0, 0);
+          for (int t = 0; t < NCIT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, bz[sh].z, acc[cls][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, bz[sh].w, acc[cls][t], 0, 0, 0);
+          for (int t = 0; t < NCIT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, bz[sh].w, acc[cls][t], 0, 0, 0);
         }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       buf ^= 1;
@@ -209,9 +212,9 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
         for (int c = 0; c < 4; ++c) {
           const int py = c >> 1, px = c & 1;
           const long long pix = ((long long)n * p.H + 2 * Y + py) * p.W + 2 * X + px;
-          const long long o = gbase + pix * Cin + cib * 64 + 4 * q;
+          const long long o = gbase + pix * Cin + cib * CIB + 4 * q;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < NCIT; ++t) {
             f32x4 v = acc[c][t];
             if (p.mask) {
               const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + o + 16 * t);
@@ -224,21 +227,21 @@ __global__ __launch_bounds__(512) void conv_s2_dgrad_lds_kernel(const DgradLdsPa
       }
     }
     if (!more_items) break;
-    ++item;
+    item += item_step;
     g = gn; cib = cibn; n0 = n0n; y0 = y0n; x0 = x0n;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int PR, int PC, int FR>
+template <int PR, int PC, int FR, int NCIT>
 static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t stream) {
   constexpr int IR = (8 / FR) * PR + 1, IC = PC + 1;
   constexpr int ZP_F4 = (4 * ((FR * IR * IC + 15) / 16 * 16) + 63) / 64 * 64;
-  constexpr size_t lds = (size_t)(2 * 9 * 64 * 4 + 2 * ZP_F4) * 16;
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr size_t lds = (size_t)(2 * 9 * NCIT * 64 + 2 * ZP_F4) * 16;
+  static_assert(lds * (NCIT == 4 ? 1 : 2) <= 160 * 1024, "LDS budget");
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_dgrad_lds_kernel<PR, PC, FR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_dgrad_lds_kernel<PR, PC, FR, NCIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -246,8 +249,8 @@ static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t str
     }
     attr_set = true;
   }
-  geeco_note_kernel("conv_s2_dgrad_lds_kernel<%d, %d, %d>", PR, PC, FR);
-  hipLaunchKernelGGL((conv_s2_dgrad_lds_kernel<PR, PC, FR>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  geeco_note_kernel("conv_s2_dgrad_lds_kernel<%d, %d, %d, %d>", PR, PC, FR, NCIT);
+  hipLaunchKernelGGL((conv_s2_dgrad_lds_kernel<PR, PC, FR, NCIT>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   return 0;
 }
 
@@ -266,7 +269,6 @@ int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask
   DgradLdsParams p = {};
   p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout;
-  p.n_cib = Cin / 64;
   static const int no_stagger = getenv("GEECO_DGRAD_NO_STAGGER") ? 1 : 0;
   p.stagger = !no_stagger;
   long long tiles;
@@ -277,15 +279,26 @@ int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask
     p.tiles_y = 1; p.tiles_x = 1;
     tiles = (N + 1) / 2;
   }
-  const long long items = (long long)groups * p.n_cib * tiles;
-  if (items >= (1ll << 30)) return 0;
   p.tiles_per_group = (int)tiles;
-  p.items = (int)items;
-  // one block per CU (94 KB of LDS): equal item counts per block, as many blocks as fit one round
-  const int rounds = (int)((items + 255) / 256);
-  p.per = rounds;
-  const int blocks = (int)((items + rounds - 1) / rounds);
-  int rc = variant == 1 ? launch_dgrad_lds<1, 16, 1>(p, blocks, stream) : launch_dgrad_lds<2, 8, 2>(p, blocks, stream);
+  // 64-channel items (one block per CU) or 32-channel items (two blocks per CU): whichever spreads the launch more evenly
+  // over the 256 CUs; cost of an item in CU-time: 1 resp. 1/2.  Ties go to the 64-channel form (more reuse per staged byte).
+  const long long items64 = (long long)groups * (Cin / 64) * tiles;
+  if (items64 * 2 >= (1ll << 30)) return 0;
+  static const int force_ncit = getenv("GEECO_DGRAD_NCIT") ? atoi(getenv("GEECO_DGRAD_NCIT")) : 0;
+  const double span64 = (double)((items64 + 255) / 256), span32 = 0.5 * (double)((2 * items64 + 255) / 256);
+  const bool use32 = force_ncit == 2 || (force_ncit != 4 && span32 < span64);
+  int rc;
+  if (use32) {
+    p.n_cib = Cin / 32;
+    p.items = (int)(2 * items64);
+    const int blocks = p.items < 512 ? p.items : 512;
+    rc = variant == 1 ? launch_dgrad_lds<1, 16, 1, 2>(p, blocks, stream) : launch_dgrad_lds<2, 8, 2, 2>(p, blocks, stream);
+  } else {
+    p.n_cib = Cin / 64;
+    p.items = (int)items64;
+    const int blocks = p.items < 256 ? p.items : 256;
+    rc = variant == 1 ? launch_dgrad_lds<1, 16, 1, 4>(p, blocks, stream) : launch_dgrad_lds<2, 8, 2, 4>(p, blocks, stream);
+  }
   if (rc) return rc;
   GEECO_LAUNCH_CHECK();
   *handled = 1;
