@@ -1295,11 +1295,18 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
   constexpr int NCH = COUT / 16;                       // chunks (steps) per tile
   constexpr int TCI = CIN / 16;                        // ci tiles per wave
   constexpr int HR = 5, HC = 33;                       // dz halo rows / cols
-  constexpr int IMG_F4 = HR * HC * 4;                  // 660 float4 per chunk image
+  // Chunk image of the dz halo, q-major: [co quad q of the chunk][pixel] with the pixel planes padded to a multiple of 16
+  // granules, and kernel rows at a pitch of 2 (mod 16) granules: a ds_read_b128 is served in four groups of 16 lanes, each
+  // holding every r = lane & 15 once from two neighbouring q; both pitches put the two q of a group on disjoint
+  // 16-granule phases (conflict free).  The pixel-major image with an XOR swizzle and the odd row pitch of round 1 measured
+  // 43 % LDS bank-conflict cycles.
+  constexpr int NPIX = HR * HC;                        // 165
+  constexpr int NPIXP = (NPIX + 15) / 16 * 16;         // 176
+  constexpr int IMG_F4 = 4 * NPIXP;                    // 704 float4 per chunk image
   constexpr int NPIECE = (IMG_F4 + 63) / 64;           // 11 DMA pieces
-  constexpr int BUF_F4 = NPIECE * 64;                  // padded: the last piece spills into padding
+  constexpr int BUF_F4 = NPIECE * 64;
   constexpr int NSLOT = (NPIECE + 7) / 8;              // pieces per wave
-  constexpr int WP = COUT / 4 + 1;                     // float4 pitch of a (tap, ci) kernel row (odd)
+  constexpr int WP = COUT / 4 + 2;                     // float4 pitch of a (tap, ci) kernel row
   constexpr int W_F4 = 9 * CIN * WP;
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1345,10 +1352,9 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
 #pragma unroll
   for (int i = 0; i < NSLOT; ++i) {
     const int sl = (wid + 8 * i) * 64 + lane;
-    const int pix = sl >> 2, slot = sl & 3;
+    const int quad = sl / NPIXP, pix = sl - quad * NPIXP;
     const int hy = pix / HC, hx = pix - hy * HC;
-    const int quad = slot ^ ((hx >> 1) & 3);
-    d_hy[i] = (short)(sl < IMG_F4 ? hy : 30000);       // out-of-range marker fails the per-tile bounds test
+    d_hy[i] = (short)((sl < IMG_F4 && pix < NPIX) ? hy : 30000);   // out-of-range marker fails the per-tile bounds test
     d_hx[i] = (short)hx;
     d_src[i] = (hy * p.Wo + hx) * COUT + quad * 4;
   }
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
       auto frag = [&](int tap, f32x4& a, f32x4 (&b)[TCI]) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int hy = row + 1 - (ky >> 1), hx = hx_lane - (kx >> 1);
-        a = hA[(hy * HC + hx) * 4 + (q ^ ((hx >> 1) & 3))];
+        a = hA[q * NPIXP + hy * HC + hx];
 #pragma unroll
         for (int t = 0; t < TCI; ++t) b[t] = hB[(tap * CIN + 16 * t) * WP];
       };
@@ -1480,7 +1486,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
 template <int CIN, int COUT>
 static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
   constexpr int BUF_F4 = ((5 * 33 * 4 + 63) / 64) * 64;
-  const size_t lds = (size_t)(9 * CIN * (COUT / 4 + 1) + 2 * BUF_F4) * 16;
+  const size_t lds = (size_t)(9 * CIN * (COUT / 4 + 2) + 2 * BUF_F4) * 16;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>),
