@@ -23,7 +23,8 @@ from geeco_amd.params import create_e2evmc_config   # noqa: E402
 from geeco_amd.runtime import TrainStepRunner  # noqa: E402
 from oracle import geeco_oracle as O           # noqa: E402
 
-WORKLOADS = [('geeco-f', 3, 32, 16)]            # (model, channels, batch, seq_len): bench.py's default = BASELINE configs[1]
+# (model, channels, batch, seq_len): bench.py's default = BASELINE configs[1]; the per-GPU shapes of configs[3] and configs[4]
+WORKLOADS = [('geeco-f', 3, 32, 16), ('e2e_vmc', 3, 64, 16), ('geeco-f', 4, 32, 32)]
 STEP_COUNTS = [3 + 5 + 20, 3 + 20 + 100]        # driver invocation (--steps 20 --warmup 5) and the default flags
 
 
@@ -44,6 +45,7 @@ def main(out_path):
     feats = {k: v.cpu().numpy() for k, v in model.inputs.items() if k not in model.label_keys}
     labels = {k: model.inputs[k].cpu().numpy() for k in model.label_keys}
     tr = O.OracleTrainer(O.make_config(**kw), goal, P, dtype=torch.float64)
+    print('oracle (fp64, chunked) for %s c%d b%d k%d ...' % (name, C, N, K), flush=True)
     loss_ref = float(O.loss_and_grads_chunked(tr, feats, labels, chunk=16)[0])
     runner = TrainStepRunner(model, use_graph=True, warmup=2)
     runner.step()
