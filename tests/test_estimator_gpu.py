@@ -185,3 +185,44 @@ def test_prefetch_uploads_during_graph_capture(dev, tmp_path):
   r = e.evaluate(input_fn=lambda: pickplace_input_fn(root, 'default', 'eval', window_size=3, fetch_target=True, batch_size=4,
                                                      prefetch_size=1, device='cuda'))
   assert np.isfinite(r['loss']) and r['global_step'] == 18
+
+
+@pytest.mark.parametrize('mode', ['cartesian', 'velocity'])
+def test_eval_metric_values_match_oracle(dev, tmp_path, mode):
+  """Estimator.evaluate's numbers, not only its keys: 'loss' = mean of the per-batch losses [TF1.15 Estimator], streaming
+  mean_squared_error of cmd_ee / pos_ee / pos_obj (and cmd_vel / cmd_grp in velocity mode) = sum of squared errors over
+  ALL elements of all batches / their count, accuracy of cmd_grp = correct / total (estimator.py:246-258), against the
+  fp64 oracle evaluated on the same three batches (the last one ragged) with the same weights."""
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import synthetic_batches
+  from oracle import geeco_oracle as O
+  kw = dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=4, control_mode=mode)
+  params = _params(**{k: v for k, v in kw.items() if k not in ('img_height', 'img_width', 'batch_size')})
+  batches = list(synthetic_batches(4, 3, 3, (136, 136), 3, True, seed=12)())
+  f3, l3 = batches[2]
+  batches[2] = ({k: v[:3] for k, v in f3.items()}, {k: v[:3] for k, v in l3.items()})
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(init_seed=6), params)
+  res = e.evaluate(input_fn=lambda: iter(batches))
+  ocfg = O.make_config(**kw)
+  P = {k: torch.tensor(e.get_variable_value(k), dtype=torch.float64) for k in e.get_variable_names()}
+  losses, sq, cnt, correct, total = [], {}, {}, 0, 0
+  for f, l in batches:
+    ft = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in f.items() if k != 'step'}
+    lt = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in l.items()}
+    pred, _ = O.model_forward(ft, P, ocfg, True)
+    tgt = O.build_targets(ft, lt, ocfg)
+    loss, _ = O.model_loss(pred, tgt, P, ocfg)
+    losses.append(float(loss))
+    keys = ['cmd_ee', 'pos_ee', 'pos_obj'] + (['cmd_vel', 'cmd_grp'] if mode == 'velocity' else [])
+    for k in keys:
+      sq[k] = sq.get(k, 0.0) + float(((pred[k] - tgt[k]) ** 2).sum())
+      cnt[k] = cnt.get(k, 0) + tgt[k].numel()
+    if mode == 'cartesian':
+      correct += int((pred['logits_cmd_grp'].argmax(dim=-1) == tgt['cmd_grp'].long()).sum())
+      total += int(tgt['cmd_grp'].numel())
+  np.testing.assert_allclose(res['loss'], np.mean(losses), rtol=1e-4)
+  for k in sq:
+    np.testing.assert_allclose(res[k], sq[k] / cnt[k], rtol=2e-4, err_msg=k)
+  if mode == 'cartesian':
+    assert abs(res['cmd_grp'] - correct / total) < 1e-9
+  assert res['global_step'] == 0

@@ -412,3 +412,58 @@ def test_bench_refuses_missing_gpus():
   assert out.returncode == 2, (out.returncode, out.stderr[-500:])
   assert '"metric"' not in out.stdout
   assert 'only' in out.stderr and 'GPU' in out.stderr
+
+
+def test_tfrecord_sequence_example_hand_assembled_golden(tmp_path):
+  """A zlib TFRecord file with one tf.train.SequenceExample assembled BY HAND in this test from the published layouts
+  (TFRecord framing: u64 length, masked CRC-32C of the length, payload, masked CRC-32C of the payload; example.proto /
+  feature.proto field numbers; proto3 wire format) with its own bit-wise CRC-32C, including encodings the repo's writer
+  never produces: UNPACKED repeated floats / int64s (one tag per element, as older writers emit), a negative int64 as a
+  10-byte varint, map entries with value before key.  Reader (geeco_amd.tfrecord) against a third party."""
+  import struct, zlib
+  from geeco_amd import tfrecord as T
+
+  def varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+      b = v & 0x7f
+      v >>= 7
+      out.append(b | (0x80 if v else 0))
+      if not v:
+        return bytes(out)
+  def ld(fnum, payload):                    # length-delimited field
+    return varint((fnum << 3) | 2) + varint(len(payload)) + payload
+  float_packed = lambda vals: ld(2, ld(1, b''.join(struct.pack('<f', v) for v in vals)))            # Feature.float_list = 2, FloatList.value = 1 (packed)
+  float_unpacked = lambda vals: ld(2, b''.join(varint((1 << 3) | 5) + struct.pack('<f', v) for v in vals))
+  int_packed = lambda vals: ld(3, ld(1, b''.join(varint(v) for v in vals)))                          # Feature.int64_list = 3
+  int_unpacked = lambda vals: ld(3, b''.join(varint((1 << 3) | 0) + varint(v) for v in vals))
+  bytes_list = lambda vals: ld(1, b''.join(ld(1, v) for v in vals))                                  # Feature.bytes_list = 1
+  entry = lambda k, feat: ld(1, ld(1, k.encode()) + ld(2, feat))                                     # map<string, X>: key = 1, value = 2
+  entry_rev = lambda k, feat: ld(1, ld(2, feat) + ld(1, k.encode()))
+  feature_list = lambda feats: b''.join(ld(1, f) for f in feats)                                     # FeatureList.feature = 1
+  context = entry('episode_length', int_packed([3])) + entry_rev('task_goal', bytes_list([b'pad2']))
+  lists = (entry('step', feature_list([int_packed([0]), int_unpacked([1]), int_packed([-7])])) +
+           entry_rev('rgb', feature_list([float_packed([0.0, 255.0, 17.0]), float_unpacked([1.0, 2.0, 3.0]), float_packed([4.5, 5.5, 6.5])])))
+  example = ld(1, context) + ld(2, lists)            # SequenceExample.context = 1, .feature_lists = 2 (each a map field = 1)
+  hdr = struct.pack('<Q', len(example))
+  rec = hdr + struct.pack('<I', _masked(hdr)) + example + struct.pack('<I', _masked(example))
+  fn = str(tmp_path / 'hand.tfrecord.zlib')
+  open(fn, 'wb').write(zlib.compress(rec + rec))     # two records in one stream
+  recs = [bytes(r) for r in T.read_records(fn)]
+  assert len(recs) == 2 and recs[0] == example
+  ctx, fl = T.parse_sequence_example(recs[1])
+  assert ctx['episode_length'].tolist() == [3] and ctx['task_goal'] == [b'pad2']
+  assert [f.tolist() for f in fl['step']] == [[0], [1], [-7]]
+  assert [f.tolist() for f in fl['rgb']] == [[0.0, 255.0, 17.0], [1.0, 2.0, 3.0], [4.5, 5.5, 6.5]]
+  assert fl['rgb'][0].dtype == np.float32 and fl['step'][2].dtype == np.int64
+  # the repo's writer produces the same record bytes for the packed forms it emits
+  ours = T.encode_sequence_example({'episode_length': np.array([3], np.int64), 'task_goal': 'pad2'},
+                                   [{'step': np.array([i], np.int64)} for i in (0, 1, -7)])
+  c2, f2 = T.parse_sequence_example(ours)
+  assert c2['episode_length'].tolist() == [3] and [f.tolist() for f in f2['step']] == [[0], [1], [-7]]
+  # a flipped payload bit is caught by the record checksum
+  bad = bytearray(rec); bad[20] ^= 0x04
+  open(str(tmp_path / 'bad.tfrecord.zlib'), 'wb').write(zlib.compress(bytes(bad)))
+  with pytest.raises(IOError):
+    list(T.read_records(str(tmp_path / 'bad.tfrecord.zlib')))
