@@ -59,7 +59,7 @@ def log(msg):
 def spawn_ranks(args):
   import torch
   have = torch.cuda.device_count()        # counting devices does not initialise the GPU
-  if have < args.gpus and not os.environ.get('GEECO_BENCH_SHARE_GPU'):
+  if have < args.gpus and not os.environ.get('GEECO_SHARE_GPU'):
     log('--gpus %d requested but only %d GPU(s) are visible' % (args.gpus, have))
     return 2
   with socket.socket() as s:
@@ -332,13 +332,11 @@ def main():
   from geeco_amd.params import create_e2evmc_config
   from geeco_amd.runtime import TrainStepRunner
 
-  # Rehearsal of the N > 1 path on a one-GPU box: GEECO_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+  # Rehearsal of the N > 1 path on a one-GPU box: GEECO_SHARE_GPU=1 puts every rank on cuda:0 and
   # GEECO_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Such a run exercises the launcher, the
   # three-graph step and the bucketed exchange; its numbers mean nothing.
-  share = os.environ.get('GEECO_BENCH_SHARE_GPU') is not None
-  if share:
-    os.environ['LOCAL_RANK'] = '0'
-  world = gdist.init_from_env(os.environ.get('GEECO_DIST_BACKEND', 'nccl'))
+  share = os.environ.get('GEECO_SHARE_GPU') is not None
+  world = gdist.init_from_env('nccl')
   rank = gdist.rank()
   if world != args.gpus:
     log('--gpus %d but the process group has %d rank(s): refusing to report a number for the wrong N' % (args.gpus, world))

@@ -34,9 +34,14 @@ def init_from_env(backend=None):
     return world_size()
   os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
   os.environ.setdefault('MASTER_PORT', '29500')
+  # Rehearsal on a one-GPU box: GEECO_SHARE_GPU=1 puts every rank on cuda:0 and GEECO_DIST_BACKEND=gloo replaces RCCL
+  # (which refuses two ranks on one device).  Production: one rank per GPU, backend 'nccl' (= RCCL over xGMI).
+  if os.environ.get('GEECO_SHARE_GPU'):
+    os.environ['LOCAL_RANK'] = '0'
+  backend = os.environ.get('GEECO_DIST_BACKEND') or backend
   if backend is None:
     backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-  if backend == 'nccl':
+  if torch.cuda.is_available():
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
   dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
   return ws

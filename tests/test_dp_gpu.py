@@ -130,3 +130,41 @@ def test_estimator_ragged_batches_two_ranks(dev):
   np.testing.assert_array_equal(res[0][1], res[1][1])                               # replicas stay identical
   np.testing.assert_allclose(res[0][1], ref, rtol=0, atol=3e-4)                     # == single process on the global batches
   assert np.mean(np.abs(res[0][1] - ref) < 2e-5) > 0.99
+
+
+def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
+  """scripts/train_e2evmc.py under torch.distributed.run with TWO ranks (sharing the one test GPU over gloo:
+  GEECO_SHARE_GPU / GEECO_DIST_BACKEND) on an on-disk dataset of THREE episodes: rank 0 reads two episodes, rank 1 one,
+  so the epoch ends with steps in which rank 1 holds fewer or no windows (dp_schedule: loss scaling, null steps); one
+  shuffle seed is broadcast; rank 0 alone writes run command, config, checkpoints (+ TF bundles) and snapshots."""
+  import json
+  import subprocess
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_host_logic_cpu import _make_dataset
+  from geeco_amd.params import create_e2evmc_config
+  root = str(tmp_path / 'ds')
+  os.makedirs(root)
+  _make_dataset(root, n_eps=3, T=9, H=136, W=136)        # 6 windows per episode (K = 3)
+  md = str(tmp_path / 'run')
+  os.makedirs(md)
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=4))
+  json.dump(cfg._asdict(), open(os.path.join(md, 'e2evmc_config.json'), 'w'))
+  env = dict(os.environ, GEECO_SHARE_GPU='1', GEECO_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+    env.pop(k, None)
+  port = 31900 + os.getpid() % 1000
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.join(ROOT, 'scripts', 'train_e2evmc.py'), '--dataset_dir', root, '--model_dir', md,
+         '--goal_condition', 'target', '--proc_obs', 'dynimg', '--proc_tgt', 'dyndiff', '--window_size', '3', '--batch_size', '4',
+         '--train_epochs', '2', '--log_steps', '1', '--num_best_ckpt', '2']
+  out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  # global batch 4 = 2 windows per rank per step: rank 0 has 12 windows (6 steps), rank 1 has 6 (3 steps) -> 6 steps per epoch
+  from geeco_amd import estimator as est
+  assert os.path.basename(est.latest_checkpoint(md)) == 'model.ckpt-12'
+  assert os.path.exists(os.path.join(md, 'model.ckpt-12.index'))
+  idx = json.load(open(os.path.join(md, 'snapshots', 'snapshot_index.json')))
+  assert len(idx) == 2
+  ev = [json.loads(l) for l in open(os.path.join(md, 'events.jsonl'))]
+  assert [e['global_step'] for e in ev] == list(range(1, 13)) and all(np.isfinite(e['loss']) for e in ev)
+  assert sum(1 for fn in os.listdir(md) if fn.endswith('runcmd.json')) == 1            # rank 0 only
