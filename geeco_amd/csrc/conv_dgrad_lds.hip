@@ -49,10 +49,12 @@ __device__ __forceinline__ bool getenv_stagger(const DgradLdsParams& p) { return
 // channels, 57 KB, TWO blocks per CU: twice as many, half as heavy items when 64-channel items cannot fill the chip evenly).
 // Blocks take items blockIdx.x, blockIdx.x + gridDim.x, ...: with two blocks per CU, blocks b and b + 256 tend to share a
 // CU, so a CU's total stays balanced when the item count is not a multiple of the grid.
-template <int PR, int PC, int FR, int NCIT>
-__global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kernel(const DgradLdsParams p) {
+// NW = waves (= pixel groups) per block: 8, or 4 for the smallest layer (one 16 x 16 frame per tile, 47 KB of LDS, three
+// blocks per CU) so that its few tiles still spread over the whole chip.
+template <int PR, int PC, int FR, int NCIT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void conv_s2_dgrad_lds_kernel(const DgradLdsParams p) {
   static_assert(PR * PC == 16, "16 pixels per MFMA column group");
-  constexpr int GPF = 8 / FR;                       // groups per frame of the tile
+  constexpr int GPF = NW / FR;                      // groups per frame of the tile
   constexpr int IR = GPF * PR + 1, IC = PC + 1;     // dz halo image of one frame: rows -1 .. GPF*PR-1, cols -1 .. PC-1
   // LDS images in 16-byte granules (4 co).  A ds_read_b128 is served in four groups of 16 lanes, each holding every
   // r = lane & 15 exactly once (from two different q = lane >> 4): the 16 lanes hit 16 distinct bank quads iff the granule
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kern
   constexpr int CIB = 16 * NCIT;
   constexpr int W_F4 = 9 * NCIT * 64;               // [tap][ci tile][q 4][ci row 16]
   constexpr int NWP = 9 * NCIT;                     // one piece per (tap, ci tile)
-  constexpr int NSLOT = (NWP + NZP + 7) / 8;
+  constexpr int NSLOT = (NWP + NZP + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sW = reinterpret_cast<f32x4*>(smem);       // 2 weight chunks
   f32x4* sZ = sW + 2 * W_F4;                        // 2 dz halo chunks
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kern
   signed char d_f[NSLOT];
 #pragma unroll
   for (int i = 0; i < NSLOT; ++i) {
-    const int k = wid + 8 * i;
+    const int k = wid + NW * i;
     if (k < NWP) {
       // piece k = (tap, ci tile): lane = q * 16 + ci row
       const int tap = k / NCIT, cit = k - tap * NCIT;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kern
     const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n0_ * p.Ho + y0_) * p.Wo + x0_) * Cout + ch * 16;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-      const int k = wid + 8 * i;                    // wave-uniform
+      const int k = wid + NW * i;                   // wave-uniform
       if (k < NWP) {
         __builtin_amdgcn_global_load_lds((gptr_t)(wg + d_off[i]), (lptr_t)(sW + buf * W_F4 + k * 64), 16, 0, 0);
       } else if (k < NWP + NZP) {
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kern
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const bool late = wid >= 4 && getenv_stagger(p);
+  const bool late = wid >= NW / 2 && getenv_stagger(p);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[4][NCIT];                               // [class py * 2 + px][ci tile]
   int buf = 0;
@@ -233,15 +235,15 @@ __global__ __launch_bounds__(512, NCIT == 4 ? 2 : 4) void conv_s2_dgrad_lds_kern
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int PR, int PC, int FR, int NCIT>
+template <int PR, int PC, int FR, int NCIT, int NW = 8>
 static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t stream) {
-  constexpr int IR = (8 / FR) * PR + 1, IC = PC + 1;
+  constexpr int IR = (NW / FR) * PR + 1, IC = PC + 1;
   constexpr int ZP_F4 = (4 * ((FR * IR * IC + 15) / 16 * 16) + 63) / 64 * 64;
   constexpr size_t lds = (size_t)(2 * 9 * NCIT * 64 + 2 * ZP_F4) * 16;
-  static_assert(lds * (NCIT == 4 ? 1 : 2) <= 160 * 1024, "LDS budget");
+  static_assert(lds * (NW == 4 ? 3 : (NCIT == 4 ? 1 : 2)) <= 160 * 1024, "LDS budget");
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_dgrad_lds_kernel<PR, PC, FR, NCIT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_dgrad_lds_kernel<PR, PC, FR, NCIT, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -249,8 +251,8 @@ static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t str
     }
     attr_set = true;
   }
-  geeco_note_kernel("conv_s2_dgrad_lds_kernel<%d, %d, %d, %d>", PR, PC, FR, NCIT);
-  hipLaunchKernelGGL((conv_s2_dgrad_lds_kernel<PR, PC, FR, NCIT>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  geeco_note_kernel("conv_s2_dgrad_lds_kernel<%d, %d, %d, %d, %d>", PR, PC, FR, NCIT, NW);
+  hipLaunchKernelGGL((conv_s2_dgrad_lds_kernel<PR, PC, FR, NCIT, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, stream, p);
   return 0;
 }
 
@@ -278,6 +280,22 @@ int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask
   } else {
     p.tiles_y = 1; p.tiles_x = 1;
     tiles = (N + 1) / 2;
+  }
+  static const int no_small = getenv("GEECO_DGRAD_NO_SMALL") ? 1 : 0;
+  if (variant == 2 && !no_small) {
+    // 8 x 8 class pixels per frame: one-frame tiles of 4 groups, 32-channel items, 256-thread blocks, three per CU.  The
+    // two-frame / 8-wave form has only groups * (Cin / 64) * N / 2 items (conv6 of the bench: 144 for 256 CUs).
+    p.tiles_per_group = N;
+    p.n_cib = Cin / 32;
+    const long long items = (long long)groups * p.n_cib * N;
+    if (items >= (1ll << 30)) return 0;
+    p.items = (int)items;
+    const int blocks = p.items < 768 ? p.items : 768;
+    int rcs = launch_dgrad_lds<2, 8, 1, 2, 4>(p, blocks, stream);
+    if (rcs) return rcs;
+    GEECO_LAUNCH_CHECK();
+    *handled = 1;
+    return 0;
   }
   p.tiles_per_group = (int)tiles;
   // 64-channel items (one block per CU) or 32-channel items (two blocks per CU): whichever spreads the launch more evenly
