@@ -1077,7 +1077,7 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
 //   py = 0: (ky = 0, oy = Y'), (ky = 2, oy = Y' - 1);   py = 1: (ky = 1, oy = Y')          (same in x),
 // i.e. four parity classes with 4 / 2 / 2 / 1 taps.  A block owns 8 x 64 input pixels (4 x 32 per
 // class), stages the 5 x 33 dz halo as [co/4][row][col] float4 planes and keeps the HWIO kernel
-// resident as [tap][ci][15 float4] rows (b128 B-fragments straight from the TF layout, pitch 15 =
+// resident as [tap][ci][15 float4] rows (b128 B-fragments straight from the TF layout; in this unfused kernel pitch 15 =
 // -1 mod 16 => at most one 2-way conflict per read).  Wave = (column half, Y' row): 4 classes x 2
 // ci tiles = 8 accumulator tiles, 27 (tap, 16-co block) steps of 8 MFMAs per tile.
 // ------------------------------------------------------------------------------------------------
