@@ -418,7 +418,7 @@ def main():
     ms_step = dt / args.steps * 1e3
     frames = world * args.batch * args.seq_len
     out = {
-        'metric': 'train-step frames/sec (256x256 RGB, seq_len=%d)' % args.seq_len,
+        'metric': 'train-step frames/sec (256x256 %s, seq_len=%d)' % ('RGB' if args.channels == 3 else 'RGB-D', args.seq_len),
         'value': round(frames * args.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not share else 'synthetic (REHEARSAL: ranks share one GPU)',
