@@ -429,16 +429,25 @@ class Estimator:
       nb += 1
       if steps is not None and nb >= steps:
         break
-    if nb == 0:
+    # metric keys are fixed by the control mode (estimator.py:246-258): a rank whose shard of the eval split is empty still
+    # takes part in the reduction, with zeros, instead of leaving the others waiting
+    cfg = self.params.get('e2evmc_config')
+    keys = sorted(sums) if sums else sorted(['cmd_ee', 'pos_ee', 'pos_obj'] + (
+        ['cmd_grp'] if (cfg is None or cfg.control_mode == 'cartesian') else ['cmd_vel', 'cmd_grp']))
+    if nb == 0 and world == 1:
       raise RuntimeError('evaluate(): input_fn produced no batches')
-    dev = loss_sum.device
-    vec = torch.stack([loss_sum, torch.tensor(float(nb), device=dev)] +
-                      [x for k in sorted(sums) for x in (sums[k][0], torch.tensor(float(sums[k][1]), device=dev))])
+    dev = loss_sum.device if loss_sum is not None else self._device()
+    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    vec = torch.stack([loss_sum if loss_sum is not None else zero, torch.tensor(float(nb), device=dev)] +
+                      [x for k in keys for x in ((sums[k][0], torch.tensor(float(sums[k][1]), device=dev)) if k in sums
+                                                 else (zero, zero))])
     if world > 1:
       torch.distributed.all_reduce(vec)
     vec = vec.double().cpu()
+    if float(vec[1]) == 0.0:
+      raise RuntimeError('evaluate(): input_fn produced no batches on any rank')
     out = {'loss': float(vec[0] / vec[1])}
-    for i, k in enumerate(sorted(sums)):
+    for i, k in enumerate(keys):
       out[k] = float(vec[2 + 2 * i] / vec[3 + 2 * i])
     out['global_step'] = int(self._store.global_step.item())
     return out
