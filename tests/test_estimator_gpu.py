@@ -226,3 +226,26 @@ def test_eval_metric_values_match_oracle(dev, tmp_path, mode):
   if mode == 'cartesian':
     assert abs(res['cmd_grp'] - correct / total) < 1e-9
   assert res['global_step'] == 0
+
+
+def test_estimator_predict_mode(dev, tmp_path):
+  """Estimator.predict (ModeKeys.PREDICT, estimator.py:63-70 / 183-197): label-side inputs may be absent, predictions carry
+  the reference's keys and equal the oracle's forward on the same weights; an unknown mode raises RuntimeError."""
+  from geeco_amd import estimator as est
+  from geeco_amd.input_fn import synthetic_batches
+  from oracle import geeco_oracle as O
+  params = _params()
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(init_seed=8), params)
+  batches = list(synthetic_batches(4, 3, 2, (136, 136), 3, True, seed=21)())
+  feats_only = [{k: v for k, v in f.items() if k in ('rgb', 'target_rgb', 'jnt_state', 'step')} for f, _ in batches]
+  outs = list(e.predict(input_fn=lambda: iter(feats_only)))
+  assert len(outs) == 2 and set(outs[0]) == {'cmd_ee', 'logits_cmd_grp', 'pos_ee', 'pos_obj'}
+  ocfg = O.make_config(**params['e2evmc_config']._asdict())
+  P = {k: torch.tensor(e.get_variable_value(k), dtype=torch.float64) for k in e.get_variable_names()}
+  for f, out in zip(feats_only, outs):
+    ft = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in f.items() if k != 'step'}
+    pred, _ = O.model_forward(ft, P, ocfg, True)
+    for k in out:
+      np.testing.assert_allclose(out[k], pred[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+  with pytest.raises(RuntimeError):
+    est.goal_e2evmc_model_fn({'rgb': torch.zeros(1, 3, 136, 136, 3, device=dev)}, None, 'train_and_eval', params)
