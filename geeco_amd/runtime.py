@@ -29,6 +29,9 @@ from . import dist as gdist
 # thread during the capture window (the input prefetcher uploads episodes in a background thread): both sides take
 # this lock (geeco_amd/input_fn.py: episode_to_device).
 CAPTURE_LOCK = threading.RLock()
+# 'thread_local': HIP calls of OTHER threads (the RCCL watchdog polling its events, a prefetch upload that slipped past
+# the lock) neither fail nor invalidate the capture; only this thread's stream work is recorded.
+_CAPTURE_MODE = 'thread_local'
 
 _LATE = re.compile(r'/conv[12]/(kernel|bias)$')
 
@@ -118,7 +121,7 @@ class TrainStepRunner:
     with CAPTURE_LOCK:
       for fn in parts:
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
           fn()
         graphs.append(g.replay)
     self._graphs = graphs
@@ -178,7 +181,7 @@ class EvalStepRunner:
     if self.use_graph and self._g is None and self._calls >= self._warm:
       g = torch.cuda.CUDAGraph()
       with CAPTURE_LOCK:
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
           self.model.forward(backward_too=False)
       self._g = g
     self._calls += 1
