@@ -1509,11 +1509,14 @@ static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
 // conv1 has no input gradient (its input is data), so dz1 has exactly one consumer; produced and consumed inside one
 // kernel it never goes to HBM: the unfused pair writes and re-reads 805 MB per step and needs a second launch.
 // Built on conv_s2_halo_dgrad_kernel (same tiles, resident kernel, dz2 halo, MFMA schedule).  Per tile the block
-// also stages the 10 x 66 halo of conv1's input x (RGB padded to 4 channels) by LDS-DMA; in the epilogue each wave
-// takes its 64 masked pixels class by class: 16 pixels x 32 channels go through a private LDS staging [ch][17]
-// (transposition: the MFMA needs the pixel on the k index) and feed 4 k-groups x 4 MFMAs (2 co tiles x 2 tiles of
-// the 27 (tap, RGB) columns) into 4 accumulator tiles that live for the block's whole tile range; at the end the 8
-// waves are summed through LDS into one slab per block (wgrad_reduce_kernel adds the slabs in a fixed order).
+// also stages the 10 x 66 halo of conv1's input x (RGB padded to 4 channels) by LDS-DMA, double buffered.
+// The dgrad MFMAs take the dz2 halo as the A operand (rows = 16 pixels of one parity class) and the kernel as B
+// (columns = 16 conv1 channels), so a lane (r, q) ends up with dz1[pixels 4 q + 0..3][channel r]: register s of that
+// accumulator IS the B operand (k = pixel, j = channel) of the filter-gradient MFMA whose k-group s takes the pixels
+// {4 q + s}: no transposition, no LDS staging between the two products.  The A operand of that MFMA (rows = the 27
+// (tap, RGB) columns) is read from the x halo at the same permuted pixels.  4 accumulator tiles (2 column tiles x 2
+// channel tiles) live for the block's whole tile range; at the end the 8 waves are summed through LDS into one slab
+// per block (wgrad_reduce_kernel adds the slabs in a fixed order).
 // ------------------------------------------------------------------------------------------------
 struct FusedBottomParams {
   const float* dz;      // dz2 [G][N][Ho][Wo][48]
@@ -1526,6 +1529,9 @@ struct FusedBottomParams {
   int N, H, W, Ho, Wo;
   int tiles_x, tiles_y, tiles_per_group, S;
 };
+
+constexpr int FB_WP = 14, FB_PLANE = 176, FB_XW = 67, FB_XPIECES = (10 * FB_XW + 63) / 64;
+constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 * FB_XPIECES * 64) * 16;
 
 // CREAL = real input channels of conv1 (3: RGB padded to 4, the pad column is skipped; 4: RGB-D)
 template <int CREAL>
@@ -1541,23 +1547,24 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   // SQ_LDS_BANK_CONFLICT 49 % of the LDS cycles with 165), and the kernel row pitch WP gives (WP r + q) mod 16 distinct
   // over a group: 14 does (even phases for one q, odd for the other), 15 left one 2-way conflict per read.
   constexpr int PLANE_USED = HR * HC;                  // 165
-  constexpr int PLANE = (PLANE_USED + 15) / 16 * 16;   // 176
+  constexpr int PLANE = FB_PLANE;                      // 176
+  static_assert(PLANE >= PLANE_USED && PLANE % 16 == 0, "plane pitch");
   constexpr int HALO_USED = COQ * PLANE_USED;          // 1980 granules are loaded
   constexpr int HALO_F4 = COQ * PLANE;                 // 2112 granules per buffer
   constexpr int NLOAD = (HALO_USED + NT - 1) / NT;
-  constexpr int WP = 14;
+  constexpr int WP = FB_WP;
   constexpr int W_F4 = 9 * CIN * WP;                   // 4032
-  constexpr int XH = 10, XW = 66;                      // x halo of the 8 x 64 pixel tile (conv1: stride 1, pad 1)
-  constexpr int X_F4 = XH * XW;                        // 660 float4 (one pixel = RGB0)
-  constexpr int NXP = (X_F4 + 63) / 64;                // 11 DMA pieces
+  // x halo of the 8 x 64 pixel tile (conv1: stride 1, pad 1): 10 rows x 66 pixels, one pixel = RGB0 = one granule.
+  // Row pitch 67 pixels = 268 floats = 12 (mod 64): the 16 (tap, channel) offsets a ds_read_b32 spreads over its r
+  // lanes then span < 32 banks in each column tile and the pixel stride between q neighbours is 32 floats.
+  constexpr int XH = 10, XW = FB_XW, XUSED = 66;
+  constexpr int X_F4 = XH * XW;                        // 670 granules
+  constexpr int NXP = FB_XPIECES;                      // 11 DMA pieces
   constexpr int SX_F4 = NXP * 64;                      // 704 (padded)
-  constexpr int TP = 17;                               // staging pitch: [channel][16 pixels + 1]
-  constexpr int ST_F = CIN * TP;                       // 544 floats per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sW = reinterpret_cast<f32x4*>(smem);
   f32x4* sH = sW + W_F4;                               // 2 dz2 halo buffers
-  f32x4* sX = sH + 2 * HALO_F4;                        // x halo of the current tile
-  float* sT = reinterpret_cast<float*>(sX + SX_F4);    // 8 private transposition stagings
+  f32x4* sX = sH + 2 * HALO_F4;                        // 2 x halo buffers
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1612,8 +1619,8 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
       stage[i] = v ? *reinterpret_cast<const f32x4*>(zg + l_src[i]) : zero4;
     }
   };
-  // x halo: LDS-DMA, pieces wid and wid + 8 (11 pieces): lane -> halo pixel (hy, hx), row-major
-  auto dma_x = [&](int n_, int ty_, int tx_) {
+  // x halo: LDS-DMA, pieces wid and wid + 8 (11 pieces): lane -> halo pixel (hy, hx), row-major with pitch XW
+  auto dma_x = [&](int n_, int ty_, int tx_, f32x4* dst) {
     const int y0 = ty_ * 8 - 1, x0 = tx_ * 64 - 1;
     const float* xg = p.x + (long long)g * p.gs_x + (long long)n_ * p.H * p.W * 4;
 #pragma unroll
@@ -1623,9 +1630,9 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
         const int idx = k * 64 + lane;
         const int hy = idx / XW, hx = idx - hy * XW;
         const int iy = y0 + hy, ix = x0 + hx;
-        const bool v = idx < X_F4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const bool v = idx < X_F4 && hx < XUSED && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const float* src = v ? xg + ((long long)iy * p.W + ix) * 4 : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + k * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + k * 64), 16, 0, 0);
       }
     }
   };
@@ -1637,6 +1644,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     }
   }
   if (tile < tend) {
+    dma_x(n, ty, tx, sX);
     load_halo(n, ty, tx);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i)
@@ -1648,50 +1656,50 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   constexpr int NCOL = 9 * CREAL;
   constexpr int NJ = (NCOL + 15) / 16;
   int xoff[NJ];
-  float xkeep[NJ];
 #pragma unroll
   for (int tj = 0; tj < NJ; ++tj) {
     const int jj = 16 * tj + r;
     const int tap = jj / CREAL, c = jj - tap * CREAL;
-    const bool v = jj < NCOL;
     const int ky = tap / 3, kx = tap - ky * 3;
-    xoff[tj] = v ? ((ky * XW + kx) << 2) + c : 0;
-    xkeep[tj] = v ? 1.f : 0.f;
+    xoff[tj] = jj < NCOL ? ((ky * XW + kx) << 2) + c : 0;    // columns >= NCOL: any valid address, never stored
   }
-  f32x4 accw[2][NJ];
+  f32x4 accw[NJ][2];    // [column tile][channel tile]: lane (r, q) register k = dw1[column 16 j + 4 q + k][channel 16 t + r]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accw[i][j] = zero4;
-  f32x4 dbl[2] = {zero4, zero4};
-  float* st = sT + wid * ST_F;
+    for (int t = 0; t < 2; ++t) accw[j][t] = zero4;
+  float dbl[2] = {0.f, 0.f};
 
-  __syncthreads();
+  dma_barrier();
   const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;
   const int b_lane = r * WP + q;
   int buf = 0;
   for (; tile < tend; ++tile) {
     const bool more = tile + 1 < tend;
     int n2 = n, ty2 = ty, tx2 = tx;
-    dma_x(n, ty, tx);                      // this tile's x halo: needed in the epilogue (published by the mid barrier)
     if (more) {
       advance(n2, ty2, tx2);
+      dma_x(n2, ty2, tx2, sX + (buf ^ 1) * SX_F4);
       load_halo(n2, ty2, tx2);
     }
-    // ReluGrad mask of this wave's 4 x 2 output float4s: issued now, consumed in the epilogue
-    const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + r);
+    // ReluGrad mask of this wave's outputs in the accumulator layout: class c = (py, px), pixel j = 4 q + k of the
+    // wave's 16 class pixels (x = 2 (tx 32 + 16 half + j) + px), channel 16 t + r.  Issued now, consumed in the epilogue.
+    const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + 4 * q);
     f32x4 mk[4][2];
-    bool okc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int y = yb + (c >> 1), x = xb + (c & 1);
-      okc[c] = y < p.H && x < p.W;
+      // pixels outside the image contribute nothing to dw1: the load address is clamped, the value zeroed
+      const int y = yb + (c >> 1), yc = y < p.H ? y : p.H - 1;
+      const float* mrow = p.mask + (long long)g * p.gs_y + ((long long)n * p.H + yc) * p.W * CIN + r;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        mk[c][t] = zero4;                  // pixels outside the image contribute nothing to dw1
-        if (okc[c])
-          mk[c][t] = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_y +
-                                                     (((long long)n * p.H + y) * p.W + x) * CIN + 16 * t + 4 * q);
+      for (int k = 0; k < 4; ++k) {
+        const int x = xb + (c & 1) + 2 * k, xc = x < p.W ? x : p.W - 1;
+        const bool ok = y < p.H && x < p.W;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float m = mrow[xc * CIN + 16 * t];
+          mk[c][t][k] = ok ? m : 0.f;
+        }
       }
     }
     f32x4 acc[4][2];
@@ -1724,56 +1732,58 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
         const int tap = it / KB;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int c = (ky & 1) * 2 + (kx & 1);
+        // D[i = pixel][j = channel]: A = dz2 halo (i = pixel r, k = co quad q), B = kernel (k, j = channel r)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[t][s], a_cur[s], acc[c][t], 0, 0, 0);
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[t][s], acc[c][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       a_cur = a_nxt;
       b_cur[0] = b_nxt[0];
       b_cur[1] = b_nxt[1];
     }
-    dma_barrier();      // mid barrier: the x halo has landed (every wave waited for its own pieces)
-    // ---- epilogue: ReluGrad, then conv1's filter gradient class by class ------------------------------------
+    // ---- epilogue: ReluGrad, then conv1's filter gradient class by class, straight from the accumulators ----------
+    const float* xt = reinterpret_cast<const float*>(sX + buf * SX_F4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      // this wave's 16 pixels of class c = (py, px): (yb + py, 2 (tx*32 + 16 half + j) + px), j = 0..15 (lane r = j)
       const int py = c >> 1, px = c & 1;
       f32x4 v[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        v[t] = acc[c][t];
-        const f32x4 m = mk[c][t];
-        v[t].x = m.x > 0.f ? v[t].x : 0.f; v[t].y = m.y > 0.f ? v[t].y : 0.f;
-        v[t].z = m.z > 0.f ? v[t].z : 0.f; v[t].w = m.w > 0.f ? v[t].w : 0.f;
-        dbl[t] += v[t];
-        float* d = st + (16 * t + 4 * q) * TP + r;        // [channel][pixel]
-        d[0] = v[t].x; d[TP] = v[t].y; d[2 * TP] = v[t].z; d[3 * TP] = v[t].w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[t][k] = mk[c][t][k] > 0.f ? acc[c][t][k] : 0.f;
+          dbl[t] += v[t][k];
+        }
       }
-      if (p.dx && okc[c]) {
-        float* o = p.dx + (long long)g * p.gs_y + (((long long)n * p.H + yb + py) * p.W + xb + px) * CIN + 4 * q;
-        *reinterpret_cast<f32x4*>(o) = v[0];
-        *reinterpret_cast<f32x4*>(o + 16) = v[1];
+      if (p.dx) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int y = yb + py, x = xb + px + 2 * k;
+          if (y < p.H && x < p.W) {
+            float* o = p.dx + (long long)g * p.gs_y + (((long long)n * p.H + y) * p.W + x) * CIN + r;
+            o[0] = v[0][k];
+            o[16] = v[1][k];
+          }
+        }
       }
-      // same-wave LDS round trip (the compiler's lgkmcnt wait orders the reads behind the writes)
-      // k-group s: pixels j = 4 s + q;  A(i = co, k = pixel) from the staging, B(k = pixel, j = (tap, c)) from the x halo
-      const float* xs = reinterpret_cast<const float*>(sX) + (((2 * row + py) * XW + 2 * (16 * half + q) + px) << 2);
+      // k-group s: k index q <-> class pixel 4 q + s, i.e. tile pixel (2 row + py, 2 (16 half + 4 q + s) + px)
+      const float* xs = xt + (((2 * row + py) * XW + 2 * (16 * half + 4 * q) + px) << 2);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        float a[2], b[NJ];
+        float a[NJ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = st[(16 * i + r) * TP + 4 * s + q];
+        for (int j = 0; j < NJ; ++j) a[j] = xs[((2 * s) << 2) + xoff[j]];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = xs[((2 * 4 * s) << 2) + xoff[j]] * xkeep[j];
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) accw[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], accw[i][j], 0, 0, 0);
+          for (int t = 0; t < 2; ++t)
+            accw[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], v[t][s], accw[j][t], 0, 0, 0);
       }
     }
-    lds_barrier();      // end of tile: next dz2 halo complete; everyone is done with this buffer and with the x halo
+    dma_barrier();      // end of tile: next dz2 / x halos complete; everyone is done with this tile's buffers
     n = n2; ty = ty2; tx = tx2;
     buf ^= 1;
   }
@@ -1782,29 +1792,20 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   __syncthreads();
   f32x4* sR = sH;
   constexpr int NTL = 2 * NJ;
+  float* sD = reinterpret_cast<float*>(sR + 8 * NTL * 64);    // [wave 8][32 channels]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) sR[(wid * NTL + i * NJ + j) * 64 + lane] = accw[i][j];
-  // bias gradient: lane holds sums over its pixels for channels 16 t + 4 q .. +3; fold the 16 pixel lanes
+    for (int t = 0; t < 2; ++t) sR[(wid * NTL + j * 2 + t) * 64 + lane] = accw[j][t];
+  // bias gradient: lane (r, q) holds the sum over its pixels for channels r and 16 + r; fold the 4 q lanes
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-      dbl[t].x += __shfl_xor(dbl[t].x, off);
-      dbl[t].y += __shfl_xor(dbl[t].y, off);
-      dbl[t].z += __shfl_xor(dbl[t].z, off);
-      dbl[t].w += __shfl_xor(dbl[t].w, off);
-    }
+    dbl[t] += __shfl_xor(dbl[t], 16);
+    dbl[t] += __shfl_xor(dbl[t], 32);
   }
-  float* sD = sT;       // [wave 8][32 channels]
-  __syncthreads();      // (stagings are free; sR writes done)
-  if (r == 0) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float* d = sD + wid * 32 + 16 * t + 4 * q;
-      d[0] = dbl[t].x; d[1] = dbl[t].y; d[2] = dbl[t].z; d[3] = dbl[t].w;
-    }
+  if (q == 0) {
+    sD[wid * 32 + r] = dbl[0];
+    sD[wid * 32 + 16 + r] = dbl[1];
   }
   __syncthreads();
   for (int e = tid; e < NTL * 64; e += NT) {
@@ -1812,11 +1813,15 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     f32x4 s4 = sR[(0 * NTL + k) * 64 + ln];
 #pragma unroll
     for (int w = 1; w < 8; ++w) s4 += sR[(w * NTL + k) * 64 + ln];
-    const int i = k / NJ, j = k - i * NJ;
-    const int jj = 16 * j + (ln & 15), co = 16 * i + 4 * (ln >> 4);
-    if (jj < NCOL) {                       // slab layout [tap][4][32]: row tap * 4 + c
-      const int tap = jj / CREAL, c = jj - tap * CREAL;
-      *reinterpret_cast<f32x4*>(part + (tap * 4 + c) * 32 + co) = s4;
+    const int j = k >> 1, t = k & 1;
+    const int co = 16 * t + (ln & 15);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int jj = 16 * j + 4 * (ln >> 4) + kk;
+      if (jj < NCOL) {                     // slab layout [tap][4][32]: row tap * 4 + c
+        const int tap = jj / CREAL, c = jj - tap * CREAL;
+        part[(tap * 4 + c) * 32 + co] = s4[kk];
+      }
     }
   }
   if (CREAL == 3 && tid < 9 * 8) {         // the padding channel's rows of the slab: zeros
@@ -1856,7 +1861,7 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
   p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
   p.tiles_per_group = N * p.tiles_x * p.tiles_y;
   p.S = fused_bottom_S(groups);
-  const size_t lds = (size_t)(9 * 32 * 14 + 2 * 12 * 176 + 11 * 64) * 16 + (size_t)8 * 32 * 17 * 4;
+  const size_t lds = FB_LDS_BYTES;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<3>),
