@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_LIB: A/B builds side by side
@@ -21,6 +21,13 @@ class GeecoNativeError(RuntimeError):
 _P = c_void_p          # device (or host) pointer
 _PP = POINTER(c_void_p)
 _I, _L, _F = c_int, c_int64, c_float
+
+
+class SlabReduce(Structure):
+  """geeco_slab_reduce (include/geeco_hip.h): one pending slab sum of a filter-gradient kernel."""
+  _fields_ = [('part', c_void_p), ('dw', c_void_p), ('db', c_void_p), ('gs_dw', c_int64), ('gs_db', c_int64),
+              ('KC', c_int64), ('S', c_int32), ('Cout', c_int32), ('groups', c_int32), ('reserved', c_int32)]
+
 
 # symbol -> (restype, argtypes); mirrors include/geeco_hip.h one to one
 SIGNATURES = {
@@ -45,6 +52,11 @@ SIGNATURES = {
     'geeco_conv3x3_wgrad': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv2_dgrad_conv1_wgrad_ws_bytes': (_L, [_I]),
     'geeco_conv2_dgrad_conv1_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
+    'geeco_conv3x3_wgrad_partial': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P,
+                                         POINTER(SlabReduce)]),
+    'geeco_conv2_dgrad_conv1_wgrad_partial': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I,
+                                                   _P, _P, POINTER(SlabReduce)]),
+    'geeco_slab_reduce_batch': (_I, [POINTER(SlabReduce), _I, _P]),
     'geeco_transpose_hwio': (_I, [_P, _P, _I, _L, _L, _I, _I, _P]),
     'geeco_derive_conv_weights': (_I, [_I, _PP, _PP, POINTER(_I), POINTER(_I), POINTER(_L), _I, _L, _P, _P, _I, _I, _I, _L,
                                        _P]),

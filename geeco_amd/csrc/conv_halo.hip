@@ -1523,7 +1523,7 @@ struct FusedBottomParams {
   const float* w;       // conv2 kernel HWIO [G][9][32][48]
   const float* mask;    // y1 [G][N][H][W][32]
   const float* x;       // conv1 input [G][N][H][W][4]
-  float* part;          // [G][S][9*4*32 + 32]
+  float* part;          // [G][S][9*CREAL*32 + 32]
   float* dx;            // optional: also store dz1 (null in training)
   long long gs_dz, gs_w, gs_y, gs_x;
   int N, H, W, Ho, Wo;
@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   const int per = (p.tiles_per_group + p.S - 1) / p.S;
   int tile = split * per;
   const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
-  const long long slab = 9 * 4 * 32 + 32;
+  const long long slab = 9 * CREAL * 32 + 32;       // [tap][real channel][32] + bias
   float* part = p.part + ((long long)g * p.S + split) * slab;
   int n, ty, tx;
   {
@@ -1818,20 +1818,13 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int jj = 16 * j + 4 * (ln >> 4) + kk;
-      if (jj < NCOL) {                     // slab layout [tap][4][32]: row tap * 4 + c
-        const int tap = jj / CREAL, c = jj - tap * CREAL;
-        part[(tap * 4 + c) * 32 + co] = s4[kk];
-      }
+      if (jj < NCOL) part[jj * 32 + co] = s4[kk];     // slab layout [tap][real channel][32]: row jj
     }
-  }
-  if (CREAL == 3 && tid < 9 * 8) {         // the padding channel's rows of the slab: zeros
-    const int tap = tid >> 3, c4 = tid & 7;
-    *reinterpret_cast<f32x4*>(part + (tap * 4 + 3) * 32 + c4 * 4) = zero4;
   }
   if (tid < 32) {
     float s1 = 0.f;
     for (int w = 0; w < 8; ++w) s1 += sD[w * 32 + tid];
-    part[9 * 4 * 32 + tid] = s1;
+    part[NCOL * 32 + tid] = s1;
   }
 }
 
@@ -1882,9 +1875,24 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
   else
     hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel<4>, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
   GEECO_LAUNCH_CHECK();
-  geeco_launch_wgrad_reduce((const float*)ws, dw1, db1, gs_dw1, gs_db1, p.S, 9 * 4 * 32, 32, groups, s);
+  geeco_launch_wgrad_reduce((const float*)ws, dw1, db1, gs_dw1, gs_db1, p.S, 9 * real_channels * 32, 32, groups, s);
   GEECO_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, const float* y1, const float* x,
+                                                     float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
+                                                     int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
+                                                     int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
+                                                     void* stream, geeco_slab_reduce* pending) {
+  GEECO_CHECK_ARG(pending, "conv2_dgrad_conv1_wgrad_partial: null pending");
+  geeco_slab_reduce none = {};
+  *pending = none;
+  geeco_set_pending_reduce(pending);
+  const int rc = geeco_conv2_dgrad_conv1_wgrad(dz2, w2, y1, x, dw1, db1, dz1, groups, gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1,
+                                               gs_db1, N, H, W, real_channels, ws, stream);
+  geeco_set_pending_reduce(nullptr);
+  return rc;
 }
 
 int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,

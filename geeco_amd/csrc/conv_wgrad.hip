@@ -211,14 +211,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 // to the 4 waves of a block and combines them through LDS as ((w0 + w1) + (w2 + w3)), otherwise every
 // wave sums all S slabs of its own 256 elements.  KC and the slab pitch are multiples of 4.
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           float* __restrict__ db, long long gs_dw, long long gs_db,
-                                                           int S, long long KC, int Cout) {
-  __shared__ f32x4 sred[SPLIT ? 4 : 1][64];
-  const int g = blockIdx.y;
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw,
+                                                  float* __restrict__ db, long long gs_dw, long long gs_db, int S,
+                                                  long long KC, int Cout, int g, int bx, f32x4 (*sred)[64]) {
   const long long slab = KC + Cout;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long long i = SPLIT ? ((long long)blockIdx.x * 64 + lane) * 4 : ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long i = SPLIT ? ((long long)bx * 64 + lane) * 4 : ((long long)bx * 256 + threadIdx.x) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < slab) {
     const float* src = part + (long long)g * S * slab + i;
@@ -251,11 +249,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ db, long long gs_dw, long long gs_db,
+                                                           int S, long long KC, int Cout) {
+  __shared__ f32x4 sred[SPLIT ? 4 : 1][64];
+  wgrad_reduce_body<SPLIT>(part, dw, db, gs_dw, gs_db, S, KC, Cout, blockIdx.y, blockIdx.x, sred);
+}
+
+// few float4 columns and many slabs: split the slabs over the waves to get enough parallelism
+static bool reduce_splits_slabs(int S, long long KC, int Cout, int groups) {
+  return S >= 16 && (KC + Cout) / 4 * groups < 64 * 1024;
+}
+
+// Several pending slab sums in one launch (geeco_slab_reduce_batch): block -> (item, group, column block) through the
+// prefix table; every item is summed exactly as its own wgrad_reduce_kernel launch would.
+struct SlabReduceBatch {
+  geeco_slab_reduce it[GEECO_SLAB_REDUCE_MAX];
+  int first[GEECO_SLAB_REDUCE_MAX];   // first block of item i
+  int bpg[GEECO_SLAB_REDUCE_MAX];     // blocks per group
+  int split[GEECO_SLAB_REDUCE_MAX];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const SlabReduceBatch b) {
+  __shared__ f32x4 sred[4][64];
+  const int bid = blockIdx.x;
+  // static indices only (a dynamically indexed by-value argument would be copied to scratch)
+  geeco_slab_reduce it = b.it[0];
+  int first = 0, bpg = b.bpg[0], split = b.split[0];
+#pragma unroll
+  for (int i = 1; i < GEECO_SLAB_REDUCE_MAX; ++i) {
+    if (i < b.n && bid >= b.first[i]) {
+      it = b.it[i]; first = b.first[i]; bpg = b.bpg[i]; split = b.split[i];
+    }
+  }
+  const int lb = bid - first;
+  const int g = lb / bpg, bx = lb - g * bpg;
+  if (split)
+    wgrad_reduce_body<true>(it.part, it.dw, it.db, it.gs_dw, it.gs_db, it.S, it.KC, it.Cout, g, bx, sred);
+  else
+    wgrad_reduce_body<false>(it.part, it.dw, it.db, it.gs_dw, it.gs_db, it.S, it.KC, it.Cout, g, bx, sred);
+}
+
+// while a *_partial entry point runs on this thread, the slab sum is recorded here instead of launched
+static thread_local geeco_slab_reduce* tl_pending = nullptr;
+void geeco_set_pending_reduce(geeco_slab_reduce* p) { tl_pending = p; }
+
 void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
                                long long KC, int Cout, int groups, hipStream_t s) {
+  if (tl_pending) {
+    geeco_slab_reduce r = {part, dw, db, gs_dw, gs_db, KC, S, Cout, groups, 0};
+    *tl_pending = r;
+    return;
+  }
   const long long n4 = (KC + Cout) / 4;
-  // few float4 columns and many slabs: split the slabs over the waves to get enough parallelism
-  if (S >= 16 && n4 * groups < 64 * 1024) {
+  if (reduce_splits_slabs(S, KC, Cout, groups)) {
     dim3 rgrid((unsigned)cdiv64(n4, 64), (unsigned)groups);
     geeco_note_kernel("wgrad_reduce_kernel<true>");
     hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
@@ -264,6 +313,30 @@ void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long lon
     geeco_note_kernel("wgrad_reduce_kernel<false>");
     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, s, part, dw, db, gs_dw, gs_db, S, KC, Cout);
   }
+}
+
+extern "C" int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream) {
+  GEECO_CHECK_ARG(n >= 0 && n <= GEECO_SLAB_REDUCE_MAX && (items || n == 0), "slab_reduce_batch: n = %d (0..%d)", n,
+                  GEECO_SLAB_REDUCE_MAX);
+  SlabReduceBatch b = {};
+  long long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const geeco_slab_reduce& r = items[i];
+    if (r.S == 0) continue;             // nothing pending for this one
+    GEECO_CHECK_ARG(r.part && r.dw && r.S >= 1 && r.groups >= 1 && r.KC >= 4 && r.KC % 4 == 0 && r.Cout % 4 == 0,
+                    "slab_reduce_batch: item %d is malformed", i);
+    const int k = b.n++;
+    b.it[k] = r;
+    b.split[k] = reduce_splits_slabs(r.S, r.KC, r.Cout, r.groups) ? 1 : 0;
+    b.bpg[k] = (int)cdiv64((r.KC + r.Cout) / 4, b.split[k] ? 64 : 256);
+    b.first[k] = (int)blocks;
+    blocks += (long long)b.bpg[k] * r.groups;
+  }
+  if (b.n == 0) return 0;
+  geeco_note_kernel("wgrad_reduce_batch_kernel");
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+  GEECO_LAUNCH_CHECK();
+  return 0;
 }
 
 int64_t geeco_halo_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
@@ -365,4 +438,18 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
     GEECO_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int geeco_conv3x3_wgrad_partial(const float* x, const float* dz, float* dw, float* db, int groups,
+                                           int64_t gs_x, int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H,
+                                           int W, int Cin, int Cout, int stride, void* ws, void* stream,
+                                           geeco_slab_reduce* pending) {
+  GEECO_CHECK_ARG(pending, "conv3x3_wgrad_partial: null pending");
+  geeco_slab_reduce none = {};
+  *pending = none;
+  geeco_set_pending_reduce(pending);
+  const int rc = geeco_conv3x3_wgrad(x, dz, dw, db, groups, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws,
+                                     stream);
+  geeco_set_pending_reduce(nullptr);
+  return rc;
 }

@@ -12,6 +12,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 void geeco_set_error(const char* fmt, ...);
 // records the name of the kernel a dispatcher is about to launch (no-op unless a trace was begun on this thread)
 void geeco_note_kernel(const char* fmt, ...);
+// conv_wgrad.hip: while set (per thread), geeco_launch_wgrad_reduce records the slab sum there instead of launching it
+void geeco_set_pending_reduce(geeco_slab_reduce* p);
 
 #define GEECO_CHECK_ARG(cond, ...)              \
   do {                                          \

@@ -78,6 +78,8 @@ class ConvEncoderStack:
     # with the LDS-staged wgrad kernels every big launch fills the chip by itself and the two schedules measure the same
     # (3.717 vs 3.719 ms), so the simpler one is the default.  GEECO_MULTI_STREAM=1 restores the side streams.
     self.two_streams = os.environ.get('GEECO_MULTI_STREAM') is not None
+    # the filter-gradient kernels' slab sums of a backward part go into one launch (GEECO_NO_BATCH_REDUCE: one per layer)
+    self.batch_reduce = os.environ.get('GEECO_NO_BATCH_REDUCE') is None
     self.derived_version = -1
     # Only the FIRST training stack built on a store may rely on the post-Adam refresh of its derived
     # weight copies; eval / predict stacks and any later training stack (e.g. the model built for a
@@ -212,8 +214,9 @@ class ConvEncoderStack:
     ops.conv3x3_fwd_into(y, x, w, self._b(l), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(), Nf, L['H'], L['W'],
                          L['Cin'], L['Cout'], L['stride'], relu=True, ws=self.fws)
 
-  def launch_wgrad(self, l):
-    """Filter + bias gradient of layer l (skipped for conv1 when the encoder bottom is fused: launch_dgrad(1) does it)."""
+  def launch_wgrad(self, l, pending=None):
+    """Filter + bias gradient of layer l (skipped for conv1 when the encoder bottom is fused: launch_dgrad(1) does it).
+    ``pending`` (a list): the kernel's final slab sum is deferred to ``ops.slab_reduce_batch(pending)``."""
     G, Nf, L = self.G, self.Nf, self.layers[l]
     if l == 0 and self.fused_bottom:
       return
@@ -228,13 +231,15 @@ class ConvEncoderStack:
       dw, gs_dw = self.dw1p, self.dw1p[0].numel()
     else:
       dw, gs_dw = self._dw(l), self.gs_p
+    if l == 0 and self.pad1:
+      pending = None     # the padded gradient is repacked right below
     ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
-                           L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l])
+                           L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l], pending=pending)
     if l == 0 and self.pad1:
       for g in range(G):
         ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
 
-  def launch_dgrad(self, l):
+  def launch_dgrad(self, l, pending=None):
     """Input gradient of layer l >= 1 into dz[l-1] (ReluGrad of the layer below fused).  With the fused encoder
     bottom, l == 1 also produces conv1's filter / bias gradient: dz1 has no other consumer and stays on chip
     (805 MB less written and read again per step, one big launch less)."""
@@ -247,14 +252,10 @@ class ConvEncoderStack:
     x = self.acts[l - 1]
     dz = self.dz[l]
     if l == 1 and self.fused_bottom:
-      L0 = self.layers[0]
-      dw1, gs_dw1 = (self.dw1p, self.dw1p[0].numel()) if self.pad1 else (self._dw(0), self.gs_p)
-      ops.conv2_dgrad_conv1_wgrad_into(dw1, self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
-                                       x[0].numel(), self.x_in[0].numel(), gs_dw1, self.gs_p, Nf, L['H'], L['W'],
-                                       self.fws_fused, real_channels=self.Cin)
-      if self.pad1:
-        for g in range(G):
-          ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L0['Cout'])
+      # the kernel writes conv1's gradient in the variable's own [3][3][Cin][32] layout (no padded copy to repack)
+      ops.conv2_dgrad_conv1_wgrad_into(self._dw(0), self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
+                                       x[0].numel(), self.x_in[0].numel(), self.gs_p, self.gs_p, Nf, L['H'], L['W'],
+                                       self.fws_fused, real_channels=self.Cin, pending=pending)
       return
     wt = self.wt[l]
     dx = self.dz[l - 1]
@@ -272,6 +273,7 @@ class ConvEncoderStack:
     hi..lo (the data-parallel runner splits the chain at conv3 / conv2 to start the gradient exchange early)."""
     main = torch.cuda.current_stream()
     sides = self.sides if self.two_streams else []
+    pending = [] if self.batch_reduce else None   # slab sums of all layers of this part: one launch at the end
     for l in range(hi, lo - 1, -1):
       # wgrad(l) of the upper layers is off the critical path (the dgrad chain on `main`): it goes to a side
       # stream; the bottom layers' (LDS-halo kernels, one or two blocks per CU) stay on `main`
@@ -281,14 +283,16 @@ class ConvEncoderStack:
       if side is not None:
         side.wait_stream(main)          # dz[l] is ready
       with torch.cuda.stream(side if side is not None else main):
-        self.launch_wgrad(l)
+        self.launch_wgrad(l, pending)
       if l == 0:
         break   # conv1's input is data: no dgrad
-      self.launch_dgrad(l)
+      self.launch_dgrad(l, pending)
       if l == 1 and self.fused_bottom:
         break
     for side in sides:
       main.wait_stream(side)
+    if pending:
+      ops.slab_reduce_batch(pending)
 
   SPLIT = 2   # backward(part='upper') = layers 7..SPLIT, 'bottom' = SPLIT-1..0
 

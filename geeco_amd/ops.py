@@ -159,9 +159,29 @@ def conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
   return int(_lib().geeco_conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride))
 
 
-def conv3x3_wgrad_into(dw, db, x, dz, G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws):
-  check(_lib().geeco_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin,
-                                   Cout, stride, _p(ws), _stream()), 'geeco_conv3x3_wgrad')
+def conv3x3_wgrad_into(dw, db, x, dz, G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws, pending=None):
+  """``pending`` (a list): the kernel's final slab sum is not launched but appended to it (``slab_reduce_batch``
+  finishes all of them in one launch; ``ws`` must stay untouched until then)."""
+  if pending is None:
+    check(_lib().geeco_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin,
+                                     Cout, stride, _p(ws), _stream()), 'geeco_conv3x3_wgrad')
+    return
+  item = _native.SlabReduce()
+  check(_lib().geeco_conv3x3_wgrad_partial(_p(x), _p(dz), _p(dw), _p(db), G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin,
+                                           Cout, stride, _p(ws), _stream(), ctypes.byref(item)),
+        'geeco_conv3x3_wgrad_partial')
+  if item.S > 0:
+    pending.append(item)
+
+
+def slab_reduce_batch(pending):
+  """Finishes the deferred slab sums of ``pending`` (<= 8 per launch) and empties the list."""
+  MAX = 8
+  for i in range(0, len(pending), MAX):
+    chunk = pending[i:i + MAX]
+    arr = (_native.SlabReduce * len(chunk))(*chunk)
+    check(_lib().geeco_slab_reduce_batch(arr, len(chunk), _stream()), 'geeco_slab_reduce_batch')
+  del pending[:]
 
 
 def conv2_dgrad_conv1_wgrad_ws_bytes(G):
@@ -169,11 +189,21 @@ def conv2_dgrad_conv1_wgrad_ws_bytes(G):
 
 
 def conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x, G, gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, ws,
-                                 dz1=None, real_channels=3):
-  """Fused encoder bottom backward: conv2's input gradient + conv1's filter/bias gradient (dz1 stays on chip)."""
-  check(_lib().geeco_conv2_dgrad_conv1_wgrad(_p(dz2), _p(w2), _p(y1), _p(x), _p(dw1), _p(db1), _p(dz1), G, gs_dz2, gs_w2,
-                                             gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, real_channels, _p(ws), _stream()),
-        'geeco_conv2_dgrad_conv1_wgrad')
+                                 dz1=None, real_channels=3, pending=None):
+  """Fused encoder bottom backward: conv2's input gradient + conv1's filter/bias gradient (dz1 stays on chip).
+  dw1 [G][3][3][real_channels][32]; ``pending`` as for ``conv3x3_wgrad_into``."""
+  if pending is None:
+    check(_lib().geeco_conv2_dgrad_conv1_wgrad(_p(dz2), _p(w2), _p(y1), _p(x), _p(dw1), _p(db1), _p(dz1), G, gs_dz2,
+                                               gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, real_channels, _p(ws),
+                                               _stream()), 'geeco_conv2_dgrad_conv1_wgrad')
+    return
+  item = _native.SlabReduce()
+  check(_lib().geeco_conv2_dgrad_conv1_wgrad_partial(_p(dz2), _p(w2), _p(y1), _p(x), _p(dw1), _p(db1), _p(dz1), G,
+                                                     gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, real_channels,
+                                                     _p(ws), _stream(), ctypes.byref(item)),
+        'geeco_conv2_dgrad_conv1_wgrad_partial')
+  if item.S > 0:
+    pending.append(item)
 
 
 def transpose_hwio_into(wt, w, G, gs_w, gs_wt, Cin, Cout):

@@ -120,9 +120,9 @@ int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* db, i
 /* Encoder bottom, backward, fused (autodiff of graph.py:76-85 via estimator.py:243-244): conv2's input gradient and
  * conv1's filter/bias gradient in one kernel - conv1's input is data, so dz1 = (y1 > 0) * conv2_dgrad(dz2) has a
  * single consumer and never has to reach HBM:
- *   dw1[g][3][3][4][32], db1[g][32]  <-  x [G][N][H][W][4], dz1
- * real_channels = 3: x is RGB zero-padded to 4 channels (the pad channel's rows of dw1 are written as zeros);
- * real_channels = 4: RGB-D, all four input channels are real.
+ *   dw1[g][3][3][real_channels][32], db1[g][32]  <-  x [G][N][H][W][4], dz1
+ * real_channels = 3: x is RGB zero-padded to 4 channels; dw1 has the reference's own [3][3][3][32] layout (the pad
+ * channel has no row); real_channels = 4: RGB-D, all four input channels are real.
  * dz2 [G][N][H/2][W/2][48], w2 [G][3][3][32][48] (HWIO), y1 [G][N][H][W][32] (conv1's output: the ReLU mask).
  * dz1 (optional, may be NULL): if given, dz1 is ALSO written ([G][N][H][W][32], group stride gs_y1).
  * Shapes are fixed to the reference encoder's conv1 (4 -> 32, stride 1) / conv2 (32 -> 48, stride 2); H, W even.
@@ -133,6 +133,31 @@ int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float
                                   int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
                                   int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
                                   void* stream);
+
+/* Deferred slab sums.  The filter-gradient kernels leave one partial slab per split in `ws` and finish with a small
+ * slab-sum launch.  The *_partial forms skip that launch and describe it in *pending instead (pending->S == 0: the
+ * kernel wrote dw/db itself, nothing is pending); geeco_slab_reduce_batch then finishes up to GEECO_SLAB_REDUCE_MAX
+ * of them in ONE launch (a training step: one per part of the backward instead of one per layer).  The `ws` of a
+ * pending item must stay untouched until the batch has run.  Results are bitwise those of the plain calls (same
+ * summation order). */
+typedef struct geeco_slab_reduce {
+  const float* part;      /* [groups][S][KC + Cout] partial slabs */
+  float* dw;              /* [groups] x KC floats, group stride gs_dw */
+  float* db;              /* [groups] x Cout floats, group stride gs_db (may be NULL) */
+  int64_t gs_dw, gs_db, KC;
+  int32_t S, Cout, groups, reserved;
+} geeco_slab_reduce;
+#define GEECO_SLAB_REDUCE_MAX 8
+int geeco_conv3x3_wgrad_partial(const float* x, const float* dz, float* dw, float* db, int groups,
+                                int64_t gs_x, int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H,
+                                int W, int Cin, int Cout, int stride, void* ws, void* stream,
+                                geeco_slab_reduce* pending);
+int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, const float* y1, const float* x,
+                                          float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
+                                          int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
+                                          int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
+                                          void* stream, geeco_slab_reduce* pending);
+int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream);
 
 /* [G][9][A][B] -> [G][9][B][A] per-tap transpose (HWIO -> HWOI) feeding geeco_conv3x3_dgrad. */
 int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,
