@@ -1522,19 +1522,35 @@ struct FusedBottomParams {
   const float* dz;      // dz2 [G][N][Ho][Wo][48]
   const float* w;       // conv2 kernel HWIO [G][9][32][48]
   const float* mask;    // y1 [G][N][H][W][32]
+  const unsigned* bits; // BITS kernels: y1's ReLU sign bits [G][N][H][Wp] (geeco_conv1_fwd_relu_bits) instead of y1
+  long long gs_bits;
+  int Wp;
   const float* x;       // conv1 input [G][N][H][W][4]
   float* part;          // [G][S][9*CREAL*32 + 32]
   float* dx;            // optional: also store dz1 (null in training)
   long long gs_dz, gs_w, gs_y, gs_x;
   int N, H, W, Ho, Wo;
   int tiles_x, tiles_y, tiles_per_group, S;
+  unsigned long long* stamps;   // -DGEECO_STAMPS builds only (scripts/dev/fused_stamps.py)
 };
 
 constexpr int FB_WP = 14, FB_PLANE = 176, FB_XW = 67, FB_XPIECES = (10 * FB_XW + 63) / 64;
 constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 * FB_XPIECES * 64) * 16;
 
+#ifdef GEECO_STAMPS
+#define FSTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    if (lane == 0 && (wid & 3) == 0 && blockIdx.y == 0 && p.stamps && (i) < 64)                          \
+      p.stamps[((long long)blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define FSTAMP(i)
+#endif
+
 // CREAL = real input channels of conv1 (3: RGB padded to 4, the pad column is skipped; 4: RGB-D)
-template <int CREAL>
+// BITS: the ReluGrad mask comes as one sign-bit word per pixel (2 KB per tile) instead of y1 itself (64 KB per tile,
+// 805 MB per step: the kernel's largest read by far, and what its waves queue behind in the vector-memory pipe)
+template <int CREAL, bool BITS>
 __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const FusedBottomParams p) {
   constexpr int CIN = 32, COUT = 48;
   constexpr int NT = 512;
@@ -1609,15 +1625,16 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     l_src[i] = (hy * p.Wo + hx) * COUT + cq * 4;
   }
   f32x4 stage[NLOAD];
-  auto load_halo = [&](int n_, int ty_, int tx_) {
+  auto load_halo_i = [&](int i, int n_, int ty_, int tx_) {
     const int oy0 = ty_ * 4 - 1, ox0 = tx_ * 32 - 1;
     const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + oy0) * p.Wo + ox0) * COUT;
+    int oy = oy0 + l_hy[i], ox = ox0 + l_hx[i];
+    bool v = l_off[i] >= 0 && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+    stage[i] = v ? *reinterpret_cast<const f32x4*>(zg + l_src[i]) : zero4;
+  };
+  auto load_halo = [&](int n_, int ty_, int tx_) {
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      int oy = oy0 + l_hy[i], ox = ox0 + l_hx[i];
-      bool v = l_off[i] >= 0 && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
-      stage[i] = v ? *reinterpret_cast<const f32x4*>(zg + l_src[i]) : zero4;
-    }
+    for (int i = 0; i < NLOAD; ++i) load_halo_i(i, n_, ty_, tx_);
   };
   // x halo: LDS-DMA, pieces wid and wid + 8 (11 pieces): lane -> halo pixel (hy, hx), row-major with pitch XW
   auto dma_x = [&](int n_, int ty_, int tx_, f32x4* dst) {
@@ -1674,34 +1691,51 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;
   const int b_lane = r * WP + q;
   int buf = 0;
-  for (; tile < tend; ++tile) {
+  int tcount = 0;
+  for (; tile < tend; ++tile, ++tcount) {
     const bool more = tile + 1 < tend;
     int n2 = n, ty2 = ty, tx2 = tx;
-    if (more) {
-      advance(n2, ty2, tx2);
-      dma_x(n2, ty2, tx2, sX + (buf ^ 1) * SX_F4);
-      load_halo(n2, ty2, tx2);
-    }
+    FSTAMP(tcount < 10 ? 6 * tcount + 0 : 64);
+    if (more) advance(n2, ty2, tx2);
     // ReluGrad mask of this wave's outputs in the accumulator layout: class c = (py, px), pixel j = 4 q + k of the
-    // wave's 16 class pixels (x = 2 (tx 32 + 16 half + j) + px), channel 16 t + r.  Issued now, consumed in the epilogue.
+    // wave's 16 class pixels (x = 2 (tx 32 + 16 half + j) + px), channel 16 t + r.  A wave that issues all its global
+    // loads at the top of the tile sits in vector-memory back-pressure for ~4 k cycles (in-kernel timeline,
+    // scripts/dev/fused_stamps.py) while its SIMD's MFMA pipe idles, so every global load of the tile - the next
+    // dz2 halo, the next x halo, the 32 mask dwords - is issued from inside the MFMA loop, two per step.
+    // Pixels outside the image contribute nothing to dw1: the load address is clamped, the value zeroed by okf.
     const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + 4 * q);
-    f32x4 mk[4][2];
+    const float* mbase[2];
+    float oky[2];
+    int moff[2][4];
+    float okx[2][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      // pixels outside the image contribute nothing to dw1: the load address is clamped, the value zeroed
-      const int y = yb + (c >> 1), yc = y < p.H ? y : p.H - 1;
-      const float* mrow = p.mask + (long long)g * p.gs_y + ((long long)n * p.H + yc) * p.W * CIN + r;
+    for (int py = 0; py < 2; ++py) {
+      const int y = yb + py, yc = y < p.H ? y : p.H - 1;
+      mbase[py] = p.mask + (long long)g * p.gs_y + ((long long)n * p.H + yc) * p.W * CIN;
+      oky[py] = y < p.H ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int x = xb + (c & 1) + 2 * k, xc = x < p.W ? x : p.W - 1;
-        const bool ok = y < p.H && x < p.W;
+        const int x = xb + px + 2 * k, xc = x < p.W ? x : p.W - 1;
+        moff[px][k] = xc * CIN + r;
+        okx[px][k] = x < p.W ? 1.f : 0.f;
+      }
+    f32x4 mk[BITS ? 1 : 4][2];
+    // BITS: words of the 8 consecutive pixels x = xb .. xb + 7 of both rows (class pixel (px, k) <-> word px + 2 k)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 mb[2][2];
+    const unsigned* bbase[2];
+    if constexpr (BITS) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const float m = mrow[xc * CIN + 16 * t];
-          mk[c][t][k] = ok ? m : 0.f;
-        }
+      for (int py = 0; py < 2; ++py) {
+        const int y = yb + py, yc = y < p.H ? y : p.H - 1;
+        bbase[py] = p.bits + (long long)g * p.gs_bits + ((long long)n * p.H + yc) * p.Wp + xb;   // xb % 8 == 0, Wp % 8 == 0
       }
     }
+    float xv[4][4][NJ];       // x halo operands of the epilogue, prefetched during the last steps of the MFMA loop
+    const float* xt = reinterpret_cast<const float*>(sX + buf * SX_F4);
     f32x4 acc[4][2];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -1719,6 +1753,8 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
       b[1] = hB[(tap * CIN + 16) * WP + 4 * kb];
     };
     constexpr int NIT = 9 * KB;
+    __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
     frag(0, a_cur, b_cur);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1726,6 +1762,27 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
       if (more && it >= NIT - NLOAD - 4 && it < NIT - 4) {
         const int j = it - (NIT - NLOAD - 4);
         if (l_off[j] >= 0) hN[l_off[j]] = stage[j];
+      }
+      if (more && it < NLOAD) load_halo_i(it, n2, ty2, tx2);
+      if (more && it == NLOAD) dma_x(n2, ty2, tx2, sX + (buf ^ 1) * SX_F4);
+      if constexpr (BITS) {
+        if (it > NLOAD && it <= NLOAD + 4) {          // the tile's sign words: 4 x 16 B per lane
+          const int m = it - NLOAD - 1;
+          mb[m >> 1][m & 1] = *reinterpret_cast<const u32x4*>(bbase[m >> 1] + 4 * (m & 1));
+        }
+      } else if (it > NLOAD && it <= NLOAD + 16) {    // two mask dwords per step: (class, pixel k) of both channel tiles
+        const int m = it - NLOAD - 1, c = m >> 2, k = m & 3;
+        const float* mp = mbase[c >> 1] + moff[c & 1][k];
+        mk[c][0][k] = mp[0];
+        mk[c][1][k] = mp[16];
+      }
+      if (it >= NIT - 4) {                            // class c's x operands: k-group s <-> class pixel 4 q + s
+        const int c = it - (NIT - 4), py = c >> 1, px = c & 1;
+        const float* xs = xt + (((2 * row + py) * XW + 2 * (16 * half + 4 * q) + px) << 2);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) xv[c][s][j] = xs[((2 * s) << 2) + xoff[j]];
       }
       __builtin_amdgcn_sched_barrier(0);
       {
@@ -1744,18 +1801,32 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
       b_cur[0] = b_nxt[0];
       b_cur[1] = b_nxt[1];
     }
+    FSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
     // ---- epilogue: ReluGrad, then conv1's filter gradient class by class, straight from the accumulators ----------
-    const float* xt = reinterpret_cast<const float*>(sX + buf * SX_F4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int py = c >> 1, px = c & 1;
       f32x4 v[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int k = 0; k < 4; ++k) {
+        const float okf = okx[px][k] * oky[py];
+        if constexpr (BITS) {
+          // channel 16 t + r <-> bit (r & 3) * 8 + (r >> 2) + 4 t of the pixel's word; bfe_i32 gives 0 / all ones
+          const int wi = px + 2 * k;
+          const unsigned word = okf > 0.f ? mb[py][wi >> 2][wi & 3] : 0u;
+          const int sh = (r & 3) * 8 + (r >> 2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[t][k] = mk[c][t][k] > 0.f ? acc[c][t][k] : 0.f;
-          dbl[t] += v[t][k];
+          for (int t = 0; t < 2; ++t) {
+            const int keep = __builtin_amdgcn_sbfe((int)word, sh + 4 * t, 1);
+            v[t][k] = __int_as_float(__float_as_int(acc[c][t][k]) & keep);
+            dbl[t] += v[t][k];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            v[t][k] = mk[c][t][k] * okf > 0.f ? acc[c][t][k] : 0.f;
+            dbl[t] += v[t][k];
+          }
         }
       }
       if (p.dx) {
@@ -1770,20 +1841,18 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
         }
       }
       // k-group s: k index q <-> class pixel 4 q + s, i.e. tile pixel (2 row + py, 2 (16 half + 4 q + s) + px)
-      const float* xs = xt + (((2 * row + py) * XW + 2 * (16 * half + 4 * q) + px) << 2);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float a[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) a[j] = xs[((2 * s) << 2) + xoff[j]];
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            accw[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], v[t][s], accw[j][t], 0, 0, 0);
-      }
+            accw[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c][s][j], v[t][s], accw[j][t], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(tcount < 10 ? 6 * tcount + 3 : 64);
     dma_barrier();      // end of tile: next dz2 / x halos complete; everyone is done with this tile's buffers
+    FSTAMP(tcount < 10 ? 6 * tcount + 4 : 64);
     n = n2; ty = ty2; tx = tx2;
     buf ^= 1;
   }
@@ -1837,18 +1906,25 @@ extern "C" int64_t geeco_conv2_dgrad_conv1_wgrad_ws_bytes(int groups) {
   return (int64_t)groups * fused_bottom_S(groups) * (9 * 4 * 32 + 32) * 4;
 }
 
-extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float* y1, const float* x,
-                                             float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
-                                             int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
-                                             int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
-                                             void* stream) {
-  GEECO_CHECK_ARG(dz2 && w2 && y1 && x && dw1 && db1 && ws, "conv2_dgrad_conv1_wgrad: null pointer");
+template <int CREAL, bool BITS>
+static hipError_t fused_bottom_attr(size_t lds) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<CREAL, BITS>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+// y1 (ReluGrad mask = conv1's output) or y1_bits (its sign bits): exactly one is given
+static int fused_bottom_impl(const float* dz2, const float* w2, const float* y1, const uint32_t* y1_bits,
+                             const float* x, float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
+                             int64_t gs_w2, int64_t gs_y1, int64_t gs_bits, int64_t gs_x, int64_t gs_dw1, int64_t gs_db1,
+                             int N, int H, int W, int real_channels, void* ws, void* stream) {
+  GEECO_CHECK_ARG(dz2 && w2 && (y1 || y1_bits) && x && dw1 && db1 && ws, "conv2_dgrad_conv1_wgrad: null pointer");
   GEECO_CHECK_ARG(real_channels == 3 || real_channels == 4, "conv2_dgrad_conv1_wgrad: real_channels = %d (3 or 4)",
                   real_channels);
   GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
                   "conv2_dgrad_conv1_wgrad: H = %d, W = %d must be even", H, W);
   FusedBottomParams p = {};
   p.dz = dz2; p.w = w2; p.mask = y1; p.x = x; p.part = (float*)ws; p.dx = dz1;
+  p.bits = y1_bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W);
   p.gs_dz = gs_dz2; p.gs_w = gs_w2; p.gs_y = gs_y1; p.gs_x = gs_x;
   p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
   p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
@@ -1857,27 +1933,47 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, 
   const size_t lds = FB_LDS_BYTES;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dgrad_conv1_wgrad_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = fused_bottom_attr<3, false>(lds);
+    if (e == hipSuccess) e = fused_bottom_attr<4, false>(lds);
+    if (e == hipSuccess) e = fused_bottom_attr<3, true>(lds);
+    if (e == hipSuccess) e = fused_bottom_attr<4, true>(lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
       return (int)e;
     }
     attr_set = true;
   }
+#ifdef GEECO_STAMPS
+  if (!g_hstamps) (void)hipMalloc(&g_hstamps, 256 * 2 * 64 * 8);
+  (void)hipMemset(g_hstamps, 0, 256 * 2 * 64 * 8);
+  p.stamps = g_hstamps;
+#endif
   hipStream_t s = (hipStream_t)stream;
-  geeco_note_kernel("conv2_dgrad_conv1_wgrad_kernel<%d>", real_channels == 3 ? 3 : 4);
-  if (real_channels == 3)
-    hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel<3>, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
+  const dim3 grid((unsigned)p.S, (unsigned)groups);
+  const bool bits = y1_bits != nullptr;
+  geeco_note_kernel("conv2_dgrad_conv1_wgrad_kernel<%d, %s>", real_channels == 3 ? 3 : 4, bits ? "true" : "false");
+  if (real_channels == 3 && bits)
+    hipLaunchKernelGGL((conv2_dgrad_conv1_wgrad_kernel<3, true>), grid, dim3(512), lds, s, p);
+  else if (real_channels == 3)
+    hipLaunchKernelGGL((conv2_dgrad_conv1_wgrad_kernel<3, false>), grid, dim3(512), lds, s, p);
+  else if (bits)
+    hipLaunchKernelGGL((conv2_dgrad_conv1_wgrad_kernel<4, true>), grid, dim3(512), lds, s, p);
   else
-    hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel<4>, dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv2_dgrad_conv1_wgrad_kernel<4, false>), grid, dim3(512), lds, s, p);
   GEECO_LAUNCH_CHECK();
   geeco_launch_wgrad_reduce((const float*)ws, dw1, db1, gs_dw1, gs_db1, p.S, 9 * real_channels * 32, 32, groups, s);
   GEECO_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float* y1, const float* x,
+                                             float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
+                                             int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
+                                             int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
+                                             void* stream) {
+  GEECO_CHECK_ARG(y1, "conv2_dgrad_conv1_wgrad: null y1");
+  return fused_bottom_impl(dz2, w2, y1, nullptr, x, dw1, db1, dz1, groups, gs_dz2, gs_w2, gs_y1, 0, gs_x, gs_dw1, gs_db1,
+                           N, H, W, real_channels, ws, stream);
 }
 
 extern "C" int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, const float* y1, const float* x,
@@ -1885,13 +1981,30 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const flo
                                                      int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
                                                      int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
                                                      void* stream, geeco_slab_reduce* pending) {
-  GEECO_CHECK_ARG(pending, "conv2_dgrad_conv1_wgrad_partial: null pending");
+  GEECO_CHECK_ARG(pending && y1, "conv2_dgrad_conv1_wgrad_partial: null pending / y1");
   geeco_slab_reduce none = {};
   *pending = none;
   geeco_set_pending_reduce(pending);
-  const int rc = geeco_conv2_dgrad_conv1_wgrad(dz2, w2, y1, x, dw1, db1, dz1, groups, gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1,
-                                               gs_db1, N, H, W, real_channels, ws, stream);
+  const int rc = fused_bottom_impl(dz2, w2, y1, nullptr, x, dw1, db1, dz1, groups, gs_dz2, gs_w2, gs_y1, 0, gs_x, gs_dw1,
+                                   gs_db1, N, H, W, real_channels, ws, stream);
   geeco_set_pending_reduce(nullptr);
+  return rc;
+}
+
+extern "C" int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float* w2, const uint32_t* y1_bits,
+                                                  const float* x, float* dw1, float* db1, int groups, int64_t gs_dz2,
+                                                  int64_t gs_w2, int64_t gs_bits, int64_t gs_x, int64_t gs_dw1,
+                                                  int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
+                                                  void* stream, geeco_slab_reduce* pending) {
+  GEECO_CHECK_ARG(y1_bits, "conv2_dgrad_conv1_wgrad_bits: null y1_bits");
+  if (pending) {
+    geeco_slab_reduce none = {};
+    *pending = none;
+    geeco_set_pending_reduce(pending);
+  }
+  const int rc = fused_bottom_impl(dz2, w2, nullptr, y1_bits, x, dw1, db1, nullptr, groups, gs_dz2, gs_w2, 0, gs_bits, gs_x,
+                                   gs_dw1, gs_db1, N, H, W, real_channels, ws, stream);
+  if (pending) geeco_set_pending_reduce(nullptr);
   return rc;
 }
 
@@ -1955,8 +2068,9 @@ struct Conv1FwdParams {
   const float* w;       // [G][9][4][32]
   const float* bias;
   float* y;             // [G][N][H][W][32]
-  long long gs_x, gs_w, gs_b, gs_y;
-  int N, H, W, tiles_x, tiles_y, relu;
+  unsigned* bits;       // optional [G][N][H][Wp]: ReLU sign bits of y (geeco_conv1_fwd_relu_bits), else null
+  long long gs_x, gs_w, gs_b, gs_y, gs_bits;
+  int N, H, W, tiles_x, tiles_y, relu, Wp;
 };
 
 __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParams p) {
@@ -2028,6 +2142,7 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
     // wave w: rows 2w, 2w+1; 2 column halves => 4 strips of 16 pixels.  The 16 x 32 output strip is 2 KB
     // contiguous in NHWC memory: it is transposed through LDS so that each store instruction writes 1 KB
     // of consecutive bytes (lane l -> pixel l / 8 (+8), channel quad l % 8) instead of 16 separate 64 B pieces.
+    unsigned myword = 0;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int oyl = 2 * wid + (st >> 1), oxl0 = 16 * (st & 1);
@@ -2056,7 +2171,27 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
         const f32x4 v = *reinterpret_cast<const f32x4*>(so + px * 36 + c4 * 4);
         const int ox = x0 + oxl0 + px;
         if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4*>(yg + ((long long)oy * p.W + ox) * 32 + c4 * 4) = v;
+        if (p.bits) {
+          // sign bits of the 8 pixels this instruction stores: a compare IS a ballot (lane = 8 pixel + channel quad),
+          // so byte `pixel` of the four masks holds the bits of channels 4 c4 + {0, 1, 2, 3}; every lane assembles
+          // the word of pixel lane & 7 (bit (c & 3) * 8 + (c >> 2) <-> channel c) and the lanes 8 (2 st + h) + j keep
+          // it: after the four strips lane L holds the word of tile pixel (row 2 wid + (L >> 5), column L & 31)
+          const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f), bz = __ballot(v.z > 0.f),
+                                   bw = __ballot(v.w > 0.f);
+          // byte lane & 7 of each 64-bit mask, placed in byte 0 / 1 / 2 / 3: one v_perm_b32 each (a 64-bit shift by a
+          // per-lane amount is quarter rate and made this HBM-bound kernel 11 % slower)
+          const unsigned j = lane & 7;
+          const unsigned word = __builtin_amdgcn_perm((unsigned)(bx >> 32), (unsigned)bx, 0x0c0c0c00u | j) |
+                                __builtin_amdgcn_perm((unsigned)(by >> 32), (unsigned)by, 0x0c0c000cu | (j << 8)) |
+                                __builtin_amdgcn_perm((unsigned)(bz >> 32), (unsigned)bz, 0x0c000c0cu | (j << 16)) |
+                                __builtin_amdgcn_perm((unsigned)(bw >> 32), (unsigned)bw, 0x000c0c0cu | (j << 24));
+          if ((lane >> 3) == 2 * st + h) myword = word;
+        }
       }
+    }
+    if (p.bits) {         // one coalesced store per wave: 2 rows x 32 words
+      const int oy = y0 + 2 * wid + (lane >> 5), ox = x0 + (lane & 31);
+      if (oy < p.H && ox < p.W) p.bits[(long long)g * p.gs_bits + ((long long)n * p.H + oy) * p.Wp + ox] = myword;
     }
     if (!more) break;
     store_halo(buf ^ 1);
@@ -2066,14 +2201,36 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
   }
 }
 
+static int launch_conv1_fwd(const float* x, const float* w, const float* b, float* y, unsigned* bits, int groups,
+                            int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H, int W,
+                            int relu, hipStream_t stream);
+
 int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
                         int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                         int relu, hipStream_t stream, int* handled) {
   *handled = 0;
   static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !b || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
+  *handled = 1;
+  return launch_conv1_fwd(x, w, b, y, nullptr, groups, gs_x, gs_w, gs_b, gs_y, 0, N, H, W, relu, stream);
+}
+
+extern "C" int64_t geeco_relu_bits_pitch(int W) { return (int64_t)(W + 7) / 8 * 8; }
+
+extern "C" int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const float* b, float* y, uint32_t* bits,
+                                         int groups, int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y,
+                                         int64_t gs_bits, int N, int H, int W, void* stream) {
+  GEECO_CHECK_ARG(x && w && b && y && bits, "conv1_fwd_relu_bits: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv1_fwd_relu_bits: bad dims");
+  return launch_conv1_fwd(x, w, b, y, bits, groups, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H, W, 1, (hipStream_t)stream);
+}
+
+static int launch_conv1_fwd(const float* x, const float* w, const float* b, float* y, unsigned* bits, int groups,
+                            int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H, int W,
+                            int relu, hipStream_t stream) {
   Conv1FwdParams p = {};
   p.x = x; p.w = w; p.bias = b; p.y = y; p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
+  p.bits = bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W);
   p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.relu = relu;
   const int ntiles = N * p.tiles_x * p.tiles_y;
   static const int bpg = getenv("GEECO_C1_BLOCKS") ? atoi(getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)
@@ -2081,7 +2238,6 @@ int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y
   geeco_note_kernel("conv1_halo_fwd_kernel");
   hipLaunchKernelGGL(conv1_halo_fwd_kernel, grid, dim3(256), 0, stream, p);
   GEECO_LAUNCH_CHECK();
-  *handled = 1;
   return 0;
 }
 

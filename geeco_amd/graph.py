@@ -130,6 +130,11 @@ class ConvEncoderStack:
       self.fused_bottom = (os.environ.get('GEECO_NO_FUSED_BOTTOM') is None and os.environ.get('GEECO_NO_HALO') is None
                            and self.Cpad == 4 and self.Cin in (3, 4) and L0['Cout'] == 32 and L0['stride'] == 1
                            and L1['Cout'] == 48 and L1['stride'] == 2 and L1['H'] % 2 == 0 and L1['W'] % 2 == 0)
+      # the fused bottom only needs the SIGN of conv1's output (ReluGrad): conv1's forward writes one bit word per pixel
+      # next to y1 and the backward reads those 25 MB instead of the 805 MB of y1 (GEECO_NO_RELU_BITS: read y1)
+      self.relu_bits = self.fused_bottom and os.environ.get('GEECO_NO_RELU_BITS') is None
+      if self.relu_bits:
+        self.bits1 = torch.zeros(G, Nf, L0['H'], ops.relu_bits_pitch(L0['W']), dtype=torch.int32, device=dev)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
       self.dz = [None if (i == 0 and self.fused_bottom) else
                  ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]
@@ -211,6 +216,10 @@ class ConvEncoderStack:
       w, gs_w = self.w1p, self.w1p[0].numel()
     else:
       w, gs_w = self._w(l), self.gs_p
+    if l == 0 and self.training and self.relu_bits:
+      ops.conv1_fwd_relu_bits_into(y, self.bits1, x, w, self._b(0), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),
+                                   self.bits1[0].numel(), Nf, L['H'], L['W'])
+      return
     ops.conv3x3_fwd_into(y, x, w, self._b(l), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(), Nf, L['H'], L['W'],
                          L['Cin'], L['Cout'], L['stride'], relu=True, ws=self.fws)
 
@@ -253,6 +262,12 @@ class ConvEncoderStack:
     dz = self.dz[l]
     if l == 1 and self.fused_bottom:
       # the kernel writes conv1's gradient in the variable's own [3][3][Cin][32] layout (no padded copy to repack)
+      if self.relu_bits:
+        ops.conv2_dgrad_conv1_wgrad_bits_into(self._dw(0), self._db(0), dz, self._w(1), self.bits1, self.x_in, G,
+                                              dz[0].numel(), self.gs_p, self.bits1[0].numel(), self.x_in[0].numel(),
+                                              self.gs_p, self.gs_p, Nf, L['H'], L['W'], self.fws_fused,
+                                              real_channels=self.Cin, pending=pending)
+        return
       ops.conv2_dgrad_conv1_wgrad_into(self._dw(0), self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
                                        x[0].numel(), self.x_in[0].numel(), self.gs_p, self.gs_p, Nf, L['H'], L['W'],
                                        self.fws_fused, real_channels=self.Cin, pending=pending)

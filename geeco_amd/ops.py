@@ -25,7 +25,7 @@ def _stream():
 def _p(t):
   if t is None:
     return None
-  assert t.is_cuda and t.dtype in (torch.float32, torch.int64), (t.device, t.dtype)
+  assert t.is_cuda and t.dtype in (torch.float32, torch.int64, torch.int32), (t.device, t.dtype)
   return ctypes.c_void_p(t.data_ptr())
 
 
@@ -203,6 +203,28 @@ def conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x, G, gs_dz2, gs_w2, gs_
                                                      _p(ws), _stream(), ctypes.byref(item)),
         'geeco_conv2_dgrad_conv1_wgrad_partial')
   if item.S > 0:
+    pending.append(item)
+
+
+def relu_bits_pitch(W):
+  return int(_lib().geeco_relu_bits_pitch(W))
+
+
+def conv1_fwd_relu_bits_into(y, bits, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H, W):
+  """conv1 forward (4 -> 32, stride 1, bias, ReLU) that also writes y's sign bits (int32 [G][N][H][Wp])."""
+  check(_lib().geeco_conv1_fwd_relu_bits(_p(x), _p(w), _p(b), _p(y), _p(bits), G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H,
+                                         W, _stream()), 'geeco_conv1_fwd_relu_bits')
+
+
+def conv2_dgrad_conv1_wgrad_bits_into(dw1, db1, dz2, w2, y1_bits, x, G, gs_dz2, gs_w2, gs_bits, gs_x, gs_dw1, gs_db1, N, H,
+                                      W, ws, real_channels=3, pending=None):
+  """Fused encoder bottom backward with the ReluGrad mask given as conv1's sign bits."""
+  item = _native.SlabReduce() if pending is not None else None
+  check(_lib().geeco_conv2_dgrad_conv1_wgrad_bits(_p(dz2), _p(w2), _p(y1_bits), _p(x), _p(dw1), _p(db1), G, gs_dz2, gs_w2,
+                                                  gs_bits, gs_x, gs_dw1, gs_db1, N, H, W, real_channels, _p(ws), _stream(),
+                                                  ctypes.byref(item) if item is not None else None),
+        'geeco_conv2_dgrad_conv1_wgrad_bits')
+  if item is not None and item.S > 0:
     pending.append(item)
 
 

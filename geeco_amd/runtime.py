@@ -103,6 +103,10 @@ class TrainStepRunner:
         pos += n
     self.model.apply_gradients()
 
+  def _whole_step(self):
+    self._part1()
+    self._part3()
+
   def _exchange_early(self):
     if self.skip_allreduce:
       return []
@@ -116,7 +120,8 @@ class TrainStepRunner:
 
   def _capture(self):
     # the warm-up steps before this call already ran eagerly
-    parts = [self._part1, self._part3] if self.world == 1 else [self._part1, self._part2, self._part3]
+    # single process: the whole step is one graph (no inter-graph launch gap); data parallel: the exchange sits between
+    parts = [self._whole_step] if self.world == 1 else [self._part1, self._part2, self._part3]
     graphs = []
     with CAPTURE_LOCK:
       for fn in parts:
@@ -141,10 +146,9 @@ class TrainStepRunner:
     if self._graphs is not None:
       run = self._graphs
     else:
-      run = [self._part1, self._part3] if self.world == 1 else [self._part1, self._part2, self._part3]
+      run = [self._whole_step] if self.world == 1 else [self._part1, self._part2, self._part3]
     if self.world == 1:
       run[0]()
-      run[1]()
       return
     run[0]()
     works = self._exchange_early()         # on the communicator's stream, behind part 1, beside part 2

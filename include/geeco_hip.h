@@ -159,6 +159,22 @@ int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, con
                                           void* stream, geeco_slab_reduce* pending);
 int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream);
 
+/* ReLU sign bits as the ReluGrad mask of the encoder bottom.  conv1's output y1 (805 MB at the bench shape) is read by
+ * the fused bottom backward only for its sign; geeco_conv1_fwd_relu_bits is conv1's forward (4 -> 32, stride 1, bias,
+ * ReLU: geeco_conv3x3_fwd on those shapes) that ALSO writes one uint32 per pixel,
+ *   bits[g][n][y][x] (row pitch Wp = geeco_relu_bits_pitch(W) pixels, group stride gs_bits words),
+ *   bit (c & 3) * 8 + (c >> 2) set iff y1[g][n][y][x][c] > 0,
+ * and geeco_conv2_dgrad_conv1_wgrad_bits is geeco_conv2_dgrad_conv1_wgrad taking those words instead of y1 (no dz1
+ * output; pending: NULL = finish the slab sum, else defer it as geeco_conv2_dgrad_conv1_wgrad_partial does). */
+int64_t geeco_relu_bits_pitch(int W);
+int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const float* b, float* y, uint32_t* bits, int groups,
+                              int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H,
+                              int W, void* stream);
+int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float* w2, const uint32_t* y1_bits, const float* x,
+                                       float* dw1, float* db1, int groups, int64_t gs_dz2, int64_t gs_w2,
+                                       int64_t gs_bits, int64_t gs_x, int64_t gs_dw1, int64_t gs_db1, int N, int H, int W,
+                                       int real_channels, void* ws, void* stream, geeco_slab_reduce* pending);
+
 /* [G][9][A][B] -> [G][9][B][A] per-tap transpose (HWIO -> HWOI) feeding geeco_conv3x3_dgrad. */
 int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,
                          int Cout, void* stream);

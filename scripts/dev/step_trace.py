@@ -8,13 +8,18 @@ a, b = idx[which - 1] + 1, idx[which] + 1
 tot = 0
 t0 = int(rows[a]['Start_Timestamp'])
 agg = {}
+prev_end = None
+gaps = 0.0
 for r in rows[a:b]:
   d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
   tot += d
   name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
   g = (r.get('Grid_Size_X') or r.get('Grid_Size', '?'), r.get('Grid_Size_Y', ''), r.get('Grid_Size_Z', ''))
-  print('%9.1f us  @%8.1f  %-45s grid %s' % (d, (int(r['Start_Timestamp']) - t0) / 1e3, name[:45], g))
+  gap = (int(r['Start_Timestamp']) - prev_end) / 1e3 if prev_end is not None else 0.0
+  gaps += max(gap, 0.0)
+  prev_end = int(r['End_Timestamp'])
+  print('%9.1f us  @%8.1f  gap %5.1f  %-45s grid %s' % (d, (int(r['Start_Timestamp']) - t0) / 1e3, gap, name[:45], g))
   agg[name] = agg.get(name, 0) + d
-print('sum of kernel time %.1f us; wall %.1f us' % (tot, (int(rows[b - 1]['End_Timestamp']) - t0) / 1e3))
+print('sum of kernel time %.1f us; wall %.1f us; gaps between dispatches %.1f us' % (tot, (int(rows[b - 1]['End_Timestamp']) - t0) / 1e3, gaps))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
   print('%9.1f us %5.1f%%  %s' % (v, 100 * v / tot, k))

@@ -365,6 +365,59 @@ def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W, C):
         _close(dz1[g], dz1_ref[g], 2e-5, 2e-5, 'fused dz1, encoder %d' % g)
 
 
+@pytest.mark.parametrize('G,N,H,W,C', [(1, 2, 16, 64, 3), (3, 3, 24, 72, 3), (2, 3, 24, 72, 4)])
+def test_conv1_relu_bits_and_fused_bits(dev, G, N, H, W, C):
+  """conv1's forward with the sign-bit side output (bit (c & 3) * 8 + (c >> 2) of a pixel's word <-> y1[c] > 0) and the
+  fused bottom backward fed by those words: y1 equals the plain forward, the words equal the packed signs of y1, and
+  dw1 / db1 equal (bitwise) the gradients of the kernel that reads y1 itself; ragged tiles, row pitch > W."""
+  from geeco_amd import ops
+  r = np.random.default_rng(37)
+  x3 = r.standard_normal([G, N, H, W, C]).astype(np.float32)
+  x4 = np.concatenate([x3, np.zeros([G, N, H, W, 4 - C], np.float32)], -1)
+  w1 = np.zeros([G, 3, 3, 4, 32], np.float32)
+  w1[:, :, :, :C] = (r.standard_normal([G, 3, 3, C, 32]) / np.sqrt(9 * C)).astype(np.float32)
+  b1 = (0.1 * r.standard_normal([G, 32])).astype(np.float32)
+  w2 = (r.standard_normal([G, 3, 3, 32, 48]) / np.sqrt(288)).astype(np.float32)
+  dz2 = r.standard_normal([G, N, H // 2, W // 2, 48]).astype(np.float32)
+  xd, w1d, b1d = torch.tensor(x4, device=dev), torch.tensor(w1, device=dev), torch.tensor(b1, device=dev)
+  w2d, dz2d = torch.tensor(w2, device=dev), torch.tensor(dz2, device=dev)
+  Wp = ops.relu_bits_pitch(W)
+  assert Wp % 8 == 0 and W <= Wp < W + 8
+  y_plain = torch.empty(G, N, H, W, 32, device=dev)
+  ws = torch.empty(ops.conv3x3_fwd_ws_bytes(G, N, H, W, 4, 32, 1) // 4 + 4, device=dev)
+  ops.conv3x3_fwd_into(y_plain, xd, w1d, b1d, G, xd[0].numel(), w1d[0].numel(), 32, y_plain[0].numel(), N, H, W, 4, 32, 1,
+                       relu=True, ws=ws)
+  y = torch.empty_like(y_plain)
+  bits = torch.full((G, N, H, Wp), -1, dtype=torch.int32, device=dev)
+  ops.conv1_fwd_relu_bits_into(y, bits, xd, w1d, b1d, G, xd[0].numel(), w1d[0].numel(), 32, y[0].numel(), bits[0].numel(),
+                               N, H, W)
+  torch.cuda.synchronize()
+  assert torch.equal(y, y_plain)
+  c = np.arange(32)
+  weights = (1 << ((c & 3) * 8 + (c >> 2))).astype(np.int64)
+  want = ((y.cpu().numpy() > 0).astype(np.int64) * weights).sum(-1).astype(np.uint32)
+  got = bits.cpu().numpy().view(np.uint32)
+  assert np.array_equal(got[..., :W], want)
+  assert (got[..., W:] == 0xFFFFFFFF).all()                  # the row padding is never written
+  wsf = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, device=dev)
+  outs = []
+  for use_bits in (False, True):
+    dw1 = torch.full((G, 9, C, 32), float('nan'), device=dev)
+    db1 = torch.full((G, 32), float('nan'), device=dev)
+    if use_bits:
+      names = ops.kernel_trace(lambda: ops.conv2_dgrad_conv1_wgrad_bits_into(
+          dw1, db1, dz2d, w2d, bits, xd, G, dz2d[0].numel(), w2d[0].numel(), bits[0].numel(), xd[0].numel(), dw1[0].numel(),
+          32, N, H, W, wsf, real_channels=C))
+      assert names[0] == 'conv2_dgrad_conv1_wgrad_kernel<%d, true>' % C, names
+    else:
+      ops.conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2d, w2d, y, xd, G, dz2d[0].numel(), w2d[0].numel(), y[0].numel(),
+                                       xd[0].numel(), dw1[0].numel(), 32, N, H, W, wsf, real_channels=C)
+    torch.cuda.synchronize()
+    outs.append((dw1, db1))
+  assert not torch.isnan(outs[1][0]).any()
+  assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_slab_reduce_batch_bitwise(dev):
   """Deferred slab sums (geeco_conv3x3_wgrad_partial x 4 layers of different kernels + the fused bottom, then ONE
   geeco_slab_reduce_batch) give bitwise the gradients of the plain calls."""
