@@ -962,9 +962,10 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
       if (tid + NT * i < DZ_F4) dbsum[i] += sZ[buf * DZ_F4 + tid + NT * i];
     const float* hx = reinterpret_cast<const float*>(sH + buf * HALO_F4) + (2 * strip) * ROW * 4;
     const float* hz = reinterpret_cast<const float*>(sZ + buf * DZ_F4) + za_lane;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float a[TI], b[9];
+    // operands of k-group s + 1 are read while the 27 MFMAs of k-group s run (the reads of a group issued right in
+    // front of its MFMAs left ~150 cycles of LDS latency exposed four times per tile)
+    float a_cur[TI], b_cur[9], a_nxt[TI], b_nxt[9];
+    auto frag = [&](int s, float (&a)[TI], float (&b)[9]) {
 #pragma unroll
       for (int i = 0; i < TI; ++i) a[i] = hz[(4 * s) * COUT + 16 * i];
 #pragma unroll
@@ -972,12 +973,22 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
         const int ky = t / 3, kx = t - ky * 3;
         b[t] = hx[(ky * ROW + 4 * s * 16) * 4 + xe[kx]];
       }
+    };
+    frag(0, a_cur, b_cur);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) frag(s + 1, a_nxt, b_nxt);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < TI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t], acc[t][i], 0, 0, 0);
+        for (int i = 0; i < TI; ++i)
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], b_cur[t], acc[t][i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
     }
     dma_barrier();
     n = n2; ty = ty2; tx = tx2;
@@ -1522,9 +1533,9 @@ struct FusedBottomParams {
   const float* dz;      // dz2 [G][N][Ho][Wo][48]
   const float* w;       // conv2 kernel HWIO [G][9][32][48]
   const float* mask;    // y1 [G][N][H][W][32]
-  const unsigned* bits; // BITS kernels: y1's ReLU sign bits [G][N][H][Wp] (geeco_conv1_fwd_relu_bits) instead of y1
+  const unsigned* bits; // BITS kernels: y1's ReLU sign bits [G][N][Hp][Wp] (geeco_conv1_fwd_relu_bits) instead of y1
   long long gs_bits;
-  int Wp;
+  int Wp, Hp;
   const float* x;       // conv1 input [G][N][H][W][4]
   float* part;          // [G][S][9*CREAL*32 + 32]
   float* dx;            // optional: also store dz1 (null in training)
@@ -1534,6 +1545,18 @@ struct FusedBottomParams {
   unsigned long long* stamps;   // -DGEECO_STAMPS builds only (scripts/dev/fused_stamps.py)
 };
 
+#ifndef FB_PRIO
+#define FB_PRIO 0     // dev: s_setprio experiments (1: upper half waves high, 2: alternating per step, 3: high while issuing MFMAs)
+#endif
+#ifndef FB_INTERLEAVE
+#define FB_INTERLEAVE 0   // 1: the filter-gradient work of a finished class rides inside the MFMA loop (measured: 484 vs 466 us); 0: after the loop
+#endif
+#ifndef FB_ABL
+#define FB_ABL 0      // dev ablations (wrong results): 1 = no LDS fragment reads, 2 = no global loads / halo stores
+#endif
+#ifndef FB_SCHED
+#define FB_SCHED 0    // dev: 0 = fenced groups (reads | MFMAs), 1 = compiler's own schedule, 2 = fenced steps, interleaved inside
+#endif
 constexpr int FB_WP = 14, FB_PLANE = 176, FB_XW = 67, FB_XPIECES = (10 * FB_XW + 63) / 64;
 constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 * FB_XPIECES * 64) * 16;
 
@@ -1552,6 +1575,7 @@ constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 
 // 805 MB per step: the kernel's largest read by far, and what its waves queue behind in the vector-memory pipe)
 template <int CREAL, bool BITS>
 __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const FusedBottomParams p) {
+  constexpr bool INTERLEAVE = FB_INTERLEAVE != 0;
   constexpr int CIN = 32, COUT = 48;
   constexpr int NT = 512;
   constexpr int COQ = COUT / 4;
@@ -1620,8 +1644,10 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     int idx = tid + NT * i;
     int pix = idx / COQ, cq = idx - pix * COQ;
     int hy = pix / HC, hx = pix - hy * HC;
-    l_hy[i] = (short)hy; l_hx[i] = (short)hx;
-    l_off[i] = (idx < HALO_USED) ? cq * PLANE + hy * HC + hx : -1;
+    // lanes beyond the halo: row marker that fails every bounds test (they fetch the zero page) and a pad granule of
+    // plane 0 as their LDS slot, so that neither the load nor the store needs a predicate
+    l_hy[i] = (short)(idx < HALO_USED ? hy : 30000); l_hx[i] = (short)hx;
+    l_off[i] = (idx < HALO_USED) ? cq * PLANE + hy * HC + hx : PLANE_USED + (tid & 7);
     l_src[i] = (hy * p.Wo + hx) * COUT + cq * 4;
   }
   f32x4 stage[NLOAD];
@@ -1629,8 +1655,8 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     const int oy0 = ty_ * 4 - 1, ox0 = tx_ * 32 - 1;
     const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + oy0) * p.Wo + ox0) * COUT;
     int oy = oy0 + l_hy[i], ox = ox0 + l_hx[i];
-    bool v = l_off[i] >= 0 && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
-    stage[i] = v ? *reinterpret_cast<const f32x4*>(zg + l_src[i]) : zero4;
+    bool v = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+    stage[i] = *reinterpret_cast<const f32x4*>(v ? zg + l_src[i] : g_zero_page);     // TF SAME zero padding
   };
   auto load_halo = [&](int n_, int ty_, int tx_) {
 #pragma unroll
@@ -1664,8 +1690,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     dma_x(n, ty, tx, sX);
     load_halo(n, ty, tx);
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i)
-      if (l_off[i] >= 0) sH[l_off[i]] = stage[i];
+    for (int i = 0; i < NLOAD; ++i) sH[l_off[i]] = stage[i];
   }
 
   // conv1 wgrad: only the 9 * CREAL real (tap, channel) columns are computed (RGB: the 4th input channel is
@@ -1687,6 +1712,22 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     for (int t = 0; t < 2; ++t) accw[j][t] = zero4;
   float dbl[2] = {0.f, 0.f};
 
+  // BITS: sign words of the wave's outputs, 8 consecutive pixels x = xb .. xb + 7 of both rows (class pixel (px, k) <->
+  // word px + 2 k); those of the NEXT tile are loaded during the current tile's MFMA loop (mbn)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 mb[2][2], mbn[2][2];
+  // (rows and columns of the word array are padded to whole tiles and the padding is zero: no bounds logic here)
+  auto bits_row = [&](int py, int n_, int ty_, int tx_) {
+    const int y = 2 * (ty_ * 4 + row) + py;
+    return p.bits + (long long)g * p.gs_bits + ((long long)n_ * p.Hp + y) * p.Wp + 2 * (tx_ * 32 + 16 * half + 4 * q);
+  };
+  if constexpr (BITS) {
+    if (tile < tend) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        mb[m >> 1][m & 1] = *reinterpret_cast<const u32x4*>(bits_row(m >> 1, n, ty, tx) + 4 * (m & 1));
+    }
+  }
   dma_barrier();
   const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;
   const int b_lane = r * WP + q;
@@ -1723,18 +1764,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
         okx[px][k] = x < p.W ? 1.f : 0.f;
       }
     f32x4 mk[BITS ? 1 : 4][2];
-    // BITS: words of the 8 consecutive pixels x = xb .. xb + 7 of both rows (class pixel (px, k) <-> word px + 2 k)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 mb[2][2];
-    const unsigned* bbase[2];
-    if constexpr (BITS) {
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        const int y = yb + py, yc = y < p.H ? y : p.H - 1;
-        bbase[py] = p.bits + (long long)g * p.gs_bits + ((long long)n * p.H + yc) * p.Wp + xb;   // xb % 8 == 0, Wp % 8 == 0
-      }
-    }
-    float xv[4][4][NJ];       // x halo operands of the epilogue, prefetched during the last steps of the MFMA loop
+    float xv[4][4][NJ];       // x halo operands of the filter-gradient MFMAs, read one step before their class starts
     const float* xt = reinterpret_cast<const float*>(sX + buf * SX_F4);
     f32x4 acc[4][2];
 #pragma unroll
@@ -1745,87 +1775,50 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     const f32x4* hB = sW + b_lane;
     f32x4* hN = sH + (buf ^ 1) * HALO_F4;
     f32x4 a_cur, b_cur[2], a_nxt, b_nxt[2];
+    // Tap order: the parity classes of the input gradient complete one after the other - class 3 = (odd, odd) has the
+    // centre tap only, class 2 taps 3 / 5, class 1 taps 1 / 7, class 0 the four corners - so that (BITS) the
+    // filter-gradient work of a finished class (mask, 16 MFMAs, 4 per step) runs inside the loop next to the taps of
+    // the following class instead of as a latency-bound tail after it.
+    constexpr int ORDER[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
     auto frag = [&](int it, f32x4& a, f32x4 (&b)[2]) {
-      const int tap = it / KB, kb = it - tap * KB;
+      const int tap = ORDER[it / KB], kb = it % KB;
       const int ky = tap / 3, kx = tap - ky * 3;
       a = hA[kb * 4 * PLANE - (ky >> 1) * HC - (kx >> 1)];
       b[0] = hB[(tap * CIN) * WP + 4 * kb];
       b[1] = hB[(tap * CIN + 16) * WP + 4 * kb];
     };
     constexpr int NIT = 9 * KB;
-    __builtin_amdgcn_sched_barrier(0);
-    FSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
-    frag(0, a_cur, b_cur);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      if (it + 1 < NIT) frag(it + 1, a_nxt, b_nxt);
-      if (more && it >= NIT - NLOAD - 4 && it < NIT - 4) {
-        const int j = it - (NIT - NLOAD - 4);
-        if (l_off[j] >= 0) hN[l_off[j]] = stage[j];
-      }
-      if (more && it < NLOAD) load_halo_i(it, n2, ty2, tx2);
-      if (more && it == NLOAD) dma_x(n2, ty2, tx2, sX + (buf ^ 1) * SX_F4);
-      if constexpr (BITS) {
-        if (it > NLOAD && it <= NLOAD + 4) {          // the tile's sign words: 4 x 16 B per lane
-          const int m = it - NLOAD - 1;
-          mb[m >> 1][m & 1] = *reinterpret_cast<const u32x4*>(bbase[m >> 1] + 4 * (m & 1));
-        }
-      } else if (it > NLOAD && it <= NLOAD + 16) {    // two mask dwords per step: (class, pixel k) of both channel tiles
-        const int m = it - NLOAD - 1, c = m >> 2, k = m & 3;
-        const float* mp = mbase[c >> 1] + moff[c & 1][k];
-        mk[c][0][k] = mp[0];
-        mk[c][1][k] = mp[16];
-      }
-      if (it >= NIT - 4) {                            // class c's x operands: k-group s <-> class pixel 4 q + s
-        const int c = it - (NIT - 4), py = c >> 1, px = c & 1;
-        const float* xs = xt + (((2 * row + py) * XW + 2 * (16 * half + 4 * q) + px) << 2);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) xv[c][s][j] = xs[((2 * s) << 2) + xoff[j]];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const int tap = it / KB;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int c = (ky & 1) * 2 + (kx & 1);
-        // D[i = pixel][j = channel]: A = dz2 halo (i = pixel r, k = co quad q), B = kernel (k, j = channel r)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[t][s], acc[c][t], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      a_cur = a_nxt;
-      b_cur[0] = b_nxt[0];
-      b_cur[1] = b_nxt[1];
-    }
-    FSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
-    // ---- epilogue: ReluGrad, then conv1's filter gradient class by class, straight from the accumulators ----------
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    f32x4 vv[2];              // dz1 of the class in flight: lane (r, q) register k = pixel 4 q + k, channel 16 t + r
+    auto class_x = [&](int c) {         // class c's x operands: k-group s <-> class pixel 4 q + s
       const int py = c >> 1, px = c & 1;
-      f32x4 v[2];
+      const float* xs = xt + (((2 * row + py) * XW + 2 * (16 * half + 4 * q) + px) << 2);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xv[c][s][j] = xs[((2 * s) << 2) + xoff[j]];
+    };
+    auto class_mask = [&](int c) {      // ReluGrad of class c's finished accumulators -> vv, bias gradient
+      const int py = c >> 1, px = c & 1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float okf = okx[px][k] * oky[py];
         if constexpr (BITS) {
           // channel 16 t + r <-> bit (r & 3) * 8 + (r >> 2) + 4 t of the pixel's word; bfe_i32 gives 0 / all ones
+          // (pixels outside the image have zero words: they contribute nothing to dw1)
           const int wi = px + 2 * k;
-          const unsigned word = okf > 0.f ? mb[py][wi >> 2][wi & 3] : 0u;
+          const unsigned word = mb[py][wi >> 2][wi & 3];
           const int sh = (r & 3) * 8 + (r >> 2);
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const int keep = __builtin_amdgcn_sbfe((int)word, sh + 4 * t, 1);
-            v[t][k] = __int_as_float(__float_as_int(acc[c][t][k]) & keep);
-            dbl[t] += v[t][k];
+            vv[t][k] = __int_as_float(__float_as_int(acc[c][t][k]) & keep);
+            dbl[t] += vv[t][k];
           }
         } else {
+          const float okf = okx[px][k] * oky[py];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            v[t][k] = mk[c][t][k] * okf > 0.f ? acc[c][t][k] : 0.f;
-            dbl[t] += v[t][k];
+            vv[t][k] = mk[c][t][k] * okf > 0.f ? acc[c][t][k] : 0.f;
+            dbl[t] += vv[t][k];
           }
         }
       }
@@ -1835,19 +1828,130 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
           const int y = yb + py, x = xb + px + 2 * k;
           if (y < p.H && x < p.W) {
             float* o = p.dx + (long long)g * p.gs_y + (((long long)n * p.H + y) * p.W + x) * CIN + r;
-            o[0] = v[0][k];
-            o[16] = v[1][k];
+            o[0] = vv[0][k];
+            o[16] = vv[1][k];
           }
         }
       }
-      // k-group s: k index q <-> class pixel 4 q + s, i.e. tile pixel (2 row + py, 2 (16 half + 4 q + s) + px)
+    };
+    auto class_mfma = [&](int c, int s) {   // k-group s of class c: k index q <-> class pixel 4 q + s
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int t = 0; t < 2; ++t)
+          accw[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c][s][j], vv[t][s], accw[j][t], 0, 0, 0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
+    frag(0, a_cur, b_cur);
+#if FB_PRIO == 1
+    if (half) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#if FB_PRIO == 2
+      if (half) { if (it & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      else      { if (it & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#elif FB_PRIO == 3
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#if (FB_ABL & 1) == 0
+      if (it + 1 < NIT) frag(it + 1, a_nxt, b_nxt);
+#else
+      a_nxt = a_cur; b_nxt[0] = b_cur[0]; b_nxt[1] = b_cur[1];
+#endif
+#if (FB_ABL & 2) == 0
+      if (more && it >= NIT - NLOAD - 4 && it < NIT - 4) {
+        const int j = it - (NIT - NLOAD - 4);
+        hN[l_off[j]] = stage[j];
+      }
+      if (more && it < NLOAD) load_halo_i(it, n2, ty2, tx2);
+      if (more && it == NLOAD) dma_x(n2, ty2, tx2, sX + (buf ^ 1) * SX_F4);
+#endif
+      if constexpr (BITS) {
+#if (FB_ABL & 2) == 0
+        if (more && it > NLOAD && it <= NLOAD + 4) {  // the NEXT tile's sign words: 4 x 16 B per lane
+          const int m = it - NLOAD - 1;
+          mbn[m >> 1][m & 1] = *reinterpret_cast<const u32x4*>(bits_row(m >> 1, n2, ty2, tx2) + 4 * (m & 1));
+        }
+#endif
+        if constexpr (INTERLEAVE) {
+          if (it == 1 * KB - 1) class_x(3);           // one step before each class's filter-gradient work starts
+          if (it == 3 * KB - 1) class_x(2);
+          if (it == 5 * KB - 1) class_x(1);
+          if (it == NIT - 1) class_x(0);
+        } else if (it >= NIT - 4) {
+          class_x(it - (NIT - 4));
+        }
+      } else {
+        if (it > NLOAD && it <= NLOAD + 16) {         // two mask dwords per step: (class, pixel k) of both channel tiles
+          const int m = it - NLOAD - 1, c = m >> 2, k = m & 3;
+          const float* mp = mbase[c >> 1] + moff[c & 1][k];
+          mk[c][0][k] = mp[0];
+          mk[c][1][k] = mp[16];
+        }
+        if (it >= NIT - 4) class_x(it - (NIT - 4));
+      }
+#if FB_SCHED == 0
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#if FB_PRIO == 3
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      {
+        const int tap = ORDER[it / KB];
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int c = (ky & 1) * 2 + (kx & 1);
+        // D[i = pixel][j = channel]: A = dz2 halo (i = pixel r, k = co quad q), B = kernel (k, j = channel r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            accw[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c][s][j], v[t][s], accw[j][t], 0, 0, 0);
+            acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[t][s], acc[c][t], 0, 0, 0);
+      }
+      if constexpr (BITS && INTERLEAVE) {
+        // classes 3 / 2 / 1 are complete after taps 1 / 3 / 5 of ORDER: their filter gradient rides on the next 4 steps
+        constexpr int S3 = 1 * KB, S2 = 3 * KB, S1 = 5 * KB;
+        if (it == S3) class_mask(3);
+        if (it >= S3 && it < S3 + 4) class_mfma(3, it - S3);
+        if (it == S2) class_mask(2);
+        if (it >= S2 && it < S2 + 4) class_mfma(2, it - S2);
+        if (it == S1) class_mask(1);
+        if (it >= S1 && it < S1 + 4) class_mfma(1, it - S1);
+      }
+#if FB_SCHED == 2
+      // one MFMA, then at most one LDS op, one global load and two VALU ops in its shadow
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#endif
+#if FB_SCHED != 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      a_cur = a_nxt;
+      b_cur[0] = b_nxt[0];
+      b_cur[1] = b_nxt[1];
+    }
+#if FB_PRIO != 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    FSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
+    // ---- the classes still open: ReluGrad, then conv1's filter gradient straight from the accumulators ----------
+#pragma unroll
+    for (int c = (BITS && INTERLEAVE ? 0 : 3); c >= 0; --c) {     // same class order (3, 2, 1, 0) everywhere: bitwise equal sums
+      class_mask(c);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) class_mfma(c, s);
+    }
+    if constexpr (BITS) {
+      if (more) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) mb[m >> 1][m & 1] = mbn[m >> 1][m & 1];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     FSTAMP(tcount < 10 ? 6 * tcount + 3 : 64);
@@ -1924,7 +2028,7 @@ static int fused_bottom_impl(const float* dz2, const float* w2, const float* y1,
                   "conv2_dgrad_conv1_wgrad: H = %d, W = %d must be even", H, W);
   FusedBottomParams p = {};
   p.dz = dz2; p.w = w2; p.mask = y1; p.x = x; p.part = (float*)ws; p.dx = dz1;
-  p.bits = y1_bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W);
+  p.bits = y1_bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W); p.Hp = (int)geeco_relu_bits_rows(H);
   p.gs_dz = gs_dz2; p.gs_w = gs_w2; p.gs_y = gs_y1; p.gs_x = gs_x;
   p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
   p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
@@ -2068,9 +2172,9 @@ struct Conv1FwdParams {
   const float* w;       // [G][9][4][32]
   const float* bias;
   float* y;             // [G][N][H][W][32]
-  unsigned* bits;       // optional [G][N][H][Wp]: ReLU sign bits of y (geeco_conv1_fwd_relu_bits), else null
+  unsigned* bits;       // optional [G][N][Hp][Wp]: ReLU sign bits of y (geeco_conv1_fwd_relu_bits), else null
   long long gs_x, gs_w, gs_b, gs_y, gs_bits;
-  int N, H, W, tiles_x, tiles_y, relu, Wp;
+  int N, H, W, tiles_x, tiles_y, relu, Wp, Hp;
 };
 
 __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParams p) {
@@ -2191,7 +2295,7 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
     }
     if (p.bits) {         // one coalesced store per wave: 2 rows x 32 words
       const int oy = y0 + 2 * wid + (lane >> 5), ox = x0 + (lane & 31);
-      if (oy < p.H && ox < p.W) p.bits[(long long)g * p.gs_bits + ((long long)n * p.H + oy) * p.Wp + ox] = myword;
+      if (oy < p.H && ox < p.W) p.bits[(long long)g * p.gs_bits + ((long long)n * p.Hp + oy) * p.Wp + ox] = myword;
     }
     if (!more) break;
     store_halo(buf ^ 1);
@@ -2215,7 +2319,8 @@ int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y
   return launch_conv1_fwd(x, w, b, y, nullptr, groups, gs_x, gs_w, gs_b, gs_y, 0, N, H, W, relu, stream);
 }
 
-extern "C" int64_t geeco_relu_bits_pitch(int W) { return (int64_t)(W + 7) / 8 * 8; }
+extern "C" int64_t geeco_relu_bits_pitch(int W) { return (int64_t)(W + 63) / 64 * 64; }
+extern "C" int64_t geeco_relu_bits_rows(int H) { return (int64_t)(H + 7) / 8 * 8; }
 
 extern "C" int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const float* b, float* y, uint32_t* bits,
                                          int groups, int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y,
@@ -2230,7 +2335,7 @@ static int launch_conv1_fwd(const float* x, const float* w, const float* b, floa
                             int relu, hipStream_t stream) {
   Conv1FwdParams p = {};
   p.x = x; p.w = w; p.bias = b; p.y = y; p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
-  p.bits = bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W);
+  p.bits = bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W); p.Hp = (int)geeco_relu_bits_rows(H);
   p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.relu = relu;
   const int ntiles = N * p.tiles_x * p.tiles_y;
   static const int bpg = getenv("GEECO_C1_BLOCKS") ? atoi(getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)

@@ -134,7 +134,7 @@ class ConvEncoderStack:
       # next to y1 and the backward reads those 25 MB instead of the 805 MB of y1 (GEECO_NO_RELU_BITS: read y1)
       self.relu_bits = self.fused_bottom and os.environ.get('GEECO_NO_RELU_BITS') is None
       if self.relu_bits:
-        self.bits1 = torch.zeros(G, Nf, L0['H'], ops.relu_bits_pitch(L0['W']), dtype=torch.int32, device=dev)
+        self.bits1 = torch.zeros(G, Nf, ops.relu_bits_rows(L0['H']), ops.relu_bits_pitch(L0['W']), dtype=torch.int32, device=dev)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
       self.dz = [None if (i == 0 and self.fused_bottom) else
                  ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]

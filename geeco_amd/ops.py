@@ -210,8 +210,12 @@ def relu_bits_pitch(W):
   return int(_lib().geeco_relu_bits_pitch(W))
 
 
+def relu_bits_rows(H):
+  return int(_lib().geeco_relu_bits_rows(H))
+
+
 def conv1_fwd_relu_bits_into(y, bits, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H, W):
-  """conv1 forward (4 -> 32, stride 1, bias, ReLU) that also writes y's sign bits (int32 [G][N][H][Wp])."""
+  """conv1 forward (4 -> 32, stride 1, bias, ReLU) that also writes y's sign bits (int32 [G][N][Hp][Wp], zero-filled once by the caller)."""
   check(_lib().geeco_conv1_fwd_relu_bits(_p(x), _p(w), _p(b), _p(y), _p(bits), G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H,
                                          W, _stream()), 'geeco_conv1_fwd_relu_bits')
 

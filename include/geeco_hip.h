@@ -162,11 +162,13 @@ int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream)
 /* ReLU sign bits as the ReluGrad mask of the encoder bottom.  conv1's output y1 (805 MB at the bench shape) is read by
  * the fused bottom backward only for its sign; geeco_conv1_fwd_relu_bits is conv1's forward (4 -> 32, stride 1, bias,
  * ReLU: geeco_conv3x3_fwd on those shapes) that ALSO writes one uint32 per pixel,
- *   bits[g][n][y][x] (row pitch Wp = geeco_relu_bits_pitch(W) pixels, group stride gs_bits words),
- *   bit (c & 3) * 8 + (c >> 2) set iff y1[g][n][y][x][c] > 0,
- * and geeco_conv2_dgrad_conv1_wgrad_bits is geeco_conv2_dgrad_conv1_wgrad taking those words instead of y1 (no dz1
+ *   bits[g][n][y][x]: Hp = geeco_relu_bits_rows(H) rows of Wp = geeco_relu_bits_pitch(W) words per image (whole 8 x 64
+ *   tiles), group stride gs_bits words; bit (c & 3) * 8 + (c >> 2) set iff y1[g][n][y][x][c] > 0.
+ * Only the words of real pixels are written: the caller zero-fills the array ONCE, the backward relies on zero padding.
+ * geeco_conv2_dgrad_conv1_wgrad_bits is geeco_conv2_dgrad_conv1_wgrad taking those words instead of y1 (no dz1
  * output; pending: NULL = finish the slab sum, else defer it as geeco_conv2_dgrad_conv1_wgrad_partial does). */
 int64_t geeco_relu_bits_pitch(int W);
+int64_t geeco_relu_bits_rows(int H);
 int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const float* b, float* y, uint32_t* bits, int groups,
                               int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H,
                               int W, void* stream);

@@ -381,14 +381,14 @@ def test_conv1_relu_bits_and_fused_bits(dev, G, N, H, W, C):
   dz2 = r.standard_normal([G, N, H // 2, W // 2, 48]).astype(np.float32)
   xd, w1d, b1d = torch.tensor(x4, device=dev), torch.tensor(w1, device=dev), torch.tensor(b1, device=dev)
   w2d, dz2d = torch.tensor(w2, device=dev), torch.tensor(dz2, device=dev)
-  Wp = ops.relu_bits_pitch(W)
-  assert Wp % 8 == 0 and W <= Wp < W + 8
+  Wp, Hp = ops.relu_bits_pitch(W), ops.relu_bits_rows(H)
+  assert Wp % 64 == 0 and W <= Wp < W + 64 and Hp % 8 == 0 and H <= Hp < H + 8
   y_plain = torch.empty(G, N, H, W, 32, device=dev)
   ws = torch.empty(ops.conv3x3_fwd_ws_bytes(G, N, H, W, 4, 32, 1) // 4 + 4, device=dev)
   ops.conv3x3_fwd_into(y_plain, xd, w1d, b1d, G, xd[0].numel(), w1d[0].numel(), 32, y_plain[0].numel(), N, H, W, 4, 32, 1,
                        relu=True, ws=ws)
   y = torch.empty_like(y_plain)
-  bits = torch.full((G, N, H, Wp), -1, dtype=torch.int32, device=dev)
+  bits = torch.zeros(G, N, Hp, Wp, dtype=torch.int32, device=dev)     # zero-filled once: the padding stays zero
   ops.conv1_fwd_relu_bits_into(y, bits, xd, w1d, b1d, G, xd[0].numel(), w1d[0].numel(), 32, y[0].numel(), bits[0].numel(),
                                N, H, W)
   torch.cuda.synchronize()
@@ -397,8 +397,8 @@ def test_conv1_relu_bits_and_fused_bits(dev, G, N, H, W, C):
   weights = (1 << ((c & 3) * 8 + (c >> 2))).astype(np.int64)
   want = ((y.cpu().numpy() > 0).astype(np.int64) * weights).sum(-1).astype(np.uint32)
   got = bits.cpu().numpy().view(np.uint32)
-  assert np.array_equal(got[..., :W], want)
-  assert (got[..., W:] == 0xFFFFFFFF).all()                  # the row padding is never written
+  assert np.array_equal(got[:, :, :H, :W], want)
+  assert (got[:, :, :, W:] == 0).all() and (got[:, :, H:] == 0).all()      # the padding is never written
   wsf = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, device=dev)
   outs = []
   for use_bits in (False, True):
