@@ -817,6 +817,7 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
 // slab; wgrad_reduce_kernel (conv_wgrad.hip) sums the slabs in a fixed order.
 // ------------------------------------------------------------------------------------------------
 struct HaloWgradParams {
+  unsigned long long* stamps;   // -DGEECO_STAMPS builds only (scripts/dev/wgrad2_stamps.py)
   const float* x;
   const float* dz;
   float* part;               // [G][S][9*CIN*COUT + COUT]
@@ -827,6 +828,22 @@ struct HaloWgradParams {
   int S;                     // blocks (slabs) per group
 };
 
+#ifdef GEECO_STAMPS
+#define WSTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    if (lane == 0 && (wid & 3) == 0 && wid < 8 && blockIdx.y == 0 && p.stamps && (i) < 64)               \
+      p.stamps[((long long)blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define WSTAMP(i)
+#endif
+
+// Measured on this kernel (in-kernel timeline, scripts/dev/wgrad2_stamps.py; tile = 9.8 k cycles, its 216 MFMAs per SIMD
+// = 6.9 k): the seven DMA pieces per wave hold both waves of a SIMD in the vector-memory queue for 1.3 - 2 k cycles per
+// tile; issued from inside the MFMA loop they lengthen the loop by the same amount; without any DMA the tile takes
+// 8.1 k; with four extra loader waves doing all DMA the MFMA waves finish after 7.3 k and then wait at the tile barrier
+// until 10.8 k for the 51 KB to land.  The CU ingests ~5 B/clk here (3.1 TB/s chip-wide for 1.2 GB, all of it
+// compulsory): the kernel is bound by that, not by where the loads sit.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgradParams p) {
   constexpr int NT = 512;
@@ -949,13 +966,16 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
   }
   const int za_lane = (16 * strip + q) * COUT + r;
   int buf = 0;
-  for (; tile < tend; ++tile) {
+  [[maybe_unused]] int tcount = 0;
+  for (; tile < tend; ++tile, ++tcount) {
     const bool more = tile + 1 < tend;
     int n2 = n, ty2 = ty, tx2 = tx;
+    WSTAMP(tcount < 10 ? 6 * tcount + 0 : 64);
     if (more) {
       advance(n2, ty2, tx2);
       dma_tile(buf ^ 1, n2, ty2, tx2);                    // lands behind this tile's MFMAs
     }
+    WSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
     // bias gradient: every thread adds its share of the dz tile (NDZ float4 reads per tile)
 #pragma unroll
     for (int i = 0; i < NDZ; ++i)
@@ -974,6 +994,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
         b[t] = hx[(ky * ROW + 4 * s * 16) * 4 + xe[kx]];
       }
     };
+    WSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
     frag(0, a_cur, b_cur);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -990,7 +1011,9 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
 #pragma unroll
       for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
     }
+    WSTAMP(tcount < 10 ? 6 * tcount + 3 : 64);
     dma_barrier();
+    WSTAMP(tcount < 10 ? 6 * tcount + 4 : 64);
     n = n2; ty = ty2; tx = tx2;
     buf ^= 1;
   }
@@ -1058,12 +1081,18 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
     p.tiles_x = cdiv(p.Wo, 16); p.tiles_y = cdiv(p.Ho, 4);
     p.tiles_per_group = N * p.tiles_x * p.tiles_y;
     p.S = halo_wgrad_S(groups);
+#ifdef GEECO_STAMPS
+    if (!g_hstamps) (void)hipMalloc(&g_hstamps, 256 * 2 * 64 * 8);
+    (void)hipMemset(g_hstamps, 0, 256 * 2 * 64 * 8);
+    p.stamps = g_hstamps;
+#endif
     constexpr int HALO_F4 = ((9 * 17 * 16 + 63) / 64) * 64;
     const size_t lds = (size_t)(2 * HALO_F4 + 2 * 4 * 16 * 12) * 16;
     static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_wgrad_kernel<32, 48>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+
       if (e != hipSuccess) {
         geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
         return (int)e;
