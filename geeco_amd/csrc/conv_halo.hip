@@ -73,6 +73,20 @@ extern "C" int geeco_debug_dump_halo_stamps(const char* path) {
 
 __device__ float g_zero_page[64];   // source of LDS-DMA lanes that fall outside the image (TF SAME zero padding)
 
+// Output stores of the big layers.  Bit SITE of GEECO_NT selects a non-temporal store (the tensor is far larger than the
+// caches and streams to HBM: measured on conv1's 805 MB output, 207 -> 190 us); sites: 0 conv1 fwd, 1 conv2 fwd,
+// 2 conv3 fwd, 3 conv3 dgrad.
+#ifndef GEECO_NT
+#define GEECO_NT 1
+#endif
+template <int SITE>
+__device__ __forceinline__ void stream_store(float* dst, const f32x4& v) {
+  if constexpr ((GEECO_NT >> SITE) & 1)
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+  else
+    *reinterpret_cast<f32x4*>(dst) = v;
+}
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
         const int m = lane + 64 * jj;
         const int px = m / C4, c4 = m - px * C4;
         const f32x4 v = so[px * OP + c4];
-        if (oy < p.Ho && tx * TW + px < p.Wo) *reinterpret_cast<f32x4*>(yo + m * 4) = v;
+        if (oy < p.Ho && tx * TW + px < p.Wo) stream_store<1>(yo + m * 4, v);
       }
     }
     HSTAMP(tcount < 10 ? 6 * tcount + 5 : 64);
@@ -741,7 +755,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
         if (p.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (ok) *reinterpret_cast<f32x4*>(yo + i * 16 + 4 * q) = v;
+        if (ok) stream_store<2>(yo + i * 16 + 4 * q, v);
       }
     }
     if (!more) break;
@@ -1509,7 +1523,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
         const f32x4 m = mk[c][t];
         v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
         v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-        *reinterpret_cast<f32x4*>(o + 16 * t) = v;
+        stream_store<3>(o + 16 * t, v);
       }
     }
     if (!more) break;
@@ -2303,7 +2317,7 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
         const int px = 8 * h + (lane >> 3), c4 = lane & 7;
         const f32x4 v = *reinterpret_cast<const f32x4*>(so + px * 36 + c4 * 4);
         const int ox = x0 + oxl0 + px;
-        if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4*>(yg + ((long long)oy * p.W + ox) * 32 + c4 * 4) = v;
+        if (oy < p.H && ox < p.W) stream_store<0>(yg + ((long long)oy * p.W + ox) * 32 + c4 * 4, v);
         if (p.bits) {
           // sign bits of the 8 pixels this instruction stores: a compare IS a ballot (lane = 8 pixel + channel quad),
           // so byte `pixel` of the four masks holds the bits of channels 4 c4 + {0, 1, 2, 3}; every lane assembles
