@@ -44,6 +44,10 @@ struct HaloFwdParams {
   int tiles_per_group;       // N*tiles_y*tiles_x
   int relu;
   unsigned long long* stamps;   // -DGEECO_STAMPS builds only: [block][2 waves][64] s_memtime timeline
+  // optional ReLU sign fields of y (geeco_conv2_fwd_relu_fields): [G][N][fHp][fWp][4] uint16, field q bit 4 i + j <-> channel 16 i + 4 q + j
+  unsigned short* fields;
+  long long gs_fields;
+  int fHp, fWp;
 };
 
 #ifdef GEECO_STAMPS
@@ -502,6 +506,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
       // writes 1 KiB of consecutive bytes instead of 16 separate 64-byte pieces (in-kernel timeline: the three
       // piecewise stores held the wave ~3.6k cycles per tile - the kernel's critical path).
       f32x4* so = sO + strip * 16 * OP;
+      unsigned field = 0;        // sign bits of this lane's 4 TI outputs (after the ReLU: > 0 <=> non-zero bits)
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         f32x4 v = acc[i] + red[(strip * TI + i) * 64 + lane] + bias_r[i];
@@ -509,6 +514,17 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         so[r * OP + 4 * i + q] = v;
+        if (p.fields) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) field |= min(__float_as_uint(v[j]), 1u) << (4 * i + j);
+        }
+      }
+      if (p.fields) {
+        // the consumer (conv3's input-gradient kernel) holds the same (pixel r, quad q) layout in its accumulators, so
+        // every lane stores its own 16-bit field: no cross-lane assembly; 16 pixels x 4 fields = 128 consecutive bytes
+        const int fy = ty * TH + strip, fx = tx * TW + r;
+        if (fy < p.Ho && fx < p.Wo)
+          p.fields[(long long)g * p.gs_fields + (((long long)n * p.fHp + fy) * p.fWp + fx) * 4 + q] = (unsigned short)field;
       }
       // same-wave LDS round trip: the compiler's lgkmcnt wait orders the reads behind the writes
       const int oy = ty * TH + strip;
@@ -1139,6 +1155,9 @@ struct HaloDgradParams {
   const float* dz;
   const float* w;      // HWIO [G][9][CIN][COUT]
   const float* mask;   // [G][N][H][W][CIN] or null
+  const unsigned short* fields;   // FIELDS kernels: sign fields of the mask tensor (see HaloFwdParams) instead of mask
+  long long gs_fields;
+  int fHp, fWp;
   float* dx;
   long long gs_dz, gs_w, gs_dx;
   int N, H, W, Ho, Wo;
@@ -1343,7 +1362,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_dgrad_kernel(const HaloDg
 // Why it pays: the gather GEMM re-fetches dz once per tap beyond L2 (PMC: 1.1 GB per conv3 launch for a
 // 100 MB tensor) and runs at the per-CU miss rate of the vector memory path; here dz is read once.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool FIELDS>
 __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const HaloDgradParams p) {
   constexpr int NT = 512;
   constexpr int NCH = COUT / 16;                       // chunks (steps) per tile
@@ -1450,18 +1469,26 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
     if (more) advance(g2, n2, ty2, tx2);
     // ReluGrad mask of this wave's 4 x TCI output float4s: issued now, consumed in the epilogue
     const int yb = 2 * (ty * 4 + row), xb = 2 * (tx * 32 + 16 * half + r);
-    f32x4 mk[4][TCI];
+    // FIELDS: one 16-bit sign field per class pixel (this lane's quad q: bit 4 t + j <-> channel 16 t + 4 q + j) instead
+    // of TCI float4 of the activation itself: 4 two-byte loads per tile and lane instead of 12 sixteen-byte ones (the
+    // field array is padded to whole tiles, so no bounds logic on the load)
+    f32x4 mk[FIELDS ? 1 : 4][TCI];
+    unsigned short mf[4];
     bool okc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int y = yb + (c >> 1), x = xb + (c & 1);
       okc[c] = y < p.H && x < p.W;
+      if constexpr (FIELDS) {
+        mf[c] = p.fields[(long long)g * p.gs_fields + (((long long)n * p.fHp + y) * p.fWp + x) * 4 + q];
+      } else {
 #pragma unroll
-      for (int t = 0; t < TCI; ++t) {
-        mk[c][t] = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (p.mask && okc[c])
-          mk[c][t] = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_dx +
-                                                     (((long long)n * p.H + y) * p.W + x) * CIN + 16 * t + 4 * q);
+        for (int t = 0; t < TCI; ++t) {
+          mk[c][t] = f32x4{1.f, 1.f, 1.f, 1.f};
+          if (p.mask && okc[c])
+            mk[c][t] = *reinterpret_cast<const f32x4*>(p.mask + (long long)g * p.gs_dx +
+                                                       (((long long)n * p.H + y) * p.W + x) * CIN + 16 * t + 4 * q);
+        }
       }
     }
     f32x4 acc[4][TCI];
@@ -1520,9 +1547,15 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
 #pragma unroll
       for (int t = 0; t < TCI; ++t) {
         f32x4 v = acc[c][t];
-        const f32x4 m = mk[c][t];
-        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        if constexpr (FIELDS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe((int)mf[c], 4 * t + j, 1));
+        } else {
+          const f32x4 m = mk[c][t];
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+          v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
         stream_store<3>(o + 16 * t, v);
       }
     }
@@ -1537,13 +1570,13 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
   }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool FIELDS = false>
 static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
   constexpr int BUF_F4 = ((5 * 33 * 4 + 63) / 64) * 64;
   const size_t lds = (size_t)(9 * CIN * (COUT / 4 + 2) + 2 * BUF_F4) * 16;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_halo_dgrad_chunked_kernel<CIN, COUT, FIELDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
@@ -1552,8 +1585,8 @@ static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
     attr_set = true;
   }
   long long blocks = p.ntiles < 256 ? p.ntiles : 256;
-  geeco_note_kernel("conv_s2_halo_dgrad_chunked_kernel<%d, %d>", CIN, COUT);
-  hipLaunchKernelGGL((conv_s2_halo_dgrad_chunked_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+  geeco_note_kernel("conv_s2_halo_dgrad_chunked_kernel<%d, %d, %s>", CIN, COUT, FIELDS ? "true" : "false");
+  hipLaunchKernelGGL((conv_s2_halo_dgrad_chunked_kernel<CIN, COUT, FIELDS>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   return 0;
 }
 
@@ -2360,6 +2393,49 @@ int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y
   if (disabled || !b || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
   *handled = 1;
   return launch_conv1_fwd(x, w, b, y, nullptr, groups, gs_x, gs_w, gs_b, gs_y, 0, N, H, W, relu, stream);
+}
+
+// ---- ReLU sign fields of conv2's output for conv3's input gradient (see HaloFwdParams::fields) ---------------------
+extern "C" int64_t geeco_relu_fields_elems(int N, int H, int W) {    // uint16 elements per encoder; H, W of the 48-channel tensor
+  return (int64_t)N * ((H + 7) / 8 * 8) * ((W + 63) / 64 * 64) * 4;
+}
+
+extern "C" int geeco_conv2_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint16_t* fields,
+                                           int groups, int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y,
+                                           int64_t gs_fields, int N, int H, int W, void* stream) {
+  GEECO_CHECK_ARG(x && w && b && y && fields, "conv2_fwd_relu_fields: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                  "conv2_fwd_relu_fields: H = %d, W = %d must be even", H, W);
+  HaloFwdParams p = {};
+  p.x = x; p.w = w; p.bias = b; p.y = y;
+  p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
+  p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+  p.tiles_x = cdiv(p.Wo, 16); p.tiles_y = cdiv(p.Ho, 4);
+  p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+  p.ntiles = (long long)groups * p.tiles_per_group;
+  p.relu = 1;
+  p.fields = fields; p.gs_fields = gs_fields; p.fHp = (p.Ho + 7) / 8 * 8; p.fWp = (p.Wo + 63) / 64 * 64;
+  return launch_s2_halo_fwd_ws<32, 48, 4>(p, (hipStream_t)stream);
+}
+
+extern "C" int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_t* y2_fields, float* dx,
+                                             int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx,
+                                             int N, int H, int W, void* stream) {
+  GEECO_CHECK_ARG(dz && w && y2_fields && dx, "conv3_dgrad_relu_fields: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                  "conv3_dgrad_relu_fields: H = %d, W = %d must be even", H, W);
+  HaloDgradParams p = {};
+  p.dz = dz; p.w = w; p.mask = nullptr; p.dx = dx;
+  p.fields = y2_fields; p.gs_fields = gs_fields; p.fHp = (H + 7) / 8 * 8; p.fWp = (W + 63) / 64 * 64;
+  p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
+  p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+  p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
+  p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+  p.ntiles = (long long)groups * p.tiles_per_group;
+  int rc = launch_dgrad_chunked<48, 64, true>(p, (hipStream_t)stream);
+  if (rc) return rc;
+  GEECO_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int64_t geeco_relu_bits_pitch(int W) { return (int64_t)(W + 63) / 64 * 64; }

@@ -135,6 +135,15 @@ class ConvEncoderStack:
       self.relu_bits = self.fused_bottom and os.environ.get('GEECO_NO_RELU_BITS') is None
       if self.relu_bits:
         self.bits1 = torch.zeros(G, Nf, ops.relu_bits_rows(L0['H']), ops.relu_bits_pitch(L0['W']), dtype=torch.int32, device=dev)
+      # the same one layer up: conv2's forward leaves 16-bit sign fields of y2 for conv3's input-gradient kernel
+      L2 = self.layers[2]
+      self.relu_fields = (os.environ.get('GEECO_NO_RELU_BITS') is None and os.environ.get('GEECO_NO_HALO') is None
+                          and os.environ.get('GEECO_NO_HALO3') is None and os.environ.get('GEECO_HALO_WS') is None
+                          and (L1['Cin'], L1['Cout'], L1['stride']) == (32, 48, 2)
+                          and (L2['Cin'], L2['Cout'], L2['stride']) == (48, 64, 2)
+                          and L1['H'] % 2 == 0 and L1['W'] % 2 == 0 and L2['H'] % 2 == 0 and L2['W'] % 2 == 0)
+      if self.relu_fields:
+        self.fields2 = torch.zeros(G, ops.relu_fields_elems(Nf, L2['H'], L2['W']), dtype=torch.int16, device=dev)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
       self.dz = [None if (i == 0 and self.fused_bottom) else
                  ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]
@@ -216,6 +225,10 @@ class ConvEncoderStack:
       w, gs_w = self.w1p, self.w1p[0].numel()
     else:
       w, gs_w = self._w(l), self.gs_p
+    if l == 1 and self.training and self.relu_fields:
+      ops.conv2_fwd_relu_fields_into(y, self.fields2, x, w, self._b(1), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),
+                                     self.fields2[0].numel(), Nf, L['H'], L['W'])
+      return
     if l == 0 and self.training and self.relu_bits:
       ops.conv1_fwd_relu_bits_into(y, self.bits1, x, w, self._b(0), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),
                                    self.bits1[0].numel(), Nf, L['H'], L['W'])
@@ -274,6 +287,10 @@ class ConvEncoderStack:
       return
     wt = self.wt[l]
     dx = self.dz[l - 1]
+    if l == 2 and self.relu_fields:
+      ops.conv3_dgrad_relu_fields_into(dx, dz, self._w(2), self.fields2, G, dz[0].numel(), self.gs_p, self.fields2[0].numel(),
+                                       dx[0].numel(), Nf, L['H'], L['W'])
+      return
     ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
                            L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
 

@@ -25,7 +25,7 @@ def _stream():
 def _p(t):
   if t is None:
     return None
-  assert t.is_cuda and t.dtype in (torch.float32, torch.int64, torch.int32), (t.device, t.dtype)
+  assert t.is_cuda and t.dtype in (torch.float32, torch.int64, torch.int32, torch.int16), (t.device, t.dtype)
   return ctypes.c_void_p(t.data_ptr())
 
 
@@ -230,6 +230,22 @@ def conv2_dgrad_conv1_wgrad_bits_into(dw1, db1, dz2, w2, y1_bits, x, G, gs_dz2, 
         'geeco_conv2_dgrad_conv1_wgrad_bits')
   if item is not None and item.S > 0:
     pending.append(item)
+
+
+def relu_fields_elems(N, H, W):
+  return int(_lib().geeco_relu_fields_elems(N, H, W))
+
+
+def conv2_fwd_relu_fields_into(y, fields, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs_fields, N, H, W):
+  """conv2 forward (32 -> 48, stride 2, bias, ReLU) that also writes y's sign fields (int16, relu_fields_elems per encoder)."""
+  check(_lib().geeco_conv2_fwd_relu_fields(_p(x), _p(w), _p(b), _p(y), _p(fields), G, gs_x, gs_w, gs_b, gs_y, gs_fields, N,
+                                           H, W, _stream()), 'geeco_conv2_fwd_relu_fields')
+
+
+def conv3_dgrad_relu_fields_into(dx, dz, w, fields, G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W):
+  """conv3 input gradient (48 -> 64, stride 2) masked by the sign fields of conv2's output; H, W = dims of dx."""
+  check(_lib().geeco_conv3_dgrad_relu_fields(_p(dz), _p(w), _p(fields), _p(dx), G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W,
+                                             _stream()), 'geeco_conv3_dgrad_relu_fields')
 
 
 def transpose_hwio_into(wt, w, G, gs_w, gs_wt, Cin, Cout):

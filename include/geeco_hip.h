@@ -172,6 +172,18 @@ int64_t geeco_relu_bits_rows(int H);
 int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const float* b, float* y, uint32_t* bits, int groups,
                               int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H,
                               int W, void* stream);
+/* The same idea one layer up: conv2's forward (32 -> 48, stride 2, bias, ReLU; x [G][N][H][W][32]) that also writes the
+ * sign fields of its output y2, and conv3's input gradient (48 -> 64, stride 2; dz [G][N][H/2][W/2][64], dx = d(y2)
+ * [G][N][H][W][48]) masked by those fields instead of by y2 itself (302 MB at the bench shape).
+ *   fields[g][n][y][x][q], q = 0..3: uint16, bit 4 i + j set iff y2[g][n][y][x][16 i + 4 q + j] > 0; rows / columns
+ *   padded to whole 8 x 64 tiles (geeco_relu_fields_elems uint16 per encoder), group stride gs_fields elements. */
+int64_t geeco_relu_fields_elems(int N, int H, int W);
+int geeco_conv2_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint16_t* fields, int groups,
+                                int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_fields, int N, int H,
+                                int W, void* stream);
+int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_t* y2_fields, float* dx, int groups,
+                                  int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H, int W,
+                                  void* stream);
 int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float* w2, const uint32_t* y1_bits, const float* x,
                                        float* dw1, float* db1, int groups, int64_t gs_dz2, int64_t gs_w2,
                                        int64_t gs_bits, int64_t gs_x, int64_t gs_dw1, int64_t gs_db1, int N, int H, int W,

@@ -418,6 +418,56 @@ def test_conv1_relu_bits_and_fused_bits(dev, G, N, H, W, C):
   assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize('G,N,H,W', [(1, 2, 16, 64), (3, 2, 24, 72)])
+def test_conv2_relu_fields_and_conv3_dgrad_fields(dev, G, N, H, W):
+  """conv2's forward with the sign-field side output (uint16 per (pixel, quad q): bit 4 i + j <-> channel 16 i + 4 q + j)
+  and conv3's input gradient masked by those fields: y2 equals the plain forward, the fields equal the packed signs of
+  y2, dx equals (bitwise) the gradient masked by y2 itself; ragged tiles (H x W = conv2's input, y2 is H/2 x W/2)."""
+  from geeco_amd import ops
+  r = np.random.default_rng(39)
+  x = torch.tensor(r.standard_normal([G, N, H, W, 32]).astype(np.float32), device=dev)
+  w2 = torch.tensor((r.standard_normal([G, 3, 3, 32, 48]) / 17).astype(np.float32), device=dev)
+  b2 = torch.tensor((0.1 * r.standard_normal([G, 48])).astype(np.float32), device=dev)
+  H2, W2 = H // 2, W // 2
+  y_plain = torch.empty(G, N, H2, W2, 48, device=dev)
+  ws = torch.empty(ops.conv3x3_fwd_ws_bytes(G, N, H, W, 32, 48, 2) // 4 + 4, device=dev)
+  ops.conv3x3_fwd_into(y_plain, x, w2, b2, G, x[0].numel(), w2[0].numel(), 48, y_plain[0].numel(), N, H, W, 32, 48, 2,
+                       relu=True, ws=ws)
+  y = torch.empty_like(y_plain)
+  ne = ops.relu_fields_elems(N, H2, W2)
+  Hp, Wp = (H2 + 7) // 8 * 8, (W2 + 63) // 64 * 64
+  assert ne == N * Hp * Wp * 4
+  fields = torch.zeros(G, ne, dtype=torch.int16, device=dev)
+  names = ops.kernel_trace(lambda: ops.conv2_fwd_relu_fields_into(y, fields, x, w2, b2, G, x[0].numel(), w2[0].numel(), 48,
+                                                                  y[0].numel(), ne, N, H, W))
+  torch.cuda.synchronize()
+  assert names[0].startswith('conv_s2_halo_fwd_ws_kernel'), names
+  assert torch.equal(y, y_plain)
+  pos = (y.cpu().numpy() > 0).reshape(G, N, H2, W2, 3, 4, 4)          # [.., i, q, j]
+  want = np.zeros([G, N, H2, W2, 4], np.uint16)
+  for i in range(3):
+    for j in range(4):
+      want |= (pos[..., i, :, j].astype(np.uint16) << (4 * i + j))
+  got = fields.cpu().numpy().view(np.uint16).reshape(G, N, Hp, Wp, 4)
+  assert np.array_equal(got[:, :, :H2, :W2], want)
+  assert (got[:, :, H2:] == 0).all() and (got[:, :, :, W2:] == 0).all()
+  # conv3's input gradient (48 -> 64, stride 2) on the y2 grid
+  w3 = torch.tensor((r.standard_normal([G, 3, 3, 48, 64]) / 20).astype(np.float32), device=dev)
+  dz3 = torch.tensor(r.standard_normal([G, N, H2 // 2, W2 // 2, 64]).astype(np.float32), device=dev)
+  wt = torch.empty(G, 3, 3, 64, 48, device=dev)
+  ops.transpose_hwio_into(wt, w3, G, w3[0].numel(), wt[0].numel(), 48, 64)
+  dx_ref = torch.full((G, N, H2, W2, 48), float('nan'), device=dev)
+  dws = torch.empty(ops.conv3x3_dgrad_ws_bytes(G, N, H2, W2, 48, 64, 2) // 4 + 4, device=dev)
+  ops.conv3x3_dgrad_into(dx_ref, dz3, wt, y, G, dz3[0].numel(), wt[0].numel(), dx_ref[0].numel(), N, H2, W2, 48, 64, 2,
+                         ws=dws, w=w3, gs_w=w3[0].numel())
+  dx = torch.full_like(dx_ref, float('nan'))
+  names = ops.kernel_trace(lambda: ops.conv3_dgrad_relu_fields_into(dx, dz3, w3, fields, G, dz3[0].numel(), w3[0].numel(), ne,
+                                                                    dx[0].numel(), N, H2, W2))
+  torch.cuda.synchronize()
+  assert names == ['conv_s2_halo_dgrad_chunked_kernel<48, 64, true>'], names
+  assert not torch.isnan(dx).any() and torch.equal(dx, dx_ref)
+
+
 def test_slab_reduce_batch_bitwise(dev):
   """Deferred slab sums (geeco_conv3x3_wgrad_partial x 4 layers of different kernels + the fused bottom, then ONE
   geeco_slab_reduce_batch) give bitwise the gradients of the plain calls."""
