@@ -4,8 +4,8 @@ mkdir -p gpurun_out/layersweep
 for e in "" "$@"; do
   env $e timeout -k 10 200 python bench.py --steps 20 --warmup 5 --skip-cpu > gpurun_out/layersweep/b.json 2>gpurun_out/layersweep/b.err
   python - "$e" <<'PY'
-import json, sys
+import json, os, sys
 d = json.loads(open('gpurun_out/layersweep/b.json').read().strip().splitlines()[-1])
-print('[%s]' % sys.argv[1], d['value'], d['step_ms']['median'], [(r['layer'], r['op'], r['us']) for r in d['layers'][:6]])
+print('[%s]' % sys.argv[1], d['value'], d['step_ms']['median'], [(r['layer'], r['op'], r['us']) for r in d["layers"][4:16]])
 PY
 done
