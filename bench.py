@@ -227,7 +227,16 @@ def hbm_table(model, args, iters):
     tbs = nbytes / (ms * 1e-3) / 1e12
     rows.append({'piece': name, 'bytes': int(nbytes), 'us': round(ms * 1e3, 1), 'TB/s': round(tbs, 3),
                  'frac': round(tbs / PEAK_HBM_TBS, 4)})
-  if args.model == 'geeco-f':
+  if args.model == 'geeco-f' and getattr(model, 'split_rgbd', False):
+    # RGB-D: the dynimg kernels read rgb and depth from their own tensors (no packed copy of the frames)
+    inp, x_in = model.inputs, model.enc.x_in
+    rgb, dep = inp['rgb'], inp['depth']
+    add('dynimg buffer image (K=%d), rgb + depth unpacked' % K, 4.0 * N * HW * C * (K + 1),
+        lambda: ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, model.dyn_ws, K * HW * 3, HW * 3, K * HW, HW))
+    add('dynimg diff image (K=2), rgb + depth unpacked', 4.0 * N * HW * C * 3,
+        lambda: ops.dynimg_rgbd_into(x_in[2], rgb[:, K - 1], dep[:, K - 1], 2, N, HW, model.dyn_ws, K * HW * 3, 0, K * HW, 0,
+                                     rgb2=inp['target_rgb'], depth2=inp['target_depth']))
+  elif args.model == 'geeco-f':
     frames, tgt = model._frames()
     x_in = model.enc.x_in
     cur = frames[:, K - 1]
