@@ -4,7 +4,9 @@ set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libgeeco_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
+# -amdgpu-mfma-vgpr-form: accumulators stay in VGPRs (unified file on gfx950); without it the allocator parks them in AGPRs in
+# some kernels and pays v_accvgpr_read/write copies, each of which costs MFMA issue time
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 rm -rf build && mkdir -p build
 pids=()
 for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do

@@ -22,6 +22,7 @@
 //   sB[k][BN + 4]: ds_read_b32, row pitch = 4 (mod 8) dwords => the two k-rows of a 32-lane half
 //       land in different bank halves (conflict free).
 #include "geeco_common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -81,6 +82,9 @@ struct ConvGemmParams {
 #else
 #define STAMP(i)
 #endif
+
+constexpr int GEMM_ZERO_PAGE = 4096;   // floats: a whole tap of the widest layer the uniform-tap path serves
+static __device__ float g_gemm_zero_page[GEMM_ZERO_PAGE + 64];
 
 template <int BM, int BN, int BK, int WM, int WN, bool UT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const float* u_ap[PA];
   bool u_av[PA];
   const float* u_bp[PB];
+  long long u_bstep[PB];
   bool u_bv[PB];
   auto ut_setup = [&]() {     // (re)derive pointers for tap u_tap at channel offset u_cc
     const int t = u_tap < 9 ? u_tap : 8;
@@ -201,12 +206,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int j = 0; j < PA; ++j) {
       int iy = iy0[j] + dy, ix = ix0[j] + dx;
       u_av[j] = tv && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-      u_ap[j] = xg + rb[j] + toff + u_cc + kq * 4;
+      // rows outside the image (TF SAME padding, M tail) walk a zero page instead of being predicated per K-step: a
+      // select per load and K-step is VALU work next to the MFMAs (the page covers a whole tap: C <= ZERO_PAGE floats)
+      u_ap[j] = u_av[j] ? xg + rb[j] + toff + u_cc + kq * 4 : g_gemm_zero_page + u_cc + kq * 4;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       u_bv[i] = (tid + i * 256 < NB4) && tv && (n0 + b_c4[i] * 4 < p.Nout);
-      u_bp[i] = wg + (long long)(sTap[36 + t] + u_cc + b_row[i]) * p.Nout + n0 + b_c4[i] * 4;
+      u_bp[i] = u_bv[i] ? wg + (long long)(sTap[36 + t] + u_cc + b_row[i]) * p.Nout + n0 + b_c4[i] * 4 : g_gemm_zero_page;
+      u_bstep[i] = u_bv[i] ? (long long)BK * p.Nout : 0;
     }
   };
   if constexpr (UT) {
@@ -219,9 +227,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   auto load_tiles = [&]() {
     if constexpr (UT) {
 #pragma unroll
-      for (int j = 0; j < PA; ++j) ra[j] = u_av[j] ? *reinterpret_cast<const f32x4*>(u_ap[j]) : zero4;
+      for (int j = 0; j < PA; ++j) ra[j] = *reinterpret_cast<const f32x4*>(u_ap[j]);
 #pragma unroll
-      for (int i = 0; i < PB; ++i) rbv[i] = u_bv[i] ? *reinterpret_cast<const f32x4*>(u_bp[i]) : zero4;
+      for (int i = 0; i < PB; ++i) rbv[i] = *reinterpret_cast<const f32x4*>(u_bp[i]);
       return;
     }
     {
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
         for (int j = 0; j < PA; ++j) u_ap[j] += BK;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) u_bp[i] += (long long)BK * p.Nout;
+        for (int i = 0; i < PB; ++i) u_bp[i] += u_bstep[i];
       }
       return;
     }
@@ -309,8 +317,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   __syncthreads();
   STAMP(5);
 
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
+  // The K loop is unrolled by two by hand so that the LDS buffer index is a compile-time constant: the fragment
+  // addresses then are loop-invariant registers + immediates (they cost 16 VALU instructions per K-step, and every
+  // VALU instruction next to f32 MFMAs costs ~4 cycles of MFMA time).
+  auto kstep = [&](auto bufc, int ks) {
+    constexpr int buf = decltype(bufc)::value;
     const bool more = ks + 1 < nk;
     STAMP(ks < 18 ? 6 + 3 * ks : 64);
     if (more) {
@@ -342,6 +353,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     STAMP(ks < 18 ? 8 + 3 * ks : 64);
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
+  };
+  for (int ks = 0; ks < nk; ks += 2) {
+    kstep(std::integral_constant<int, 0>{}, ks);
+    if (ks + 1 < nk) kstep(std::integral_constant<int, 1>{}, ks + 1);
   }
   STAMP(60);
 
@@ -435,8 +450,9 @@ static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
   }
   dim3 grid((unsigned)tiles, (unsigned)(cdiv(p.Nout, BN) * p.ksplit), (unsigned)groups);
   static const int no_ut = getenv("GEECO_CONV_NO_UT") ? 1 : 0;
-  geeco_note_kernel("conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, BK, WM, WN, (p.C % BK == 0 && !no_ut) ? "true" : "false");
-  if (p.C % BK == 0 && !no_ut)
+  const bool ut = p.C % BK == 0 && p.C <= GEMM_ZERO_PAGE && !no_ut;   // uniform taps; a tap fits the zero page
+  geeco_note_kernel("conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, BK, WM, WN, ut ? "true" : "false");
+  if (ut)
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, true>), grid, dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, false>), grid, dim3(256), 0, s, p);

@@ -8,7 +8,7 @@ for v in "$@"; do
   python - "$v" <<'PY'
 import json, sys
 d = json.loads(open('gpurun_out/libsweep/b.json').read().strip().splitlines()[-1])
-print('[%s]' % sys.argv[1], d['value'], d['step_ms']['median'], [(r['layer'], r['op'], r['us']) for r in d["layers"][:7]])
+print('[%s]' % sys.argv[1], d['value'], d['step_ms']['median'], [(r['layer'], r['op'], r['us']) for r in d["layers"]])
 PY
 done
 done
