@@ -122,19 +122,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
     y0_ = ty * (GPF * PR);
     x0_ = (tt - ty * p.tiles_x) * PC;
   };
-  auto dma_chunk = [&](int buf, int g_, int cib_, int n0_, int y0_, int x0_, int ch) {
-    const float* wg = p.w + (long long)g_ * p.gs_w + (long long)cib_ * CIB * Cout + ch * 16;
-    const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n0_ * p.Ho + y0_) * p.Wo + x0_) * Cout + ch * 16;
+  // Source pointers of this wave's pieces for the NEXT chunk to fetch, set once per item (bounds tests, frame offsets:
+  // ~12 VALU instructions per piece) and then advanced by 16 channels per chunk (one 64-bit add per piece): address
+  // work inside the chunk loop is VALU work next to the MFMAs.  Lanes outside the image stay on the zero page (step 0).
+  const float* d_ptr[NSLOT];
+  int d_step[NSLOT];
+  auto setup_item = [&](int g_, int cib_, int n0_, int y0_, int x0_) {
+    const float* wg = p.w + (long long)g_ * p.gs_w + (long long)cib_ * CIB * Cout;
+    const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n0_ * p.Ho + y0_) * p.Wo + x0_) * Cout;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const int k = wid + NW * i;                   // wave-uniform
       if (k < NWP) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(wg + d_off[i]), (lptr_t)(sW + buf * W_F4 + k * 64), 16, 0, 0);
+        d_ptr[i] = wg + d_off[i];
+        d_step[i] = 16;
       } else if (k < NWP + NZP) {
         const int f = d_f[i];
         const bool v = n0_ + f < p.N && (unsigned)(y0_ + d_a[i]) < (unsigned)p.Ho && (unsigned)(x0_ + d_b[i]) < (unsigned)p.Wo;
-        const float* src = v ? zg + (long long)f * p.Ho * p.Wo * Cout + d_off[i] : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * ZP_F4 + (k - NWP) * 64), 16, 0, 0);
+        d_ptr[i] = v ? zg + (long long)f * p.Ho * p.Wo * Cout + d_off[i] : g_zero_page;
+        d_step[i] = v ? 16 : 0;
+      }
+    }
+  };
+  auto dma_next = [&](int buf) {                    // the chunk d_ptr points at -> LDS buffer buf; then one chunk further
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int k = wid + NW * i;                   // wave-uniform
+      if (k < NWP) {
+        __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[i], (lptr_t)(sW + buf * W_F4 + k * 64), 16, 0, 0);
+        d_ptr[i] += d_step[i];
+      } else if (k < NWP + NZP) {
+        __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[i], (lptr_t)(sZ + buf * ZP_F4 + (k - NWP) * 64), 16, 0, 0);
+        d_ptr[i] += d_step[i];
       }
     }
   };
@@ -149,7 +168,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
 
   int g, cib, n0, y0, x0;
   decode(item, g, cib, n0, y0, x0);
-  dma_chunk(0, g, cib, n0, y0, x0, 0);
+  setup_item(g, cib, n0, y0, x0);
+  dma_next(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -170,8 +190,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
       // the head of the chunk, waves 4-7 (their SIMD partners) in the middle of the tap loop: an LDS-DMA instruction
       // holds its wave for 100-200 cycles, and partners that stall at the same time leave the SIMD's MFMA pipe idle.
       auto prefetch = [&]() {
-        if (ch + 1 < nch) dma_chunk(buf ^ 1, g, cib, n0, y0, x0, ch + 1);
-        else if (more_items) dma_chunk(buf ^ 1, gn, cibn, n0n, y0n, x0n, 0);
+        if (ch + 1 < nch) {
+          dma_next(buf ^ 1);
+        } else if (more_items) {
+          setup_item(gn, cibn, n0n, y0n, x0n);
+          dma_next(buf ^ 1);
+        }
       };
       if (!late) prefetch();
       const f32x4* zb = sZ + buf * ZP_F4;
