@@ -48,6 +48,7 @@ SIGNATURES = {
     'geeco_conv3x3_fwd_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_dgrad': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv3x3_dgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
+    'geeco_conv3x3_dgrad_needs_wt': (_I, [_I, _I, _I, _I, _I]),
     'geeco_conv3x3_wgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_wgrad': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv2_dgrad_conv1_wgrad_ws_bytes': (_L, [_I]),

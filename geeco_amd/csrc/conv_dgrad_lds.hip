@@ -280,6 +280,16 @@ static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t str
   return 0;
 }
 
+// does the dispatcher below take this shape (given the HWIO kernel)?  Such layers never read the transposed copy.
+int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride) {
+  static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
+  if (disabled || stride != 2 || (H & 1) || (W & 1) || Cin % 64 != 0 || Cout % 16 != 0 || Cout < 32) return 0;
+  const int Ho = H / 2, Wo = W / 2;
+  if (!((Ho % 8 == 0 && Wo % 16 == 0) || (Ho == 8 && Wo == 8))) return 0;
+  if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 31)) return 0;
+  return 1;
+}
+
 int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups, int64_t gs_dz,
                         int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride,
                         hipStream_t stream, int* handled) {

@@ -668,6 +668,13 @@ extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b,
   return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
 }
 
+int geeco_halo_dgrad_handles(int H, int W, int Cin, int Cout, int stride);
+int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride);
+
+extern "C" int geeco_conv3x3_dgrad_needs_wt(int H, int W, int Cin, int Cout, int stride) {
+  return !(geeco_halo_dgrad_handles(H, W, Cin, Cout, stride) || geeco_dgrad_lds_handles(H, W, Cin, Cout, stride));
+}
+
 extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* w, const float* wt, const float* ymask, float* dx,
                                    int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_wt, int64_t gs_dx, int N,
                                    int H, int W, int Cin, int Cout, int stride, void* ws, void* stream) {

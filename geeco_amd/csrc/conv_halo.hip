@@ -2188,6 +2188,14 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float*
   return rc;
 }
 
+// does the dispatcher below take this shape (given the HWIO kernel)?  Such layers never read the transposed copy.
+int geeco_halo_dgrad_handles(int H, int W, int Cin, int Cout, int stride) {
+  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int no_chunked = getenv("GEECO_NO_HALO3") ? 1 : 0;
+  if (disabled || stride != 2 || (H % 2) || (W % 2)) return 0;
+  return (!no_chunked && Cin == 48 && Cout == 64) || (Cin == 32 && Cout == 48);
+}
+
 int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups,
                          int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
                          int stride, hipStream_t stream, int* handled) {

@@ -148,6 +148,8 @@ class ConvEncoderStack:
       self.dz = [None if (i == 0 and self.fused_bottom) else
                  ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]
       self.wt = [None] + [torch.empty(G, 3, 3, L['Cout'], L['Cin'], **f32) for L in self.layers[1:]]
+      self.needs_wt = [False] + [ops.conv3x3_dgrad_needs_wt(L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
+                                 for L in self.layers[1:]]
       if self.split_top:
         self.wt[7] = [torch.empty(3, 3, d, self.layers[7]['Cin'], **f32) for d in self.dim_outs]
       if self.pad1:
@@ -199,7 +201,8 @@ class ConvEncoderStack:
     per-tap transposed kernels of the dgrad GEMMs).  Training calls it right after Adam (inside the
     Adam hipGraph), so the forward / backward graphs contain no pad or transpose launches."""
     G = self.G
-    ls = list(range(1, 7 if self.split_top else 8)) if self.training else []
+    # only the layers whose input-gradient kernel reads the transposed copy (the LDS-staged ones read the HWIO kernel)
+    ls = [l for l in range(1, 7 if self.split_top else 8) if self.needs_wt[l]] if self.training else []
     if self.training and self.split_top:
       L7 = self.layers[7]
       for g in range(G):

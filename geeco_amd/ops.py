@@ -155,6 +155,10 @@ def _ws(nbytes, device):
   return torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=device) if nbytes > 0 else None
 
 
+def conv3x3_dgrad_needs_wt(H, W, Cin, Cout, stride):
+  return bool(_lib().geeco_conv3x3_dgrad_needs_wt(H, W, Cin, Cout, stride))
+
+
 def conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
   return int(_lib().geeco_conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride))
 

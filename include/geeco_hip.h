@@ -108,6 +108,9 @@ int geeco_conv3x3_dgrad(const float* dz, const float* w, const float* wt, const 
                         int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
                         void* stream);
 int64_t geeco_conv3x3_dgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
+/* 0 if geeco_conv3x3_dgrad, GIVEN the HWIO kernel `w`, runs a kernel that reads `w` itself for this shape (the caller
+ * then need not keep the transposed copy `wt` up to date: any valid pointer will do); 1 if `wt` is read. */
+int geeco_conv3x3_dgrad_needs_wt(int H, int W, int Cin, int Cout, int stride);
 
 /* Conv2DBackpropFilter + BiasAddGrad:  dw[ky][kx][ci][co] = sum_m x[pix(m,ky,kx)][ci] dz[m][co],
  * db[co] = sum_m dz[m][co].  dw/db are OVERWRITTEN (not accumulated).
