@@ -1462,7 +1462,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
   // lane r = X' column inside the wave's 16-column strip; q selects the co quad of the chunk
   const int hx_lane = 16 * half + r + 1;                                  // - dx
   const int b_lane = r * WP + q;                                          // + (tap*CIN + 16 t)*WP + 4 chunk
-  int buf = 0;
+  static_assert(NCH % 2 == 0, "the chunk loop is unrolled with the LDS buffer index = chunk & 1: a tile must take an even number of chunks");
   for (;;) {
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
@@ -1497,8 +1497,11 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
 #pragma unroll
       for (int t = 0; t < TCI; ++t) acc[c][t] = zero4;
 
-#pragma unroll 1
+    // fully unrolled: the buffer index is a compile-time constant, so the fragment addresses are loop-invariant
+    // registers + immediates instead of a dozen VALU adds per chunk (VALU work is paid in MFMA time)
+#pragma unroll
     for (int chunk = 0; chunk < NCH; ++chunk) {
+      const int buf = chunk & 1;
       // the next step's image lands in the other buffer while this one is consumed
       if (chunk + 1 < NCH)
         dma_chunk(buf ^ 1, g, n, ty, tx, chunk + 1);
@@ -1536,7 +1539,6 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
         for (int t = 0; t < TCI; ++t) b_cur[t] = b_nxt[t];
       }
       if (chunk + 1 < NCH || more) dma_barrier();   // next image landed; everyone is done with this one
-      buf ^= 1;
     }
     // epilogue: class c -> pixel (yb + py, xb + px); lane owns ci = 16 t + 4 q .. +3
 #pragma unroll
