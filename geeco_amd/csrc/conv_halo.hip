@@ -15,6 +15,7 @@
 // MFMA: v_mfma_f32_16x16x4_f32, roles as in conv_gemm.hip (row i = output channel, column j =
 // pixel) so every lane owns 4 consecutive NHWC channels of one pixel.
 #include "geeco_common.h"
+#include <type_traits>
 #include <atomic>
 #include <stdlib.h>
 #include <stdio.h>
@@ -718,16 +719,20 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
   __syncthreads();
 
   const f32x4* hB = sW + q * COUT + cohalf * (COUT / 2) + r;     // + ((tap*CQ + 4 chunk) * COUT + 16 i)
-  int buf = 0;
-  for (;;) {
+  // One tile; b0 = LDS buffer of its first chunk.  The chunk loop is fully unrolled and the tile loop below alternates
+  // b0 (NCH is odd for conv3: the parity flips per tile), so the buffer index is a compile-time constant everywhere:
+  // the fragment addresses are loop-invariant registers + immediates instead of VALU adds per chunk.
+  auto tile_body = [&](auto b0c) -> bool {
+    constexpr int b0 = decltype(b0c)::value;
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
     if (more) advance(g2, n2, ty2, tx2);
     f32x4 acc[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) acc[i] = zero4;
-#pragma unroll 1
+#pragma unroll
     for (int chunk = 0; chunk < NCH; ++chunk) {
+      const int buf = (b0 + chunk) & 1;
       if (chunk + 1 < NCH)
         dma_chunk(buf ^ 1, g, n, ty, tx, chunk + 1);
       else if (more)
@@ -758,7 +763,6 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
         for (int i = 0; i < TI; ++i) b_cur[i] = b_nxt[i];
       }
       if (chunk + 1 < NCH || more) dma_barrier();   // next image landed; everyone is done with this one
-      buf ^= 1;
     }
     {
       // epilogue: pixel (oy, ox) = (ty*4 + strip, tx*16 + r); channels cohalf*COUT/2 + 16 i + 4 q .. +3
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
         if (ok) stream_store<2>(yo + i * 16 + 4 * q, v);
       }
     }
-    if (!more) break;
+    if (!more) return false;
     if (g2 != g_w) {             // the range crosses into the next encoder: refresh the resident kernel
       load_weights(g2);
       g_w = g2;
@@ -785,6 +789,11 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
     }
     g = g2; n = n2; ty = ty2; tx = tx2;
     ++tile;
+    return true;
+  };
+  for (;;) {
+    if (!tile_body(std::integral_constant<int, 0>{})) break;
+    if (!tile_body(std::integral_constant<int, NCH & 1>{})) break;
   }
 }
 
