@@ -476,7 +476,8 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
   pl.bm = 128;
   if (pl.bn == 64 && Mtot * groups < 128 * 256) pl.bm = 64;
   // 128-wide N tiles halve the gathered A bytes per MFMA; only when they still fill the chip
-  static const int no_bn128 = getenv("GEECO_CONV_BN128") ? 0 : 1;   // measured neutral-to-slower: off by default
+  // (round 1: neutral to slower; since the kernel's VALU diet of round 2 the gathered bytes weigh more: -11 us per step)
+  static const int no_bn128 = getenv("GEECO_CONV_NO_BN128") ? 1 : 0;
   if (!no_bn128 && p.Nout % 128 == 0 && pl.bm == 128 && (Mtot / 128) * (p.Nout / 128) * groups >= 512) pl.bn = 128;
   long long blocks = 0;
   for (int c = 0; c < p.ncls; ++c) blocks += cdiv64(p.cls[c].M, pl.bm);
