@@ -21,6 +21,7 @@ struct DynParams {
   long long HW;
   int C, Cpad;
   float* out;
+  float* last;   // optional [N][HW][4]: the LAST frame of the stack channel-padded (conv1's input of the current frame)
   float* part;   // [N][nblk][2]
   int nblk;
   float alpha[DYN_MAXK];
@@ -66,10 +67,19 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
       a0 += w * v0;
       a1 += w * v1;
       a2 += w * v2;
+      f32x4 v3 = {0.f, 0.f, 0.f, 0.f};
       if (DEPTH) {
         const float* dp = (p.depth2 && t == 1) ? p.depth2 + (long long)n * p.HW
                                                : p.depth + (long long)n * p.dsample_stride + (long long)t * p.dframe_stride;
-        a3 += w * reinterpret_cast<const f32x4*>(dp)[u];
+        v3 = reinterpret_cast<const f32x4*>(dp)[u];
+        a3 += w * v3;
+      }
+      if (p.last && t == p.K - 1) {     // the frame is in registers anyway: its channel-padded copy costs no extra read
+        f32x4* lo = reinterpret_cast<f32x4*>(p.last + ((long long)n * p.HW + u * 4) * 4);
+        lo[0] = f32x4{v0.x, v0.y, v0.z, v3.x};
+        lo[1] = f32x4{v0.w, v1.x, v1.y, v3.y};
+        lo[2] = f32x4{v1.z, v1.w, v2.x, v3.z};
+        lo[3] = f32x4{v2.y, v2.z, v2.w, v3.w};
       }
     }
     float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
@@ -203,16 +213,36 @@ extern "C" int64_t geeco_dynimg_ws_bytes(int N, int64_t hwc) {
   return (int64_t)N * (cdiv64(hwc, 256) + 1) * 2 * 4;
 }
 
+static int dynimg_fwd_impl(const float* frames, const float* frames2, int64_t sample_stride, int64_t frame_stride,
+                           const float* alpha_host, int N, int K, int64_t HW, int C, int Cpad, float* out, float* last,
+                           void* ws, void* stream);
+
 extern "C" int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_stride,
                                 int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW, int C,
                                 int Cpad, float* out, void* ws, void* stream) {
+  return dynimg_fwd_impl(frames, frames2, sample_stride, frame_stride, alpha_host, N, K, HW, C, Cpad, out, nullptr, ws,
+                         stream);
+}
+
+extern "C" int geeco_dynimg_fwd_last(const float* frames, int64_t sample_stride, int64_t frame_stride,
+                                     const float* alpha_host, int N, int K, int64_t HW, float* out, float* last, void* ws,
+                                     void* stream) {
+  GEECO_CHECK_ARG(last, "dynimg_fwd_last: null pointer");
+  GEECO_CHECK_ARG((HW & 3) == 0 && sample_stride % 4 == 0 && frame_stride % 4 == 0,
+                  "dynimg_fwd_last: RGB frames, HW %% 4 == 0, 16-byte aligned strides");
+  return dynimg_fwd_impl(frames, nullptr, sample_stride, frame_stride, alpha_host, N, K, HW, 3, 4, out, last, ws, stream);
+}
+
+static int dynimg_fwd_impl(const float* frames, const float* frames2, int64_t sample_stride, int64_t frame_stride,
+                           const float* alpha_host, int N, int K, int64_t HW, int C, int Cpad, float* out, float* last,
+                           void* ws, void* stream) {
   GEECO_CHECK_ARG(frames && alpha_host && out && ws, "dynimg_fwd: null pointer");
   GEECO_CHECK_ARG(K >= 1 && K <= DYN_MAXK, "dynimg_fwd: K=%d outside 1..%d", K, DYN_MAXK);
   GEECO_CHECK_ARG(N >= 1 && HW >= 1 && C >= 1 && C <= Cpad && Cpad <= 8, "dynimg_fwd: bad dims");
   GEECO_CHECK_ARG(!frames2 || K == 2, "dynimg_fwd: frames2 only with K == 2");
   DynParams p = {};
   p.frames = frames; p.frames2 = frames2; p.sample_stride = sample_stride; p.frame_stride = frame_stride;
-  p.N = N; p.K = K; p.HW = HW; p.C = C; p.Cpad = Cpad; p.out = out; p.part = (float*)ws;
+  p.N = N; p.K = K; p.HW = HW; p.C = C; p.Cpad = Cpad; p.out = out; p.last = last; p.part = (float*)ws;
   p.nblk = dyn_nblk(HW, C);
   for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
   hipStream_t s = (hipStream_t)stream;
@@ -233,9 +263,30 @@ extern "C" int geeco_dynimg_fwd(const float* frames, const float* frames2, int64
   return 0;
 }
 
+static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
+                            const float* depth, const float* depth2, int64_t dsample_stride, int64_t dframe_stride,
+                            const float* alpha_host, int N, int K, int64_t HW, float* out, float* last, void* ws,
+                            void* stream);
+
 extern "C" int geeco_dynimg_rgbd_fwd(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
                                      const float* depth, const float* depth2, int64_t dsample_stride, int64_t dframe_stride,
                                      const float* alpha_host, int N, int K, int64_t HW, float* out, void* ws, void* stream) {
+  return dynimg_rgbd_impl(rgb, rgb2, sample_stride, frame_stride, depth, depth2, dsample_stride, dframe_stride, alpha_host, N,
+                          K, HW, out, nullptr, ws, stream);
+}
+
+extern "C" int geeco_dynimg_rgbd_fwd_last(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* depth,
+                                          int64_t dsample_stride, int64_t dframe_stride, const float* alpha_host, int N,
+                                          int K, int64_t HW, float* out, float* last, void* ws, void* stream) {
+  GEECO_CHECK_ARG(last, "dynimg_rgbd_fwd_last: null pointer");
+  return dynimg_rgbd_impl(rgb, nullptr, sample_stride, frame_stride, depth, nullptr, dsample_stride, dframe_stride, alpha_host,
+                          N, K, HW, out, last, ws, stream);
+}
+
+static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
+                            const float* depth, const float* depth2, int64_t dsample_stride, int64_t dframe_stride,
+                            const float* alpha_host, int N, int K, int64_t HW, float* out, float* last, void* ws,
+                            void* stream) {
   GEECO_CHECK_ARG(rgb && depth && alpha_host && out && ws, "dynimg_rgbd_fwd: null pointer");
   GEECO_CHECK_ARG(K >= 1 && K <= DYN_MAXK, "dynimg_rgbd_fwd: K=%d outside 1..%d", K, DYN_MAXK);
   GEECO_CHECK_ARG(N >= 1 && HW >= 4 && (HW & 3) == 0, "dynimg_rgbd_fwd: HW=%lld must be a multiple of 4", (long long)HW);
@@ -245,7 +296,7 @@ extern "C" int geeco_dynimg_rgbd_fwd(const float* rgb, const float* rgb2, int64_
   DynParams p = {};
   p.frames = rgb; p.frames2 = rgb2; p.sample_stride = sample_stride; p.frame_stride = frame_stride;
   p.depth = depth; p.depth2 = depth2; p.dsample_stride = dsample_stride; p.dframe_stride = dframe_stride;
-  p.N = N; p.K = K; p.HW = HW; p.C = 3; p.Cpad = 4; p.out = out; p.part = (float*)ws;
+  p.N = N; p.K = K; p.HW = HW; p.C = 3; p.Cpad = 4; p.out = out; p.last = last; p.part = (float*)ws;
   p.nblk = dyn_nblk(HW, 3);
   for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
   hipStream_t s = (hipStream_t)stream;

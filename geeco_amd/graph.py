@@ -474,6 +474,7 @@ class _ModelBase:
     # RGB-D: rgb || depth (estimator.py:36,169,172).  The dynimg branch of the goal model forms the concat inside its
     # input kernels (no packed copy of all N * K frames: 1.07 GB read + 1.43 GB written per step at K = 32); the other
     # graphs pack once per step.
+    self.last_from_dynimg = os.environ.get('GEECO_PACK_CURRENT') is None   # current frame's padded copy out of the buffer-image kernel
     self.split_rgbd = (self.C == 4 and goal and cfg.proc_obs == 'dynimg' and (H * W) % 4 == 0 and
                        os.environ.get('GEECO_PACK_RGBD') is None and os.environ.get('GEECO_FUSED_INPUTS') is None)
     if self.C == 4 and not self.split_rgbd:
@@ -616,8 +617,11 @@ class GoalE2EVMC(_ModelBase):
       inp = self.inputs
       rgb, dep = inp['rgb'], inp['depth']
       cur_rgb, cur_dep = rgb[:, K - 1], dep[:, K - 1]
-      ops.pack_pixels_into(x_in[0], cur_rgb, K * HW * 3, N, HW, 3, 4, cur_dep, K * HW, 1)
-      ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
+      if self.last_from_dynimg:
+        ops.dynimg_rgbd_last_into(x_in[1], x_in[0], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
+      else:
+        ops.pack_pixels_into(x_in[0], cur_rgb, K * HW * 3, N, HW, 3, 4, cur_dep, K * HW, 1)
+        ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
       ops.dynimg_rgbd_into(x_in[2], cur_rgb, cur_dep, 2, N, HW, self.dyn_ws, K * HW * 3, 0, K * HW, 0,
                            rgb2=inp['target_rgb'], depth2=inp['target_depth'])
       self.enc.forward()
@@ -633,6 +637,10 @@ class GoalE2EVMC(_ModelBase):
       # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)
       if self.fused_inputs:
         ops.goal_inputs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, C, self.gin_ws, K * HW * C, HW * C)
+      elif C == 3 and HW % 4 == 0 and self.last_from_dynimg:
+        # the buffer-image kernel has the current frame in registers: it writes its channel-padded copy too
+        ops.dynimg_last_into(x_in[1], x_in[0], frames, K, N, HW, self.dyn_ws, K * HW * C, HW * C)
+        ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)
       else:
         ops.pack_pixels_into(x_in[0], cur, K * HW * C, N, HW, C, 4)
         ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, self.dyn_ws, K * HW * C, HW * C)

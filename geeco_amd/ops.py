@@ -87,6 +87,19 @@ def dynimg_rgbd_into(out, rgb, depth, K, N, HW, ws, sample_stride, frame_stride,
                                      _stream()), 'geeco_dynimg_rgbd_fwd')
 
 
+def dynimg_last_into(out, last, frames, K, N, HW, ws, sample_stride, frame_stride):
+  """RGB stack: out [N][HW][4] <- normalised dynamic image; last [N][HW][4] <- the stack's last frame, channel-padded."""
+  check(_lib().geeco_dynimg_fwd_last(_p(frames), sample_stride, frame_stride, ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N,
+                                     K, HW, _p(out), _p(last), _p(ws), _stream()), 'geeco_dynimg_fwd_last')
+
+
+def dynimg_rgbd_last_into(out, last, rgb, depth, K, N, HW, ws, sample_stride, frame_stride, dsample_stride, dframe_stride):
+  """RGB-D stack (rgb / depth in separate tensors): dynamic image + the last frame's (R, G, B, depth)."""
+  check(_lib().geeco_dynimg_rgbd_fwd_last(_p(rgb), sample_stride, frame_stride, _p(depth), dsample_stride, dframe_stride,
+                                          ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N, K, HW, _p(out), _p(last), _p(ws),
+                                          _stream()), 'geeco_dynimg_rgbd_fwd_last')
+
+
 def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
   """frames [N,K,H,W,C] contiguous -> [N,H,W,Cpad]."""
   N, K, H, W, C = frames.shape

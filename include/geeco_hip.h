@@ -52,6 +52,12 @@ int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_s
                      int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW,
                      int C, int Cpad, float* out, void* ws, void* stream);
 
+/* geeco_dynimg_fwd for RGB stacks (C = 3 -> Cpad = 4, HW % 4 == 0, 16-byte aligned strides) that ALSO writes the LAST
+ * frame of the stack channel-padded, last [N][HW][4] = (R, G, B, 0): the goal model feeds exactly that frame to its
+ * ConvEncoder (graph.py:387), and the kernel has it in registers (one launch and one read of the frame less). */
+int geeco_dynimg_fwd_last(const float* frames, int64_t sample_stride, int64_t frame_stride, const float* alpha_host,
+                          int N, int K, int64_t HW, float* out, float* last, void* ws, void* stream);
+
 /* RGB-D form of geeco_dynimg_fwd without packing: `rgb` [N][K][HW][3] and `depth` [N][K][HW] stay separate tensors
  * (each with its own sample / frame strides, 16-byte aligned, HW % 4 == 0) and tf.concat([rgb, depth], -1)
  * (estimator.py:169,172) happens in registers; out [N][HW][4] normalised over all four channels (graph.py:47-54).
@@ -59,6 +65,10 @@ int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_s
 int geeco_dynimg_rgbd_fwd(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
                           const float* depth, const float* depth2, int64_t dsample_stride, int64_t dframe_stride,
                           const float* alpha_host, int N, int K, int64_t HW, float* out, void* ws, void* stream);
+/* ... and the RGB-D form with the last frame's (R, G, B, depth) written to last [N][HW][4]. */
+int geeco_dynimg_rgbd_fwd_last(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* depth,
+                               int64_t dsample_stride, int64_t dframe_stride, const float* alpha_host, int N, int K,
+                               int64_t HW, float* out, float* last, void* ws, void* stream);
 
 /* Fused input stage of goal_e2evmc's dynimg branch (graph.py:386-402): ONE launch reads a batch of K-frame windows
  * (frames [N][K][HW][C], element strides given; C = 3 or 4 with 16-byte aligned frames) and the target frames

@@ -468,6 +468,32 @@ def test_conv2_relu_fields_and_conv3_dgrad_fields(dev, G, N, H, W):
   assert not torch.isnan(dx).any() and torch.equal(dx, dx_ref)
 
 
+@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4)])
+def test_dynimg_with_last_frame(dev, N, K, H, W, C):
+  """The buffer-image kernel that also writes the stack's last frame channel-padded: image bitwise as without the extra
+  output, last frame = the packed copy pack_pixels makes (rgb: (R, G, B, 0); rgbd: rgb || depth from separate tensors)."""
+  from geeco_amd import ops
+  r = np.random.default_rng(53)
+  HW = H * W
+  rgb = torch.tensor(r.random([N, K, H, W, 3]).astype(np.float32), device=dev)
+  ws = ops.dynimg_ws(N, HW * 4, dev)
+  out_ref = torch.empty(N, H, W, 4, device=dev)
+  out = torch.full((N, H, W, 4), float('nan'), device=dev)
+  last = torch.full((N, H, W, 4), float('nan'), device=dev)
+  last_ref = torch.empty(N, H, W, 4, device=dev)
+  if C == 3:
+    ops.dynimg_into(out_ref, rgb, K, N, HW, 3, 4, ws, K * HW * 3, HW * 3)
+    ops.pack_pixels_into(last_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4)
+    ops.dynimg_last_into(out, last, rgb, K, N, HW, ws, K * HW * 3, HW * 3)
+  else:
+    dep = torch.tensor((0.5 + 2.5 * r.random([N, K, H, W, 1])).astype(np.float32), device=dev)
+    ops.dynimg_rgbd_into(out_ref, rgb, dep, K, N, HW, ws, K * HW * 3, HW * 3, K * HW, HW)
+    ops.pack_pixels_into(last_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4, dep[:, K - 1], K * HW, 1)
+    ops.dynimg_rgbd_last_into(out, last, rgb, dep, K, N, HW, ws, K * HW * 3, HW * 3, K * HW, HW)
+  torch.cuda.synchronize()
+  assert torch.equal(out, out_ref) and torch.equal(last, last_ref)
+
+
 def test_slab_reduce_batch_bitwise(dev):
   """Deferred slab sums (geeco_conv3x3_wgrad_partial x 4 layers of different kernels + the fused bottom, then ONE
   geeco_slab_reduce_batch) give bitwise the gradients of the plain calls."""
