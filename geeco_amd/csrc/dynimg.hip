@@ -145,8 +145,12 @@ __global__ __launch_bounds__(256) void dynimg_wsum_generic_kernel(const DynParam
 
 // Pass 2: fold partials, normalise in place.  One thread = 4 consecutive floats of out.
 __global__ __launch_bounds__(256) void dynimg_norm_kernel(float* out, const float* part, int nblk, long long HW,
-                                                          int C, int Cpad) {
+                                                          int C, int Cpad, float* out2, const float* part2) {
   const int n = blockIdx.y;
+  if (blockIdx.z == 1) {      // second image of a pair (geeco_goal_dynimgs_fwd): same shape, its own partials
+    out = out2;
+    part = part2;
+  }
   __shared__ float s_mn, s_rng;
   {
     float mn = INFINITY, mx = -INFINITY;
@@ -258,7 +262,8 @@ static int dynimg_fwd_impl(const float* frames, const float* frames2, int64_t sa
   }
   GEECO_LAUNCH_CHECK();
   dim3 g2((unsigned)cdiv64(HW * Cpad, 1024), (unsigned)N);
-  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, C, Cpad);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, C, Cpad, (float*)nullptr,
+                     (const float*)nullptr);
   GEECO_LAUNCH_CHECK();
   return 0;
 }
@@ -303,7 +308,52 @@ static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_
   hipLaunchKernelGGL(dynimg_wsum3_kernel<true>, dim3((unsigned)p.nblk, (unsigned)N), dim3(256), 0, s, p);
   GEECO_LAUNCH_CHECK();
   dim3 g2((unsigned)cdiv64(HW * 4, 1024), (unsigned)N);
-  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, 4, 4);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, 4, 4, (float*)nullptr,
+                     (const float*)nullptr);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+// The goal model's three conv1 inputs (graph.py:386-401) in three launches instead of five: buffer image (+ the current
+// frame's padded copy), diff image of (current frame, target), and ONE normalisation launch for both images.
+extern "C" int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* tgt_rgb,
+                                      const float* depth, int64_t dsample_stride, int64_t dframe_stride,
+                                      const float* tgt_depth, const float* alpha_host, const float* alpha2_host, int N, int K,
+                                      int64_t HW, float* cur_out, float* buf_out, float* diff_out, void* ws, void* stream) {
+  GEECO_CHECK_ARG(rgb && tgt_rgb && alpha_host && alpha2_host && cur_out && buf_out && diff_out && ws,
+                  "goal_dynimgs_fwd: null pointer");
+  GEECO_CHECK_ARG((!depth) == (!tgt_depth), "goal_dynimgs_fwd: depth and tgt_depth come together");
+  GEECO_CHECK_ARG(K >= 1 && K <= DYN_MAXK, "goal_dynimgs_fwd: K=%d outside 1..%d", K, DYN_MAXK);
+  GEECO_CHECK_ARG(N >= 1 && HW >= 4 && (HW & 3) == 0, "goal_dynimgs_fwd: HW=%lld must be a multiple of 4", (long long)HW);
+  GEECO_CHECK_ARG(sample_stride % 4 == 0 && frame_stride % 4 == 0 && dsample_stride % 4 == 0 && dframe_stride % 4 == 0,
+                  "goal_dynimgs_fwd: 16-byte aligned frames");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = dyn_nblk(HW, 3);
+  float* part1 = (float*)ws;
+  float* part2 = part1 + (long long)N * nblk * 2;
+  DynParams p = {};
+  p.frames = rgb; p.sample_stride = sample_stride; p.frame_stride = frame_stride;
+  p.depth = depth; p.dsample_stride = dsample_stride; p.dframe_stride = dframe_stride;
+  p.N = N; p.K = K; p.HW = HW; p.C = 3; p.Cpad = 4; p.out = buf_out; p.last = cur_out; p.part = part1; p.nblk = nblk;
+  for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
+  DynParams d = {};
+  d.frames = rgb + (long long)(K - 1) * frame_stride; d.frames2 = tgt_rgb; d.sample_stride = sample_stride;
+  if (depth) { d.depth = depth + (long long)(K - 1) * dframe_stride; d.depth2 = tgt_depth; d.dsample_stride = dsample_stride; }
+  d.N = N; d.K = 2; d.HW = HW; d.C = 3; d.Cpad = 4; d.out = diff_out; d.part = part2; d.nblk = nblk;
+  d.alpha[0] = alpha2_host[0]; d.alpha[1] = alpha2_host[1];
+  const dim3 grid((unsigned)nblk, (unsigned)N);
+  if (depth) {
+    hipLaunchKernelGGL(dynimg_wsum3_kernel<true>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dynimg_wsum3_kernel<true>, grid, dim3(256), 0, s, d);
+  } else {
+    hipLaunchKernelGGL(dynimg_wsum3_kernel<false>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dynimg_wsum3_kernel<false>, grid, dim3(256), 0, s, d);
+  }
+  GEECO_LAUNCH_CHECK();
+  const int C = depth ? 4 : 3;
+  dim3 g2((unsigned)cdiv64(HW * 4, 1024), (unsigned)N, 2);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, buf_out, (const float*)part1, nblk, (long long)HW, C, 4, diff_out,
+                     (const float*)part2);
   GEECO_LAUNCH_CHECK();
   return 0;
 }

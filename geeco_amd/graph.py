@@ -598,6 +598,7 @@ class GoalE2EVMC(_ModelBase):
     self.decoder = LSTMDecoder(self.store, root + '/LSTMDecoder', cfg, N, T, D, training)
     self._bind_labels()
     self.dyn_ws = ops.dynimg_ws(N, H * W * 4, self.device)
+    self.dyn_ws2 = torch.empty(2 * self.dyn_ws.numel(), dtype=torch.float32, device=self.device)   # partials of two images
     # geeco-f: ONE launch for the three conv1 inputs (current frame, buffer image, diff image), every byte moved once,
     # normalisation from registers after a per-sample rendezvous.  Opt-in: measured SLOWER than the five separate
     # launches at the bench shape (161 us vs 144 us alone) although it moves 30 % fewer bytes.
@@ -616,14 +617,15 @@ class GoalE2EVMC(_ModelBase):
     if self.mode == 'dynimg' and self.split_rgbd:
       inp = self.inputs
       rgb, dep = inp['rgb'], inp['depth']
-      cur_rgb, cur_dep = rgb[:, K - 1], dep[:, K - 1]
       if self.last_from_dynimg:
-        ops.dynimg_rgbd_last_into(x_in[1], x_in[0], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
+        ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], rgb, inp['target_rgb'], K, N, HW, self.dyn_ws2, K * HW * 3, HW * 3,
+                              depth=dep, tgt_depth=inp['target_depth'], dsample_stride=K * HW, dframe_stride=HW)
       else:
+        cur_rgb, cur_dep = rgb[:, K - 1], dep[:, K - 1]
         ops.pack_pixels_into(x_in[0], cur_rgb, K * HW * 3, N, HW, 3, 4, cur_dep, K * HW, 1)
         ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
-      ops.dynimg_rgbd_into(x_in[2], cur_rgb, cur_dep, 2, N, HW, self.dyn_ws, K * HW * 3, 0, K * HW, 0,
-                           rgb2=inp['target_rgb'], depth2=inp['target_depth'])
+        ops.dynimg_rgbd_into(x_in[2], cur_rgb, cur_dep, 2, N, HW, self.dyn_ws, K * HW * 3, 0, K * HW, 0,
+                             rgb2=inp['target_rgb'], depth2=inp['target_depth'])
       self.enc.forward()
       feats = self.enc.features
       ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], self.feat_ch, 2, jnts[:, K - 1], K * jn,
@@ -638,9 +640,9 @@ class GoalE2EVMC(_ModelBase):
       if self.fused_inputs:
         ops.goal_inputs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, C, self.gin_ws, K * HW * C, HW * C)
       elif C == 3 and HW % 4 == 0 and self.last_from_dynimg:
-        # the buffer-image kernel has the current frame in registers: it writes its channel-padded copy too
-        ops.dynimg_last_into(x_in[1], x_in[0], frames, K, N, HW, self.dyn_ws, K * HW * C, HW * C)
-        ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)
+        # three launches: the buffer-image kernel has the current frame in registers and writes its channel-padded copy
+        # too; one normalisation launch serves both images
+        ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, self.dyn_ws2, K * HW * C, HW * C)
       else:
         ops.pack_pixels_into(x_in[0], cur, K * HW * C, N, HW, C, 4)
         ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, self.dyn_ws, K * HW * C, HW * C)

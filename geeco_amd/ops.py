@@ -100,6 +100,15 @@ def dynimg_rgbd_last_into(out, last, rgb, depth, K, N, HW, ws, sample_stride, fr
                                           _stream()), 'geeco_dynimg_rgbd_fwd_last')
 
 
+def goal_dynimgs_into(cur_out, buf_out, diff_out, rgb, tgt_rgb, K, N, HW, ws, sample_stride, frame_stride, depth=None,
+                      tgt_depth=None, dsample_stride=0, dframe_stride=0):
+  """The goal model's three conv1 inputs (current frame padded, buffer image, diff image) in three launches."""
+  check(_lib().geeco_goal_dynimgs_fwd(_p(rgb), sample_stride, frame_stride, _p(tgt_rgb), _p(depth), dsample_stride,
+                                      dframe_stride, _p(tgt_depth), ctypes.cast(_alpha_buf(K), ctypes.c_void_p),
+                                      ctypes.cast(_alpha_buf(2), ctypes.c_void_p), N, K, HW, _p(cur_out), _p(buf_out),
+                                      _p(diff_out), _p(ws), _stream()), 'geeco_goal_dynimgs_fwd')
+
+
 def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
   """frames [N,K,H,W,C] contiguous -> [N,H,W,Cpad]."""
   N, K, H, W, C = frames.shape

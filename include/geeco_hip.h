@@ -70,6 +70,15 @@ int geeco_dynimg_rgbd_fwd_last(const float* rgb, int64_t sample_stride, int64_t 
                                int64_t dsample_stride, int64_t dframe_stride, const float* alpha_host, int N, int K,
                                int64_t HW, float* out, float* last, void* ws, void* stream);
 
+/* All three conv1 inputs of the goal model's dynimg branch (graph.py:386-401) in three launches: buf_out = dynimg of the
+ * K-frame stack, diff_out = dynimg of (last frame, target) with the 2-frame coefficients alpha2, cur_out = the last
+ * frame channel-padded; both images are normalised by ONE launch.  depth / tgt_depth NULL: RGB ((R, G, B, 0) pixels),
+ * else RGB-D from separate tensors.  ws: 2 x geeco_dynimg_ws_bytes(N, HW * 4) bytes. */
+int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* tgt_rgb,
+                           const float* depth, int64_t dsample_stride, int64_t dframe_stride, const float* tgt_depth,
+                           const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW, float* cur_out,
+                           float* buf_out, float* diff_out, void* ws, void* stream);
+
 /* Fused input stage of goal_e2evmc's dynimg branch (graph.py:386-402): ONE launch reads a batch of K-frame windows
  * (frames [N][K][HW][C], element strides given; C = 3 or 4 with 16-byte aligned frames) and the target frames
  * (tgt [N][HW][C]) once and writes the three conv1 inputs [N][HW][4]:

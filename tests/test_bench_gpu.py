@@ -35,7 +35,7 @@ def test_bench_tables_small(model_name, channels):
   hbm = bench.hbm_table(model, args, 1)
   assert hbm and hbm[-1]['piece'].startswith('adam') and all(r['us'] > 0 for r in hbm)
   if goal:
-    assert len(hbm) == 3 and hbm[0]['piece'].startswith('dynimg buffer image')
+    assert len(hbm) == 4 and hbm[0]['piece'].startswith('dynimg buffer image') and hbm[2]['piece'].startswith('goal inputs as in the step')
   layers = bench.layer_table(model, 1)
   assert len(layers) >= 20 and all(r['us'] > 0 and r['kernel'] for r in layers)
   rl = bench.dominant_roofline(layers)
