@@ -62,6 +62,8 @@ SIGNATURES = {
                                                    _P, _P, POINTER(SlabReduce)]),
     'geeco_slab_reduce_batch': (_I, [POINTER(SlabReduce), _I, _P]),
     'geeco_relu_bits_pitch': (_L, [_I]),
+    'geeco_conv3_fwd_relu_fields': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
+    'geeco_conv3x3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     'geeco_relu_fields_elems': (_L, [_I, _I, _I]),
     'geeco_conv2_fwd_relu_fields': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_conv3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _P]),

@@ -32,6 +32,8 @@ struct DgradLdsParams {
   const float* dz;       // [G][N][Ho][Wo][Cout]
   const float* w;        // HWIO [G][9][Cin][Cout]
   const float* mask;     // y of the layer below [G][N][H][W][Cin] (ReluGrad) or null
+  const unsigned char* fields;   // instead of mask: its sign fields [G][N][H][W][Cin / 8] (byte (T >> 1) * 4 + q, bit 4 (T & 1) + j <-> channel 16 T + 4 q + j)
+  long long gs_fields;
   float* dx;             // [G][N][H][W][Cin]
   long long gs_dz, gs_w, gs_dx;
   int N, H, W, Ho, Wo, Cin, Cout;
@@ -239,10 +241,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
           const int py = c >> 1, px = c & 1;
           const long long pix = ((long long)n * p.H + 2 * Y + py) * p.W + 2 * X + px;
           const long long o = gbase + pix * Cin + cib * CIB + 4 * q;
+          // sign fields: one byte per pair of channel tiles (this lane's quad q) instead of NCIT float4 of the activation
+          unsigned fld[(NCIT + 1) / 2];
+          if (p.fields) {
+            const unsigned char* fp = p.fields + (long long)g * p.gs_fields + pix * (Cin >> 3) + ((cib * NCIT) >> 1) * 4 + q;
+#pragma unroll
+            for (int u = 0; u < (NCIT + 1) / 2; ++u) fld[u] = fp[4 * u];
+          }
 #pragma unroll
           for (int t = 0; t < NCIT; ++t) {
             f32x4 v = acc[c][t];
-            if (p.mask) {
+            if (p.fields) {
+              const int T = cib * NCIT + t;      // (NCIT even: T & 1 == t & 1, the byte index is u = t >> 1)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe((int)fld[t >> 1], 4 * (T & 1) + j, 1));
+            } else if (p.mask) {
               const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + o + 16 * t);
               v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
               v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
@@ -290,9 +304,35 @@ int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride) {
   return 1;
 }
 
+static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* ymask, const unsigned char* fields,
+                          int64_t gs_fields, float* dx, int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H,
+                          int W, int Cin, int Cout, int stride, hipStream_t stream, int* handled);
+
 int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask, float* dx, int groups, int64_t gs_dz,
                         int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride,
                         hipStream_t stream, int* handled) {
+  return dgrad_lds_impl(dz, w_hwio, ymask, nullptr, 0, dx, groups, gs_dz, gs_w, gs_dx, N, H, W, Cin, Cout, stride, stream,
+                        handled);
+}
+
+// geeco_conv3x3_dgrad for the shapes this file serves, with the ReluGrad mask given as sign fields
+extern "C" int geeco_conv3x3_dgrad_relu_fields(const float* dz, const float* w, const uint8_t* y_fields, float* dx, int groups,
+                                               int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H,
+                                               int W, int Cin, int Cout, int stride, void* stream) {
+  GEECO_CHECK_ARG(dz && w && y_fields && dx, "conv3x3_dgrad_relu_fields: null pointer");
+  GEECO_CHECK_ARG(Cin % 32 == 0, "conv3x3_dgrad_relu_fields: Cin = %d (whole tile pairs)", Cin);
+  int handled = 0;
+  const int rc = dgrad_lds_impl(dz, w, nullptr, y_fields, gs_fields, dx, groups, gs_dz, gs_w, gs_dx, N, H, W, Cin, Cout, stride,
+                                (hipStream_t)stream, &handled);
+  if (rc) return rc;
+  GEECO_CHECK_ARG(handled, "conv3x3_dgrad_relu_fields: shape %dx%d, %d -> %d channels, stride %d is not served by the "
+                           "LDS-staged input-gradient kernel", H, W, Cin, Cout, stride);
+  return 0;
+}
+
+static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* ymask, const unsigned char* fields,
+                          int64_t gs_fields, float* dx, int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H,
+                          int W, int Cin, int Cout, int stride, hipStream_t stream, int* handled) {
   *handled = 0;
   static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
   if (disabled || !w_hwio || stride != 2 || (H & 1) || (W & 1) || Cin % 64 != 0 || Cout % 16 != 0 || Cout < 32) return 0;
@@ -303,7 +343,7 @@ int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask
   if (!variant) return 0;
   if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 31)) return 0;
   DgradLdsParams p = {};
-  p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
+  p.dz = dz; p.w = w_hwio; p.mask = ymask; p.fields = fields; p.gs_fields = gs_fields; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout;
   static const int no_stagger = getenv("GEECO_DGRAD_NO_STAGGER") ? 1 : 0;
   p.stagger = !no_stagger;

@@ -49,6 +49,9 @@ struct HaloFwdParams {
   unsigned short* fields;
   long long gs_fields;
   int fHp, fWp;
+  // chunked forward (conv3): byte fields [G][N][Ho][Wo][COUT / 8]: byte (T >> 1) * 4 + q, bit 4 (T & 1) + j <-> channel 16 T + 4 q + j
+  unsigned char* fields8;
+  long long gs_fields8;
 };
 
 #ifdef GEECO_STAMPS
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
       const int oy = ty * TH + strip, ox = tx * TW + r;
       const bool ok = oy < p.Ho && ox < p.Wo;
       float* yo = p.y + (long long)g * p.gs_y + (((long long)n * p.Ho + oy) * p.Wo + ox) * COUT + cohalf * (COUT / 2);
+      unsigned sign = 0;     // sign bits of this lane's 4 TI outputs (after the ReLU: > 0 <=> non-zero bits): bit 4 i + j
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         f32x4 v = acc[i] + bias_r[i];
@@ -776,6 +780,16 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (ok) stream_store<2>(yo + i * 16 + 4 * q, v);
+        if (p.fields8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sign |= min(__float_as_uint(v[j]), 1u) << (4 * i + j);
+        }
+      }
+      // sign fields for the next layer's input-gradient kernel (same (pixel r, quad q) accumulator layout: the lane owns
+      // whole bytes: its TI = 2 channel tiles are tile pair `cohalf`)
+      if (p.fields8 && ok) {
+        static_assert(TI == 2, "one byte per lane = one pair of 16-channel tiles");
+        p.fields8[(long long)g * p.gs_fields8 + (((long long)n * p.Ho + oy) * p.Wo + ox) * (COUT / 8) + cohalf * 4 + q] = (unsigned char)sign;
       }
     }
     if (!more) return false;
@@ -2455,6 +2469,25 @@ extern "C" int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, co
   if (rc) return rc;
   GEECO_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- ... and of conv3's output for conv4's input gradient (byte fields, see HaloFwdParams::fields8) ------------------
+extern "C" int geeco_conv3_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint8_t* fields,
+                                           int groups, int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y,
+                                           int64_t gs_fields, int N, int H, int W, void* stream) {
+  GEECO_CHECK_ARG(x && w && b && y && fields, "conv3_fwd_relu_fields: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                  "conv3_fwd_relu_fields: H = %d, W = %d must be even", H, W);
+  HaloFwdParams p = {};
+  p.x = x; p.w = w; p.bias = b; p.y = y;
+  p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
+  p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
+  p.tiles_x = cdiv(p.Wo, 16); p.tiles_y = cdiv(p.Ho, 4);
+  p.tiles_per_group = N * p.tiles_x * p.tiles_y;
+  p.ntiles = (long long)groups * p.tiles_per_group;
+  p.relu = 1;
+  p.fields8 = fields; p.gs_fields8 = gs_fields;
+  return launch_s2_halo_fwd_chunked<48, 64>(p, (hipStream_t)stream);
 }
 
 extern "C" int64_t geeco_relu_bits_pitch(int W) { return (int64_t)(W + 63) / 64 * 64; }

@@ -144,6 +144,12 @@ class ConvEncoderStack:
                           and L1['H'] % 2 == 0 and L1['W'] % 2 == 0 and L2['H'] % 2 == 0 and L2['W'] % 2 == 0)
       if self.relu_fields:
         self.fields2 = torch.zeros(G, ops.relu_fields_elems(Nf, L2['H'], L2['W']), dtype=torch.int16, device=dev)
+      # ... and conv3's forward leaves byte sign fields of y3 for conv4's LDS-staged input-gradient kernel
+      L3 = self.layers[3]
+      self.relu_fields3 = (self.relu_fields and os.environ.get('GEECO_NO_DGRAD_LDS') is None and os.environ.get('GEECO_NO_FIELDS3') is None and L3['Cin'] == 64
+                           and L3['stride'] == 2 and not ops.conv3x3_dgrad_needs_wt(L3['H'], L3['W'], L3['Cin'], L3['Cout'], 2))
+      if self.relu_fields3:
+        self.fields3 = torch.zeros(G, Nf, L3['H'], L3['W'], L3['Cin'] // 8, dtype=torch.uint8, device=dev)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
       self.dz = [None if (i == 0 and self.fused_bottom) else
                  ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]
@@ -228,6 +234,10 @@ class ConvEncoderStack:
       w, gs_w = self.w1p, self.w1p[0].numel()
     else:
       w, gs_w = self._w(l), self.gs_p
+    if l == 2 and self.training and self.relu_fields3:
+      ops.conv3_fwd_relu_fields_into(y, self.fields3, x, w, self._b(2), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),
+                                     self.fields3[0].numel(), Nf, L['H'], L['W'])
+      return
     if l == 1 and self.training and self.relu_fields:
       ops.conv2_fwd_relu_fields_into(y, self.fields2, x, w, self._b(1), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),
                                      self.fields2[0].numel(), Nf, L['H'], L['W'])
@@ -290,6 +300,10 @@ class ConvEncoderStack:
       return
     wt = self.wt[l]
     dx = self.dz[l - 1]
+    if l == 3 and self.relu_fields3:
+      ops.conv3x3_dgrad_relu_fields_into(dx, dz, self._w(3), self.fields3, G, dz[0].numel(), self.gs_p, self.fields3[0].numel(),
+                                         dx[0].numel(), Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
+      return
     if l == 2 and self.relu_fields:
       ops.conv3_dgrad_relu_fields_into(dx, dz, self._w(2), self.fields2, G, dz[0].numel(), self.gs_p, self.fields2[0].numel(),
                                        dx[0].numel(), Nf, L['H'], L['W'])

@@ -25,7 +25,7 @@ def _stream():
 def _p(t):
   if t is None:
     return None
-  assert t.is_cuda and t.dtype in (torch.float32, torch.int64, torch.int32, torch.int16), (t.device, t.dtype)
+  assert t.is_cuda and t.dtype in (torch.float32, torch.int64, torch.int32, torch.int16, torch.uint8), (t.device, t.dtype)
   return ctypes.c_void_p(t.data_ptr())
 
 
@@ -272,6 +272,18 @@ def conv3_dgrad_relu_fields_into(dx, dz, w, fields, G, gs_dz, gs_w, gs_fields, g
   """conv3 input gradient (48 -> 64, stride 2) masked by the sign fields of conv2's output; H, W = dims of dx."""
   check(_lib().geeco_conv3_dgrad_relu_fields(_p(dz), _p(w), _p(fields), _p(dx), G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W,
                                              _stream()), 'geeco_conv3_dgrad_relu_fields')
+
+
+def conv3_fwd_relu_fields_into(y, fields, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs_fields, N, H, W):
+  """conv3 forward (48 -> 64, stride 2, bias, ReLU) that also writes y's byte sign fields (uint8 [G][N][H/2][W/2][8])."""
+  check(_lib().geeco_conv3_fwd_relu_fields(_p(x), _p(w), _p(b), _p(y), _p(fields), G, gs_x, gs_w, gs_b, gs_y, gs_fields, N,
+                                           H, W, _stream()), 'geeco_conv3_fwd_relu_fields')
+
+
+def conv3x3_dgrad_relu_fields_into(dx, dz, w, fields, G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W, Cin, Cout, stride):
+  """LDS-staged input gradient masked by the byte sign fields of the layer below ([G][N][H][W][Cin / 8])."""
+  check(_lib().geeco_conv3x3_dgrad_relu_fields(_p(dz), _p(w), _p(fields), _p(dx), G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W,
+                                               Cin, Cout, stride, _stream()), 'geeco_conv3x3_dgrad_relu_fields')
 
 
 def transpose_hwio_into(wt, w, G, gs_w, gs_wt, Cin, Cout):

@@ -206,6 +206,17 @@ int geeco_conv2_fwd_relu_fields(const float* x, const float* w, const float* b, 
 int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_t* y2_fields, float* dx, int groups,
                                   int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H, int W,
                                   void* stream);
+/* ... and one more layer up: conv3's forward (48 -> 64, stride 2) writing byte sign fields of its output y3, and the
+ * LDS-staged input-gradient kernel of the next layer (any shape geeco_conv3x3_dgrad_needs_wt reports 0 for with
+ * Cin % 64 == 0, e.g. conv4: 64 -> 128) masked by them instead of by y3 (100 MB at the bench shape):
+ *   fields[g][n][y][x][Cin / 8] bytes: byte (T >> 1) * 4 + q, bit 4 (T & 1) + j set iff y[g][n][y][x][16 T + 4 q + j] > 0
+ *   (T = 16-channel tile, q = channel quad inside it); group stride gs_fields bytes; no padding. */
+int geeco_conv3_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint8_t* fields, int groups,
+                                int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_fields, int N, int H,
+                                int W, void* stream);
+int geeco_conv3x3_dgrad_relu_fields(const float* dz, const float* w, const uint8_t* y_fields, float* dx, int groups,
+                                    int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H, int W,
+                                    int Cin, int Cout, int stride, void* stream);
 int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float* w2, const uint32_t* y1_bits, const float* x,
                                        float* dw1, float* db1, int groups, int64_t gs_dz2, int64_t gs_w2,
                                        int64_t gs_bits, int64_t gs_x, int64_t gs_dw1, int64_t gs_db1, int N, int H, int W,

@@ -494,6 +494,52 @@ def test_dynimg_with_last_frame(dev, N, K, H, W, C):
   assert torch.equal(out, out_ref) and torch.equal(last, last_ref)
 
 
+@pytest.mark.parametrize('G,N,H,W', [(1, 2, 32, 64), (3, 2, 64, 64)])
+def test_conv3_relu_fields_and_conv4_dgrad_fields(dev, G, N, H, W):
+  """conv3's forward with the byte sign fields of its output (byte (T >> 1) * 4 + q, bit 4 (T & 1) + j <-> channel
+  16 T + 4 q + j) and the LDS-staged input gradient of the next layer (64 -> 128) masked by them: y3 equals the plain
+  forward, the fields equal the packed signs, dx equals (bitwise) the gradient masked by y3 itself."""
+  from geeco_amd import ops
+  r = np.random.default_rng(59)
+  x = torch.tensor(r.standard_normal([G, N, H, W, 48]).astype(np.float32), device=dev)
+  w3 = torch.tensor((r.standard_normal([G, 3, 3, 48, 64]) / 20).astype(np.float32), device=dev)
+  b3 = torch.tensor((0.1 * r.standard_normal([G, 64])).astype(np.float32), device=dev)
+  H3, W3 = H // 2, W // 2
+  y_plain = torch.empty(G, N, H3, W3, 64, device=dev)
+  ws = torch.empty(ops.conv3x3_fwd_ws_bytes(G, N, H, W, 48, 64, 2) // 4 + 4, device=dev)
+  ops.conv3x3_fwd_into(y_plain, x, w3, b3, G, x[0].numel(), w3[0].numel(), 64, y_plain[0].numel(), N, H, W, 48, 64, 2,
+                       relu=True, ws=ws)
+  y = torch.empty_like(y_plain)
+  fields = torch.zeros(G, N, H3, W3, 8, dtype=torch.uint8, device=dev)
+  names = ops.kernel_trace(lambda: ops.conv3_fwd_relu_fields_into(y, fields, x, w3, b3, G, x[0].numel(), w3[0].numel(), 64,
+                                                                  y[0].numel(), fields[0].numel(), N, H, W))
+  torch.cuda.synchronize()
+  assert names[0].startswith('conv_s2_halo_fwd_chunked_kernel'), names
+  assert torch.equal(y, y_plain)
+  pos = (y.cpu().numpy() > 0).reshape(G, N, H3, W3, 4, 4, 4)          # [.., T, q, j]
+  want = np.zeros([G, N, H3, W3, 8], np.uint8)
+  for T in range(4):
+    for q in range(4):
+      for j in range(4):
+        want[..., (T >> 1) * 4 + q] |= (pos[..., T, q, j].astype(np.uint8) << (4 * (T & 1) + j))
+  assert np.array_equal(fields.cpu().numpy(), want)
+  # the next layer's input gradient (64 -> 128, stride 2) on the y3 grid
+  w4 = torch.tensor((r.standard_normal([G, 3, 3, 64, 128]) / 24).astype(np.float32), device=dev)
+  dz4 = torch.tensor(r.standard_normal([G, N, H3 // 2, W3 // 2, 128]).astype(np.float32), device=dev)
+  wt = torch.empty(G, 3, 3, 128, 64, device=dev)
+  ops.transpose_hwio_into(wt, w4, G, w4[0].numel(), wt[0].numel(), 64, 128)
+  dx_ref = torch.full((G, N, H3, W3, 64), float('nan'), device=dev)
+  dws = torch.empty(ops.conv3x3_dgrad_ws_bytes(G, N, H3, W3, 64, 128, 2) // 4 + 4, device=dev)
+  n0 = ops.kernel_trace(lambda: ops.conv3x3_dgrad_into(dx_ref, dz4, wt, y, G, dz4[0].numel(), wt[0].numel(), dx_ref[0].numel(), N,
+                                                       H3, W3, 64, 128, 2, ws=dws, w=w4, gs_w=w4[0].numel()))
+  dx = torch.full_like(dx_ref, float('nan'))
+  n1 = ops.kernel_trace(lambda: ops.conv3x3_dgrad_relu_fields_into(dx, dz4, w4, fields, G, dz4[0].numel(), w4[0].numel(),
+                                                                   fields[0].numel(), dx[0].numel(), N, H3, W3, 64, 128, 2))
+  torch.cuda.synchronize()
+  assert n0 == n1 and n1[0].startswith('conv_s2_dgrad_lds_kernel'), (n0, n1)
+  assert not torch.isnan(dx).any() and torch.equal(dx, dx_ref)
+
+
 def test_slab_reduce_batch_bitwise(dev):
   """Deferred slab sums (geeco_conv3x3_wgrad_partial x 4 layers of different kernels + the fused bottom, then ONE
   geeco_slab_reduce_batch) give bitwise the gradients of the plain calls."""
