@@ -25,6 +25,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 
 // One parity class of a launch (forward: a single class with all 9 taps; dgrad of a stride-s conv:
 // s*s classes, each with its own subset of taps and its own sub-grid of destination pixels).
@@ -479,6 +480,12 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
   // (round 1: neutral to slower; since the kernel's VALU diet of round 2 the gathered bytes weigh more: -11 us per step)
   static const int no_bn128 = getenv("GEECO_CONV_NO_BN128") ? 1 : 0;
   if (!no_bn128 && p.Nout % 128 == 0 && pl.bm == 128 && (Mtot / 128) * (p.Nout / 128) * groups >= 512) pl.bn = 128;
+  // 96-wide N tiles where they (and not the 64-wide ones) make the block count a whole multiple of the CUs
+  // (conv5 forward: 768 blocks instead of 1152 = 4.5 per CU: -10 us)
+  static const int no_bn96 = getenv("GEECO_CONV_NO_BN96") ? 1 : 0;
+  if (!no_bn96 && pl.bn == 64 && pl.bm == 64 && p.Nout % 96 == 0 && p.ncls == 1 &&
+      (cdiv64(Mtot, 64) * (p.Nout / 96) * groups) % 256 == 0 && (cdiv64(Mtot, 64) * (p.Nout / 64) * groups) % 256 != 0)
+    pl.bn = 96;
   long long blocks = 0;
   for (int c = 0; c < p.ncls; ++c) blocks += cdiv64(p.cls[c].M, pl.bm);
   blocks *= (long long)cdiv(p.Nout, pl.bn) * groups;
@@ -488,7 +495,27 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
     long long want = cdiv64(1024, blocks);
     long long maxs = nk / 8;   // at least 8 K-steps per block
     if (want > maxs) want = maxs;
+    // prefer the factor nearest to that which makes the block count a whole multiple of the 256 CUs: all blocks are
+    // co-resident and dealt evenly (scripts/dev/ub/placement.hip), so a ragged count leaves some CUs with one block
+    // more than the others for the whole launch (conv6 forward: 3 -> 2 splits, 768 blocks, -4 us)
+    static const int no_align = getenv("GEECO_NO_KSPLIT_ALIGN") ? 1 : 0;
+    if (!no_align) {
+      long long best = 0;
+      for (long long k = 2; k <= maxs; ++k)
+        if ((blocks * k) % 256 == 0 && blocks * k <= 2048 && (best == 0 || llabs(k - want) < llabs(best - want))) best = k;
+      if (best) want = best;
+    }
     if (want > 1) pl.ksplit = (int)want;
+  }
+  // dev: GEECO_CONV_FORCE="C:Nout:ncls:bm:bn:ksplit[;...]" overrides the plan of the matching launches (tile sweeps)
+  static const char* force = getenv("GEECO_CONV_FORCE");
+  for (const char* f = force; f && *f;) {
+    int c, n, k, bm, bn, ks;
+    if (sscanf(f, "%d:%d:%d:%d:%d:%d", &c, &n, &k, &bm, &bn, &ks) == 6 && c == p.C && n == p.Nout && k == p.ncls) {
+      pl.bm = bm; pl.bn = bn; pl.ksplit = ks;
+    }
+    f = strchr(f, ';');
+    if (f) ++f;
   }
   return pl;
 }
@@ -552,6 +579,8 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
     }
   } else if (pl.bn == 128) {
     launch_cfg<128, 128, 16, 2, 2>(p, groups, s);
+  } else if (pl.bn == 96) {
+    launch_cfg<64, 96, 16, 2, 2>(p, groups, s);
   } else if (pl.bn == 64) {
     if (pl.bm == 64)
       launch_cfg<64, 64, 16, 2, 2>(p, groups, s);

@@ -6,6 +6,6 @@ for e in "" "$@"; do
   python - "$e" <<'PY'
 import json, os, sys
 d = json.loads(open('gpurun_out/layersweep/b.json').read().strip().splitlines()[-1])
-print('[%s]' % sys.argv[1], d['value'], d['step_ms']['median'], [(r['layer'], r['op'], r['us']) for r in d["layers"][4:16]])
+print('[%s]' % sys.argv[1], d['value'], d['step_ms']['median'], [(r['layer'], r['op'], r['us']) for r in d["layers"][int(os.environ.get("ROWS0", 4)):int(os.environ.get("ROWS1", 16))]])
 PY
 done
