@@ -34,6 +34,10 @@ static __device__ float g_zero_page[64];   // source of the DMA lanes that fall 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#ifndef WL_ABL
+#define WL_ABL 0   // dev ablations (timing only, wrong results): 1 = no DMA inside the tile loop, 2 = no MFMAs
+#endif
+
 struct WgradHaloParams {
   const float* x;
   const float* dz;
@@ -49,7 +53,10 @@ struct WgradHaloParams {
 void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
                                long long KC, int Cout, int groups, hipStream_t s);
 
-// CIB = 16 NCI input channels per block; 64 = 16 NCO COT output channels per block; NW = NCI * NCO waves.
+// CIB = 16 NCI input channels per block; COB = 16 NCO COT output channels per block (64, 96 or 128); NW = NCI * NCO waves.
+// Wide co blocks (COT = 3, 4) halve the number of blocks that fetch the same x halo: a 64-channel co block needs
+// 47 KB of DMA per 9.2k cycles of MFMA work per SIMD (conv4: 5.1 B/clk/CU - the ingest limit next to MFMA waves), a
+// 128-channel one 55 KB per 18.4k.
 // NBUF = 2: halo / dz double buffered, one block per CU;  NBUF = 1: single buffers (half the LDS), the host launches
 // TWO blocks per CU (MINW waves per SIMD in total) which fill each other's DMA waits and barrier stalls.
 template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ, int NBUF, int MINW>
@@ -60,13 +67,14 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
   constexpr int X_USED = HY * HX * XPQ;                  // float4 granules of the halo image
   constexpr int NXP = (X_USED + 63) / 64;                // its 1 KiB DMA pieces
   constexpr int X_F4 = NXP * 64;
-  constexpr int Z_F4 = TH * TW * 16;                     // dz tile: [pixel][16 granules]
+  constexpr int COB = 16 * NCO * COT, ZQ = COB / 4;      // co block and its float4 granules per pixel
+  constexpr int Z_F4 = TH * TW * ZQ;                     // dz tile: [pixel][ZQ granules]
   constexpr int NZP = Z_F4 / 64;
   constexpr int NSLOT = (NXP + NZP + NW - 1) / NW;       // DMA pieces per wave and tile
   constexpr int KG = TW / 4;                             // k-groups (4 consecutive pixels) per tile row
-  static_assert(NCO * COT == 4 && TW % 4 == 0 && Z_F4 % 64 == 0, "co block = 64 channels");
+  static_assert((ZQ == 16 || ZQ == 24 || ZQ == 32) && TW % 4 == 0 && Z_F4 % 64 == 0, "co block = 64, 96 or 128 channels");
   static_assert(XPQ >= CQ && (SWZ ? (XPQ == 16 && CQ == 16) : (XPQ % 4 == 2)), "x pixel pitch must be 8 (mod 16) floats or swizzled");
-  static_assert(Z_F4 <= NT, "one dz granule per thread for the bias gradient");
+  constexpr int NDB = (Z_F4 + NT - 1) / NT;              // dz granules per thread for the bias gradient
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sX = reinterpret_cast<f32x4*>(smem);            // NBUF halo buffers
   f32x4* sZ = sX + NBUF * X_F4;                          // NBUF dz tiles
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
   const int split = sigma % p.S;
   const int cib = (sigma / p.S) % p.n_cib;
   const int g = sigma / (p.S * p.n_cib);
-  const int ci0 = cib * CIB, co0 = cob * 64;
+  const int ci0 = cib * CIB, co0 = cob * COB;
   const int Cin = p.Cin, Cout = p.Cout;
 
   const int per = (p.tiles_per_group + p.S - 1) / p.S;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
       d_src[i] = (rw * p.W + hx) * Cin + ci0 + quad * 4;
     } else {
       const int f = (k - NXP) * 64 + lane;
-      const int px = f >> 4, qs = f & 15;
+      const int px = f / ZQ, qs = f - px * ZQ;
       const int zr = px / TW, zc = px - zr * TW;
       const int quad = qs ^ ((zc & 1) << 2);
       d_a[i] = (short)(k < NXP + NZP ? zr : 30000);
@@ -161,7 +169,9 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
     }
   };
 
-  f32x4 dbsum = zero4;
+  f32x4 dbsum[NDB];
+#pragma unroll
+  for (int k = 0; k < NDB; ++k) dbsum[k] = zero4;
   f32x4 acc[9][COT];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
 #pragma unroll
   for (int i = 0; i < COT; ++i) {
     const int quad = (cog * COT + i) * 4 + (r >> 2);
-    ze[i] = (q * 16 + (quad ^ ((q & 1) << 2))) * 4 + (r & 3);           // pixel 4 s + q has the parity of q
+    ze[i] = (q * ZQ + (quad ^ ((q & 1) << 2))) * 4 + (r & 3);           // pixel 4 s + q has the parity of q
   }
 
   int buf = 0;
@@ -197,9 +207,13 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
     // 0.4 % slower here.)
     if (more) {
       advance(n2, ty2, tx2);
+#if WL_ABL != 1
       if (NBUF == 2) dma_tile(buf ^ 1, n2, ty2, tx2);     // lands behind this tile's MFMAs
+#endif
     }
-    if (tid < Z_F4) dbsum += sZ[buf * Z_F4 + tid];        // bias gradient: one dz granule per thread and tile
+#pragma unroll
+    for (int k = 0; k < NDB; ++k)                         // bias gradient: NDB dz granules per thread and tile
+      if (tid + k * NT < Z_F4) dbsum[k] += sZ[buf * Z_F4 + tid + k * NT];
     const float* hx = reinterpret_cast<const float*>(sX + buf * X_F4);
     const float* hz = reinterpret_cast<const float*>(sZ + buf * Z_F4);
     // software pipeline over the TH * KG k-groups: the fragments of group u + 1 are read while group u's MFMAs run
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
     auto load_frags = [&](int u, int set) {
       const int oyl = u / KG, s = u - oyl * KG;
 #pragma unroll
-      for (int i = 0; i < COT; ++i) a[set][i] = hz[(oyl * TW + 4 * s) * 64 + ze[i]];
+      for (int i = 0; i < COT; ++i) a[set][i] = hz[(oyl * TW + 4 * s) * (ZQ * 4) + ze[i]];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ky = t / 3, kx = t - ky * 3;
@@ -224,7 +238,11 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < COT; ++i)
+#if WL_ABL == 2
+          acc[t][i][0] += a[u & 1][i] * b[u & 1][t];
+#else
           acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u & 1][i], b[u & 1][t], acc[t][i], 0, 0, 0);
+#endif
     }
     if (NBUF == 2) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -249,14 +267,16 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
   // ---- bias gradient (blocks of the first ci block only): per-thread granule sums -> LDS -> fixed-order column sums -----
   if (cib == 0) {
     f32x4* sB = sX;                                       // the main loop ended with a barrier: LDS is free
-    if (tid < Z_F4) sB[tid] = dbsum;
+#pragma unroll
+    for (int k = 0; k < NDB; ++k)
+      if (tid + k * NT < Z_F4) sB[tid + k * NT] = dbsum[k];
     __syncthreads();
-    if (tid < 64) {
+    if (tid < COB) {
       const float* bf = reinterpret_cast<const float*>(sB);
       float s1 = 0.f;
 #pragma unroll 4
       for (int px = 0; px < TH * TW; ++px)
-        s1 += bf[(px * 16 + ((tid >> 2) ^ (((px % TW) & 1) << 2))) * 4 + (tid & 3)];
+        s1 += bf[(px * ZQ + ((tid >> 2) ^ (((px % TW) & 1) << 2))) * 4 + (tid & 3)];
       part[9ll * Cin * Cout + co0 + tid] = s1;
     }
   }
@@ -266,7 +286,8 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 struct WgradHaloPlan {
-  int variant;       // 0 = not handled; 1 = CIB 48 (conv3 type), TW 16; 4 = CIB 48, TW 8; 2 = CIB 64, TW 16; 3 = CIB 64, TW 8
+  int variant;       // 0 = not handled; 1 = CIB 48 (conv3 type), TW 16; 4 = CIB 48, TW 8; 2 = CIB 64, TW 16; 3 = CIB 64, TW 8;
+                     // 5 = CIB 32 x COB 128, TW 8
   int TH, TW, n_cib, n_cob, S;
   int bpc;           // blocks per CU: 1 = double-buffered images, 2 = single-buffered
 };
@@ -302,6 +323,14 @@ static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, i
   // rounds while the others idle (measured on conv5: 33 blocks on four XCDs took 200 us instead of 100).
   static const int bpc_env = getenv("GEECO_WGRAD_BPC") ? atoi(getenv("GEECO_WGRAD_BPC")) : 0;
   pl.bpc = bpc_env == 1 || bpc_env == 2 ? bpc_env : 1;
+  // 32 x 128 blocks of dw instead of 64 x 64 (same slab bytes): 35.6 KB of DMA per tile instead of 47 KB for the same
+  // MFMA work - the 64 x 64 blocks sit at the CU's ingest limit (5.1 B/clk next to MFMA waves)
+  static const int cob128 = getenv("GEECO_WGRAD_NO_COB128") ? 0 : 1;
+  if (cob128 && pl.bpc == 1 && pl.variant == 3 && Cout % 128 == 0) {
+    pl.variant = 5;
+    pl.n_cib = Cin / 32;
+    pl.n_cob = Cout / 128;
+  }
   int S = (8 * (32 * pl.bpc / pl.n_cob)) / (groups * pl.n_cib);
   if (S < 1) S = 1;
   if (S > tiles) S = (int)tiles;
@@ -318,7 +347,7 @@ int64_t geeco_wgrad_lds_ws_bytes(int groups, int N, int H, int W, int Cin, int C
 template <int NCI, int NCO, int COT, int TH, int TW, int XPQ, bool SWZ, int NBUF, int MINW>
 static int launch_wgrad_lds(const WgradHaloParams& p, int blocks, hipStream_t stream) {
   constexpr int X_F4 = ((2 * TH + 1) * (2 * TW + 1) * XPQ + 63) / 64 * 64;
-  constexpr size_t lds = (size_t)(NBUF * X_F4 + NBUF * TH * TW * 16) * 16;
+  constexpr size_t lds = (size_t)(NBUF * X_F4 + NBUF * TH * TW * 4 * NCO * COT) * 16;
   static_assert(lds * (3 - NBUF) <= 160 * 1024, "LDS budget (two blocks per CU when single-buffered)");
   static int attr_state = 0;          // 0 = not set; set once (idempotent: racing threads set the same value)
   if (__atomic_load_n(&attr_state, __ATOMIC_ACQUIRE) == 0) {
@@ -356,6 +385,7 @@ int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, i
       case 1: rc = launch_wgrad_lds<3, 4, 1, 2, 16, 14, false, 2, 3>(p, blocks, stream); break;
       case 4: rc = launch_wgrad_lds<3, 4, 1, 4, 8, 14, false, 2, 3>(p, blocks, stream); break;
       case 2: rc = launch_wgrad_lds<4, 2, 2, 2, 16, 16, true, 2, 2>(p, blocks, stream); break;
+      case 5: rc = launch_wgrad_lds<2, 4, 2, 4, 8, 10, false, 2, 2>(p, blocks, stream); break;
       default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true, 2, 2>(p, blocks, stream); break;
     }
   } else {
