@@ -69,6 +69,7 @@ struct ConvGemmParams {
   int ncls;
   int ksplit;           // K-steps are dealt to ksplit blocks (blockIdx.y = ntile * ksplit + split)
   int groups;
+  int rot;              // != 0: M tiles per class; the M tile index is rotated by it per 256 blocks (see the kernel)
   ConvClass cls[4];
 };
 
@@ -118,16 +119,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int g = blockIdx.z;
+  // Input gradients (ncls == 4 parity classes with 1 / 2 / 2 / 4 taps, i.e. K loops of unequal length): all blocks of a
+  // launch are co-resident and dealt to the CUs in dispatch order, so blocks L, L + 256, L + 512 share a CU - and with
+  // the M tile as the fastest grid index they would be tiles of the SAME class (conv7: three 4-tap blocks on one CU,
+  // three 1-tap blocks on another).  p.rot rotates the M tile index by one class per 256 blocks.
+  int bx = blockIdx.x;
+  if (p.rot) {
+    const int row = blockIdx.y + gridDim.y * blockIdx.z;
+    bx = (bx + (int)(((long long)row * gridDim.x) >> 8) * p.rot) % (int)gridDim.x;
+  }
   const float* __restrict__ xg = p.x + (long long)g * p.gs_x;
   const float* __restrict__ wg = p.w + (long long)g * p.gs_w;
   int ci = 0;
 #pragma unroll
   for (int c = 1; c < 4; ++c)
-    if (c < p.ncls && (int)blockIdx.x >= p.cls[c].tile0) ci = c;
+    if (c < p.ncls && bx >= p.cls[c].tile0) ci = c;
   const ConvClass& cl = p.cls[ci];
   const long long clsM = cl.M;
   const int clsHc = cl.Hc, clsWc = cl.Wc, ntaps = cl.ntaps;
-  const long long m0 = (long long)((int)blockIdx.x - cl.tile0) * BM;
+  const long long m0 = (long long)(bx - cl.tile0) * BM;
   const int ntile = blockIdx.y / p.ksplit;
   const int split = blockIdx.y - ntile * p.ksplit;
   const int n0 = ntile * BN;
@@ -450,6 +460,12 @@ static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
     tiles += (int)cdiv64(p.cls[c].M, BM);
   }
   dim3 grid((unsigned)tiles, (unsigned)(cdiv(p.Nout, BN) * p.ksplit), (unsigned)groups);
+  {
+    static const int no_rot = getenv("GEECO_CONV_NO_ROT") ? 1 : 0;
+    bool equal = p.ncls > 1;                    // rotation by whole classes needs equally many tiles per class
+    for (int c = 1; c < p.ncls; ++c) equal = equal && cdiv64(p.cls[c].M, BM) == cdiv64(p.cls[0].M, BM);
+    p.rot = (equal && !no_rot) ? tiles / p.ncls : 0;
+  }
   static const int no_ut = getenv("GEECO_CONV_NO_UT") ? 1 : 0;
   const bool ut = p.C % BK == 0 && p.C <= GEMM_ZERO_PAGE && !no_ut;   // uniform taps; a tap fits the zero page
   geeco_note_kernel("conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, BK, WM, WN, ut ? "true" : "false");

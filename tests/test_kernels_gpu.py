@@ -37,6 +37,7 @@ CONV_CASES = [
     (3, 40, 72, 32, 48, 2),     # conv2 halo kernel, ragged tiles (Ho = 20, Wo = 36)
     (16, 64, 64, 64, 128, 2),   # conv4-like at a size that takes the 128x128 tile path
     (8, 32, 32, 128, 192, 2),   # conv5-like (128-row wgrad tiles)
+    (8, 64, 64, 128, 192, 2),   # conv5-like with 128 M tiles: the forward takes the 64 x 96 tiles (256 blocks instead of 384)
     (2, 32, 32, 4, 32, 1),      # conv1 shape
     (1, 20, 44, 4, 32, 1),      # conv1 shape, ragged
 ]
