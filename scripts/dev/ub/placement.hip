@@ -1,4 +1,5 @@
-// Microbenchmark: where do the blocks of a SMALL grid land?  Each block notes its (XCC, SE, CU) and spins ~10 us;
+// Microbenchmark: where do the blocks of a SMALL grid land?  Each block notes its (XCC, SE, CU) and spins 30k shader
+// clocks (~14 us: every block is still resident when the last one starts);
 // the host counts blocks per CU.  Question behind it: a launch of 432 blocks that could all be co-resident (4-8 per
 // CU by registers / LDS) - is it dealt one or two per CU over all 256 CUs, or packed onto a part of the chip?
 //   hipcc --offload-arch=gfx950 -O2 placement.hip -o placement && ./placement
@@ -33,19 +34,15 @@ int main() {
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   for (int lds : ldss)
     for (int grid : grids) {
-      hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, d_where, d_when, 1000ll);   // s_memtime ticks at 100 MHz: 10 us
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, d_where, d_when, 30000ll);   // s_memtime counts shader clocks here
       hipDeviceSynchronize();
       hipMemcpy(h, d_where, grid * 4, hipMemcpyDeviceToHost);
       hipMemcpy(hw, d_when, 2 * 65536 * 8, hipMemcpyDeviceToHost);
       std::map<unsigned, int> per_cu;
       std::map<unsigned, int> per_xcc;
-      unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
       for (int b = 0; b < grid; ++b) {
         per_cu[h[b] & 0xfffff00u]++;       // xcc, se, sh, cu
         per_xcc[h[b] >> 16]++;
-        if (hw[b] < t0) t0 = hw[b];
-        if (hw[b] > s1) s1 = hw[b];
-        if (hw[65536 + b] > t1) t1 = hw[65536 + b];
       }
       int hist[16] = {0};
       for (auto& kv : per_cu) hist[kv.second < 15 ? kv.second : 15]++;
@@ -54,7 +51,7 @@ int main() {
         if (hist[i]) printf(" %dx%d", hist[i], i);
       printf("; per XCC:");
       for (auto& kv : per_xcc) printf(" %d", kv.second);
-      printf("; last start %.1f us, end %.1f us after the first start\n", (s1 - t0) / 100.0, (t1 - t0) / 100.0);
+      printf("\n");
     }
   return 0;
 }
