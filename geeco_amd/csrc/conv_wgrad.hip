@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   bool a_ok[PAS];
   int a_n[PAS], a_oy[PAS], a_ox[PAS];
   const long long HoWo = (long long)p.Ho * p.Wo;
+  const int adv_x = MK % p.Wo, adv_y = (MK / p.Wo) % p.Ho, adv_n = MK / (p.Wo * p.Ho);   // MK pixels as (columns, rows, frames)
 #pragma unroll
   for (int i = 0; i < PAS; ++i) {
     int idx = tid + i * 256;
@@ -107,15 +108,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       bool v = a_ok[i] && (mb + a_mrow[i] < mend) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       ra[i] = v ? *reinterpret_cast<const f32x4*>(xg + (((long long)a_n[i] * p.H + iy) * p.W + ix) * Cin + a_coff[i])
                 : zero4;
-      // advance this thread's pixel by MK for the next stage
-      a_ox[i] += MK;
-      while (a_ox[i] >= p.Wo) {
-        a_ox[i] -= p.Wo;
-        if (++a_oy[i] >= p.Ho) {
-          a_oy[i] = 0;
-          ++a_n[i];
-        }
-      }
+      // advance this thread's pixel by MK for the next stage: carries instead of a wrap loop (conv8: Wo = 2, i.e. 16
+      // divergent loop trips per entry and stage - VALU work that the f32 MFMAs pay for)
+      a_ox[i] += adv_x;
+      const int cx = a_ox[i] >= p.Wo ? 1 : 0;
+      a_ox[i] -= cx * p.Wo;
+      a_oy[i] += adv_y + cx;
+      const int cy = a_oy[i] >= p.Ho ? 1 : 0;
+      a_oy[i] -= cy * p.Ho;
+      a_n[i] += adv_n + cy;
     }
 #pragma unroll
     for (int i = 0; i < PBS; ++i) {
