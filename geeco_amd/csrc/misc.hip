@@ -244,7 +244,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   float s = 0.f;
-  for (int i = 0; i < M; ++i) s += a[(long long)i * lda + j];
+  int i = 0;
+  for (; i + 8 <= M; i += 8) {          // 8 loads in flight; the sum keeps the row order
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = a[(long long)(i + u) * lda + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; i < M; ++i) s += a[(long long)i * lda + j];
   out[j] = accumulate ? out[j] + s : s;
 }
 
