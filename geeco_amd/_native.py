@@ -52,6 +52,7 @@ SIGNATURES = {
     'geeco_conv3x3_dgrad': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv3x3_dgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_dgrad_needs_wt': (_I, [_I, _I, _I, _I, _I]),
+    'geeco_conv3x3_dgrad_relu_fields_supported': (_I, [_I, _I, _I, _I, _I]),
     'geeco_conv3x3_wgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_wgrad': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv2_dgrad_conv1_wgrad_ws_bytes': (_L, [_I]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     'geeco_conv3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_relu_bits_rows': (_L, [_I]),
     'geeco_conv1_fwd_relu_bits': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
+    'geeco_conv1_fwd_relu_bits_rgb': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_conv2_dgrad_conv1_wgrad_bits': (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P,
                                                 POINTER(SlabReduce)]),
     'geeco_transpose_hwio': (_I, [_P, _P, _I, _L, _L, _I, _I, _P]),

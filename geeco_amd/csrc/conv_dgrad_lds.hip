@@ -315,6 +315,11 @@ int geeco_try_dgrad_lds(const float* dz, const float* w_hwio, const float* ymask
                         handled);
 }
 
+// shapes geeco_conv3x3_dgrad_relu_fields serves (the LDS-staged kernel's, with whole 32-channel tile pairs)
+extern "C" int geeco_conv3x3_dgrad_relu_fields_supported(int H, int W, int Cin, int Cout, int stride) {
+  return geeco_dgrad_lds_handles(H, W, Cin, Cout, stride) && Cin % 32 == 0;
+}
+
 // geeco_conv3x3_dgrad for the shapes this file serves, with the ReluGrad mask given as sign fields
 extern "C" int geeco_conv3x3_dgrad_relu_fields(const float* dz, const float* w, const uint8_t* y_fields, float* dx, int groups,
                                                int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H,

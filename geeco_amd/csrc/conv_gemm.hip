@@ -69,6 +69,7 @@ struct ConvGemmParams {
   int ncls;
   int ksplit;           // K-steps are dealt to ksplit blocks (blockIdx.y = ntile * ksplit + split)
   int groups;
+  int bt;               // B operand from the HWIO kernel itself ([tap][n][k]: k contiguous) instead of a per-tap transposed copy
   int rot;              // != 0: M tiles per class; the M tile index is rotated by it per 256 blocks (see the kernel)
   ConvClass cls[4];
 };
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   constexpr int KB = BK / 16;
   static_assert(PA >= 1 && TJ >= 1 && TI >= 1 && WM * WN == 4, "bad tile");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM * BK + BK * LDB) + 48];
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM * BK + BK * LDB) + 60];
   float* sA = smem;
   float* sB = smem + 2 * BM * BK;
   int* sTap = reinterpret_cast<int*>(smem + 2 * (BM * BK + BK * LDB));
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     sTap[12 + t] = ok ? cl.dx[t] : 0;
     sTap[24 + t] = ok ? (cl.dy[t] * p.Ws + cl.dx[t]) * C : 0;
     sTap[36 + t] = ok ? cl.wslab[t] * C : 0;
+    sTap[48 + t] = ok ? cl.wslab[t] : 0;
   }
   __syncthreads();
   STAMP(1);
@@ -199,6 +201,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     b_c[i] = k0 - b_tap[i] * C;
   }
 
+  int bt_n[PB], bt_k4[PB];      // bt: column and K quad of this thread's float4 (BK / 4 quads per column)
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int idx = tid + i * 256;
+    bt_n[i] = idx / (BK / 4);
+    bt_k4[i] = idx - bt_n[i] * (BK / 4);
+  }
   f32x4 ra[PA], rbv[PB];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -223,9 +232,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      u_bv[i] = (tid + i * 256 < NB4) && tv && (n0 + b_c4[i] * 4 < p.Nout);
-      u_bp[i] = u_bv[i] ? wg + (long long)(sTap[36 + t] + u_cc + b_row[i]) * p.Nout + n0 + b_c4[i] * 4 : g_gemm_zero_page;
-      u_bstep[i] = u_bv[i] ? (long long)BK * p.Nout : 0;
+      if (p.bt) {
+        // HWIO kernel w[tap][n][k]: this thread's float4 = 4 consecutive k of ONE column n (bt_n, bt_k4 below); the
+        // K-step advances along the contiguous axis
+        u_bv[i] = (tid + i * 256 < NB4) && tv && (n0 + bt_n[i] < p.Nout);
+        u_bp[i] = u_bv[i] ? wg + ((long long)sTap[48 + t] * p.Nout + n0 + bt_n[i]) * C + u_cc + bt_k4[i] * 4 : g_gemm_zero_page;
+        u_bstep[i] = u_bv[i] ? BK : 0;
+      } else {
+        u_bv[i] = (tid + i * 256 < NB4) && tv && (n0 + b_c4[i] * 4 < p.Nout);
+        u_bp[i] = u_bv[i] ? wg + (long long)(sTap[36 + t] + u_cc + b_row[i]) * p.Nout + n0 + b_c4[i] * 4 : g_gemm_zero_page;
+        u_bstep[i] = u_bv[i] ? (long long)BK * p.Nout : 0;
+      }
     }
   };
   if constexpr (UT) {
@@ -302,7 +319,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     float* b = sB + buf * (BK * LDB);
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      if (tid + i * 256 < NB4) *reinterpret_cast<f32x4*>(b + b_row[i] * LDB + b_c4[i] * 4) = rbv[i];
+      if (tid + i * 256 < NB4) {
+        if (UT && p.bt) {        // transposing store: 4 consecutive k of column bt_n
+          float* d = b + bt_k4[i] * 4 * LDB + bt_n[i];
+          d[0] = rbv[i].x; d[LDB] = rbv[i].y; d[2 * LDB] = rbv[i].z; d[3 * LDB] = rbv[i].w;
+        } else {
+          *reinterpret_cast<f32x4*>(b + b_row[i] * LDB + b_c4[i] * 4) = rbv[i];
+        }
+      }
     }
   };
 
@@ -717,14 +741,22 @@ extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b,
 int geeco_halo_dgrad_handles(int H, int W, int Cin, int Cout, int stride);
 int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride);
 
+// The gather GEMM reads the HWIO kernel itself (transposing it on the way into LDS) where its K-steps stay inside one
+// tap: Cout a multiple of 16 that fits the zero page.  Only the remaining shapes need the per-tap transposed copy.
+static bool dgrad_reads_hwio(int Cout) {
+  static const int no_bt = (getenv("GEECO_CONV_NO_BT") || getenv("GEECO_CONV_NO_UT") || getenv("GEECO_CONV_BK32")) ? 1 : 0;
+  return !no_bt && Cout % 16 == 0 && Cout <= GEMM_ZERO_PAGE;
+}
+
 extern "C" int geeco_conv3x3_dgrad_needs_wt(int H, int W, int Cin, int Cout, int stride) {
-  return !(geeco_halo_dgrad_handles(H, W, Cin, Cout, stride) || geeco_dgrad_lds_handles(H, W, Cin, Cout, stride));
+  return !(geeco_halo_dgrad_handles(H, W, Cin, Cout, stride) || geeco_dgrad_lds_handles(H, W, Cin, Cout, stride) ||
+           dgrad_reads_hwio(Cout));
 }
 
 extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* w, const float* wt, const float* ymask, float* dx,
                                    int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_wt, int64_t gs_dx, int N,
                                    int H, int W, int Cin, int Cout, int stride, void* ws, void* stream) {
-  GEECO_CHECK_ARG(dz && wt && dx, "conv3x3_dgrad: null pointer");
+  GEECO_CHECK_ARG(dz && dx && (wt || w), "conv3x3_dgrad: null pointer");
   GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv3x3_dgrad: bad dims");
   GEECO_CHECK_ARG(Cout % 4 == 0, "conv3x3_dgrad: Cout=%d must be a multiple of 4", Cout);
   GEECO_CHECK_ARG(Cin % 16 == 0, "conv3x3_dgrad: Cin=%d must be a multiple of 16", Cin);
@@ -742,6 +774,10 @@ extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* w, const float*
   fill_dgrad(&p, N, H, W, Cin, Cout, stride);
   p.x = dz; p.w = wt; p.bias = nullptr; p.mask = ymask; p.out = dx;
   p.gs_x = gs_dz; p.gs_w = gs_wt; p.gs_b = 0; p.gs_out = gs_dx;
+  if (w && dgrad_reads_hwio(Cout)) {
+    p.w = w; p.gs_w = gs_w; p.bt = 1;
+  }
+  GEECO_CHECK_ARG(p.w, "conv3x3_dgrad: this shape (Cout = %d) needs the per-tap transposed kernel wt", Cout);
   if (p.ncls == 0) return 0;
   return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
 }

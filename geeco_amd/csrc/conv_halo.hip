@@ -2278,12 +2278,12 @@ int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymas
 // ------------------------------------------------------------------------------------------------
 struct Conv1FwdParams {
   const float* x;       // [G][N][H][W][4]
-  const float* w;       // [G][9][4][32]
+  const float* w;       // [G][9][w_cin][32]: w_cin = 4 (padded copy) or 3 (the RGB variable itself, channel 3 taken as zero)
   const float* bias;
   float* y;             // [G][N][H][W][32]
   unsigned* bits;       // optional [G][N][Hp][Wp]: ReLU sign bits of y (geeco_conv1_fwd_relu_bits), else null
   long long gs_x, gs_w, gs_b, gs_y, gs_bits;
-  int N, H, W, tiles_x, tiles_y, relu, Wp, Hp;
+  int N, H, W, tiles_x, tiles_y, relu, Wp, Hp, w_cin;
 };
 
 __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParams p) {
@@ -2310,7 +2310,7 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) wf[tp][i] = wg[(tp * 4 + q) * 32 + i * 16 + r];
+    for (int i = 0; i < 2; ++i) wf[tp][i] = q < p.w_cin ? wg[(tp * p.w_cin + q) * 32 + i * 16 + r] : 0.f;
   f32x4 bias_r[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + i * 16 + 4 * q);
@@ -2416,7 +2416,7 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
 
 static int launch_conv1_fwd(const float* x, const float* w, const float* b, float* y, unsigned* bits, int groups,
                             int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H, int W,
-                            int relu, hipStream_t stream);
+                            int relu, hipStream_t stream, int w_cin = 4);
 
 int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
                         int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
@@ -2501,10 +2501,21 @@ extern "C" int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const f
   return launch_conv1_fwd(x, w, b, y, bits, groups, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H, W, 1, (hipStream_t)stream);
 }
 
+// ... reading the RGB model's kernel variable [G][3][3][3][32] as it is stored (x stays channel-padded to 4; the pad
+// channel's kernel rows are taken as zero): no padded copy to re-derive after every optimiser step
+extern "C" int geeco_conv1_fwd_relu_bits_rgb(const float* x, const float* w3, const float* b, float* y, uint32_t* bits,
+                                             int groups, int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y,
+                                             int64_t gs_bits, int N, int H, int W, void* stream) {
+  GEECO_CHECK_ARG(x && w3 && b && y && bits, "conv1_fwd_relu_bits_rgb: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1, "conv1_fwd_relu_bits_rgb: bad dims");
+  return launch_conv1_fwd(x, w3, b, y, bits, groups, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H, W, 1, (hipStream_t)stream, 3);
+}
+
 static int launch_conv1_fwd(const float* x, const float* w, const float* b, float* y, unsigned* bits, int groups,
                             int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H, int W,
-                            int relu, hipStream_t stream) {
+                            int relu, hipStream_t stream, int w_cin) {
   Conv1FwdParams p = {};
+  p.w_cin = w_cin;
   p.x = x; p.w = w; p.bias = b; p.y = y; p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
   p.bits = bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W); p.Hp = (int)geeco_relu_bits_rows(H);
   p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.relu = relu;

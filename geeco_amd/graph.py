@@ -122,6 +122,7 @@ class ConvEncoderStack:
       L7 = self.layers[7]
       self.acts[7] = [torch.empty(Nf, L7['Ho'], L7['Wo'], d, **f32) for d in self.dim_outs]
     self.pad1 = self.Cpad != Cin
+    self.pad1_copy = self.pad1      # the channel-padded copy of conv1's kernel is kept up to date (see below)
     if self.pad1:
       self.w1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
     if training:
@@ -133,6 +134,11 @@ class ConvEncoderStack:
       # the fused bottom only needs the SIGN of conv1's output (ReluGrad): conv1's forward writes one bit word per pixel
       # next to y1 and the backward reads those 25 MB instead of the 805 MB of y1 (GEECO_NO_RELU_BITS: read y1)
       self.relu_bits = self.fused_bottom and os.environ.get('GEECO_NO_RELU_BITS') is None
+      # with the fused bottom and the sign bits nothing reads the channel-padded copy of conv1's kernel any more: conv1's
+      # forward takes the RGB variable itself (together with the gather GEMM reading HWIO kernels this leaves NO weight
+      # copy to re-derive after Adam: one launch less per step)
+      if self.relu_bits and self.Cin == 3 and os.environ.get('GEECO_PAD1_COPY') is None:
+        self.pad1_copy = False
       if self.relu_bits:
         self.bits1 = torch.zeros(G, Nf, ops.relu_bits_rows(L0['H']), ops.relu_bits_pitch(L0['W']), dtype=torch.int32, device=dev)
       # the same one layer up: conv2's forward leaves 16-bit sign fields of y2 for conv3's input-gradient kernel
@@ -147,7 +153,7 @@ class ConvEncoderStack:
       # ... and conv3's forward leaves byte sign fields of y3 for conv4's LDS-staged input-gradient kernel
       L3 = self.layers[3]
       self.relu_fields3 = (self.relu_fields and os.environ.get('GEECO_NO_DGRAD_LDS') is None and os.environ.get('GEECO_NO_FIELDS3') is None and L3['Cin'] == 64
-                           and L3['stride'] == 2 and not ops.conv3x3_dgrad_needs_wt(L3['H'], L3['W'], L3['Cin'], L3['Cout'], 2))
+                           and L3['stride'] == 2 and ops.conv3x3_dgrad_relu_fields_supported(L3['H'], L3['W'], L3['Cin'], L3['Cout'], 2))
       if self.relu_fields3:
         self.fields3 = torch.zeros(G, Nf, L3['H'], L3['W'], L3['Cin'] // 8, dtype=torch.uint8, device=dev)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
@@ -214,7 +220,7 @@ class ConvEncoderStack:
       for g in range(G):
         ops.derive_conv_weights([self._w(7, g)], [self.wt[7][g].unsqueeze(0)], [L7['Cin']], [self.dim_outs[g]], 1, 0)
     pad = dict(pad_src=self._w(0), pad_dst=self.w1p, pad_cin=self.Cin, pad_cin_padded=self.Cpad,
-               pad_cout=self.layers[0]['Cout']) if self.pad1 else {}
+               pad_cout=self.layers[0]['Cout']) if self.pad1_copy else {}
     if ls or pad:
       ops.derive_conv_weights([self._w(l) for l in ls], [self.wt[l] for l in ls], [self.layers[l]['Cin'] for l in ls],
                               [self.layers[l]['Cout'] for l in ls], G, self.gs_p, **pad)
@@ -241,6 +247,10 @@ class ConvEncoderStack:
     if l == 1 and self.training and self.relu_fields:
       ops.conv2_fwd_relu_fields_into(y, self.fields2, x, w, self._b(1), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),
                                      self.fields2[0].numel(), Nf, L['H'], L['W'])
+      return
+    if l == 0 and self.training and self.relu_bits and self.pad1 and not self.pad1_copy:
+      ops.conv1_fwd_relu_bits_rgb_into(y, self.bits1, x, self._w(0), self._b(0), G, x[0].numel(), self.gs_p, self.gs_p, y[0].numel(),
+                                       self.bits1[0].numel(), Nf, L['H'], L['W'])
       return
     if l == 0 and self.training and self.relu_bits:
       ops.conv1_fwd_relu_bits_into(y, self.bits1, x, w, self._b(0), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(),

@@ -181,6 +181,10 @@ def conv3x3_dgrad_needs_wt(H, W, Cin, Cout, stride):
   return bool(_lib().geeco_conv3x3_dgrad_needs_wt(H, W, Cin, Cout, stride))
 
 
+def conv3x3_dgrad_relu_fields_supported(H, W, Cin, Cout, stride):
+  return bool(_lib().geeco_conv3x3_dgrad_relu_fields_supported(H, W, Cin, Cout, stride))
+
+
 def conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
   return int(_lib().geeco_conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride))
 
@@ -244,6 +248,12 @@ def conv1_fwd_relu_bits_into(y, bits, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs_bit
   """conv1 forward (4 -> 32, stride 1, bias, ReLU) that also writes y's sign bits (int32 [G][N][Hp][Wp], zero-filled once by the caller)."""
   check(_lib().geeco_conv1_fwd_relu_bits(_p(x), _p(w), _p(b), _p(y), _p(bits), G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H,
                                          W, _stream()), 'geeco_conv1_fwd_relu_bits')
+
+
+def conv1_fwd_relu_bits_rgb_into(y, bits, x, w3, b, G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H, W):
+  """conv1_fwd_relu_bits_into reading the RGB kernel variable [G][3][3][3][32] itself (no channel-padded copy)."""
+  check(_lib().geeco_conv1_fwd_relu_bits_rgb(_p(x), _p(w3), _p(b), _p(y), _p(bits), G, gs_x, gs_w, gs_b, gs_y, gs_bits, N, H,
+                                             W, _stream()), 'geeco_conv1_fwd_relu_bits_rgb')
 
 
 def conv2_dgrad_conv1_wgrad_bits_into(dw1, db1, dz2, w2, y1_bits, x, G, gs_dz2, gs_w2, gs_bits, gs_x, gs_dw1, gs_db1, N, H,

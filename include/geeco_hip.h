@@ -127,9 +127,11 @@ int geeco_conv3x3_dgrad(const float* dz, const float* w, const float* wt, const 
                         int64_t gs_dx, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
                         void* stream);
 int64_t geeco_conv3x3_dgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
-/* 0 if geeco_conv3x3_dgrad, GIVEN the HWIO kernel `w`, runs a kernel that reads `w` itself for this shape (the caller
- * then need not keep the transposed copy `wt` up to date: any valid pointer will do); 1 if `wt` is read. */
+/* 0 if geeco_conv3x3_dgrad, GIVEN the HWIO kernel `w`, runs a kernel that reads `w` itself for this shape (the LDS-staged
+ * kernels, and the gather GEMM whenever Cout % 16 == 0: it transposes the kernel tile on its way into LDS); the caller then
+ * need not keep the transposed copy `wt` up to date and may pass NULL for it.  1 if `wt` is read. */
 int geeco_conv3x3_dgrad_needs_wt(int H, int W, int Cin, int Cout, int stride);
+int geeco_conv3x3_dgrad_relu_fields_supported(int H, int W, int Cin, int Cout, int stride);
 
 /* Conv2DBackpropFilter + BiasAddGrad:  dw[ky][kx][ci][co] = sum_m x[pix(m,ky,kx)][ci] dz[m][co],
  * db[co] = sum_m dz[m][co].  dw/db are OVERWRITTEN (not accumulated).
@@ -194,6 +196,12 @@ int64_t geeco_relu_bits_rows(int H);
 int geeco_conv1_fwd_relu_bits(const float* x, const float* w, const float* b, float* y, uint32_t* bits, int groups,
                               int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H,
                               int W, void* stream);
+/* ... with the RGB model's kernel variable w3 [G][3][3][3][32] as it is stored (x stays channel-padded; the pad channel's
+ * kernel rows count as zero): bitwise the same y / bits as with the padded copy, which then need not be re-derived after
+ * every optimiser step. */
+int geeco_conv1_fwd_relu_bits_rgb(const float* x, const float* w3, const float* b, float* y, uint32_t* bits, int groups,
+                                  int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H,
+                                  int W, void* stream);
 /* The same idea one layer up: conv2's forward (32 -> 48, stride 2, bias, ReLU; x [G][N][H][W][32]) that also writes the
  * sign fields of its output y2, and conv3's input gradient (48 -> 64, stride 2; dz [G][N][H/2][W/2][64], dx = d(y2)
  * [G][N][H][W][48]) masked by those fields instead of by y2 itself (302 MB at the bench shape).
@@ -207,8 +215,8 @@ int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_
                                   int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H, int W,
                                   void* stream);
 /* ... and one more layer up: conv3's forward (48 -> 64, stride 2) writing byte sign fields of its output y3, and the
- * LDS-staged input-gradient kernel of the next layer (any shape geeco_conv3x3_dgrad_needs_wt reports 0 for with
- * Cin % 64 == 0, e.g. conv4: 64 -> 128) masked by them instead of by y3 (100 MB at the bench shape):
+ * LDS-staged input-gradient kernel of the next layer (the shapes geeco_conv3x3_dgrad_relu_fields_supported reports,
+ * e.g. conv4: 64 -> 128) masked by them instead of by y3 (100 MB at the bench shape):
  *   fields[g][n][y][x][Cin / 8] bytes: byte (T >> 1) * 4 + q, bit 4 (T & 1) + j set iff y[g][n][y][x][16 T + 4 q + j] > 0
  *   (T = 16-channel tile, q = channel quad inside it); group stride gs_fields bytes; no padding. */
 int geeco_conv3_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint8_t* fields, int groups,

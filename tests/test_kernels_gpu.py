@@ -680,3 +680,57 @@ def test_conv3x3_dgrad_grouped_lds(dev, Cin, Cout, H, W, Nd):
       yy.backward(torch.tensor(dz[g], dtype=torch.float64))
       ref = xg.grad * (torch.tensor(mask[g]) > 0) if use_mask else xg.grad
       _close(dx[g], ref, 2e-5, 2e-5, 'grouped dgrad (mask %s), encoder %d' % (use_mask, g))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 4, 4, 192, 256, 2), (4, 2, 2, 256, 256, 2), (1, 10, 10, 16, 64, 1),
+                                                  (2, 9, 7, 16, 16, 2), (3, 8, 8, 64, 96, 2)])
+def test_conv3x3_dgrad_hwio_vs_transposed_copy(dev, N, H, W, Cin, Cout, stride):
+  """The gather-GEMM input gradient reading the HWIO kernel itself (tile transposed on its way into LDS; the default when
+  the caller hands over `w`) against the same kernel fed the per-tap transposed copy `wt` (w = NULL): same K order, so the
+  results are bitwise equal; wt may be NULL in the first form."""
+  from geeco_amd import ops
+  r = np.random.default_rng(91)
+  Ho, Wo = -(-H // stride), -(-W // stride)
+  dz = torch.tensor(r.standard_normal([N, Ho, Wo, Cout]).astype(np.float32), device=dev)
+  w = torch.tensor((r.standard_normal([3, 3, Cin, Cout]) / np.sqrt(9 * Cout)).astype(np.float32), device=dev)
+  mask = torch.tensor(r.standard_normal([N, H, W, Cin]).astype(np.float32), device=dev)
+  wt = torch.empty(3, 3, Cout, Cin, device=dev)
+  ops.transpose_hwio_into(wt, w, 1, 0, 0, Cin, Cout)
+  ws = ops._ws(ops.conv3x3_dgrad_ws_bytes(1, N, H, W, Cin, Cout, stride), dev)
+  assert not ops.conv3x3_dgrad_needs_wt(H, W, Cin, Cout, stride)
+  a = torch.full((N, H, W, Cin), float('nan'), device=dev)
+  b = torch.full((N, H, W, Cin), float('nan'), device=dev)
+  names = ops.kernel_trace(lambda: ops.conv3x3_dgrad_into(a, dz, None, mask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride, ws, w=w))
+  ops.conv3x3_dgrad_into(b, dz, wt, mask, 1, 0, 0, 0, N, H, W, Cin, Cout, stride, ws, w=None)
+  torch.cuda.synchronize()
+  if names[0].startswith('conv_gemm_kernel'):
+    assert torch.equal(a, b)
+  else:                     # an LDS-staged kernel took the shape (it reads HWIO anyway)
+    _close(a, b.double(), 2e-5, 2e-5, 'dgrad')
+
+
+@pytest.mark.parametrize('G,N,H,W', [(1, 2, 16, 64), (3, 2, 20, 44)])
+def test_conv1_rgb_kernel_variable(dev, G, N, H, W):
+  """conv1's forward reading the RGB model's kernel variable [3][3][3][32] itself == reading its channel-padded copy:
+  y1 and the sign words bitwise."""
+  from geeco_amd import ops
+  r = np.random.default_rng(97)
+  x = torch.tensor(r.standard_normal([G, N, H, W, 4]).astype(np.float32), device=dev)
+  x[..., 3] = 0
+  w3 = torch.tensor((r.standard_normal([G, 3, 3, 3, 32]) / 5).astype(np.float32), device=dev)
+  w4 = torch.zeros(G, 3, 3, 4, 32, device=dev)
+  w4[:, :, :, :3] = w3
+  b = torch.tensor((0.1 * r.standard_normal([G, 32])).astype(np.float32), device=dev)
+  Wp, Hp = ops.relu_bits_pitch(W), ops.relu_bits_rows(H)
+  ys, bs = [], []
+  for rgb in (False, True):
+    y = torch.full((G, N, H, W, 32), float('nan'), device=dev)
+    bits = torch.zeros(G, N, Hp, Wp, dtype=torch.int32, device=dev)
+    if rgb:
+      ops.conv1_fwd_relu_bits_rgb_into(y, bits, x, w3, b, G, x[0].numel(), w3[0].numel(), 32, y[0].numel(), bits[0].numel(), N, H, W)
+    else:
+      ops.conv1_fwd_relu_bits_into(y, bits, x, w4, b, G, x[0].numel(), w4[0].numel(), 32, y[0].numel(), bits[0].numel(), N, H, W)
+    ys.append(y); bs.append(bits)
+  torch.cuda.synchronize()
+  assert torch.equal(ys[0], ys[1]) and torch.equal(bs[0], bs[1])
+
