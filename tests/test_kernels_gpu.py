@@ -683,7 +683,8 @@ def test_conv3x3_dgrad_grouped_lds(dev, Cin, Cout, H, W, Nd):
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,stride', [(2, 4, 4, 192, 256, 2), (4, 2, 2, 256, 256, 2), (1, 10, 10, 16, 64, 1),
-                                                  (2, 9, 7, 16, 16, 2), (3, 8, 8, 64, 96, 2)])
+                                                  (2, 9, 7, 16, 16, 2), (3, 8, 8, 64, 96, 2),
+                                                  (64, 33, 33, 128, 192, 2)])   # the last one takes 128 x 128 tiles
 def test_conv3x3_dgrad_hwio_vs_transposed_copy(dev, N, H, W, Cin, Cout, stride):
   """The gather-GEMM input gradient reading the HWIO kernel itself (tile transposed on its way into LDS; the default when
   the caller hands over `w`) against the same kernel fed the per-tap transposed copy `wt` (w = NULL): same K order, so the
@@ -705,6 +706,8 @@ def test_conv3x3_dgrad_hwio_vs_transposed_copy(dev, N, H, W, Cin, Cout, stride):
   torch.cuda.synchronize()
   if names[0].startswith('conv_gemm_kernel'):
     assert torch.equal(a, b)
+    if N == 64:
+      assert names[0].startswith('conv_gemm_kernel<128, 128'), names
   else:                     # an LDS-staged kernel took the shape (it reads HWIO anyway)
     _close(a, b.double(), 2e-5, 2e-5, 'dgrad')
 
