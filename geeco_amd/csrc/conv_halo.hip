@@ -897,9 +897,6 @@ struct HaloWgradParams {
 // 8.1 k; with four extra loader waves doing all DMA the MFMA waves finish after 7.3 k and then wait at the tile barrier
 // until 10.8 k for the 51 KB to land.  The CU ingests ~5 B/clk here (3.1 TB/s chip-wide for 1.2 GB, all of it
 // compulsory): the kernel is bound by that, not by where the loads sit.
-#ifndef HW_FAST
-#define HW_FAST 1   // 0: every tile takes the general DMA issue path (A/B)
-#endif
 template <int CIN, int COUT>
 __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgradParams p) {
   constexpr int NT = 512;
@@ -980,30 +977,10 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
       d_src[i] = ((px >> 4) * p.Wo + (px & 15)) * COUT + c4 * 4;
     }
   }
-  // Tiles whose halo and dz tile lie wholly inside the image (85 % of them at 256 x 256) take a DMA issue path without
-  // vector ALU work: uniform tile base (SGPRs) + this lane's byte offset, no bounds test, no select - the 9 VALU
-  // instructions per piece of the general path are paid in MFMA time (finding 1).  Lanes of pad slots, which
-  // no fragment read touches, fetch the tile's first granule instead of the zero page.
-  unsigned d_fast[NSLOT];
-#pragma unroll
-  for (int i = 0; i < NSLOT; ++i) d_fast[i] = d_a[i] == 30000 ? 0u : (unsigned)d_src[i] * 4u;
   auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
     const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
     const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN;
     const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * COUT;
-    if (HW_FAST && iy0 + 2 * TH < p.H && ix0 + 2 * TW < p.W && (ty_ + 1) * TH <= p.Ho && (tx_ + 1) * TW <= p.Wo) {
-      const char* xb = reinterpret_cast<const char*>(xg);
-      const char* zb = reinterpret_cast<const char*>(zg);
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i) {
-        const int k = wid + 8 * i;                        // wave-uniform
-        if (k < NHP)
-          __builtin_amdgcn_global_load_lds((gptr_t)(xb + d_fast[i]), (lptr_t)(sH + buf * HALO_F4 + k * 64), 16, 0, 0);
-        else if (k < NHP + NZP)
-          __builtin_amdgcn_global_load_lds((gptr_t)(zb + d_fast[i]), (lptr_t)(sZ + buf * DZ_F4 + (k - NHP) * 64), 16, 0, 0);
-      }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const int k = wid + 8 * i;                          // wave-uniform
