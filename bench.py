@@ -10,11 +10,14 @@ of synthetic 256x256 RGB x 16-frame windows (BASELINE.json configs[1]: batch 32 
 resident in HBM before the timed region.  ``value`` = global_batch * seq_len * steps / wall time of the
 timed region (barrier + synchronize on both sides, max over ranks).
 
-Extra objects (N = 1): ``layers`` (every conv launch of the step timed alone with HIP events: FLOP, us,
-TFLOP/s, fraction of the fp32 MFMA peak), ``roofline`` (the kernel with the largest share of the step,
-taken from that table), ``hbm`` (dynimg calls and Adam against the HBM peak), ``encoder_forward`` and
-``cpu_baseline`` (the CPU restatement in oracle/, timed on the host cores).  N > 1 adds the measured
-all-reduce time and its exposed part.
+Extra objects (N = 1): ``layers`` (every conv launch of the step timed alone, one HIP event pair per launch,
+median of >= 30: FLOP, us, TFLOP/s, fraction of the fp32 MFMA peak), ``roofline`` (the kernel with the largest
+share of the step, taken from that table, plus the same by kernel family), ``hbm`` (dynimg calls and Adam against the
+HBM peak), ``encoder_forward``, ``other_configs`` (config 4 and the per-GPU shape of config 5, a few steps each, with
+their own oracle-pinned loss check) and ``cpu_baseline`` (the CPU restatement in oracle/, timed on the host cores).
+N > 1 adds ``ranks`` (per-rank ms/step, device identities: the run refuses ranks that share a GPU) and ``comm`` (the
+all-reduce alone and the step with the exchange overlapped / serial / skipped; ``--dp-serial`` makes the serial order
+the timed one).
 """
 import argparse
 import json
@@ -44,8 +47,14 @@ def parse_args():
   ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying hipGraphs')
   ap.add_argument('--skip-cpu', action='store_true', help='skip the cpu_baseline leg')
   ap.add_argument('--skip-layers', action='store_true', help='skip the per-layer / roofline / hbm legs (profiling runs)')
-  ap.add_argument('--cpu-steps', type=int, default=6)
+  ap.add_argument('--cpu-steps', type=int, default=60, help='upper bound; the leg stops after ~12 s of CPU work')
   ap.add_argument('--cpu-batch', type=int, default=4)
+  ap.add_argument('--dp-serial', action='store_true',
+                  help='N > 1: run the gradient exchange AFTER the backward instead of beside its bottom part (the timed '
+                       'region then measures the serial step; comm.step_ms always reports both)')
+  ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
+  ap.add_argument('--allow-shared-gpu', action='store_true',
+                  help='REHEARSAL on a one-GPU box (tests/_dp_launch.py): do not refuse ranks that share a device')
   return ap.parse_args()
 
 
@@ -59,7 +68,7 @@ def log(msg):
 def spawn_ranks(args):
   import torch
   have = torch.cuda.device_count()        # counting devices does not initialise the GPU
-  if have < args.gpus and not os.environ.get('GEECO_SHARE_GPU'):
+  if have < args.gpus:
     log('--gpus %d requested but only %d GPU(s) are visible' % (args.gpus, have))
     return 2
   with socket.socket() as s:
@@ -135,6 +144,24 @@ def time_region(fn, iters):
   return e0.elapsed_time(e1) / iters
 
 
+def time_launches(fn, samples=30):
+  """One HIP event pair PER call of ``fn`` (on the current stream, the one our kernels are launched on), `samples`
+  calls; returns (median, p10, p90) in milliseconds.  A busy-wait kernel is queued first so that the host enqueues
+  all samples while the GPU is still busy: the pairs then measure the launch itself, not the host's enqueue rate, and
+  one hiccup moves one sample, not the reported median."""
+  import torch
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(samples)]
+  torch.cuda.synchronize()
+  torch.cuda._sleep(int(8e6))        # ~3-4 ms of GPU time at ~2.3 GHz
+  for a, b in evs:
+    a.record()
+    fn()
+    b.record()
+  torch.cuda.synchronize()
+  ts = sorted(a.elapsed_time(b) for a, b in evs)
+  return percentile(ts, 0.5), percentile(ts, 0.1), percentile(ts, 0.9)
+
+
 def percentile(sorted_vals, q):
   if not sorted_vals:
     return None
@@ -145,11 +172,11 @@ def percentile(sorted_vals, q):
 # ======================================================================================================
 # per-layer table, dominant-kernel roofline, HBM-bound pieces
 # ======================================================================================================
-def layer_table(model, iters):
-  """Every conv launch of one step, timed ALONE (HIP events over `iters` back-to-back launches): forward,
-  input gradient and filter gradient of conv1..conv8 over all encoder frames.  FLOP = 2 * MACs of the layer
-  (bias / ReLU / mask excluded).  A call that also runs a small reduce / epilogue kernel is timed
-  as a whole (its names are listed)."""
+def layer_table(model, samples):
+  """Every conv launch of one step, timed ALONE: forward, input gradient and filter gradient of conv1..conv8 over all
+  encoder frames, each call with its own HIP event pair, `samples` (>= 30) calls, MEDIAN reported (p10 / p90 beside it).
+  FLOP = 2 * MACs of the layer (bias / ReLU / mask excluded).  A call that also runs a small reduce /
+  epilogue kernel is timed as a whole (its names are listed)."""
   from geeco_amd import ops
   enc = model.enc
   rows = []
@@ -170,11 +197,11 @@ def layer_table(model, iters):
     for what, fn, fl in todo:
       names = ops.kernel_trace(fn)
       fn()
-      ms = time_region(fn, iters)
+      ms, p10, p90 = time_launches(fn, samples)
       tf = fl / (ms * 1e-3) / 1e12
       rows.append({'layer': 'conv%d' % (l + 1), 'op': what, 'kernel': names[0] if names else '?', 'kernels': names,
-                   'flop': int(fl), 'us': round(ms * 1e3, 1), 'tflops': round(tf, 2),
-                   'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+                   'flop': int(fl), 'us': round(ms * 1e3, 1), 'us_p10': round(p10 * 1e3, 1), 'us_p90': round(p90 * 1e3, 1),
+                   'tflops': round(tf, 2), 'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
   return rows
 
 
@@ -190,28 +217,43 @@ def dominant_roofline(rows):
   name, d = max(by.items(), key=lambda kv: kv[1]['us'])
   achieved = d['flop'] / (d['us'] * 1e-6) / 1e12
   n = len(d['launches'])
+  total = sum(r['us'] for r in rows)
+  traffic, source = recorded_traffic(name)
+  # the same ranking by kernel FAMILY (template name without its arguments): several instantiations of one kernel
+  # (e.g. the LDS-staged filter gradient of conv3..conv6) can together outweigh the largest single instantiation
+  fam = {}
+  for r in rows:
+    f = fam.setdefault(r['kernel'].split('<')[0], {'us': 0.0, 'flop': 0.0, 'launches': []})
+    f['us'] += r['us']
+    f['flop'] += r['flop']
+    f['launches'].append('%s %s' % (r['layer'], r['op']))
+  fname, f = max(fam.items(), key=lambda kv: kv[1]['us'])
+  fach = f['flop'] / (f['us'] * 1e-6) / 1e12
   return {'bound': 'mfma', 'kernel': name, 'launches_per_step': d['launches'], 'achieved': round(achieved, 2),
           'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-          'traffic': recorded_traffic(name), 'avg_launch_ms': round(d['us'] / n * 1e-3, 4),
-          'flop_per_launch': int(d['flop'] / n),
-          'share_of_conv_time': round(d['us'] / sum(r['us'] for r in rows), 4)}
+          'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': round(d['us'] / n * 1e-3, 4),
+          'flop_per_launch': int(d['flop'] / n), 'share_of_conv_time': round(d['us'] / total, 4),
+          'timer': 'HIP event pair per launch on the launch stream, median of the samples',
+          'family': {'kernel': fname, 'launches_per_step': f['launches'], 'achieved': round(fach, 2),
+                     'frac': round(fach / PEAK_F32_MFMA_TFLOPS, 4), 'us_per_step': round(f['us'], 1),
+                     'share_of_conv_time': round(f['us'] / total, 4)}}
 
 
 def recorded_traffic(kname):
-  """HBM bytes per launch (average over the kernel's launches in a step) from the committed rocprofv3 PMC passes
-  (profiles/r02/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on
-  gfx950, + WRITE_SIZE; separate --pmc passes).  PMC counters cannot be read from inside this process, so this is
-  the recorded measurement of the same kernel and shapes, or null when there is none."""
-  for rnd in ('r02', 'r01'):
-    path = os.path.join(ROOT, 'profiles', rnd, 'pmc_roofline_kernel.json')
+  """(HBM bytes per launch, where the figure comes from).  PMC counters cannot be read from inside this process, so
+  this is the RECORDED measurement of the same kernel and shapes from the committed rocprofv3 PMC passes
+  (profiles/rNN/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on gfx950,
+  + WRITE_SIZE; separate --pmc passes), newest round first, or (None, None) when there is none."""
+  for rnd in ('r03', 'r02', 'r01'):
+    rel = os.path.join('profiles', rnd, 'pmc_roofline_kernel.json')
     try:
-      with open(path) as f:
+      with open(os.path.join(ROOT, rel)) as f:
         rec = json.load(f)
       if rec.get('kernel', '').replace(' ', '') == kname.replace(' ', ''):
-        return rec['traffic_bytes']
+        return rec['traffic_bytes'], '%s (recorded rocprofv3 --pmc passes of this kernel at these shapes, not measured in this run)' % rel
     except (OSError, ValueError, KeyError):
       pass
-  return None
+  return None, None
 
 
 def hbm_table(model, args, iters):
@@ -223,10 +265,10 @@ def hbm_table(model, args, iters):
 
   def add(name, nbytes, fn):
     fn()
-    ms = time_region(fn, iters)
+    ms, p10, p90 = time_launches(fn, iters)
     tbs = nbytes / (ms * 1e-3) / 1e12
-    rows.append({'piece': name, 'bytes': int(nbytes), 'us': round(ms * 1e3, 1), 'TB/s': round(tbs, 3),
-                 'frac': round(tbs / PEAK_HBM_TBS, 4)})
+    rows.append({'piece': name, 'bytes': int(nbytes), 'us': round(ms * 1e3, 1), 'us_p10': round(p10 * 1e3, 1),
+                 'us_p90': round(p90 * 1e3, 1), 'TB/s': round(tbs, 3), 'frac': round(tbs / PEAK_HBM_TBS, 4)})
   if args.model == 'geeco-f' and getattr(model, 'split_rgbd', False):
     # RGB-D: the dynimg kernels read rgb and depth from their own tensors (no packed copy of the frames)
     inp, x_in = model.inputs, model.enc.x_in
@@ -273,7 +315,7 @@ def encoder_forward_tflops(model, iters, channels):
   enc = model.enc
   for _ in range(2):
     enc.forward()
-  ms = time_region(enc.forward, iters)
+  ms, _, _ = time_launches(enc.forward, iters)
   flop = ENC_FWD_FLOP_PER_FRAME[channels] * enc.G * enc.Nf
   return flop / (ms * 1e-3) / 1e12, ms
 
@@ -300,11 +342,12 @@ def cpu_baseline(args):
   tr.train_step(feats, labels)   # warm-up
   warm = time.perf_counter() - t0
   log('cpu_baseline: warm-up step %.2f s' % warm)
-  steps = max(1, min(args.cpu_steps, int(25.0 / max(warm, 1e-3))))   # keep the leg to ~25 s of CPU work
+  steps = max(3, min(args.cpu_steps, int(12.0 / max(warm, 1e-3))))   # a bounded sample: ~12 s of CPU work
   t0 = time.perf_counter()
   for i in range(steps):
     tr.train_step(feats, labels)
-    log('cpu_baseline: step %d/%d' % (i + 1, steps))
+    if (i + 1) % 10 == 0 or i + 1 == steps:
+      log('cpu_baseline: step %d/%d' % (i + 1, steps))
   dt = (time.perf_counter() - t0) / steps
   return {'value': round(args.cpu_batch * args.seq_len / dt, 2), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
           'box_cores': box, 'usable_cores': usable, 'kind': 'port',
@@ -340,6 +383,141 @@ def check_losses(args, first_loss, final_loss, total_steps):
 
 
 # ======================================================================================================
+def device_identity(local):
+  """A string that is the same for two ranks exactly when they sit on the same physical GPU."""
+  import torch
+  pr = torch.cuda.get_device_properties(local)
+  parts = []
+  u = getattr(pr, 'uuid', None)
+  if u is not None:
+    parts.append('uuid=%s' % u)
+  if hasattr(pr, 'pci_bus_id'):
+    parts.append('pci=%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0)))
+  if not parts:
+    parts.append('index=%d' % local)
+  return '%s %s' % (socket.gethostname(), ' '.join(parts))
+
+
+def build_model(model_name, channels, seq_len, batch, dev):
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  if model_name == 'geeco-f':
+    cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=seq_len, img_channels=channels,
+                                    batch_size=batch))
+    return cfg, graph.GoalE2EVMC(cfg, batch, dev, training=True)
+  cfg = create_e2evmc_config(dict(window_size=seq_len, img_channels=channels, batch_size=batch))
+  return cfg, graph.E2EVMC(cfg, batch, dev, training=True)
+
+
+def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=True):
+  """First optimiser step eager (its loss is the one checked against the oracle), second eager step + hipGraph capture,
+  `warmup` untimed replays, then EXACTLY `steps` steps between barrier + synchronize on both sides."""
+  import torch
+  from geeco_amd import dist as gdist
+  from geeco_amd.runtime import TrainStepRunner
+  runner = TrainStepRunner(model, use_graph=use_graph, warmup=2, overlap=overlap)
+  runner.step()
+  torch.cuda.synchronize()
+  first_loss = float(model.loss)
+  runner.prepare()     # second eager step + hipGraph capture, outside warm-up and timed region
+  torch.cuda.synchronize()
+  if verbose:
+    log('graphs captured' if use_graph else 'eager mode')
+  for i in range(warmup):
+    runner.step()
+    if i < 3 and verbose:
+      torch.cuda.synchronize()
+      log('warm-up step %d done' % (i + 1))
+  torch.cuda.synchronize()
+  evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+  if world > 1:
+    torch.distributed.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  evs[0].record()
+  for i in range(steps):
+    runner.step()
+    evs[i + 1].record()
+  torch.cuda.synchronize()
+  if world > 1:
+    torch.distributed.barrier()
+  torch.cuda.synchronize()
+  dt_local = time.perf_counter() - t0
+  return {'runner': runner, 'first_loss': first_loss, 'final_loss': float(model.loss), 'dt_local': dt_local,
+          'dt': gdist.max_over_ranks(dt_local, dev), 'total_steps': runner._calls,
+          'per_step': sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))}
+
+
+def step_flop(channels, frames):
+  """fwd + bwd FLOP of the encoders (backward = 2 x forward - conv1's input gradient)."""
+  return (3 * ENC_FWD_FLOP_PER_FRAME[channels] - 2 * 56623104 * (channels / 3.0)) * frames
+
+
+def other_configs(args, dev):
+  """The other single-GPU shapes of BASELINE.json, a few steps each, with the same oracle-pinned first-step loss check:
+  config 4 (e2e_vmc N=64 K=16: 1024 frame passes) and the per-GPU shape of config 5 (geeco-f rgbd N=32 K=32).  Not bench
+  lines (the headline metric is quoted on configs[1]); here so that their numbers are driver-run, not only DESIGN text."""
+  import argparse
+  import torch
+  out = []
+  for label, mname, ch, k, b in (('config4: e2e_vmc rgb seq_len=16 batch=64', 'e2e_vmc', 3, 16, 64),
+                                 ('config5 per-GPU shape: geeco-f rgbd seq_len=32 batch=32', 'geeco-f', 4, 32, 32)):
+    if (mname, ch, k, b) == (args.model, args.channels, args.seq_len, args.batch):
+      continue
+    cfg, model = build_model(mname, ch, k, b, dev)
+    model.store.initialize(seed=0)
+    synthetic_batch(model, 1234)
+    steps = max(5, min(args.steps, 10))
+    r = timed_steps(model, steps, 3, not args.no_graph, True, 1, dev, verbose=False)
+    ms = r['dt'] / steps * 1e3
+    a2 = argparse.Namespace(model=mname, channels=ch, batch=b, seq_len=k)
+    chk, ok = check_losses(a2, r['first_loss'], r['final_loss'], r['total_steps'])
+    frames = model.enc.G * model.enc.Nf
+    out.append({'workload': label, 'value': round(b * k * steps / r['dt'], 1), 'unit': 'frames/s', 'steps': steps,
+                'ms_per_step': round(ms, 3), 'encoder_frame_passes': frames,
+                'step_frac_of_f32_mfma_peak': round(step_flop(ch, frames) / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                'loss_check': chk})
+    log('other config "%s": %.3f ms/step, loss check %s' % (label, ms, chk['status']))
+    del r, model
+    torch.cuda.empty_cache()
+    if not ok:
+      return out, False
+  return out, True
+
+
+def comm_report(args, model, runner, dev, world, step_ms):
+  """N > 1 (every rank takes part): the exchange alone, and the step in BOTH orders of the exchange plus without it, so
+  that one multi-GPU call shows whether RCCL beside the persistent 255-block kernels of the bottom backward helps."""
+  import torch
+  from geeco_amd import dist as gdist
+  iters = max(5, min(args.steps, 20))
+  g = model.store.grads
+
+  def exchange():
+    for w in runner._exchange_early() + runner._exchange_late():
+      w.wait()
+  exchange()
+  torch.distributed.barrier()
+  ar_ms = gdist.max_over_ranks(time_region(exchange, iters), dev)
+  modes = {}
+  main_mode = runner.overlap
+  for name, overlap, skip in (('overlap', True, False), ('serial', False, False), ('no_exchange', True, True)):
+    runner.overlap, runner.skip_allreduce = overlap, skip
+    for _ in range(3):
+      runner.step()
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    modes[name] = round(gdist.max_over_ranks(time_region(runner.step, iters), dev), 4)
+  runner.overlap, runner.skip_allreduce = main_mode, False
+  wire = 4 * sum(n for _, n in runner.early_calls) + (runner.staging.numel() * 4 if runner.staging is not None else 0)
+  return {'mode': 'overlap' if main_mode else 'serial', 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
+          'allreduce_bytes_on_the_wire': int(wire),
+          'bus_GB/s': round(2.0 * (world - 1) / world * wire / (ar_ms * 1e-3) / 1e9, 1),
+          'step_ms': modes, 'step_ms_without_allreduce': modes['no_exchange'],
+          'allreduce_exposed_ms': round(max(step_ms - modes['no_exchange'], 0.0), 4),
+          'overlap_gain_ms': round(modes['serial'] - modes['overlap'], 4), 'buckets': runner.bucket_info()}
+
+
 def main():
   args = parse_args()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -347,90 +525,35 @@ def main():
 
   import torch
   from geeco_amd import dist as gdist
-  from geeco_amd import graph
-  from geeco_amd.params import create_e2evmc_config
-  from geeco_amd.runtime import TrainStepRunner
 
-  # Rehearsal of the N > 1 path on a one-GPU box: GEECO_SHARE_GPU=1 puts every rank on cuda:0 and
-  # GEECO_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Such a run exercises the launcher, the
-  # three-graph step and the bucketed exchange; its numbers mean nothing.
-  share = os.environ.get('GEECO_SHARE_GPU') is not None
-  world = gdist.init_from_env('nccl')
+  world = gdist.init_from_env('nccl')      # a launcher that formed the group already (tests/_dp_launch.py) is respected
   rank = gdist.rank()
   if world != args.gpus:
     log('--gpus %d but the process group has %d rank(s): refusing to report a number for the wrong N' % (args.gpus, world))
     sys.exit(3)
-  local = int(os.environ.get('LOCAL_RANK', '0'))
+  local = torch.cuda.current_device() if gdist.group_active() else int(os.environ.get('LOCAL_RANK', '0'))
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
+  # N ranks must sit on N distinct GPUs: two ranks on one device would report a number for the wrong machine
+  idents = gdist.gather_strings(device_identity(local), dev)
+  shared = len(set(idents)) < world
+  if shared and not args.allow_shared_gpu:
+    log('%d ranks but only %d distinct GPU(s): %s' % (world, len(set(idents)), idents))
+    sys.exit(3)
 
-  if args.model == 'geeco-f':
-    cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=args.seq_len,
-                                    img_channels=args.channels, batch_size=args.batch))
-    model = graph.GoalE2EVMC(cfg, args.batch, dev, training=True)
-  else:
-    cfg = create_e2evmc_config(dict(window_size=args.seq_len, img_channels=args.channels, batch_size=args.batch))
-    model = graph.E2EVMC(cfg, args.batch, dev, training=True)
+  cfg, model = build_model(args.model, args.channels, args.seq_len, args.batch, dev)
   model.store.initialize(seed=0)
   gdist.broadcast_variables(model.store)
   synthetic_batch(model, 1234 + rank)
-
   log('model built: %d parameters, batch %d/GPU, world %d' % (model.store.count_parameters(), args.batch, world))
-  runner = TrainStepRunner(model, use_graph=not args.no_graph, warmup=2)
-  runner.step()                       # first optimiser step, eager: its loss is checked against the oracle's
-  torch.cuda.synchronize()
-  first_loss = float(model.loss)
-  runner.prepare()     # second eager step + hipGraph capture, outside warm-up and timed region
-  torch.cuda.synchronize()
-  log('graphs captured' if not args.no_graph else 'eager mode')
-  for i in range(args.warmup):
-    runner.step()
-    if i < 3:
-      torch.cuda.synchronize()
-      log('warm-up step %d done' % (i + 1))
-  torch.cuda.synchronize()
-  evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-  if world > 1:
-    torch.distributed.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  evs[0].record()
-  for i in range(args.steps):
-    runner.step()
-    evs[i + 1].record()
-  torch.cuda.synchronize()
-  if world > 1:
-    torch.distributed.barrier()
-  torch.cuda.synchronize()
-  dt = time.perf_counter() - t0
-  dt = gdist.max_over_ranks(dt, dev)
-  loss = float(model.loss)
-  total_steps = runner._calls
-  per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-  log('timed region: %d steps in %.3f s' % (args.steps, dt))
 
-  comm = None
-  if world > 1:      # every rank takes part; rank 0 reports
-    iters = max(5, min(args.steps, 20))
-    g = model.store.grads
-    def exchange():
-      for w in runner._exchange_early() + runner._exchange_late():
-        w.wait()
-    exchange()
-    ar_ms = time_region(exchange, iters)
-    torch.distributed.barrier()
-    runner.skip_allreduce = True
-    for _ in range(3):
-      runner.step()
-    nocomm_ms = time_region(runner.step, iters)
-    runner.skip_allreduce = False
-    ar_ms = gdist.max_over_ranks(ar_ms, dev)
-    nocomm_ms = gdist.max_over_ranks(nocomm_ms, dev)
-    step_ms = dt / args.steps * 1e3
-    comm = {'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
-            'bus_GB/s': round(2.0 * (world - 1) / world * g.numel() * 4 / (ar_ms * 1e-3) / 1e9, 1),
-            'step_ms_without_allreduce': round(nocomm_ms, 4),
-            'allreduce_exposed_ms': round(max(step_ms - nocomm_ms, 0.0), 4), 'buckets': runner.bucket_info()}
+  r = timed_steps(model, args.steps, args.warmup, not args.no_graph, not args.dp_serial, world, dev)
+  runner, dt, per_step = r['runner'], r['dt'], r['per_step']
+  first_loss, loss, total_steps = r['first_loss'], r['final_loss'], r['total_steps']
+  log('timed region: %d steps in %.3f s' % (args.steps, dt))
+  rank_ms = gdist.gather_floats(r['dt_local'] / args.steps * 1e3, dev)
+
+  comm = comm_report(args, model, runner, dev, world, dt / args.steps * 1e3) if world > 1 else None
 
   rc = 0
   if rank == 0:
@@ -440,7 +563,7 @@ def main():
         'metric': 'train-step frames/sec (256x256 %s, seq_len=%d)' % ('RGB' if args.channels == 3 else 'RGB-D', args.seq_len),
         'value': round(frames * args.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not share else 'synthetic (REHEARSAL: ranks share one GPU)',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not shared else 'synthetic (REHEARSAL: ranks share one GPU)',
         'config': {'workload': '%s %s %dx%d seq_len=%d batch=%d/GPU (global %d), fwd+bwd+allreduce+Adam' %
                                (args.model, 'rgb' if args.channels == 3 else 'rgbd', cfg.img_height, cfg.img_width,
                                 args.seq_len, args.batch, world * args.batch),
@@ -449,25 +572,31 @@ def main():
                     'p90': round(percentile(per_step, 0.9), 4), 'timer': 'HIP events per step, rank 0'},
         'final_loss': round(loss, 6),
     }
+    if world > 1:
+      out['ranks'] = {'ms_per_step': [round(v, 4) for v in rank_ms], 'devices': idents, 'distinct_devices': len(set(idents))}
     out['loss_check'], ok = check_losses(args, first_loss, loss, total_steps)
     if not ok:
       rc = 4
     if comm:
       out['comm'] = comm
     if world == 1 and not args.skip_layers:
-      iters = max(10, min(args.steps, 30))
-      rows = layer_table(model, iters)
+      samples = max(30, min(args.steps, 50))
+      rows = layer_table(model, samples)
       out['roofline'] = dominant_roofline(rows)
-      for r in rows:
-        del r['kernels']
+      for row in rows:
+        del row['kernels']
       out['layers'] = rows
-      out['hbm'] = hbm_table(model, args, iters)
-      tf_, ms_enc = encoder_forward_tflops(model, iters, args.channels)
+      out['hbm'] = hbm_table(model, args, samples)
+      tf_, ms_enc = encoder_forward_tflops(model, samples, args.channels)
       out['encoder_forward'] = {'tflops': round(tf_, 2), 'frac_of_f32_mfma_peak': round(tf_ / PEAK_F32_MFMA_TFLOPS, 4),
                                 'ms': round(ms_enc, 3), 'frames': model.enc.G * model.enc.Nf}
-      out['step_frac_of_f32_mfma_peak'] = round(
-          (3 * ENC_FWD_FLOP_PER_FRAME[args.channels] - 2 * 56623104 * (args.channels / 3.0)) * model.enc.G * model.enc.Nf
-          / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+      out['step_frac_of_f32_mfma_peak'] = round(step_flop(args.channels, model.enc.G * model.enc.Nf) / (ms_step * 1e-3) / 1e12
+                                                / PEAK_F32_MFMA_TFLOPS, 4)
+    if world == 1 and not args.skip_other_configs:
+      del runner, r
+      out['other_configs'], ok2 = other_configs(args, dev)
+      if not ok2:
+        rc = 4
     if world == 1 and not args.skip_cpu:
       out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

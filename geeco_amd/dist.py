@@ -26,25 +26,32 @@ def rank() -> int:
   return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def init_from_env(backend=None):
-  """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1."""
+def init_from_env(backend=None, device_index=None, single_rank_group=False):
+  """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1 (one process per GPU,
+  backend 'nccl' = RCCL over xGMI on a GPU box, 'gloo' without a GPU).  Returns the world size.
+
+  ``device_index``: the GPU of this rank (default LOCAL_RANK).  ``single_rank_group``: form the group even for
+  WORLD_SIZE == 1, so that the collectives really go through the backend with one rank (tests).  Both exist for
+  callers that know better than the environment (the tests' launcher puts two ranks on the one test GPU over gloo);
+  nothing here reads rehearsal switches from the environment."""
   ws = int(os.environ.get('WORLD_SIZE', '1'))
-  force = os.environ.get('GEECO_FORCE_DIST') and 'RANK' in os.environ      # exercise the RCCL path with one rank
-  if (ws <= 1 and not force) or dist.is_initialized():
+  if dist.is_initialized():
     return world_size()
+  if ws <= 1 and not (single_rank_group and 'RANK' in os.environ):
+    return 1
   os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
   os.environ.setdefault('MASTER_PORT', '29500')
-  # Rehearsal on a one-GPU box: GEECO_SHARE_GPU=1 puts every rank on cuda:0 and GEECO_DIST_BACKEND=gloo replaces RCCL
-  # (which refuses two ranks on one device).  Production: one rank per GPU, backend 'nccl' (= RCCL over xGMI).
-  if os.environ.get('GEECO_SHARE_GPU'):
-    os.environ['LOCAL_RANK'] = '0'
-  backend = os.environ.get('GEECO_DIST_BACKEND') or backend
   if backend is None:
     backend = 'nccl' if torch.cuda.is_available() else 'gloo'
   if torch.cuda.is_available():
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) if device_index is None else int(device_index))
   dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
   return ws
+
+
+def group_active() -> bool:
+  """True when collectives go through a backend (also for a one-rank group)."""
+  return dist.is_available() and dist.is_initialized()
 
 
 def broadcast_variables(store, src=0):
@@ -73,7 +80,7 @@ def allreduce_async(t: torch.Tensor):
   """SUM over ranks of one gradient bucket, in place.  With RCCL the collective runs on the communicator's own
   stream, ordered behind the work already enqueued on the current stream; ``.wait()`` on the returned handle makes
   the current stream wait for it (the host does not block), so kernels enqueued in between overlap it."""
-  if world_size() == 1:
+  if not group_active():
     return _Done()
   return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -95,6 +102,32 @@ def broadcast_int(value: int, device='cpu', src=0) -> int:
   t = torch.tensor([int(value)], dtype=torch.int64, device=device)
   dist.broadcast(t, src=src)
   return int(t.item())
+
+
+def _coll_device(device):
+  """Small host-side exchanges: RCCL needs device tensors, gloo takes host tensors."""
+  return device if dist.get_backend() == 'nccl' else 'cpu'
+
+
+def gather_floats(value: float, device):
+  """Every rank's value, in rank order, on every rank."""
+  if world_size() == 1:
+    return [float(value)]
+  t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
+  out = [torch.zeros_like(t) for _ in range(world_size())]
+  dist.all_gather(out, t)
+  return [float(o.item()) for o in out]
+
+
+def gather_strings(value: str, device, width=96):
+  """Every rank's short string (a device identity), in rank order, on every rank."""
+  if world_size() == 1:
+    return [value]
+  raw = value.encode()[:width].ljust(width, b'\0')
+  t = torch.tensor(list(raw), dtype=torch.uint8, device=_coll_device(device))
+  out = [torch.zeros_like(t) for _ in range(world_size())]
+  dist.all_gather(out, t)
+  return [bytes(o.cpu().tolist()).rstrip(b'\0').decode(errors='replace') for o in out]
 
 
 def max_over_ranks(value: float, device) -> float:

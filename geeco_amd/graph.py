@@ -70,6 +70,7 @@ class ConvEncoderStack:
     whose shape differs) runs once per encoder (``split_top``)."""
     self.store, self.scopes, self.G, self.Nf = store, list(scopes), len(scopes), Nf
     self.H, self.W, self.Cin = H, W, Cin
+    self.late = None       # (staging buffer, per-encoder length): see redirect_late_gradients
     self.dim_outs = [int(d) for d in dim_out] if isinstance(dim_out, (list, tuple)) else [int(dim_out)] * len(self.scopes)
     self.split_top = len(set(self.dim_outs)) > 1
     dim_out = max(self.dim_outs)
@@ -193,11 +194,41 @@ class ConvEncoderStack:
   def _b(self, l, g=0):
     return self.store.var('%s/conv%d/bias' % (self.scopes[g], l + 1))
 
+  def _grad_view(self, l, g, kind):
+    name = '%s/conv%d/%s' % (self.scopes[g], l + 1, kind)
+    if self.late is None or l >= ConvEncoderStack.SPLIT:
+      return self.store.grad(name)
+    staging, stride = self.late
+    shp = self.store.shapes[name]
+    o = self.store.offsets[name] - self.store.offsets[self.scopes[g] + '/conv1/kernel'] + g * stride
+    n = 1
+    for d in shp:
+      n *= int(d)
+    return staging[o:o + n].view(*shp)
+
   def _dw(self, l, g=0):
-    return self.store.grad('%s/conv%d/kernel' % (self.scopes[g], l + 1))
+    return self._grad_view(l, g, 'kernel')
 
   def _db(self, l, g=0):
-    return self.store.grad('%s/conv%d/bias' % (self.scopes[g], l + 1))
+    return self._grad_view(l, g, 'bias')
+
+  def _gs_g(self, l):
+    """Group stride of layer l's gradient views (the arena's, or the late staging buffer's for conv1 / conv2)."""
+    return self.late[1] if (self.late is not None and l < ConvEncoderStack.SPLIT) else self.gs_p
+
+  def redirect_late_gradients(self, staging, late_ranges):
+    """Data parallel (runtime.TrainStepRunner): the gradients of conv1 / conv2 -- the LATE bucket, written by the last
+    launches of the backward -- go straight into ``staging`` (encoder g's block at g * len, same inner layout as the
+    arena) instead of the gradient arena, so that the arena is not written while the early bucket is being reduced.
+    Returns False (nothing changed) if the late ranges are not the uniformly strided conv1 / conv2 blocks."""
+    off = self.store.offsets
+    lo0 = off[self.scopes[0] + '/conv1/kernel']
+    length = off[self.scopes[0] + '/conv%d/kernel' % (ConvEncoderStack.SPLIT + 1)] - lo0
+    want = [(lo0 + g * self.gs_p, length) for g in range(self.G)]
+    if [tuple(r) for r in late_ranges] != want or staging.numel() != self.G * length or not self.training:
+      return False
+    self.late = (staging, length)
+    return True
 
   @property
   def features(self):
@@ -275,10 +306,10 @@ class ConvEncoderStack:
     if l == 0 and self.pad1:
       dw, gs_dw = self.dw1p, self.dw1p[0].numel()
     else:
-      dw, gs_dw = self._dw(l), self.gs_p
+      dw, gs_dw = self._dw(l), self._gs_g(l)
     if l == 0 and self.pad1:
       pending = None     # the padded gradient is repacked right below
-    ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self.gs_p, Nf, L['H'],
+    ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self._gs_g(l), Nf, L['H'],
                            L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l], pending=pending)
     if l == 0 and self.pad1:
       for g in range(G):
@@ -301,11 +332,11 @@ class ConvEncoderStack:
       if self.relu_bits:
         ops.conv2_dgrad_conv1_wgrad_bits_into(self._dw(0), self._db(0), dz, self._w(1), self.bits1, self.x_in, G,
                                               dz[0].numel(), self.gs_p, self.bits1[0].numel(), self.x_in[0].numel(),
-                                              self.gs_p, self.gs_p, Nf, L['H'], L['W'], self.fws_fused,
+                                              self._gs_g(0), self._gs_g(0), Nf, L['H'], L['W'], self.fws_fused,
                                               real_channels=self.Cin, pending=pending)
         return
       ops.conv2_dgrad_conv1_wgrad_into(self._dw(0), self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
-                                       x[0].numel(), self.x_in[0].numel(), self.gs_p, self.gs_p, Nf, L['H'], L['W'],
+                                       x[0].numel(), self.x_in[0].numel(), self._gs_g(0), self._gs_g(0), Nf, L['H'], L['W'],
                                        self.fws_fused, real_channels=self.Cin, pending=pending)
       return
     wt = self.wt[l]
@@ -541,6 +572,9 @@ class _ModelBase:
             (inp['grp_target'], inp['grp_target'].shape[1]), (ee_last, K * 7), (obj_last, K * 7)]
     self.decoder.targets = [t for t, _ in tg]
     self.decoder.target_strides = [s for _, s in tg]
+
+  def redirect_late_gradients(self, staging, late_ranges):
+    return self.enc.redirect_late_gradients(staging, late_ranges)
 
   # -- optimiser step (estimator.py:243-244) -------------------------------------------------
   def apply_gradients(self):

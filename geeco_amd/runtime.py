@@ -8,9 +8,9 @@ One GPU:      graph A (forward + backward)  ->  graph B (Adam + re-derived weigh
 Data parallel (buckets in reverse-layer order, overlapped with the backward):
   graph A1 = forward + decoder backward + encoder backward down to conv3 (every gradient except the
              encoders' conv1 / conv2 is final: 99.4 % of the bytes)
-  -> EARLY bucket: asynchronous RCCL all-reduce of those arena ranges on the communicator's stream
-  graph A2 = conv2's filter gradient + the fused encoder bottom (conv2 dgrad + conv1 wgrad, ~0.9 ms)
-             + pack of the conv1 / conv2 gradients into one small staging buffer
+  -> EARLY bucket: ONE asynchronous RCCL all-reduce over the span of those arena ranges on the communicator's stream
+  graph A2 = conv2's filter gradient + the fused encoder bottom (conv2 dgrad + conv1 wgrad, ~0.9 ms), which write
+             the conv1 / conv2 gradients straight into one small staging buffer (nothing touches the arena meanwhile)
   -> LATE bucket: all-reduce of the staging buffer (177 KB)
   graph B  = wait for both, unpack the staging buffer, Adam (grad_scale = 1 / world).
 The early bucket therefore runs beside A2's kernels; only the small late bucket is exposed.
@@ -61,11 +61,17 @@ def gradient_buckets(store):
 
 
 class TrainStepRunner:
+  """``dp``: run the three-part data-parallel step (None = when the process group has more than one rank; True forces it
+  with one rank, so that the exchange really goes through the backend -- tests).  ``overlap``: the early bucket goes out
+  beside part 2 (default); False = both buckets after part 2 (``bench.py --dp-serial``: the difference between the two
+  is what the overlap buys on a given node)."""
 
-  def __init__(self, model, use_graph=True, warmup=2):
+  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True):
     self.model = model
     self.world = gdist.world_size()
     model.world = self.world
+    self.dp = (self.world > 1) if dp is None else bool(dp)
+    self.overlap = bool(overlap)
     self.use_graph = bool(use_graph) and torch.cuda.is_available()
     self._graphs = None
     self._warm = warmup
@@ -73,30 +79,50 @@ class TrainStepRunner:
     self.skip_allreduce = False          # bench.py: measure the step without the exchange
     self.early, self.late = gradient_buckets(model.store)
     self.staging = None
-    if self.world > 1 and self.late:
-      self.staging = torch.zeros(sum(n for _, n in self.late), dtype=torch.float32, device=model.store.grads.device)
+    self.redirected = False
+    if self.dp and self.late:
+      store = model.store
+      # one staging buffer per variable store: models built for other batch sizes (ragged last batch) share it
+      if getattr(store, 'late_staging', None) is None:
+        store.late_staging = torch.zeros(sum(n for _, n in self.late), dtype=torch.float32, device=store.grads.device)
+      self.staging = store.late_staging
+      # The bottom of the backward writes the conv1 / conv2 gradients STRAIGHT into the staging buffer (no pack copies),
+      # so nothing touches the arena while the early bucket is in flight and the early bucket can be ONE all-reduce
+      # over the span of its ranges: the late variables' slots inside that span are dead (zero) until part 3 unpacks.
+      redirect = getattr(model, 'redirect_late_gradients', None)
+      self.redirected = bool(redirect and redirect(self.staging, self.late))
+    if self.redirected and self.early:
+      lo = min(off for off, _ in self.early)
+      hi = max(off + n for off, n in self.early)
+      self.early_calls = [(lo, hi - lo)]
+    else:
+      self.early_calls = list(self.early)
 
   def bucket_info(self):
     return {'early_bytes': 4 * sum(n for _, n in self.early), 'early_ranges': len(self.early),
-            'late_bytes': 4 * sum(n for _, n in self.late), 'late_ranges': len(self.late)}
+            'early_allreduce_calls': len(self.early_calls), 'early_bytes_on_the_wire': 4 * sum(n for _, n in self.early_calls),
+            'late_bytes': 4 * sum(n for _, n in self.late), 'late_ranges': len(self.late),
+            'late_written_in_place': self.redirected, 'mode': 'overlap' if self.overlap else 'serial'}
 
   # -- pieces of a step ----------------------------------------------------------------------------------
   def _part1(self):
     self.model.forward(backward_too=True)
-    if self.world > 1:
+    if self.dp:
       self.model.backward(part='upper')
     else:
       self.model.backward()
 
   def _part2(self):
     self.model.backward(part='bottom')
+    if self.redirected or self.staging is None:
+      return
     g, pos = self.model.store.grads, 0
     for off, n in self.late:
       self.staging[pos:pos + n].copy_(g[off:off + n])
       pos += n
 
   def _part3(self):
-    if self.world > 1:
+    if self.dp and self.staging is not None:
       g, pos = self.model.store.grads, 0
       for off, n in self.late:
         g[off:off + n].copy_(self.staging[pos:pos + n])
@@ -111,20 +137,22 @@ class TrainStepRunner:
     if self.skip_allreduce:
       return []
     g = self.model.store.grads
-    return [gdist.allreduce_async(g[off:off + n]) for off, n in self.early]
+    return [gdist.allreduce_async(g[off:off + n]) for off, n in self.early_calls]
 
   def _exchange_late(self):
     if self.skip_allreduce or self.staging is None:
       return []
     return [gdist.allreduce_async(self.staging)]
 
+  def _parts(self):
+    return [self._part1, self._part2, self._part3] if self.dp else [self._whole_step]
+
   def _capture(self):
     # the warm-up steps before this call already ran eagerly
     # single process: the whole step is one graph (no inter-graph launch gap); data parallel: the exchange sits between
-    parts = [self._whole_step] if self.world == 1 else [self._part1, self._part2, self._part3]
     graphs = []
     with CAPTURE_LOCK:
-      for fn in parts:
+      for fn in self._parts():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
           fn()
@@ -143,21 +171,19 @@ class TrainStepRunner:
       # NB capture itself does not execute the step; fall through to replay
       self._capture()
     self._calls += 1
-    if self._graphs is not None:
-      run = self._graphs
-    else:
-      run = [self._whole_step] if self.world == 1 else [self._part1, self._part2, self._part3]
-    if self.world == 1:
+    run = self._graphs if self._graphs is not None else self._parts()
+    if not self.dp:
       run[0]()
       return
     run[0]()
-    works = self._exchange_early()         # on the communicator's stream, behind part 1, beside part 2
+    works = self._exchange_early() if self.overlap else []   # on the communicator's stream, behind part 1, beside part 2
     run[1]()
+    if not self.overlap:
+      works = self._exchange_early()
     works += self._exchange_late()
     for w in works:
       w.wait()                             # the compute stream waits; the host does not (RCCL)
     run[2]()
-
 
   def null_step(self):
     """A step of a rank that holds no sample (ragged end of an epoch under data parallelism): zero gradients into

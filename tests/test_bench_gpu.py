@@ -32,11 +32,42 @@ def test_bench_tables_small(model_name, channels):
   runner.step()
   torch.cuda.synchronize()
   args = argparse.Namespace(model=model_name, channels=channels, seq_len=K, batch=N)
-  hbm = bench.hbm_table(model, args, 1)
+  hbm = bench.hbm_table(model, args, 5)
   assert hbm and hbm[-1]['piece'].startswith('adam') and all(r['us'] > 0 for r in hbm)
   if goal:
     assert len(hbm) == 4 and hbm[0]['piece'].startswith('dynimg buffer image') and hbm[2]['piece'].startswith('goal inputs as in the step')
-  layers = bench.layer_table(model, 1)
-  assert len(layers) >= 20 and all(r['us'] > 0 and r['kernel'] for r in layers)
+  layers = bench.layer_table(model, 5)
+  assert len(layers) >= 20 and all(r['us'] > 0 and r['kernel'] and r['us_p10'] <= r['us'] <= r['us_p90'] for r in layers)
   rl = bench.dominant_roofline(layers)
   assert rl['bound'] == 'mfma' and 0 < rl['frac'] < 1
+  assert 'traffic_source' in rl and (rl['traffic'] is None) == (rl['traffic_source'] is None)
+  fam = rl['family']
+  assert 0 < fam['frac'] < 1 and fam['us_per_step'] >= rl['avg_launch_ms'] * 1e3 * 0.999 and fam['kernel'] and '<' not in fam['kernel']
+
+
+def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
+  """bench.py as two ranks on the one test GPU over gloo (tests/_dp_launch.py): (a) without --allow-shared-gpu the run
+  refuses to report a number (the ranks' device identities are not distinct: rc 3); (b) with it, the launcher protocol, the
+  three-graph step, the one-call early bucket, the per-rank times and the comm report (overlap / serial / no exchange)
+  run end to end.  The numbers of such a run mean nothing and are not looked at."""
+  import json
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+    env.pop(k, None)
+  base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1']
+  tail = [os.path.join(root, 'tests', '_dp_launch.py'), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+          '--batch', '2', '--seq-len', '4', '--skip-cpu']
+  out = subprocess.run(base + ['--master-port', str(33100 + os.getpid() % 500)] + tail, capture_output=True, text=True, timeout=600, env=env)
+  assert out.returncode != 0 and 'distinct GPU' in out.stderr, out.stderr[-2000:]
+  out = subprocess.run(base + ['--master-port', str(33700 + os.getpid() % 500)] + tail + ['--allow-shared-gpu', '--dp-serial'],
+                       capture_output=True, text=True, timeout=600, env=env)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  line = [l for l in out.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+  assert len(line) == 1
+  d = json.loads(line[0])
+  assert d['n_gpus'] == 2 and 'REHEARSAL' in d['data'] and len(d['ranks']['ms_per_step']) == 2 and d['ranks']['distinct_devices'] == 1
+  c = d['comm']
+  assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'no_exchange'} and all(v > 0 for v in c['step_ms'].values())
+  assert c['buckets']['early_allreduce_calls'] == 1 and c['buckets']['late_written_in_place']

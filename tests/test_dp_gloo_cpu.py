@@ -43,6 +43,8 @@ def _worker(rank, world, port, tmp, q):
   gdist.allreduce_gradients(g64)
   g64 /= gdist.world_size()
   lmax = gdist.max_over_ranks(float(loss), 'cpu')
+  assert gdist.gather_floats(10.0 + rank, 'cpu') == [10.0, 11.0]                   # bench.py: per-rank ms/step
+  assert gdist.gather_strings('host gpu-%d' % rank, 'cpu') == ['host gpu-0', 'host gpu-1']   # ... and device identities
   q.put((rank, g64.numpy(), float(loss), lmax, float(np.abs(P['VMC/ConvEncoder/conv3/kernel']).sum())))
   dist.destroy_process_group()
 
@@ -97,10 +99,18 @@ class _FakeModel:
   """Stands in for a graph.* model on the CPU: 'backward' writes rank-dependent gradients, the upper part into
   the early ranges only, the bottom part into the late (conv1 / conv2) ranges only."""
 
-  def __init__(self, store, rank, early, late):
+  def __init__(self, store, rank, early, late, can_redirect=False):
     self.store, self.rank, self.early, self.late = store, rank, early, late
     self.world = 1
     self.applied = None
+    self.staging = None
+    if can_redirect:      # like graph.ConvEncoderStack.redirect_late_gradients: the bottom part writes the staging buffer
+      self.redirect_late_gradients = self._redirect
+
+  def _redirect(self, staging, late_ranges):
+    assert [tuple(r) for r in late_ranges] == [tuple(r) for r in self.late]
+    self.staging = staging
+    return True
 
   def forward(self, backward_too=False):
     self.store.grads.fill_(float('nan'))            # every element must be rewritten by the two backward parts
@@ -109,16 +119,23 @@ class _FakeModel:
     g = self.store.grads
     idx = torch.arange(g.numel(), dtype=torch.float32)
     val = (self.rank + 1) * (1.0 + 0.001 * (idx % 97))
-    for rngs, on in ((self.early, part in (None, 'upper')), (self.late, part in (None, 'bottom'))):
-      if on:
-        for off, n in rngs:
+    if part in (None, 'upper'):
+      for off, n in self.early:
+        g[off:off + n] = val[off:off + n]
+    if part in (None, 'bottom'):
+      pos = 0
+      for off, n in self.late:
+        if self.staging is not None:       # the arena's late slots stay NaN until the runner unpacks the staging buffer
+          self.staging[pos:pos + n] = val[off:off + n]
+        else:
           g[off:off + n] = val[off:off + n]
+        pos += n
 
   def apply_gradients(self):
     self.applied = self.store.grads.clone() / self.world
 
 
-def _bucket_worker(rank, world, port, q):
+def _bucket_worker(rank, world, port, q, can_redirect=False, overlap=True):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   torch.set_num_threads(1)
@@ -131,20 +148,22 @@ def _bucket_worker(rank, world, port, q):
   cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2))
   store = VariableStore(model_variable_shapes(cfg, True), 'cpu')
   early, late = gradient_buckets(store)
-  model = _FakeModel(store, rank, early, late)
-  runner = TrainStepRunner(model, use_graph=False)
+  model = _FakeModel(store, rank, early, late, can_redirect)
+  runner = TrainStepRunner(model, use_graph=False, overlap=overlap)
   assert runner.world == world and model.world == world
   runner.step()
   q.put((rank, model.applied.numpy(), early, late, runner.bucket_info()))
   dist.destroy_process_group()
 
 
-def test_bucketed_exchange_covers_the_arena():
+@pytest.mark.parametrize('can_redirect,overlap', [(False, True), (True, True), (True, False)],
+                         ids=['packed-late', 'late-in-place', 'late-in-place-serial'])
+def test_bucketed_exchange_covers_the_arena(can_redirect, overlap):
   sys.path.insert(0, ROOT)
-  world, port = 2, 31500 + (os.getpid() % 2000)
+  world, port = 2, 31500 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap)
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+  procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, can_redirect, overlap)) for r in range(world)]
   for p in procs:
     p.start()
   res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -159,6 +178,12 @@ def test_bucketed_exchange_covers_the_arena():
   assert (cover == 1).all()
   # geeco-f: conv1 + conv2 of three encoders = 3 x (3*3*3*32 + 32 + 3*3*32*48 + 48) floats
   assert info['late_bytes'] == 4 * 3 * (864 + 32 + 13824 + 48) and info['late_ranges'] == 3
+  assert info['mode'] == ('overlap' if overlap else 'serial')
+  if can_redirect:   # the bottom part writes the staging buffer: ONE early all-reduce over the span (late slots ride along)
+    assert info['early_allreduce_calls'] == 1 and info['late_written_in_place'] and info['early_ranges'] == 3
+    assert info['early_bytes_on_the_wire'] == info['early_bytes'] + info['late_bytes'] - 4 * (864 + 32 + 13824 + 48)
+  else:              # a model without redirect_late_gradients: one call per early range, late gradients packed
+    assert info['early_allreduce_calls'] == info['early_ranges'] == 3 and not info['late_written_in_place']
   assert info['early_bytes'] + info['late_bytes'] == 4 * g0.size
   # every element = mean over ranks of (rank + 1) * pattern = 1.5 * pattern, identical on both ranks
   idx = np.arange(g0.size, dtype=np.float32)

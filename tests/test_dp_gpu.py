@@ -133,8 +133,8 @@ def test_estimator_ragged_batches_two_ranks(dev):
 
 
 def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
-  """scripts/train_e2evmc.py under torch.distributed.run with TWO ranks (sharing the one test GPU over gloo:
-  GEECO_SHARE_GPU / GEECO_DIST_BACKEND) on an on-disk dataset of THREE episodes: rank 0 reads two episodes, rank 1 one,
+  """scripts/train_e2evmc.py under torch.distributed.run with TWO ranks (sharing the one test GPU over gloo through the
+  tests' launcher helper tests/_dp_launch.py) on an on-disk dataset of THREE episodes: rank 0 reads two episodes, rank 1 one,
   so the epoch ends with steps in which rank 1 holds fewer or no windows (dp_schedule: loss scaling, null steps); one
   shuffle seed is broadcast; rank 0 alone writes run command, config, checkpoints (+ TF bundles) and snapshots."""
   import json
@@ -149,12 +149,13 @@ def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
   os.makedirs(md)
   cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=4))
   json.dump(cfg._asdict(), open(os.path.join(md, 'e2evmc_config.json'), 'w'))
-  env = dict(os.environ, GEECO_SHARE_GPU='1', GEECO_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
   for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
     env.pop(k, None)
   port = 31900 + os.getpid() % 1000
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-         '--master-port', str(port), os.path.join(ROOT, 'scripts', 'train_e2evmc.py'), '--dataset_dir', root, '--model_dir', md,
+         '--master-port', str(port), os.path.join(ROOT, 'tests', '_dp_launch.py'), os.path.join(ROOT, 'scripts', 'train_e2evmc.py'),
+         '--dataset_dir', root, '--model_dir', md,
          '--goal_condition', 'target', '--proc_obs', 'dynimg', '--proc_tgt', 'dyndiff', '--window_size', '3', '--batch_size', '4',
          '--train_epochs', '2', '--log_steps', '1', '--num_best_ckpt', '2']
   out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -168,3 +169,107 @@ def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
   ev = [json.loads(l) for l in open(os.path.join(md, 'events.jsonl'))]
   assert [e['global_step'] for e in ev] == list(range(1, 13)) and all(np.isfinite(e['loss']) for e in ev)
   assert sum(1 for fn in os.listdir(md) if fn.endswith('runcmd.json')) == 1            # rank 0 only
+
+
+# ----------------------------------------------------------------------------------------------------
+# The data-parallel step through the REAL backend string: "nccl" (= RCCL) with ONE rank.  Three captured graphs
+# (thread_local capture mode beside RCCL's watchdog thread), the early bucket as ONE all-reduce over the arena span, the
+# late bucket written in place into its staging buffer, both orders of the exchange.  RCCL refuses two ranks on one
+# device, so one rank is all a one-GPU box can give; the sum over one rank is the identity, hence BITWISE equality
+# with the plain one-graph step.
+# ----------------------------------------------------------------------------------------------------
+def _rccl_worker(port, overlap, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                    HSA_ENABLE_IPC_MODE_LEGACY='0')
+  from geeco_amd import dist as gdist
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import TrainStepRunner
+  assert gdist.init_from_env('nccl', single_rank_group=True) == 1 and gdist.group_active()
+  assert torch.distributed.get_backend() == 'nccl'
+  feats, labels = _batch(4)
+  model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, 'cuda:0', training=True)
+  model.store.initialize(seed=9)
+  gdist.broadcast_variables(model.store)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap)
+  info = runner.bucket_info()
+  losses = []
+  for _ in range(5):
+    runner.step()
+    torch.cuda.synchronize()
+    losses.append(float(model.loss))
+  q.put((model.store.params.detach().cpu().numpy(), losses, info, runner._graphs is not None and len(runner._graphs) == 3))
+  torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [True, False], ids=['overlap', 'serial'])
+def test_three_graph_step_over_rccl_one_rank(dev, overlap):
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import TrainStepRunner
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  p = ctx.Process(target=_rccl_worker, args=(32800 + os.getpid() % 1000 + (0 if overlap else 1), overlap, q))
+  p.start()
+  params, losses, info, three = q.get(timeout=600)
+  p.join(timeout=120)
+  assert p.exitcode == 0
+  assert three and info['early_allreduce_calls'] == 1 and info['late_written_in_place'] and info['late_ranges'] == 3
+  assert info['mode'] == ('overlap' if overlap else 'serial')
+  feats, labels = _batch(4)
+  model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, dev, training=True)
+  model.store.initialize(seed=9)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  runner = TrainStepRunner(model, use_graph=True, warmup=1)
+  ref_losses = []
+  for _ in range(5):
+    runner.step()
+    torch.cuda.synchronize()
+    ref_losses.append(float(model.loss))
+  assert runner._graphs is not None and len(runner._graphs) == 1
+  assert losses == ref_losses
+  np.testing.assert_array_equal(params, model.store.params.detach().cpu().numpy())
+
+
+def test_bottom_backward_writes_only_the_late_bucket(dev):
+  """The overlapped exchange reduces the early arena ranges in place while the bottom of the backward runs: that is
+  race free only if backward(part='bottom') -- its deferred slab sums included -- writes nothing outside conv1 / conv2.
+  (a) plain: the early ranges are bit-identical before and after the bottom part, and early + late ranges cover the arena
+  exactly once; (b) with the late gradients redirected into the staging buffer (what the runner does) the WHOLE arena is
+  untouched by the bottom part and the staging buffer holds bitwise the gradients (a) left in the arena."""
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import gradient_buckets
+  feats, labels = _batch(4)
+  outs = []
+  for redirect in (False, True):
+    model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, dev, training=True)
+    model.store.initialize(seed=9)
+    model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+    early, late = gradient_buckets(model.store)
+    cover = np.zeros(model.store.size, np.int32)
+    for off, n in early + late:
+      cover[off:off + n] += 1
+    assert (cover == 1).all()
+    staging = torch.full((sum(n for _, n in late),), float('nan'), device=dev)
+    if redirect:
+      assert model.redirect_late_gradients(staging, late)
+    model.store.grads.fill_(float('nan'))
+    model.forward(backward_too=True)
+    model.backward(part='upper')
+    torch.cuda.synchronize()
+    before = model.store.grads.clone()
+    model.backward(part='bottom')
+    torch.cuda.synchronize()
+    after = model.store.grads
+    for off, n in early:
+      assert torch.equal(before[off:off + n].view(torch.int32), after[off:off + n].view(torch.int32))
+      assert not torch.isnan(after[off:off + n]).any()
+    if redirect:
+      assert torch.equal(before.view(torch.int32), after.view(torch.int32))        # the arena was not written at all
+      outs.append(staging.clone())
+    else:
+      outs.append(torch.cat([after[off:off + n] for off, n in late]))
+  assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])

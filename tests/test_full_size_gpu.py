@@ -9,13 +9,20 @@ One forward + backward of the HIP path vs the CPU oracle evaluated in chunks
 plain oracle in tests/test_oracle_kat.py).  Compared: loss and loss parts (1e-4 relative,
 BASELINE.json north_star), predictions, every variable's gradient, and conv8's features of the
 FIRST and the LAST frame of every encoder -- the last frame is where a 32-bit offset overflow
-would corrupt data silently.  Oracle precision: fp64 throughout for configs 2 and 5; for the
-1024-frame config 4 the encoder runs in fp32 on the CPU (fp64 would take minutes), decoder and
-loss in fp64, and the gradient bound is correspondingly looser.
+would corrupt data silently.  Oracle precision: fp64 throughout, for all three configs.
 
-Gradient tolerance (fraction of the variable's max |g|) is a FIXED cap per case, asserted, and the
-achieved worst error is printed.
+Gradient tolerance: a MEASURED yardstick, not a fitted constant.  The same chunked oracle is run a second
+time with the encoder in fp32 on the CPU; its distance from the fp64 run (err32) is what ANY fp32 implementation
+of this graph shows on these inputs (fp32 rounding flips a few ReLU decisions of near-zero pre-activations in
+conv1-4, which moves those layers' gradients by ~1e-3 of their maximum).  The HIP path must stay within
+max(2e-4, 2 x err32) per variable, in TWO norms: max-norm (fraction of the variable's max |g|) and relative L2
+(||dg|| / ||g||; a systematic error in small-magnitude entries or a mis-written slice moves this one while a
+single flipped ReLU hardly does).  Mask-independent elementwise checks of every launch at these shapes live in
+tests/test_bench_shapes_gpu.py.  The achieved errors of every variable are written to
+gpurun_out/full_size_achieved_<config>.json; the committed copy is tests/golden/full_size_achieved.json.
 """
+import json
+import os
 import time
 
 import numpy as np
@@ -26,12 +33,15 @@ from oracle import geeco_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-#        name               cfg overrides                                                     goal  N   enc dtype      grad cap
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRAD_FLOOR = 2e-4        # bound = max(GRAD_FLOOR, YARD * err32), both norms
+YARD = 2.0
+
+#        name               cfg overrides                                                     goal  N
 FULL = [
-    ('config2 geeco-f rgb N=32 K=16', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 32, torch.float64, 3e-3),
-    ('config4 e2e_vmc rgb N=64 K=16', dict(window_size=16), False, 64, torch.float32, 5e-3),
-    ('config5 geeco-f rgbd N=32 K=32', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=32, img_channels=4), True, 32,
-     torch.float64, 3e-3),
+    ('config2 geeco-f rgb N=32 K=16', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 32),
+    ('config4 e2e_vmc rgb N=64 K=16', dict(window_size=16), False, 64),
+    ('config5 geeco-f rgbd N=32 K=32', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=32, img_channels=4), True, 32),
 ]
 
 
@@ -40,8 +50,13 @@ def _rel_max(a, b):
   return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize('name,cfg_kw,goal,N,enc_dtype,gcap', FULL, ids=[c[0].split()[0] for c in FULL])
-def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype, gcap):
+def _rel_l2(a, b):
+  a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+  return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+@pytest.mark.parametrize('name,cfg_kw,goal,N', FULL, ids=[c[0].split()[0] for c in FULL])
+def test_full_size_forward_backward(dev, name, cfg_kw, goal, N):
   from geeco_amd import graph
   from geeco_amd.params import create_e2evmc_config
   cfg_kw = dict(cfg_kw, batch_size=N)
@@ -64,8 +79,12 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype, gcap)
 
   t0 = time.time()
   tr = O.OracleTrainer(ocfg, goal, P, dtype=torch.float64)
-  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(tr, feats, labels, chunk=16, enc_dtype=enc_dtype)
+  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(tr, feats, labels, chunk=16)
   t_ora = time.time() - t0
+  # the yardstick: the same oracle with its encoder in fp32 (decoder / loss stay fp64)
+  t0 = time.time()
+  _, _, grads_ref32, _, _ = O.loss_and_grads_chunked(tr, feats, labels, chunk=16, enc_dtype=torch.float32)
+  t_ora32 = time.time() - t0
 
   # ---- conv8 features of the first and the last frame of every encoder ------------------------------
   f8 = model.enc.features.cpu().numpy()                       # [G][Nf][2][2][C]
@@ -89,14 +108,27 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype, gcap)
     if k != 'loss_reg':
       assert abs(parts[k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-7, (k, parts[k], float(v))
 
-  # ---- every variable's gradient ----------------------------------------------------------------------
+  # ---- every variable's gradient: max-norm and relative L2, each against max(floor, 2 x the fp32 oracle's) ----------
   grads = model.store.to_numpy('grads')
-  worst = ('', 0.0)
+  achieved, failures = {}, []
+  worst = ('', 0.0, 0.0)
   for k, g in grads_ref.items():
-    e = _rel_max(grads[k], g.numpy())
+    g = g.numpy()
     assert np.isfinite(grads[k]).all(), k
-    assert e <= gcap, (k, e, gcap)
-    if e > worst[1]:
-      worst = (k, e)
-  print('%s: loss %.6f (oracle %.6f); worst gradient error %.2e of max|g| at %s (cap %.0e); hip %.1f s, oracle %.1f s'
-        % (name, parts['loss'], float(loss_ref), worst[1], worst[0], gcap, t_hip, t_ora))
+    e_max, e_l2 = _rel_max(grads[k], g), _rel_l2(grads[k], g)
+    y_max, y_l2 = _rel_max(grads_ref32[k].numpy(), g), _rel_l2(grads_ref32[k].numpy(), g)
+    t_max, t_l2 = max(GRAD_FLOOR, YARD * y_max), max(GRAD_FLOOR, YARD * y_l2)
+    achieved[k] = {'max': float('%.3g' % e_max), 'l2': float('%.3g' % e_l2), 'fp32_oracle_max': float('%.3g' % y_max),
+                   'fp32_oracle_l2': float('%.3g' % y_l2)}
+    if e_max > t_max or e_l2 > t_l2:
+      failures.append((k, e_max, t_max, e_l2, t_l2))
+    if e_max / t_max > worst[1]:
+      worst = (k, e_max / t_max, e_max)
+  out_dir = os.path.join(ROOT, 'gpurun_out')
+  os.makedirs(out_dir, exist_ok=True)
+  with open(os.path.join(out_dir, 'full_size_achieved_%s.json' % name.split()[0]), 'w') as f:
+    json.dump({'case': name, 'bound': 'max(%g, %g x fp32-oracle error), max-norm and relative L2' % (GRAD_FLOOR, YARD),
+               'variables': achieved}, f, indent=1)
+  print('%s: loss %.6f (oracle %.6f); worst gradient error %.2e of max|g| = %.2f of its bound at %s; hip %.1f s, oracle fp64 %.1f s, '
+        'fp32 yardstick %.1f s' % (name, parts['loss'], float(loss_ref), worst[2], worst[1], worst[0], t_hip, t_ora, t_ora32))
+  assert not failures, failures
