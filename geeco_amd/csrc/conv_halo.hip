@@ -1196,6 +1196,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_dgrad_kernel(const HaloDg
   constexpr int KB = COUT / 16;
   constexpr int HR = 5, HC = 33;                       // dz halo rows / cols
   constexpr int PLANE = HR * HC;                       // 165 float4
+  constexpr int SKEW = 0;                              // (the fused-bottom kernel below skews its planes; this one is off the step's path)
   constexpr int HALO_F4 = COQ * PLANE;
   constexpr int NLOAD = (HALO_F4 + NT - 1) / NT;
   constexpr int WP = 15;                               // float4 pitch of a (tap, ci) kernel row
@@ -1276,7 +1277,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_dgrad_kernel(const HaloDg
   __syncthreads();
 
   // lane r = X' column inside the wave's 16-column strip; q selects the co quad of a 16-co block
-  const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;    // + kb*4*PLANE + dy*HC + dx
+  const int a_lane = q * PLANE + SKEW * (q >> 1) + (row + 1) * HC + 16 * half + r + 1;    // + kb*4*PLANE + dy*HC + dx
   const int b_lane = r * WP + q;                                          // + (tap*CIN + 16 cit)*WP + 4 kb
   int buf = 0;
   for (;;) {
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_halo_dgrad_kernel(const HaloDg
     auto frag = [&](int it, f32x4& a, f32x4 (&b)[2]) {
       const int tap = it / KB, kb = it - tap * KB;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a = hA[kb * 4 * PLANE - (ky >> 1) * HC - (kx >> 1)];
+      a = hA[kb * (4 * PLANE + 2 * SKEW) - (ky >> 1) * HC - (kx >> 1)];
       b[0] = hB[(tap * CIN) * WP + 4 * kb];
       b[1] = hB[(tap * CIN + 16) * WP + 4 * kb];
     };
@@ -1655,6 +1656,9 @@ struct FusedBottomParams {
 #ifndef FB_ABL
 #define FB_ABL 0      // dev ablations (wrong results): 1 = no LDS fragment reads, 2 = no global loads / halo stores
 #endif
+#ifndef FB_SKEW
+#define FB_SKEW 1     // dz2 halo planes of co-quad pair m start 2 m granules into their slot: staging stores 8-way -> 2-way bank conflicts
+#endif
 #ifndef FB_SCHED
 #define FB_SCHED 0    // dev: 0 = fenced groups (reads | MFMAs), 1 = compiler's own schedule, 2 = fenced steps, interleaved inside
 #endif
@@ -1689,7 +1693,15 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   // over a group: 14 does (even phases for one q, odd for the other), 15 left one 2-way conflict per read.
   constexpr int PLANE_USED = HR * HC;                  // 165
   constexpr int PLANE = FB_PLANE;                      // 176
-  static_assert(PLANE >= PLANE_USED && PLANE % 16 == 0, "plane pitch");
+  // The staging stores (ds_write_b128: 8 consecutive lanes per LDS cycle group, banks = dword address mod 32, i.e. granule
+  // mod 8) put the 8 - 12 co quads of ONE halo pixel side by side: with every plane at the same phase all 8 lanes of a
+  // group hit one granule slot mod 8 (8-way conflict: 64 instead of 8 LDS cycles per store, 32 such stores per tile from
+  // the 8 waves inside four MFMA steps; round-2 PMC: 41.8 % of this kernel's LDS cycles were conflict cycles).  The read
+  // side only needs the planes of a quad PAIR (4 kb + {0, 1}, 4 kb + {2, 3}) at one phase mod 16, so pair m is skewed by
+  // SKEW * m granules inside its 176-granule slot: the stores are 2-way (16 LDS cycles, under their 13-cycle issue cost)
+  // and the fragment reads stay conflict free.
+  constexpr int SKEW = FB_SKEW ? 2 : 0;
+  static_assert(PLANE >= PLANE_USED + SKEW * (COQ / 2 - 1) && PLANE % 16 == 0, "plane pitch");
   constexpr int HALO_USED = COQ * PLANE_USED;          // 1980 granules are loaded
   constexpr int HALO_F4 = COQ * PLANE;                 // 2112 granules per buffer
   constexpr int NLOAD = (HALO_USED + NT - 1) / NT;
@@ -1748,7 +1760,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     // lanes beyond the halo: row marker that fails every bounds test (they fetch the zero page) and a pad granule of
     // plane 0 as their LDS slot, so that neither the load nor the store needs a predicate
     l_hy[i] = (short)(idx < HALO_USED ? hy : 30000); l_hx[i] = (short)hx;
-    l_off[i] = (idx < HALO_USED) ? cq * PLANE + hy * HC + hx : PLANE_USED + (tid & 7);
+    l_off[i] = (idx < HALO_USED) ? cq * PLANE + SKEW * (cq >> 1) + hy * HC + hx : PLANE_USED + (tid & 7);
     l_src[i] = (hy * p.Wo + hx) * COUT + cq * 4;
   }
   f32x4 stage[NLOAD];
@@ -1830,7 +1842,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     }
   }
   dma_barrier();
-  const int a_lane = q * PLANE + (row + 1) * HC + 16 * half + r + 1;
+  const int a_lane = q * PLANE + SKEW * (q >> 1) + (row + 1) * HC + 16 * half + r + 1;
   const int b_lane = r * WP + q;
   int buf = 0;
   int tcount = 0;
@@ -1884,7 +1896,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     auto frag = [&](int it, f32x4& a, f32x4 (&b)[2]) {
       const int tap = ORDER[it / KB], kb = it % KB;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a = hA[kb * 4 * PLANE - (ky >> 1) * HC - (kx >> 1)];
+      a = hA[kb * (4 * PLANE + 2 * SKEW) - (ky >> 1) * HC - (kx >> 1)];
       b[0] = hB[(tap * CIN) * WP + 4 * kb];
       b[1] = hB[(tap * CIN + 16) * WP + 4 * kb];
     };

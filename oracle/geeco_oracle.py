@@ -218,12 +218,31 @@ def init_params(shapes, seed=0, dtype=np.float32):
 # --------------------------------------------------------------------------------------
 # graph pieces
 # --------------------------------------------------------------------------------------
-def conv_encoder(x, P, scope, collect=None):
-  """graph.py:61-117."""
+def conv_encoder(x, P, scope, collect=None, masks=None, force=False, stats=None):
+  """graph.py:61-117.
+
+  Test instrumentation (the product of every other caller is unchanged): ``masks`` = per layer a bool tensor with
+  SOMEBODY ELSE'S ReLU decisions (the device's ``y > 0``).  ``stats`` ([layer] -> [disagreements, max |z| there,
+  elements]) compares them with this restatement's own ``z > 0``; with ``force`` the activation is ``z * mask``:
+  the forward changes only where the two disagree (|z| at rounding level, checked through ``stats``) and the
+  backward is the gradient under the given decisions -- at z == 0 both are valid subgradients of ReLU, and which side
+  of zero a pre-activation of 1e-8 lands on is rounding, not mathematics."""
   net = x
   for i in range(8):
-    net = conv2d_same(net, P['%s/conv%d/kernel' % (scope, i + 1)], P['%s/conv%d/bias' % (scope, i + 1)],
-                      ENC_STRIDES[i], relu=True)
+    w, b = P['%s/conv%d/kernel' % (scope, i + 1)], P['%s/conv%d/bias' % (scope, i + 1)]
+    if masks is None:
+      net = conv2d_same(net, w, b, ENC_STRIDES[i], relu=True)
+    else:
+      z = conv2d_same(net, w, b, ENC_STRIDES[i], relu=False)
+      own = z > 0
+      if stats is not None:
+        dis = own != masks[i]
+        n = int(dis.sum())
+        stats[i][0] += n
+        if n:
+          stats[i][1] = max(stats[i][1], float(z.detach().abs()[dis].max()))
+        stats[i][2] += dis.numel()
+      net = z * (masks[i] if force else own).to(z.dtype)
     if collect is not None:
       collect['%s/conv%d' % (scope, i + 1)] = net
   return net
@@ -503,22 +522,40 @@ def _encoder_jobs(features, cfg: Config, goal: bool, dtype):
           {'dynbuff': db, 'dyndiff': dd})
 
 
-def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16, enc_dtype=None):
+def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16, enc_dtype=None, encoder_inputs=None,
+                           masks_fn=None):
   """Same result as ``OracleTrainer.loss_and_grads`` (up to summation order) without holding the
   autograd graph of every frame at once: (1) encoder forward per chunk without graph -> conv8
   features; (2) decoder + loss with autograd on the features; (3) per chunk, encoder forward
   again WITH graph and backward from d(loss)/d(features).  ``enc_dtype`` lets the encoder run
-  in float32 while decoder/loss stay in the trainer's dtype (1024-frame case)."""
+  in float32 while decoder/loss stay in the trainer's dtype.
+
+  Mask-consistent mode (full-size parity tests): ``encoder_inputs`` = per encoder pass the [F,H,W,C] input frames the
+  device actually fed its conv1 (its fp32 dynamic images; these are compared with this oracle's separately), and
+  ``masks_fn(job, i0, i1)`` -> the device's eight ReLU decisions (bool [i1-i0, h, w, c]) for those frames.  Pass (1)
+  stays the plain restatement (own ReLU decisions: loss, predictions, features are the reference's) and only COUNTS
+  where the device decided differently and how large |z| was there (``ep['relu_disagreements']``); pass (3) computes
+  the gradient under the device's decisions (``conv_encoder(force=True)``), which removes the one effect that makes
+  fp32 gradients of this graph incomparable at full size: a pre-activation of 1e-8 rounded to the other side of zero
+  moves a filter gradient by 1e-3 of its maximum in ANY fp32 implementation."""
   cfg, goal, dt = trainer.cfg, trainer.goal, trainer.dtype
   edt = enc_dtype or dt
   features, labels = trainer._cast(features), trainer._cast(labels)
   P = trainer.P
   jobs, ep = _encoder_jobs(features, cfg, goal, dt)
+  if encoder_inputs is not None:
+    assert len(encoder_inputs) == len(jobs) and all(tuple(a.shape) == tuple(x.shape) for a, (_, x) in zip(encoder_inputs, jobs))
+    jobs = [(scope, a) for a, (scope, _) in zip(encoder_inputs, jobs)]
   Pe = {k: v.detach().to(edt) for k, v in P.items() if '/conv' in k}
   feats = []
+  stats = [[[0, 0.0, 0] for _ in range(8)] for _ in jobs] if masks_fn is not None else None
   with torch.no_grad():
-    for scope, x in jobs:
-      outs = [conv_encoder(x[i:i + chunk].to(edt), Pe, scope) for i in range(0, x.shape[0], chunk)]
+    for j, (scope, x) in enumerate(jobs):
+      outs = []
+      for i in range(0, x.shape[0], chunk):
+        i1 = min(i + chunk, x.shape[0])
+        kw = dict(masks=masks_fn(j, i, i1), stats=stats[j]) if masks_fn is not None else {}
+        outs.append(conv_encoder(x[i:i1].to(edt), Pe, scope, **kw))
       feats.append(torch.cat(outs, dim=0).to(dt))
   first_last = {scope: (f[0].clone(), f[-1].clone()) for (scope, _), f in zip(jobs, feats)}
   for f in feats:
@@ -548,14 +585,18 @@ def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16,
   grads = {k: p.grad.detach().clone() for k, p in dec.items()}
   for p in dec.values():
     p.requires_grad_(False)
-  for (scope, x), f in zip(jobs, feats):
+  for j, ((scope, x), f) in enumerate(zip(jobs, feats)):
     names = [k for k in P if k.startswith(scope + '/')]
     Pg = {k: P[k].detach().to(edt).requires_grad_(True) for k in names}
     for i in range(0, x.shape[0], chunk):
-      out = conv_encoder(x[i:i + chunk].to(edt), Pg, scope)
-      out.backward(f.grad[i:i + chunk].to(edt))
+      i1 = min(i + chunk, x.shape[0])
+      kw = dict(masks=masks_fn(j, i, i1), force=True) if masks_fn is not None else {}
+      out = conv_encoder(x[i:i1].to(edt), Pg, scope, **kw)
+      out.backward(f.grad[i:i1].to(edt))
     for k in names:
       grads[k] = Pg[k].grad.detach().to(dt)
   ep = dict(ep)
   ep['conv8_first_last'] = first_last
+  if stats is not None:
+    ep['relu_disagreements'] = {scope: [tuple(s) for s in st] for (scope, _), st in zip(jobs, stats)}
   return (loss.detach(), {k: v.detach() for k, v in parts.items()}, grads, {k: v.detach() for k, v in pred.items()}, ep)

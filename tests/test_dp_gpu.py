@@ -266,7 +266,10 @@ def test_bottom_backward_writes_only_the_late_bucket(dev):
     after = model.store.grads
     for off, n in early:
       assert torch.equal(before[off:off + n].view(torch.int32), after[off:off + n].view(torch.int32))
-      assert not torch.isnan(after[off:off + n]).any()
+    # every VARIABLE's gradient was written by one of the two parts (the alignment pads between variables never are)
+    for name, g in model.store.to_numpy('grads').items():
+      if not (redirect and ('/conv1/' in name or '/conv2/' in name)):
+        assert not np.isnan(g).any(), name
     if redirect:
       assert torch.equal(before.view(torch.int32), after.view(torch.int32))        # the arena was not written at all
       outs.append(staging.clone())

@@ -4,22 +4,28 @@
   config 4  e2e_vmc rgb   256x256  N=64 K=16   (1024 frame passes; conv1's output is exactly 2^31 floats)
   config 5  geeco-f rgbd  256x256  N=32 K=32   (per-GPU shape of the 8-GPU rgbd config)
 
-One forward + backward of the HIP path vs the CPU oracle evaluated in chunks
-(``oracle.loss_and_grads_chunked``: identical mathematics, bounded memory; checked against the
-plain oracle in tests/test_oracle_kat.py).  Compared: loss and loss parts (1e-4 relative,
-BASELINE.json north_star), predictions, every variable's gradient, and conv8's features of the
-FIRST and the LAST frame of every encoder -- the last frame is where a 32-bit offset overflow
-would corrupt data silently.  Oracle precision: fp64 throughout, for all three configs.
+One forward + backward of the HIP path vs the fp64 CPU oracle evaluated in chunks
+(``oracle.loss_and_grads_chunked``: identical mathematics, bounded memory; checked against the plain oracle in
+tests/test_oracle_kat.py).  Compared against the PLAIN oracle (its own ReLU decisions): loss and loss parts (1e-4
+relative, BASELINE.json north_star), predictions, conv8's features of the FIRST and the LAST frame of every encoder (the
+last frame is where a 32-bit offset overflow would corrupt data silently), the dynamic images.
 
-Gradient tolerance: a MEASURED yardstick, not a fitted constant.  The same chunked oracle is run a second
-time with the encoder in fp32 on the CPU; its distance from the fp64 run (err32) is what ANY fp32 implementation
-of this graph shows on these inputs (fp32 rounding flips a few ReLU decisions of near-zero pre-activations in
-conv1-4, which moves those layers' gradients by ~1e-3 of their maximum).  The HIP path must stay within
-max(2e-4, 2 x err32) per variable, in TWO norms: max-norm (fraction of the variable's max |g|) and relative L2
-(||dg|| / ||g||; a systematic error in small-magnitude entries or a mis-written slice moves this one while a
-single flipped ReLU hardly does).  Mask-independent elementwise checks of every launch at these shapes live in
-tests/test_bench_shapes_gpu.py.  The achieved errors of every variable are written to
-gpurun_out/full_size_achieved_<config>.json; the committed copy is tests/golden/full_size_achieved.json.
+Gradients -- every variable, two norms, NO fitted constant.  Round 2 bounded them by a max-norm cap (3e-3 / 5e-3 of
+max |g|) that had been raised after a red run.  Round 3 first tried the yardstick of the small-shape tests (the same oracle
+with an fp32 encoder; bound max(2e-4, 2 x its error)): it does not hold and cannot -- at these sizes a gradient's error is
+set by a HANDFUL of ReLU decisions on pre-activations of 1e-8 that each fp32 implementation rounds to its own side of zero
+(measured, tests/golden/full_size_plain_oracle_r03.json: DynDiffEncoder conv4-6 differ from the fp64 oracle by the SAME
+1.26e-4 / 1.36e-4 / 5.80e-4 on the device and in the fp32 CPU run, same flip; ConvEncoder/conv3 4.3e-4 on the device and
+1e-6 on the CPU, a flip only the device made), so the ratio of two such errors is noise.  The test therefore removes the
+effect instead of bounding it: the oracle's backward runs under the DEVICE's ReLU decisions (``masks_fn``: the sign of
+every activation the device wrote) on the device's conv1 inputs, and
+  (a) every gradient equals that oracle's to 2e-5 of max |g| AND to 2e-5 in relative L2 (the tolerance of the per-kernel
+      tests; a wrong tile edge, a mis-written slice or a systematic error in small entries cannot hide under it), and
+  (b) every ReLU decision in which the device differs from the fp64 oracle sits on a pre-activation |z| <= 2e-5 -- the
+      device never "decides" anything the forward tolerance does not already allow; the count per layer is printed.
+The achieved errors of every variable go to gpurun_out/full_size_achieved_<config>.json; the committed copy is
+tests/golden/full_size_achieved.json.  Mask-independent elementwise checks of every launch at these shapes:
+tests/test_bench_shapes_gpu.py.
 """
 import json
 import os
@@ -34,14 +40,19 @@ from oracle import geeco_oracle as O
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GRAD_FLOOR = 2e-4        # bound = max(GRAD_FLOOR, YARD * err32), both norms
-YARD = 2.0
+GRAD_TOL = 2e-5          # both norms, against the oracle under the device's ReLU decisions
+Z_TOL = 2e-5             # |pre-activation| wherever the device's ReLU decision differs from the fp64 oracle's
 
-#        name               cfg overrides                                                     goal  N
+# Oracle precision: fp64 throughout for configs 2 and 5.  The 1024-frame config 4 runs the oracle's ENCODER in fp32 (decoder
+# and loss in fp64): in fp64 it takes 286 s on the GPU box's 16 host threads (measured; the achieved errors of that run are
+# the committed tests/golden/full_size_achieved.json: worst 1.48e-6), too close to the harness's silence limit.  Under the
+# device's ReLU decisions an fp32 oracle has no flips either, so the same 2e-5 bound holds (its own rounding is ~5e-7).
+#        name               cfg overrides                                                     goal  N   oracle encoder
 FULL = [
-    ('config2 geeco-f rgb N=32 K=16', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 32),
-    ('config4 e2e_vmc rgb N=64 K=16', dict(window_size=16), False, 64),
-    ('config5 geeco-f rgbd N=32 K=32', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=32, img_channels=4), True, 32),
+    ('config2 geeco-f rgb N=32 K=16', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 32, torch.float64),
+    ('config4 e2e_vmc rgb N=64 K=16', dict(window_size=16), False, 64, torch.float32),
+    ('config5 geeco-f rgbd N=32 K=32', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=32, img_channels=4), True, 32,
+     torch.float64),
 ]
 
 
@@ -55,8 +66,8 @@ def _rel_l2(a, b):
   return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
 
 
-@pytest.mark.parametrize('name,cfg_kw,goal,N', FULL, ids=[c[0].split()[0] for c in FULL])
-def test_full_size_forward_backward(dev, name, cfg_kw, goal, N):
+@pytest.mark.parametrize('name,cfg_kw,goal,N,enc_dtype', FULL, ids=[c[0].split()[0] for c in FULL])
+def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
   from geeco_amd import graph
   from geeco_amd.params import create_e2evmc_config
   cfg_kw = dict(cfg_kw, batch_size=N)
@@ -77,23 +88,24 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N):
   torch.cuda.synchronize()
   t_hip = time.time() - t0
 
+  # ---- the oracle: plain forward (its own ReLU decisions), backward under the device's decisions ----------------------
+  enc, C = model.enc, ocfg.img_channels
+  enc_inputs = [enc.x_in[g][..., :C].cpu() for g in range(enc.G)]           # what the device fed its conv1 (fp32)
+  masks_fn = lambda g, i0, i1: [(enc.acts[l][g, i0:i1] > 0).cpu() for l in range(8)]
   t0 = time.time()
   tr = O.OracleTrainer(ocfg, goal, P, dtype=torch.float64)
-  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(tr, feats, labels, chunk=16)
+  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(tr, feats, labels, chunk=16, enc_dtype=enc_dtype,
+                                                                            encoder_inputs=enc_inputs, masks_fn=masks_fn)
   t_ora = time.time() - t0
-  # the yardstick: the same oracle with its encoder in fp32 (decoder / loss stay fp64)
-  t0 = time.time()
-  _, _, grads_ref32, _, _ = O.loss_and_grads_chunked(tr, feats, labels, chunk=16, enc_dtype=torch.float32)
-  t_ora32 = time.time() - t0
 
   # ---- conv8 features of the first and the last frame of every encoder ------------------------------
-  f8 = model.enc.features.cpu().numpy()                       # [G][Nf][2][2][C]
-  for g, scope in enumerate(model.enc.scopes):
+  f8 = enc.features.cpu().numpy()                             # [G][Nf][2][2][C]
+  for g, scope in enumerate(enc.scopes):
     first, last = ep_ref['conv8_first_last'][scope]
     scale = max(float(first.abs().max()), float(last.abs().max()), 1e-30)
     assert np.abs(f8[g, 0] - first.numpy()).max() <= 2e-4 * scale, (scope, 'first frame')
     assert np.abs(f8[g, -1] - last.numpy()).max() <= 2e-4 * scale, (scope, 'last frame')
-  if goal:
+  if goal:      # the device's dynamic images (fed to the oracle's encoders above) against the oracle's own fp64 ones
     ep = model.endpoints()
     for k in ('dynbuff', 'dyndiff'):
       assert _rel_max(ep[k].cpu().numpy(), ep_ref[k].numpy()) < 2e-5, k
@@ -108,27 +120,36 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N):
     if k != 'loss_reg':
       assert abs(parts[k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-7, (k, parts[k], float(v))
 
-  # ---- every variable's gradient: max-norm and relative L2, each against max(floor, 2 x the fp32 oracle's) ----------
+  # ---- (b) the device's ReLU decisions: different from the fp64 oracle's only at rounding-level pre-activations ----------
+  dis = ep_ref['relu_disagreements']
+  worst_z, n_dis, n_tot = 0.0, 0, 0
+  for scope, st in dis.items():
+    for l, (n, z, tot) in enumerate(st):
+      assert tot > 0
+      assert z <= Z_TOL, '%s conv%d: ReLU decision differs at |z| = %.3e (%d of %d decisions differ)' % (scope, l + 1, z, n, tot)
+      worst_z, n_dis, n_tot = max(worst_z, z), n_dis + n, n_tot + tot
+
+  # ---- (a) every variable's gradient, max-norm and relative L2 -------------------------------------------------------------
   grads = model.store.to_numpy('grads')
   achieved, failures = {}, []
-  worst = ('', 0.0, 0.0)
+  worst = ('', 0.0)
   for k, g in grads_ref.items():
     g = g.numpy()
     assert np.isfinite(grads[k]).all(), k
     e_max, e_l2 = _rel_max(grads[k], g), _rel_l2(grads[k], g)
-    y_max, y_l2 = _rel_max(grads_ref32[k].numpy(), g), _rel_l2(grads_ref32[k].numpy(), g)
-    t_max, t_l2 = max(GRAD_FLOOR, YARD * y_max), max(GRAD_FLOOR, YARD * y_l2)
-    achieved[k] = {'max': float('%.3g' % e_max), 'l2': float('%.3g' % e_l2), 'fp32_oracle_max': float('%.3g' % y_max),
-                   'fp32_oracle_l2': float('%.3g' % y_l2)}
-    if e_max > t_max or e_l2 > t_l2:
-      failures.append((k, e_max, t_max, e_l2, t_l2))
-    if e_max / t_max > worst[1]:
-      worst = (k, e_max / t_max, e_max)
+    achieved[k] = {'max': float('%.3g' % e_max), 'l2': float('%.3g' % e_l2)}
+    if e_max > GRAD_TOL or e_l2 > GRAD_TOL:
+      failures.append((k, e_max, e_l2))
+    if max(e_max, e_l2) > worst[1]:
+      worst = (k, max(e_max, e_l2))
   out_dir = os.path.join(ROOT, 'gpurun_out')
   os.makedirs(out_dir, exist_ok=True)
   with open(os.path.join(out_dir, 'full_size_achieved_%s.json' % name.split()[0]), 'w') as f:
-    json.dump({'case': name, 'bound': 'max(%g, %g x fp32-oracle error), max-norm and relative L2' % (GRAD_FLOOR, YARD),
+    json.dump({'case': name, 'bound': '%g of max|g| and %g relative L2, against the fp64 oracle under the device\'s ReLU decisions' % (GRAD_TOL, GRAD_TOL),
+               'relu_decisions': {'differing': n_dis, 'total': n_tot, 'max_abs_preactivation_where_differing': float('%.3g' % worst_z),
+                                  'per_layer': {s: [[n, float('%.3g' % z), t] for n, z, t in st] for s, st in dis.items()}},
                'variables': achieved}, f, indent=1)
-  print('%s: loss %.6f (oracle %.6f); worst gradient error %.2e of max|g| = %.2f of its bound at %s; hip %.1f s, oracle fp64 %.1f s, '
-        'fp32 yardstick %.1f s' % (name, parts['loss'], float(loss_ref), worst[2], worst[1], worst[0], t_hip, t_ora, t_ora32))
+  print('%s: loss %.6f (oracle %.6f); worst gradient error %.2e (max-norm or rel. L2, bound %.0e) at %s; %d of %d ReLU decisions '
+        'differ from the fp64 oracle, all at |z| <= %.1e; hip %.1f s, oracle %.1f s'
+        % (name, parts['loss'], float(loss_ref), worst[1], GRAD_TOL, worst[0], n_dis, n_tot, worst_z, t_hip, t_ora))
   assert not failures, failures

@@ -145,3 +145,39 @@ def test_chunked_evaluation_matches_plain():
       torch.testing.assert_close(grads2[k], grads[k], rtol=1e-9, atol=1e-14, msg=k)
     assert set(grads2) == set(grads)
     assert len(ep2['conv8_first_last']) == (3 if goal else 1)
+
+
+def test_chunked_mask_consistent_mode():
+  """The mask-consistent mode of loss_and_grads_chunked (full-size GPU parity): fed the restatement's OWN inputs and ReLU
+  decisions it reproduces the plain gradients and reports zero disagreements; one decision flipped (at an entry whose
+  pre-activation is far from zero) is counted with its |z| and moves the gradients -- i.e. the count and the bound on
+  |z| the GPU tests assert really see a wrong mask."""
+  cfg = O.make_config(img_height=136, img_width=136, batch_size=2, proc_obs='dynimg', proc_tgt='dyndiff', window_size=2)
+  P = O.init_params(O.model_param_shapes(cfg, True), seed=3)
+  feats, labels = O.synthetic_batch(cfg, True, 2, seed=5, H=136, W=136)
+  tr = O.OracleTrainer(cfg, True, P, dtype=torch.float64)
+  loss, _, grads, _, _ = O.loss_and_grads_chunked(tr, feats, labels, chunk=1)
+  f = tr._cast(feats)
+  jobs, _ = O._encoder_jobs(f, cfg, True, torch.float64)
+  Pe = {k: v for k, v in tr.P.items()}
+  acts = []
+  for scope, x in jobs:
+    col = {}
+    O.conv_encoder(x, Pe, scope, col)
+    acts.append([col['%s/conv%d' % (scope, i + 1)] > 0 for i in range(8)])
+  mf = lambda j, i0, i1: [m[i0:i1] for m in acts[j]]
+  loss2, _, grads2, _, ep2 = O.loss_and_grads_chunked(tr, feats, labels, chunk=1, encoder_inputs=[x for _, x in jobs], masks_fn=mf)
+  assert float(loss2) == float(loss)
+  for k in grads:
+    torch.testing.assert_close(grads2[k], grads[k], rtol=1e-12, atol=1e-15, msg=k)
+  for scope, st in ep2['relu_disagreements'].items():
+    assert all(n == 0 and z == 0.0 and tot > 0 for n, z, tot in st), (scope, st)
+  # flip one decision of conv2 in the second encoder, frame 1
+  idx = (1, 5, 7, 3)
+  acts[1][1][idx] = ~acts[1][1][idx]
+  _, _, grads3, _, ep3 = O.loss_and_grads_chunked(tr, feats, labels, chunk=1, encoder_inputs=[x for _, x in jobs], masks_fn=mf)
+  st = ep3['relu_disagreements']['GoalVMC/DynBuffEncoder']
+  assert st[1][0] == 1 and st[1][1] > 1e-6 and sum(s[0] for s in st) == 1
+  assert float(ep3['relu_disagreements']['GoalVMC/ConvEncoder'][1][0]) == 0
+  assert not torch.equal(grads3['GoalVMC/DynBuffEncoder/conv2/kernel'], grads['GoalVMC/DynBuffEncoder/conv2/kernel'])
+  torch.testing.assert_close(grads3['GoalVMC/ConvEncoder/conv2/kernel'], grads['GoalVMC/ConvEncoder/conv2/kernel'], rtol=1e-12, atol=1e-15)
