@@ -10,8 +10,8 @@ of synthetic 256x256 RGB x 16-frame windows (BASELINE.json configs[1]: batch 32 
 resident in HBM before the timed region.  ``value`` = global_batch * seq_len * steps / wall time of the
 timed region (barrier + synchronize on both sides, max over ranks).
 
-Extra objects (N = 1): ``layers`` (every conv launch of the step timed alone, one HIP event pair per launch,
-median of >= 30: FLOP, us, TFLOP/s, fraction of the fp32 MFMA peak), ``roofline`` (the kernel with the largest
+Extra objects (N = 1): ``layers`` (every conv launch of the step timed alone: median of >= 30 HIP-event
+samples of 5 launches each: FLOP, us, TFLOP/s, fraction of the fp32 MFMA peak), ``roofline`` (the kernel with the largest
 share of the step, taken from that table, plus the same by kernel family), ``hbm`` (dynimg calls and Adam against the
 HBM peak), ``encoder_forward``, ``other_configs`` (config 4 and the per-GPU shape of config 5, a few steps each, with
 their own oracle-pinned loss check) and ``cpu_baseline`` (the CPU restatement in oracle/, timed on the host cores).
@@ -144,21 +144,28 @@ def time_region(fn, iters):
   return e0.elapsed_time(e1) / iters
 
 
-def time_launches(fn, samples=30):
-  """One HIP event pair PER call of ``fn`` (on the current stream, the one our kernels are launched on), `samples`
-  calls; returns (median, p10, p90) in milliseconds.  A busy-wait kernel is queued first so that the host enqueues
-  all samples while the GPU is still busy: the pairs then measure the launch itself, not the host's enqueue rate, and
-  one hiccup moves one sample, not the reported median."""
+LAUNCHES_PER_SAMPLE = 5
+
+
+def time_launches(fn, samples=30, per_sample=LAUNCHES_PER_SAMPLE):
+  """(median, p10, p90) milliseconds per call of ``fn`` over `samples` samples; one sample = one HIP event pair (on the
+  current stream, the one our kernels are launched on) around `per_sample` back-to-back calls.  The median makes one
+  hiccup move one sample, not the reported number (round 2 had ONE pair around 20 launches: a 27 us kernel once read
+  78 us).  Why not one pair per single launch: measured (scripts/dev/timing_probe.py, profiles/r03/timing_probe.txt) a
+  pair around ONE launch reads 3-9 % above the kernel duration rocprofv3 reports inside the step on the big streaming
+  kernels (conv2 forward 411.6 vs 377.5 us) and, without a kernel ahead of it in the queue, measures the host's enqueue
+  rate on the small ones (conv8 forward 118 us for a 17 us kernel); pairs around 4-8 launches agree with rocprofv3 to
+  1-2 % (380.1 / 377.6 us)."""
   import torch
   evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(samples)]
   torch.cuda.synchronize()
-  torch.cuda._sleep(int(8e6))        # ~3-4 ms of GPU time at ~2.3 GHz
   for a, b in evs:
     a.record()
-    fn()
+    for _ in range(per_sample):
+      fn()
     b.record()
   torch.cuda.synchronize()
-  ts = sorted(a.elapsed_time(b) for a, b in evs)
+  ts = sorted(a.elapsed_time(b) / per_sample for a, b in evs)
   return percentile(ts, 0.5), percentile(ts, 0.1), percentile(ts, 0.9)
 
 
@@ -174,7 +181,8 @@ def percentile(sorted_vals, q):
 # ======================================================================================================
 def layer_table(model, samples):
   """Every conv launch of one step, timed ALONE: forward, input gradient and filter gradient of conv1..conv8 over all
-  encoder frames, each call with its own HIP event pair, `samples` (>= 30) calls, MEDIAN reported (p10 / p90 beside it).
+  encoder frames; `samples` (>= 30) event-pair samples of 5 back-to-back launches each, MEDIAN reported (p10 / p90 beside
+  it; see time_launches).
   FLOP = 2 * MACs of the layer (bias / ReLU / mask excluded).  A call that also runs a small reduce /
   epilogue kernel is timed as a whole (its names are listed)."""
   from geeco_amd import ops
@@ -233,7 +241,7 @@ def dominant_roofline(rows):
           'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
           'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': round(d['us'] / n * 1e-3, 4),
           'flop_per_launch': int(d['flop'] / n), 'share_of_conv_time': round(d['us'] / total, 4),
-          'timer': 'HIP event pair per launch on the launch stream, median of the samples',
+          'timer': 'HIP event pairs on the launch stream, each around %d back-to-back launches; median of >= 30 samples' % LAUNCHES_PER_SAMPLE,
           'family': {'kernel': fname, 'launches_per_step': f['launches'], 'achieved': round(fach, 2),
                      'frac': round(fach / PEAK_F32_MFMA_TFLOPS, 4), 'us_per_step': round(f['us'], 1),
                      'share_of_conv_time': round(f['us'] / total, 4)}}
@@ -282,19 +290,11 @@ def hbm_table(model, args, iters):
     frames, tgt = model._frames()
     x_in = model.enc.x_in
     cur = frames[:, K - 1]
-    if getattr(model, 'fused_inputs', False):
-      # one launch = both dynamic images + the current-frame copy; algorithmic bytes = SURVEY 8(d)'s two dynimg
-      # figures (buffer image: K frames in + 1 out; diff image: 2 in + 1 out).  The launch really moves
-      # (K + 1) frames in and 3 channel-padded frames out.
-      add('goal inputs: dynimg buffer (K=%d) + diff (K=2) + current frame, one launch' % K, 4.0 * N * HW * C * (K + 1 + 3),
-          lambda: ops.goal_inputs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, C, model.gin_ws, K * HW * C, HW * C))
-      rows[-1]['moved_bytes'] = int(4.0 * N * HW * (C * (K + 1) + 3 * 4))
-    else:
-      add('dynimg buffer image (K=%d)' % K, 4.0 * N * HW * C * (K + 1),
-          lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C))
-      add('dynimg diff image (K=2)', 4.0 * N * HW * C * 3,
-          lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
-  if args.model == 'geeco-f' and getattr(model, 'last_from_dynimg', False) and not getattr(model, 'fused_inputs', False) \
+    add('dynimg buffer image (K=%d)' % K, 4.0 * N * HW * C * (K + 1),
+        lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C))
+    add('dynimg diff image (K=2)', 4.0 * N * HW * C * 3,
+        lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
+  if args.model == 'geeco-f' and getattr(model, 'last_from_dynimg', False) \
       and HW % 4 == 0 and (C == 3 or getattr(model, 'split_rgbd', False)):
     # what the step really runs: both images + the current frame's padded copy in three launches (one shared
     # normalisation launch); algorithmic bytes = the two dynimg figures of SURVEY 8(d)

@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_LIB: A/B builds side by side
 
 
+ABI_VERSION = 3        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
+
+
 class GeecoNativeError(RuntimeError):
   pass
 
@@ -42,9 +45,6 @@ SIGNATURES = {
     'geeco_dynimg_rgbd_fwd_last': (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P, _P]),
     'geeco_goal_dynimgs_fwd': (_I, [_P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
     'geeco_dynimg_rgbd_fwd': (_I, [_P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P]),
-    'geeco_goal_inputs_ws_bytes': (_L, [_I]),
-    'geeco_goal_inputs_supported': (_I, [_I, _I, _L, _I]),
-    'geeco_goal_inputs_fwd': (_I, [_P, _L, _L, _P, _L, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P]),
     'geeco_pack_pixels': (_I, [_P, _L, _P, _L, _I, _L, _I, _I, _I, _P, _P]),
     'geeco_gather_windows': (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),
     'geeco_conv3x3_fwd': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
@@ -108,6 +108,16 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
   except OSError as e:
     raise GeecoNativeError("cannot load %s: %s" % (LIB_PATH, e))
+  # the version first: a stale build (or another one picked through GEECO_LIB) must be named as such, not fail later on a
+  # symbol or - worse - load with an entry point whose calling convention has changed
+  try:
+    lib.geeco_abi_version.restype = c_int
+    have = int(lib.geeco_abi_version())
+  except AttributeError:
+    raise GeecoNativeError("%s is not a geeco_hip library (no geeco_abi_version)" % LIB_PATH)
+  if have != ABI_VERSION:
+    raise GeecoNativeError("ABI version mismatch: %s is version %d, this binding needs %d (rebuild: geeco_amd/csrc/build.sh)"
+                           % (LIB_PATH, have, ABI_VERSION))
   for name, (res, args) in SIGNATURES.items():
     try:
       fn = getattr(lib, name)
@@ -115,8 +125,6 @@ def load():
       raise GeecoNativeError("%s does not export %s (stale build?)" % (LIB_PATH, name))
     fn.restype = res
     fn.argtypes = args
-  if lib.geeco_abi_version() != 1:
-    raise GeecoNativeError("ABI version mismatch: library %d, binding 1" % lib.geeco_abi_version())
   _lib = lib
   return lib
 

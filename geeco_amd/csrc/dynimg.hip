@@ -430,238 +430,3 @@ extern "C" int geeco_gather_windows(const void* src, int src_is_u8, const int* s
   GEECO_LAUNCH_CHECK();
   return 0;
 }
-
-// ---- fused input stage of goal_e2evmc's dynimg branch (graph.py:386-402) -------------------------------------------
-// One launch produces the three conv1 inputs of geeco-f from a batch of K-frame windows:
-//   out_obs  = frames[:, K-1]                               (rgb_frame_list[-1], :387)  channel-padded to 4
-//   out_dyn  = dynimg(frames)                                (:392)
-//   out_diff = dynimg([frames[:, K-1], tgt])                 (:397-400)
-// The separate kernels read the K frames once, D twice more (normalisation pass) and the current frame three times;
-// here every input byte is read ONCE and every output byte written ONCE: a thread keeps its raw D values in registers
-// across a per-sample rendezvous (the min / max of a sample spans all its blocks) and normalises them on the way out.
-//   phase 1: stream the frames (16 B per lane), accumulate D_buf, keep cur, load tgt, D_diff = a0 cur + a1 tgt;
-//            block min / max -> order-preserving unsigned encoding -> atomicMax on the sample's 4 sync words;
-//   rendezvous: one lane per block releases + counts in, polls until all BPS blocks of ITS sample have arrived
-//            (relaxed poll, one acquire), every block of a sample is resident by construction (grid <= 2 blocks per
-//            CU, enforced on the host), the poll is bounded anyway;
-//   phase 2: normalise from registers, write the three images; the last block to leave resets the sync words to 0,
-//            so the workspace is zero again for the next launch / graph replay.
-// The sync words must be ZERO before the first launch (ops.goal_inputs_ws zero-fills the workspace once).
-struct GoalInParams {
-  const float* frames;       // [N][K][HW][C] (strided)
-  const float* tgt;          // [N][HW][C]
-  long long sample_stride, frame_stride, tgt_stride;
-  int N, K, BPS;
-  long long items;           // per sample: 4-pixel units (C == 3) or pixels (C == 4)
-  long long HW;
-  float* out_obs;            // [N][HW][4]
-  float* out_dyn;
-  float* out_diff;
-  unsigned* sync;            // [N][64] (one 256-byte line per sample): enc(max buf), enc(-min buf), enc(max diff), enc(-min diff), arrived, left, error
-  float a2[2];
-  float alpha[DYN_MAXK];
-};
-
-__device__ __forceinline__ unsigned f32_ordered(float f) {
-  const unsigned b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);      // monotone; every float maps above 0
-}
-__device__ __forceinline__ float f32_unordered(unsigned u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-
-// NV = float4 per item and frame (3: four RGB pixels, 1: one RGBD pixel); IPT = items per thread; MINW = waves per
-// SIMD the register budget must allow (4: up to 1024 resident blocks, 2: up to 512)
-template <int NV, int IPT, int MINW>
-__global__ __launch_bounds__(256, MINW) void goal_inputs_kernel(const GoalInParams p) {
-  const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
-  const long long stride = (long long)p.BPS * 256;
-  f32x4 acc[IPT][NV], dif[IPT][NV];
-  float mnb = INFINITY, mxb = -INFINITY, mnd = INFINITY, mxd = -INFINITY;
-  const float* fbase = p.frames + (long long)n * p.sample_stride;
-  const float* tbase = p.tgt + (long long)n * p.tgt_stride;
-  // items of this thread; the tail threads of a ragged sample re-read the last item (harmless) and skip min/max + stores
-  long long it[IPT];
-  bool ok[IPT];
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {
-    const long long item = j * stride + (long long)b * 256 + tid;
-    ok[j] = item < p.items;
-    it[j] = ok[j] ? item : p.items - 1;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) acc[j][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // phase 1a: frames 0 .. K-2, all items of the thread per frame (IPT * NV independent 16-byte loads per frame)
-#pragma unroll 2
-  for (int t = 0; t < p.K - 1; ++t) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(fbase + (long long)t * p.frame_stride);
-    const float w = p.alpha[t];
-    f32x4 x[IPT][NV];
-#pragma unroll
-    for (int j = 0; j < IPT; ++j)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) x[j][v] = src[it[j] * NV + v];
-#pragma unroll
-    for (int j = 0; j < IPT; ++j)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) acc[j][v] += w * x[j][v];
-  }
-  // phase 1b: the current frame (copied out at once: it needs no normalisation) and the target frame
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(fbase + (long long)(p.K - 1) * p.frame_stride);
-    const f32x4* tg = reinterpret_cast<const f32x4*>(tbase);
-    const float w = p.alpha[p.K - 1];
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-      f32x4 cur[NV];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        cur[v] = src[it[j] * NV + v];
-        const f32x4 tv = tg[it[j] * NV + v];
-        acc[j][v] += w * cur[v];
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        d += p.a2[0] * cur[v];
-        d += p.a2[1] * tv;
-        dif[j][v] = d;
-        if (ok[j]) {
-          mnb = fminf(mnb, fminf(fminf(acc[j][v].x, acc[j][v].y), fminf(acc[j][v].z, acc[j][v].w)));
-          mxb = fmaxf(mxb, fmaxf(fmaxf(acc[j][v].x, acc[j][v].y), fmaxf(acc[j][v].z, acc[j][v].w)));
-          mnd = fminf(mnd, fminf(fminf(d.x, d.y), fminf(d.z, d.w)));
-          mxd = fmaxf(mxd, fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w)));
-        }
-      }
-      if (ok[j]) {
-        if (NV == 3) {
-          const float* c = reinterpret_cast<const float*>(&cur[0]);
-          float* o = p.out_obs + ((long long)n * p.HW + it[j] * 4) * 4;
-#pragma unroll
-          for (int px = 0; px < 4; ++px)
-            *reinterpret_cast<f32x4*>(o + px * 4) = f32x4{c[px * 3], c[px * 3 + 1], c[px * 3 + 2], 0.f};
-        } else {
-          *reinterpret_cast<f32x4*>(p.out_obs + ((long long)n * p.HW + it[j]) * 4) = cur[0];
-        }
-      }
-    }
-  }
-  // ---- block min / max -> the sample's sync words; rendezvous of the sample's BPS blocks -------------------------------
-  __shared__ float red[4][4];
-  __shared__ float res[4];
-  mnb = wave_reduce_min(mnb); mxb = wave_reduce_max(mxb);
-  mnd = wave_reduce_min(mnd); mxd = wave_reduce_max(mxd);
-  if ((tid & 63) == 0) {
-    red[tid >> 6][0] = mxb; red[tid >> 6][1] = -mnb; red[tid >> 6][2] = mxd; red[tid >> 6][3] = -mnd;
-  }
-  __syncthreads();
-  unsigned* sy = p.sync + (long long)n * 64;
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float m = fmaxf(fmaxf(red[0][k], red[1][k]), fmaxf(red[2][k], red[3][k]));
-      if (m > -INFINITY) __hip_atomic_fetch_max(sy + k, f32_ordered(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __hip_atomic_fetch_add(sy + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(sy + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.BPS) {
-      __builtin_amdgcn_s_sleep(32);
-      if (++spins > (1 << 22)) {          // never expected: every block of the grid is resident (host-side check)
-        __hip_atomic_store(sy + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-    for (int k = 0; k < 4; ++k) res[k] = f32_unordered(__hip_atomic_load(sy + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  }
-  __syncthreads();
-  const float bmn = -res[1], brng = res[0] - bmn + 1e-6f;     // graph.py:47-49
-  const float dmn = -res[3], drng = res[2] - dmn + 1e-6f;
-  // ---- phase 2: normalise from registers and write the two dynamic images ------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {
-    if (!ok[j]) continue;
-    if (NV == 3) {
-      const float* a = reinterpret_cast<const float*>(&acc[j][0]);
-      const float* d = reinterpret_cast<const float*>(&dif[j][0]);
-      const long long o = ((long long)n * p.HW + it[j] * 4) * 4;
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        *reinterpret_cast<f32x4*>(p.out_dyn + o + px * 4) =
-            f32x4{(a[px * 3] - bmn) / brng, (a[px * 3 + 1] - bmn) / brng, (a[px * 3 + 2] - bmn) / brng, 0.f};
-        *reinterpret_cast<f32x4*>(p.out_diff + o + px * 4) =
-            f32x4{(d[px * 3] - dmn) / drng, (d[px * 3 + 1] - dmn) / drng, (d[px * 3 + 2] - dmn) / drng, 0.f};
-      }
-    } else {
-      const long long o = ((long long)n * p.HW + it[j]) * 4;
-      const f32x4 a = acc[j][0], d = dif[j][0];
-      *reinterpret_cast<f32x4*>(p.out_dyn + o) = f32x4{(a.x - bmn) / brng, (a.y - bmn) / brng, (a.z - bmn) / brng, (a.w - bmn) / brng};
-      *reinterpret_cast<f32x4*>(p.out_diff + o) = f32x4{(d.x - dmn) / drng, (d.y - dmn) / drng, (d.z - dmn) / drng, (d.w - dmn) / drng};
-    }
-  }
-  // ---- leave: the last block of the sample zeroes its sync words (nobody reads them any more) --------------------------
-  if (tid == 0) {
-    const unsigned left = __hip_atomic_fetch_add(sy + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == (unsigned)p.BPS - 1) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) __hip_atomic_store(sy + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// Every block of the grid must be resident at the rendezvous: launch bounds (256, 2) keep the kernel within 256
-// registers, so 2 blocks of 256 threads fit every CU: at most 512 blocks.  (Measured at N=32, K=16, 256x256 RGB: 16 blocks
-// per sample x 4 units per thread 161 us; 32 blocks x 2 units 203 us.)
-struct GoalInPlan { int bps, ipt; };
-static GoalInPlan goal_inputs_plan(int N, int64_t HW, int C) {
-  GoalInPlan pl = {0, 0};
-  if (N < 1 || N > 512 || !(C == 3 || C == 4) || (C == 3 && (HW & 3))) return pl;
-  const long long items = C == 3 ? HW >> 2 : HW;
-  int bps = 512 / N;
-  if (bps > 16) bps = 16;
-  if (bps >= 1 && cdiv64(items, (long long)bps * 256) <= (C == 3 ? 4 : 16)) {
-    pl.bps = bps;
-    pl.ipt = (int)cdiv64(items, (long long)bps * 256);
-  }
-  return pl;
-}
-
-extern "C" int64_t geeco_goal_inputs_ws_bytes(int N) { return (int64_t)N * 64 * 4; }
-
-extern "C" int geeco_goal_inputs_supported(int N, int K, int64_t HW, int C) {
-  if (K < 1 || K > DYN_MAXK) return 0;
-  return goal_inputs_plan(N, HW, C).bps > 0;
-}
-
-template <int NV, int IPT, int MINW>
-static void launch_goal_inputs(const GoalInParams& p, hipStream_t s) {
-  geeco_note_kernel("goal_inputs_kernel<%d, %d, %d>", NV, IPT, MINW);
-  hipLaunchKernelGGL((goal_inputs_kernel<NV, IPT, MINW>), dim3((unsigned)p.BPS, (unsigned)p.N), dim3(256), 0, s, p);
-}
-
-extern "C" int geeco_goal_inputs_fwd(const float* frames, int64_t sample_stride, int64_t frame_stride, const float* tgt,
-                                     int64_t tgt_stride, const float* alpha_host, int N, int K, int64_t HW, int C,
-                                     float* out_obs, float* out_dyn, float* out_diff, void* ws, void* stream) {
-  GEECO_CHECK_ARG(frames && tgt && alpha_host && out_obs && out_dyn && out_diff && ws, "goal_inputs_fwd: null pointer");
-  GEECO_CHECK_ARG(geeco_goal_inputs_supported(N, K, HW, C), "goal_inputs_fwd: unsupported shape N=%d K=%d HW=%lld C=%d", N, K,
-                  (long long)HW, C);
-  GEECO_CHECK_ARG(sample_stride % 4 == 0 && frame_stride % 4 == 0 && tgt_stride % 4 == 0, "goal_inputs_fwd: 16-byte aligned frames");
-  GoalInParams p = {};
-  p.frames = frames; p.tgt = tgt; p.sample_stride = sample_stride; p.frame_stride = frame_stride; p.tgt_stride = tgt_stride;
-  const GoalInPlan pl = goal_inputs_plan(N, HW, C);
-  p.N = N; p.K = K; p.HW = HW; p.BPS = pl.bps;
-  p.items = C == 3 ? HW >> 2 : HW;
-  p.out_obs = out_obs; p.out_dyn = out_dyn; p.out_diff = out_diff; p.sync = (unsigned*)ws;
-  for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
-  geeco_dynimg_alpha(2, p.a2);
-  hipStream_t s = (hipStream_t)stream;
-  if (C == 3) {
-    if (pl.ipt <= 1) launch_goal_inputs<3, 1, 2>(p, s);
-    else if (pl.ipt <= 2) launch_goal_inputs<3, 2, 2>(p, s);
-    else launch_goal_inputs<3, 4, 2>(p, s);
-  } else {
-    if (pl.ipt <= 4) launch_goal_inputs<1, 4, 2>(p, s);
-    else if (pl.ipt <= 8) launch_goal_inputs<1, 8, 2>(p, s);
-    else launch_goal_inputs<1, 16, 2>(p, s);
-  }
-  GEECO_LAUNCH_CHECK();
-  return 0;
-}

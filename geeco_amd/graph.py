@@ -531,7 +531,7 @@ class _ModelBase:
     # graphs pack once per step.
     self.last_from_dynimg = os.environ.get('GEECO_PACK_CURRENT') is None   # current frame's padded copy out of the buffer-image kernel
     self.split_rgbd = (self.C == 4 and goal and cfg.proc_obs == 'dynimg' and (H * W) % 4 == 0 and
-                       os.environ.get('GEECO_PACK_RGBD') is None and os.environ.get('GEECO_FUSED_INPUTS') is None)
+                       os.environ.get('GEECO_PACK_RGBD') is None)
     if self.C == 4 and not self.split_rgbd:
       self.obs4 = torch.empty(N, K, H, W, 4, **f32)
       if goal:
@@ -657,13 +657,6 @@ class GoalE2EVMC(_ModelBase):
     self._bind_labels()
     self.dyn_ws = ops.dynimg_ws(N, H * W * 4, self.device)
     self.dyn_ws2 = torch.empty(2 * self.dyn_ws.numel(), dtype=torch.float32, device=self.device)   # partials of two images
-    # geeco-f: ONE launch for the three conv1 inputs (current frame, buffer image, diff image), every byte moved once,
-    # normalisation from registers after a per-sample rendezvous.  Opt-in: measured SLOWER than the five separate
-    # launches at the bench shape (161 us vs 144 us alone) although it moves 30 % fewer bytes.
-    self.fused_inputs = (self.mode == 'dynimg' and os.environ.get('GEECO_FUSED_INPUTS') is not None and
-                         ops.goal_inputs_supported(N, K, H * W, C))
-    if self.fused_inputs:
-      self.gin_ws = ops.goal_inputs_ws(N, self.device)
 
   def forward(self, backward_too=False):
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
@@ -695,9 +688,7 @@ class GoalE2EVMC(_ModelBase):
     if self.mode == 'dynimg':
       cur = frames[:, K - 1]                                  # rgb_frame_list[-1] (graph.py:387)
       # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)
-      if self.fused_inputs:
-        ops.goal_inputs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, C, self.gin_ws, K * HW * C, HW * C)
-      elif C == 3 and HW % 4 == 0 and self.last_from_dynimg:
+      if C == 3 and HW % 4 == 0 and self.last_from_dynimg:
         # three launches: the buffer-image kernel has the current frame in registers and writes its channel-padded copy
         # too; one normalisation launch serves both images
         ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, self.dyn_ws2, K * HW * C, HW * C)

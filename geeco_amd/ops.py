@@ -119,23 +119,6 @@ def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
   return out
 
 
-def goal_inputs_supported(N, K, HW, C):
-  return bool(_lib().geeco_goal_inputs_supported(N, K, HW, C))
-
-
-def goal_inputs_ws(N, device):
-  """Rendezvous words of geeco_goal_inputs_fwd: zero-filled ONCE here (the kernel leaves them zero)."""
-  return torch.zeros(int(_lib().geeco_goal_inputs_ws_bytes(N)) // 4, dtype=torch.float32, device=device)
-
-
-def goal_inputs_into(out_obs, out_dyn, out_diff, frames, tgt, K, N, HW, C, ws, sample_stride, frame_stride):
-  """The three conv1 inputs of geeco-f in one launch (graph.py:386-402): frames[:, K-1], dynimg(frames),
-  dynimg([frames[:, K-1], tgt]); every input byte read once, every output byte written once."""
-  check(_lib().geeco_goal_inputs_fwd(_p(frames), sample_stride, frame_stride, _p(tgt), HW * C,
-                                     ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N, K, HW, C, _p(out_obs), _p(out_dyn),
-                                     _p(out_diff), _p(ws), _stream()), 'geeco_goal_inputs_fwd')
-
-
 def pack_pixels_into(dst, src, src_sample_stride, N, HW, C1, Cpad, src2=None, src2_sample_stride=0, C2=0):
   check(_lib().geeco_pack_pixels(_p(src), src_sample_stride, _p(src2), src2_sample_stride, N, HW, C1, C2, Cpad,
                                  _p(dst), _stream()), 'geeco_pack_pixels')

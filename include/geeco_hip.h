@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GEECO_ABI_VERSION 1
+#define GEECO_ABI_VERSION 3   /* = the build round that last changed the entry points or their calling conventions */
 
 #define GEECO_EINVAL  (-1)   /* bad shape / alignment / null pointer */
 #define GEECO_ENOSUP  (-2)   /* shape outside what the kernels were built for */
@@ -79,18 +79,6 @@ int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t fram
                            const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW, float* cur_out,
                            float* buf_out, float* diff_out, void* ws, void* stream);
 
-/* Fused input stage of goal_e2evmc's dynimg branch (graph.py:386-402): ONE launch reads a batch of K-frame windows
- * (frames [N][K][HW][C], element strides given; C = 3 or 4 with 16-byte aligned frames) and the target frames
- * (tgt [N][HW][C]) once and writes the three conv1 inputs [N][HW][4]:
- *   out_obs = frames[:, K-1] (:387), out_dyn = dynimg(frames) (:392), out_diff = dynimg([frames[:, K-1], tgt]) (:397-400).
- * Replaces pack_pixels + 2 x (dynimg weighted sum + normalisation pass).  `ws`: geeco_goal_inputs_ws_bytes(N) bytes that
- * must be ZERO before the first call (the kernel leaves them zero: safe to reuse and to replay in a hipGraph).
- * geeco_goal_inputs_supported() tells whether the shape is served (else use the separate entry points). */
-int64_t geeco_goal_inputs_ws_bytes(int N);
-int geeco_goal_inputs_supported(int N, int K, int64_t HW, int C);
-int geeco_goal_inputs_fwd(const float* frames, int64_t sample_stride, int64_t frame_stride, const float* tgt,
-                          int64_t tgt_stride, const float* alpha_host, int N, int K, int64_t HW, int C,
-                          float* out_obs, float* out_dyn, float* out_diff, void* ws, void* stream);
 
 /* Copy [npix][C] -> [npix][Cpad] (zero-filled tail).  Used for the "current frame" view
  * rgb[:, -1] (graph.py:387) and for RGB||depth concat (estimator.py:169,172) via src2. */

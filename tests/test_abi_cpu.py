@@ -27,7 +27,9 @@ def test_library_exports_every_declared_symbol():
 def test_binding_loads_and_reports_version():
   from geeco_amd import _native
   lib = _native.load()
-  assert lib.geeco_abi_version() == 1
+  hdr = open(os.path.join(ROOT, 'include', 'geeco_hip.h')).read()
+  declared = int(re.search(r'#define GEECO_ABI_VERSION (\d+)', hdr).group(1))
+  assert lib.geeco_abi_version() == declared == _native.ABI_VERSION     # header, library and binding agree
   assert lib.geeco_dynimg_ws_bytes(2, 1024) > 0
   assert lib.geeco_conv3x3_wgrad_ws_bytes(3, 2, 64, 64, 32, 48, 2) > 0
   assert lib.geeco_conv3x3_fwd_ws_bytes(3, 32, 256, 256, 4, 32, 1) == 0       # big layers never split K
@@ -55,3 +57,19 @@ def test_alpha_matches_oracle():
     buf = (ctypes.c_float * K)()
     lib.geeco_dynimg_alpha(K, ctypes.cast(buf, ctypes.c_void_p))
     assert [float(v) for v in buf] == [float(v) for v in O.dynimg_alpha(K)]    # bit-exact float32
+
+
+def test_stale_library_is_refused_by_version(tmp_path, monkeypatch):
+  """A library of another ABI version (a stale build, or another build picked through GEECO_LIB) must be refused at load
+  time with a message that says so -- not load and fail later at the first changed entry point."""
+  import subprocess
+  import pytest
+  from geeco_amd import _native
+  src = tmp_path / 'stale.c'
+  src.write_text('int geeco_abi_version(void) { return 1; }\n')
+  so = tmp_path / 'libstale.so'
+  subprocess.check_call(['gcc', '-shared', '-fPIC', '-o', str(so), str(src)])
+  monkeypatch.setattr(_native, 'LIB_PATH', str(so))
+  monkeypatch.setattr(_native, '_lib', None)
+  with pytest.raises(_native.GeecoNativeError, match='ABI version mismatch'):
+    _native.load()

@@ -266,10 +266,16 @@ def test_bottom_backward_writes_only_the_late_bucket(dev):
     after = model.store.grads
     for off, n in early:
       assert torch.equal(before[off:off + n].view(torch.int32), after[off:off + n].view(torch.int32))
-    # every VARIABLE's gradient was written by one of the two parts (the alignment pads between variables never are)
+    # every VARIABLE's gradient was written by one of the two parts (never written: the alignment pads between variables,
+    # and -- one LSTM step from a zero state -- the recurrent rows of the LSTM kernel, whose gradient h_prev^T dz is
+    # identically zero; the arena is zero-initialised and Adam keeps those rows where they are)
+    D = model.decoder.D
     for name, g in model.store.to_numpy('grads').items():
-      if not (redirect and ('/conv1/' in name or '/conv2/' in name)):
-        assert not np.isnan(g).any(), name
+      if redirect and ('/conv1/' in name or '/conv2/' in name):
+        continue
+      if name.endswith('lstm_cell/kernel') and model.decoder.T == 1:
+        g = g[:D]
+      assert not np.isnan(g).any(), name
     if redirect:
       assert torch.equal(before.view(torch.int32), after.view(torch.int32))        # the arena was not written at all
       outs.append(staging.clone())

@@ -621,35 +621,6 @@ def test_conv3x3_wgrad_grouped_lds(dev, Cin, Cout, H, W):
   assert torch.isnan(dw[:, 9 * Cin * Cout:]).all() and torch.isnan(db[:, Cout:]).all()     # pads untouched
 
 
-@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 136, 136, 3), (3, 16, 256, 256, 3), (1, 1, 136, 136, 3), (2, 3, 144, 144, 4),
-                                       (32, 2, 40, 52, 3), (5, 32, 256, 256, 4)])
-def test_goal_inputs_fused(dev, N, K, H, W, C):
-  """One-launch input stage of geeco-f (current frame, buffer image, diff image) vs the oracle's dynimg; called three
-  times on changing data: the rendezvous words must be back to zero after every launch (graph replays rely on it)."""
-  from geeco_amd import ops
-  assert ops.goal_inputs_supported(N, K, H * W, C)
-  r = np.random.default_rng(41)
-  ws = ops.goal_inputs_ws(N, dev)
-  outs = [torch.full((N, H, W, 4), float('nan'), device=dev) for _ in range(3)]
-  for rep in range(3):
-    fr = r.random([N, K, H, W, C], dtype=np.float32)
-    tg = r.random([N, H, W, C], dtype=np.float32)
-    if rep == 2:
-      fr[0] = 0.25      # a constant window: D == 0 everywhere, range 1e-6
-    frd, tgd = torch.tensor(fr, device=dev), torch.tensor(tg, device=dev)
-    ops.goal_inputs_into(outs[0], outs[1], outs[2], frd, tgd, K, N, H * W, C, ws, K * H * W * C, H * W * C)
-    torch.cuda.synchronize()
-    assert int(ws.view(torch.int32).abs().sum()) == 0
-    f64, t64 = torch.tensor(fr, dtype=torch.float64), torch.tensor(tg, dtype=torch.float64)
-    cur = f64[:, K - 1]
-    assert torch.equal(outs[0][..., :C].cpu(), torch.tensor(fr[:, K - 1]))
-    _close(outs[1][..., :C], O.dynimg(f64), 0, 5e-6, 'buffer image, call %d' % rep)
-    _close(outs[2][..., :C], O.dynimg(torch.stack([cur, t64], 1)), 0, 5e-6, 'diff image, call %d' % rep)
-    if C == 3:
-      for o in outs:
-        assert float(o[..., 3].abs().max()) == 0.0        # pad channel
-
-
 @pytest.mark.parametrize('Cin,Cout,H,W,Nd', [(64, 128, 32, 32, 5), (128, 192, 16, 32, 4), (192, 256, 16, 16, 7)])
 def test_conv3x3_dgrad_grouped_lds(dev, Cin, Cout, H, W, Nd):
   """Grouped launch (G encoders, padded arena strides) of the LDS-staged input gradient with the fused ReluGrad mask and

@@ -160,19 +160,3 @@ def test_loss_trajectory_graph_replay(dev):
   assert runner._graphs is not None                      # the last steps were graph replays
   assert int(model.store.global_step.item()) == 10
   print('loss trajectory (hip, oracle):', ['%.5f/%.5f' % p for p in losses])
-
-
-def test_fused_input_stage_matches_separate_launches(dev, monkeypatch):
-  """GEECO_FUSED_INPUTS=1 (one launch for current frame + both dynamic images) gives the same conv1 inputs and the same
-  loss as the default separate launches."""
-  ocfg, P, feats, labels = _mk(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=4), True, 2, 160)
-  ref = _build(ocfg, True, P, feats, labels, dev)
-  assert not ref.fused_inputs
-  ref.forward(backward_too=False)
-  monkeypatch.setenv('GEECO_FUSED_INPUTS', '1')
-  m = _build(ocfg, True, P, feats, labels, dev)
-  assert m.fused_inputs
-  m.forward(backward_too=False)
-  torch.cuda.synchronize()
-  np.testing.assert_allclose(m.enc.x_in.cpu().numpy(), ref.enc.x_in.cpu().numpy(), rtol=0, atol=1e-6)
-  assert abs(float(m.loss) - float(ref.loss)) <= 1e-6 * abs(float(ref.loss))
