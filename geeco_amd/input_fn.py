@@ -50,6 +50,54 @@ def collect_tfrecords(dataset_dir, split_name, mode):
   return [os.path.join(record_dir, fn) for fn in names if fn.endswith('.tfrecord.zlib')]
 
 
+# ---- target frames of an episode for the controller loop (the predictor's set_goal) ------------------------------------
+def _episode_stem(tfrecord_name):
+  return os.path.basename(tfrecord_name).split('.')[0]
+
+
+def _read_rgb_png(path):
+  from PIL import Image      # only the controller-side loaders need an image decoder
+  with Image.open(path) as im:
+    return np.array(im, dtype=np.float32) / 255.0
+
+
+def load_target_frame(dataset_dir, tfrecord_name, load_depth=True):
+  """geeco_gym.py:179-192: the episode's goal image ``images/targets/rgb/<stem>.png`` as float32 [H, W, 3] in [0, 1];
+  with ``load_depth`` the raw depth map ``images/targets/depth/<stem>.npy`` becomes a 4th channel ([H, W, 4], the layout
+  ``GoalE2EVMCPredictor.set_goal`` takes).  ``tfrecord_name`` may be a path; the stem is the name up to the first dot."""
+  stem = _episode_stem(tfrecord_name)
+  frame = _read_rgb_png(os.path.join(dataset_dir, 'images', 'targets', 'rgb', stem + '.png'))
+  if load_depth:
+    depth = np.load(os.path.join(dataset_dir, 'images', 'targets', 'depth', stem + '.npy'))
+    frame = np.concatenate([frame, np.expand_dims(depth, axis=-1)], axis=-1)
+  return frame
+
+
+def load_keyframes(dataset_dir, tfrecord_name):
+  """geeco_gym.py:194-211: every key frame of the episode (``images/keyframes/{rgb,depth}/<stem>*`` in sorted order,
+  rgb and depth files paired by position) as RGB-D float32 [H, W, 4] arrays."""
+  stem = _episode_stem(tfrecord_name)
+  rgb_dir = os.path.join(dataset_dir, 'images', 'keyframes', 'rgb')
+  depth_dir = os.path.join(dataset_dir, 'images', 'keyframes', 'depth')
+  rgb_files = sorted(f for f in os.listdir(rgb_dir) if f.startswith(stem))
+  depth_files = sorted(f for f in os.listdir(depth_dir) if f.startswith(stem))
+  frames = []
+  for rf, df in zip(rgb_files, depth_files):
+    depth = np.load(os.path.join(depth_dir, df))
+    frames.append(np.concatenate([_read_rgb_png(os.path.join(rgb_dir, rf)), np.expand_dims(depth, axis=-1)], axis=-1))
+  return frames
+
+
+def load_target_frames(dataset_dir, tfrecord_name, load_depth=True):
+  """geeco_gym.py:165-177: the key frames when ``data/key_frames_<id>.json`` exists for the record (id = the first run of
+  digits in the name), else the single goal image, as a list."""
+  import re
+  record_id = re.search(r'\d+', tfrecord_name).group(0)
+  if os.path.exists(os.path.join(dataset_dir, 'data', 'key_frames_%s.json' % (record_id,))):
+    return load_keyframes(dataset_dir, tfrecord_name)
+  return [load_target_frame(dataset_dir, tfrecord_name, load_depth)]
+
+
 def load_episode(path, meta, fetch_target, raw_rgb=False):
   """One episode -> dict of per-frame arrays after _parse_v4 + _preprocess_states_v4 +
   _preprocess_targets_v3 (i.e. the last frame already dropped: T = episode_length - 1).

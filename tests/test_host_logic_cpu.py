@@ -467,3 +467,50 @@ def test_tfrecord_sequence_example_hand_assembled_golden(tmp_path):
   open(str(tmp_path / 'bad.tfrecord.zlib'), 'wb').write(zlib.compress(bytes(bad)))
   with pytest.raises(IOError):
     list(T.read_records(str(tmp_path / 'bad.tfrecord.zlib')))
+
+
+def test_target_frame_loaders_round_trip(tmp_path):
+  """load_target_frame / load_keyframes / load_target_frames (geeco_gym.py:165-211) on a dataset directory written here:
+  PNG goal images come back as float32 / 255, depth maps as the 4th channel, key frames in sorted order paired by
+  position, and the key-frame branch is taken exactly when data/key_frames_<id>.json exists."""
+  from PIL import Image
+  from geeco_amd import input_fn as I
+  root = str(tmp_path)
+  for d in ('data', 'images/targets/rgb', 'images/targets/depth', 'images/keyframes/rgb', 'images/keyframes/depth'):
+    os.makedirs(os.path.join(root, d))
+  r = np.random.default_rng(3)
+  H, W = 12, 20
+  rgb = r.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+  depth = (0.5 + 2.5 * r.random((H, W))).astype(np.float32)
+  Image.fromarray(rgb).save(os.path.join(root, 'images', 'targets', 'rgb', 'episode_0007.png'))
+  np.save(os.path.join(root, 'images', 'targets', 'depth', 'episode_0007.npy'), depth)
+  name = os.path.join(root, 'data', 'episode_0007.tfrecord.zlib')
+  f4 = I.load_target_frame(root, name)
+  assert f4.shape == (H, W, 4) and f4.dtype == np.float32
+  assert np.array_equal(f4[..., :3], rgb.astype(np.float32) / 255.0) and np.array_equal(f4[..., 3], depth)
+  f3 = I.load_target_frame(root, 'episode_0007.tfrecord.zlib', load_depth=False)
+  assert f3.shape == (H, W, 3) and np.array_equal(f3, f4[..., :3])
+  assert 0.0 <= f3.min() and f3.max() <= 1.0                     # what the predictor's range check expects
+  # no key-frame index for record 0007: the single goal image
+  got = I.load_target_frames(root, 'episode_0007.tfrecord.zlib')
+  assert len(got) == 1 and np.array_equal(got[0], f4)
+  # key frames: written out of order, another episode's files in the same directories
+  kf = []
+  for i in (2, 0, 1):
+    a = r.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    d = r.random((H, W)).astype(np.float32)
+    Image.fromarray(a).save(os.path.join(root, 'images', 'keyframes', 'rgb', 'episode_0007_key%d.png' % i))
+    np.save(os.path.join(root, 'images', 'keyframes', 'depth', 'episode_0007_key%d.npy' % i), d)
+    kf.append((i, a, d))
+  Image.fromarray(rgb).save(os.path.join(root, 'images', 'keyframes', 'rgb', 'episode_0008_key0.png'))
+  np.save(os.path.join(root, 'images', 'keyframes', 'depth', 'episode_0008_key0.npy'), depth)
+  frames = I.load_keyframes(root, name)
+  assert len(frames) == 3
+  for (i, a, d), fr in zip(sorted(kf), frames):
+    assert fr.shape == (H, W, 4) and np.array_equal(fr[..., :3], a.astype(np.float32) / 255.0) and np.array_equal(fr[..., 3], d)
+  with open(os.path.join(root, 'data', 'key_frames_0007.json'), 'w') as fp:
+    fp.write('[]')
+  got = I.load_target_frames(root, 'episode_0007.tfrecord.zlib')
+  assert len(got) == 3 and all(np.array_equal(x, y) for x, y in zip(got, frames))
+  with pytest.raises(FileNotFoundError):
+    I.load_target_frame(root, 'episode_0099.tfrecord.zlib')
