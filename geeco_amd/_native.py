@@ -10,8 +10,10 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER, Structure
 
+from . import _dev
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_LIB: A/B builds side by side
+LIB_PATH = os.path.join(_HERE, _dev.env('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_DEV=1 GEECO_LIB=...: A/B builds side by side
 
 
 ABI_VERSION = 3        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against

@@ -296,7 +296,7 @@ static int launch_dgrad_lds(const DgradLdsParams& p, int blocks, hipStream_t str
 
 // does the dispatcher below take this shape (given the HWIO kernel)?  Such layers never read the transposed copy.
 int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride) {
-  static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
+  static const int disabled = (geeco_dev_getenv("GEECO_NO_HALO") || geeco_dev_getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
   if (disabled || stride != 2 || (H & 1) || (W & 1) || Cin % 64 != 0 || Cout % 16 != 0 || Cout < 32) return 0;
   const int Ho = H / 2, Wo = W / 2;
   if (!((Ho % 8 == 0 && Wo % 16 == 0) || (Ho == 8 && Wo == 8))) return 0;
@@ -339,7 +339,7 @@ static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* yma
                           int64_t gs_fields, float* dx, int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H,
                           int W, int Cin, int Cout, int stride, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
+  static const int disabled = (geeco_dev_getenv("GEECO_NO_HALO") || geeco_dev_getenv("GEECO_NO_DGRAD_LDS")) ? 1 : 0;
   if (disabled || !w_hwio || stride != 2 || (H & 1) || (W & 1) || Cin % 64 != 0 || Cout % 16 != 0 || Cout < 32) return 0;
   const int Ho = H / 2, Wo = W / 2;
   int variant = 0;
@@ -350,7 +350,7 @@ static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* yma
   DgradLdsParams p = {};
   p.dz = dz; p.w = w_hwio; p.mask = ymask; p.fields = fields; p.gs_fields = gs_fields; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout;
-  static const int no_stagger = getenv("GEECO_DGRAD_NO_STAGGER") ? 1 : 0;
+  static const int no_stagger = geeco_dev_getenv("GEECO_DGRAD_NO_STAGGER") ? 1 : 0;
   p.stagger = !no_stagger;
   long long tiles;
   if (variant == 1) {
@@ -360,7 +360,7 @@ static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* yma
     p.tiles_y = 1; p.tiles_x = 1;
     tiles = (N + 1) / 2;
   }
-  static const int no_small = getenv("GEECO_DGRAD_NO_SMALL") ? 1 : 0;
+  static const int no_small = geeco_dev_getenv("GEECO_DGRAD_NO_SMALL") ? 1 : 0;
   if (variant == 2 && !no_small) {
     // 8 x 8 class pixels per frame: one-frame tiles of 4 groups, 32-channel items, 256-thread blocks, three per CU.  The
     // two-frame / 8-wave form has only groups * (Cin / 64) * N / 2 items (conv6 of the bench: 144 for 256 CUs).
@@ -381,7 +381,7 @@ static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* yma
   // over the 256 CUs; cost of an item in CU-time: 1 resp. 1/2.  Ties go to the 64-channel form (more reuse per staged byte).
   const long long items64 = (long long)groups * (Cin / 64) * tiles;
   if (items64 * 2 >= (1ll << 30)) return 0;
-  static const int force_ncit = getenv("GEECO_DGRAD_NCIT") ? atoi(getenv("GEECO_DGRAD_NCIT")) : 0;
+  static const int force_ncit = geeco_dev_getenv("GEECO_DGRAD_NCIT") ? atoi(geeco_dev_getenv("GEECO_DGRAD_NCIT")) : 0;
   const double span64 = (double)((items64 + 255) / 256), span32 = 0.5 * (double)((2 * items64 + 255) / 256);
   const bool use32 = force_ncit == 2 || (force_ncit != 4 && span32 < span64);
   int rc;

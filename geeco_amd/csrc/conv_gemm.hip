@@ -485,12 +485,12 @@ static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
   }
   dim3 grid((unsigned)tiles, (unsigned)(cdiv(p.Nout, BN) * p.ksplit), (unsigned)groups);
   {
-    static const int no_rot = getenv("GEECO_CONV_NO_ROT") ? 1 : 0;
+    static const int no_rot = geeco_dev_getenv("GEECO_CONV_NO_ROT") ? 1 : 0;
     bool equal = p.ncls > 1;                    // rotation by whole classes needs equally many tiles per class
     for (int c = 1; c < p.ncls; ++c) equal = equal && cdiv64(p.cls[c].M, BM) == cdiv64(p.cls[0].M, BM);
     p.rot = (equal && !no_rot) ? tiles / p.ncls : 0;
   }
-  static const int no_ut = getenv("GEECO_CONV_NO_UT") ? 1 : 0;
+  static const int no_ut = geeco_dev_getenv("GEECO_CONV_NO_UT") ? 1 : 0;
   const bool ut = p.C % BK == 0 && p.C <= GEMM_ZERO_PAGE && !no_ut;   // uniform taps; a tap fits the zero page
   geeco_note_kernel("conv_gemm_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, BK, WM, WN, ut ? "true" : "false");
   if (ut)
@@ -518,11 +518,11 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
   if (pl.bn == 64 && Mtot * groups < 128 * 256) pl.bm = 64;
   // 128-wide N tiles halve the gathered A bytes per MFMA; only when they still fill the chip
   // (round 1: neutral to slower; since the kernel's VALU diet of round 2 the gathered bytes weigh more: -11 us per step)
-  static const int no_bn128 = getenv("GEECO_CONV_NO_BN128") ? 1 : 0;
+  static const int no_bn128 = geeco_dev_getenv("GEECO_CONV_NO_BN128") ? 1 : 0;
   if (!no_bn128 && p.Nout % 128 == 0 && pl.bm == 128 && (Mtot / 128) * (p.Nout / 128) * groups >= 512) pl.bn = 128;
   // 96-wide N tiles where they (and not the 64-wide ones) make the block count a whole multiple of the CUs
   // (conv5 forward: 768 blocks instead of 1152 = 4.5 per CU: -10 us)
-  static const int no_bn96 = getenv("GEECO_CONV_NO_BN96") ? 1 : 0;
+  static const int no_bn96 = geeco_dev_getenv("GEECO_CONV_NO_BN96") ? 1 : 0;
   if (!no_bn96 && pl.bn == 64 && pl.bm == 64 && p.Nout % 96 == 0 && p.ncls == 1 &&
       (cdiv64(Mtot, 64) * (p.Nout / 96) * groups) % 256 == 0 && (cdiv64(Mtot, 64) * (p.Nout / 64) * groups) % 256 != 0)
     pl.bn = 96;
@@ -538,7 +538,7 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
     // prefer the factor nearest to that which makes the block count a whole multiple of the 256 CUs: all blocks are
     // co-resident and dealt evenly (scripts/dev/ub/placement.hip), so a ragged count leaves some CUs with one block
     // more than the others for the whole launch (conv6 forward: 3 -> 2 splits, 768 blocks, -4 us)
-    static const int no_align = getenv("GEECO_NO_KSPLIT_ALIGN") ? 1 : 0;
+    static const int no_align = geeco_dev_getenv("GEECO_NO_KSPLIT_ALIGN") ? 1 : 0;
     if (!no_align) {
       long long best = 0;
       for (long long k = 2; k <= maxs; ++k)
@@ -548,7 +548,7 @@ static ConvPlan conv_plan(const ConvGemmParams& p, int groups) {
     if (want > 1) pl.ksplit = (int)want;
   }
   // dev: GEECO_CONV_FORCE="C:Nout:ncls:bm:bn:ksplit[;...]" overrides the plan of the matching launches (tile sweeps)
-  static const char* force = getenv("GEECO_CONV_FORCE");
+  static const char* force = geeco_dev_getenv("GEECO_CONV_FORCE");
   for (const char* f = force; f && *f;) {
     int c, n, k, bm, bn, ks;
     if (sscanf(f, "%d:%d:%d:%d:%d:%d", &c, &n, &k, &bm, &bn, &ks) == 6 && c == p.C && n == p.Nout && k == p.ncls) {
@@ -603,7 +603,7 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
   p.ksplit = pl.ksplit;
   p.groups = groups;
   p.part = (float*)ws;
-  static const int bk32 = getenv("GEECO_CONV_BK32") ? 1 : 0;   // measured 3.6 % slower (LDS halves occupancy)
+  static const int bk32 = geeco_dev_getenv("GEECO_CONV_BK32") ? 1 : 0;   // measured 3.6 % slower (LDS halves occupancy)
   if (bk32 && p.C % 8 == 0 && p.ksplit == 1) {
     if (pl.bn == 64) {
       if (pl.bm == 64)
@@ -744,7 +744,7 @@ int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride);
 // The gather GEMM reads the HWIO kernel itself (transposing it on the way into LDS) where its K-steps stay inside one
 // tap: Cout a multiple of 16 that fits the zero page.  Only the remaining shapes need the per-tap transposed copy.
 static bool dgrad_reads_hwio(int Cout) {
-  static const int no_bt = (getenv("GEECO_CONV_NO_BT") || getenv("GEECO_CONV_NO_UT") || getenv("GEECO_CONV_BK32")) ? 1 : 0;
+  static const int no_bt = (geeco_dev_getenv("GEECO_CONV_NO_BT") || geeco_dev_getenv("GEECO_CONV_NO_UT") || geeco_dev_getenv("GEECO_CONV_BK32")) ? 1 : 0;
   return !no_bt && Cout % 16 == 0 && Cout <= GEMM_ZERO_PAGE;
 }
 

@@ -605,9 +605,9 @@ static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
 
 template <int CIN, int COUT>
 static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
-  static const int rw = getenv("GEECO_HALO_RW") ? atoi(getenv("GEECO_HALO_RW")) : 1;   // measured +2.4..3.6 % on the launch
+  static const int rw = geeco_dev_getenv("GEECO_HALO_RW") ? atoi(geeco_dev_getenv("GEECO_HALO_RW")) : 1;   // measured +2.4..3.6 % on the launch
   // loader waves (0 = the kernels above): 4 measured +3.5 % on the launch, 2 are too few (-5 %)
-  static const int ws = getenv("GEECO_HALO_WS") ? atoi(getenv("GEECO_HALO_WS")) : 4;
+  static const int ws = geeco_dev_getenv("GEECO_HALO_WS") ? atoi(geeco_dev_getenv("GEECO_HALO_WS")) : 4;
   if (ws == 4) return launch_s2_halo_fwd_ws<CIN, COUT, 4>(p, s);
   if (ws == 2) return launch_s2_halo_fwd_ws<CIN, COUT, 2>(p, s);
   return rw ? launch_s2_halo_fwd_v<CIN, COUT, true>(p, s) : launch_s2_halo_fwd_v<CIN, COUT, false>(p, s);
@@ -838,9 +838,9 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
                        int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                        int relu, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !b) return 0;
-  static const int no_chunked = getenv("GEECO_NO_HALO3") ? 1 : 0;
+  static const int no_chunked = geeco_dev_getenv("GEECO_NO_HALO3") ? 1 : 0;
   const bool conv2 = Cin == 32 && Cout == 48, conv3 = Cin == 48 && Cout == 64 && !no_chunked;
   if (stride == 2 && (conv2 || conv3) && (H % 2 == 0) && (W % 2 == 0)) {
     HaloFwdParams p = {};
@@ -1125,7 +1125,7 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
                          int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout,
                          int stride, void* ws, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled) return 0;
   if (stride == 2 && Cin == 32 && Cout == 48 && (H % 2 == 0) && (W % 2 == 0)) {
     HaloWgradParams p = {};
@@ -2227,8 +2227,8 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float*
 
 // does the dispatcher below take this shape (given the HWIO kernel)?  Such layers never read the transposed copy.
 int geeco_halo_dgrad_handles(int H, int W, int Cin, int Cout, int stride) {
-  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
-  static const int no_chunked = getenv("GEECO_NO_HALO3") ? 1 : 0;
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int no_chunked = geeco_dev_getenv("GEECO_NO_HALO3") ? 1 : 0;
   if (disabled || stride != 2 || (H % 2) || (W % 2)) return 0;
   return (!no_chunked && Cin == 48 && Cout == 64) || (Cin == 32 && Cout == 48);
 }
@@ -2237,9 +2237,9 @@ int geeco_try_halo_dgrad(const float* dz, const float* w_hwio, const float* ymas
                          int64_t gs_dz, int64_t gs_w, int64_t gs_dx, int N, int H, int W, int Cin, int Cout,
                          int stride, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !w_hwio) return 0;
-  static const int no_chunked = getenv("GEECO_NO_HALO3") ? 1 : 0;
+  static const int no_chunked = geeco_dev_getenv("GEECO_NO_HALO3") ? 1 : 0;
   if (!no_chunked && stride == 2 && Cin == 48 && Cout == 64 && (H % 2 == 0) && (W % 2 == 0)) {
     HaloDgradParams p = {};
     p.dz = dz; p.w = w_hwio; p.mask = ymask; p.dx = dx;
@@ -2434,7 +2434,7 @@ int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y
                         int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                         int relu, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !b || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
   *handled = 1;
   return launch_conv1_fwd(x, w, b, y, nullptr, groups, gs_x, gs_w, gs_b, gs_y, 0, N, H, W, relu, stream);
@@ -2532,7 +2532,7 @@ static int launch_conv1_fwd(const float* x, const float* w, const float* b, floa
   p.bits = bits; p.gs_bits = gs_bits; p.Wp = (int)geeco_relu_bits_pitch(W); p.Hp = (int)geeco_relu_bits_rows(H);
   p.N = N; p.H = H; p.W = W; p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.relu = relu;
   const int ntiles = N * p.tiles_x * p.tiles_y;
-  static const int bpg = getenv("GEECO_C1_BLOCKS") ? atoi(getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)
+  static const int bpg = geeco_dev_getenv("GEECO_C1_BLOCKS") ? atoi(geeco_dev_getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)
   dim3 grid((unsigned)(ntiles < bpg ? ntiles : bpg), (unsigned)groups);
   geeco_note_kernel("conv1_halo_fwd_kernel");
   hipLaunchKernelGGL(conv1_halo_fwd_kernel, grid, dim3(256), 0, stream, p);
@@ -2710,7 +2710,7 @@ int geeco_try_conv1_wgrad(const float* x, const float* dz, float* dw, float* db,
                           int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout,
                           int stride, void* ws, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
   if (disabled || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
   Conv1WgradParams p = {};
   p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;

@@ -367,7 +367,7 @@ static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int s
   // 128-row tiles halve the dz traffic per MFMA; use them unless padding 9*Cin up to 128 wastes > 12 %
   int BR = (BC >= 64 && (long long)cdiv(p->Krows, 128) * 128 * 100 <= (long long)p->Krows * 112) ? 128 : 64;
   // measured on MI355X: the 128-row / 128-col tiles lose ~1.5 % of the step (occupancy beats traffic here)
-  static const int big_tiles = getenv("GEECO_WGRAD_BIG") ? 1 : 0;
+  static const int big_tiles = geeco_dev_getenv("GEECO_WGRAD_BIG") ? 1 : 0;
   if (!big_tiles) { BR = 64; if (BC == 128) BC = 64; }
   *bc = BC + 1000 * BR;
   p->row_tiles = cdiv(p->Krows, BR);

@@ -294,14 +294,14 @@ struct WgradHaloPlan {
 
 static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
   WgradHaloPlan pl = {};
-  static const int disabled = (getenv("GEECO_NO_HALO") || getenv("GEECO_NO_WGRAD_LDS")) ? 1 : 0;
+  static const int disabled = (geeco_dev_getenv("GEECO_NO_HALO") || geeco_dev_getenv("GEECO_NO_WGRAD_LDS")) ? 1 : 0;
   if (disabled || stride != 2 || (H & 1) || (W & 1) || Cout % 64 != 0) return pl;
   const int Ho = H / 2, Wo = W / 2;
   if (Wo < 8 || Ho < 2) return pl;                        // the tiny top layers stay with the gather kernel
   // tile shape: 2 x 16 or 4 x 8 output pixels (same LDS); the squarer one has 7 % less halo ((9 x 17) / (8 x 16) = 1.20
   // input pixels fetched per input pixel used, against (5 x 33) / (4 x 32) = 1.29)
   // (measured, bench shapes: conv3 209.8 -> 203.5 us, conv4 142.3 -> 139.0, conv5 116.5 -> 113.9)
-  static const int sq_env = getenv("GEECO_WGRAD_SQUARE") ? atoi(getenv("GEECO_WGRAD_SQUARE")) : 1;
+  static const int sq_env = geeco_dev_getenv("GEECO_WGRAD_SQUARE") ? atoi(geeco_dev_getenv("GEECO_WGRAD_SQUARE")) : 1;
   const bool wide = Wo >= 16 && !(sq_env && Ho >= 4);
   if (Cin == 48 && Wo >= 16) {
     pl.variant = wide ? 1 : 4; pl.TH = wide ? 2 : 4; pl.TW = wide ? 16 : 8; pl.n_cib = 1;
@@ -321,11 +321,11 @@ static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, i
   // One block per CU (its LDS images take > 80 KB).  Blocks are dealt round-robin to the 8 XCDs and the n_cob co
   // blocks of a slice sit on one XCD: a launch must not put more than 32 blocks on any XCD, or that XCD runs two
   // rounds while the others idle (measured on conv5: 33 blocks on four XCDs took 200 us instead of 100).
-  static const int bpc_env = getenv("GEECO_WGRAD_BPC") ? atoi(getenv("GEECO_WGRAD_BPC")) : 0;
+  static const int bpc_env = geeco_dev_getenv("GEECO_WGRAD_BPC") ? atoi(geeco_dev_getenv("GEECO_WGRAD_BPC")) : 0;
   pl.bpc = bpc_env == 1 || bpc_env == 2 ? bpc_env : 1;
   // 32 x 128 blocks of dw instead of 64 x 64 (same slab bytes): 35.6 KB of DMA per tile instead of 47 KB for the same
   // MFMA work - the 64 x 64 blocks sit at the CU's ingest limit (5.1 B/clk next to MFMA waves)
-  static const int cob128 = getenv("GEECO_WGRAD_NO_COB128") ? 0 : 1;
+  static const int cob128 = geeco_dev_getenv("GEECO_WGRAD_NO_COB128") ? 0 : 1;
   if (cob128 && pl.bpc == 1 && pl.variant == 3 && Cout % 128 == 0) {
     pl.variant = 5;
     pl.n_cib = Cin / 32;
@@ -333,7 +333,7 @@ static WgradHaloPlan wgrad_halo_plan(int groups, int N, int H, int W, int Cin, i
   }
   // 64 x 96 blocks where 128 does not divide Cout (conv5: 192 = 2 x 96): 256 blocks instead of 240 and 27 MFMAs per 12
   // fragment reads instead of 18 per 11, against 1.5x the slab bytes: 114.4 -> 111.6 us, the step -2.5 us
-  static const int cob96 = getenv("GEECO_WGRAD_NO_COB96") ? 0 : 1;
+  static const int cob96 = geeco_dev_getenv("GEECO_WGRAD_NO_COB96") ? 0 : 1;
   if (cob96 && pl.bpc == 1 && pl.variant == 3 && Cout % 96 == 0) {
     pl.variant = 6;
     pl.n_cob = Cout / 96;

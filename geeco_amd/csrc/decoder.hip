@@ -836,7 +836,7 @@ extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, cons
   GEECO_CHECK_ARG(off <= 32, "heads_loss: %d outputs > 32", off);
   p.OT = off;
   p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
-  static const int no_lds = getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
+  static const int no_lds = geeco_dev_getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
   if (!no_lds && N <= HL_NMAX && H == HL_DMAX && Hfc == HL_DMAX) {
     const size_t lds = (size_t)HL_LDS_FLOATS * 4;
     static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it

@@ -1,4 +1,5 @@
 #include "geeco_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -8,6 +9,14 @@ void geeco_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+const char* geeco_dev_getenv(const char* name) {
+  static const bool dev = [] {
+    const char* v = getenv("GEECO_DEV");
+    return v && v[0] && strcmp(v, "0") != 0;
+  }();
+  return dev ? getenv(name) : nullptr;
 }
 
 extern "C" const char* geeco_last_error(void) { return g_err; }

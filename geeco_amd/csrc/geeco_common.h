@@ -15,6 +15,10 @@ void geeco_note_kernel(const char* fmt, ...);
 // conv_wgrad.hip: while set (per thread), geeco_launch_wgrad_reduce records the slab sum there instead of launching it
 void geeco_set_pending_reduce(geeco_slab_reduce* p);
 
+// Development switches (kernel-variant A/B, forced tile shapes; DESIGN.md lists them): the environment is consulted ONLY when
+// GEECO_DEV=1 is set; a production process ignores every GEECO_* variable and always runs the measured-best path.
+const char* geeco_dev_getenv(const char* name);
+
 #define GEECO_CHECK_ARG(cond, ...)              \
   do {                                          \
     if (!(cond)) {                              \

@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _dev, ops
 from .variables import ENC_FILTERS, ENC_STRIDES, VariableStore, decoder_shapes, encoder_shapes
 
 _CELLS = 4   # the reference hard-codes the 2x2 tiling of the joint state (graph.py:139,163,188)
@@ -78,15 +78,15 @@ class ConvEncoderStack:
     # streams beside the input-gradient chain (+1-2 % then: the gather wgrad kernel left MFMA slack for its neighbour);
     # with the LDS-staged wgrad kernels every big launch fills the chip by itself and the two schedules measure the same
     # (3.717 vs 3.719 ms), so the simpler one is the default.  GEECO_MULTI_STREAM=1 restores the side streams.
-    self.two_streams = os.environ.get('GEECO_MULTI_STREAM') is not None
+    self.two_streams = _dev.env('GEECO_MULTI_STREAM') is not None
     # the filter-gradient kernels' slab sums of a backward part go into one launch (GEECO_NO_BATCH_REDUCE: one per layer)
-    self.batch_reduce = os.environ.get('GEECO_NO_BATCH_REDUCE') is None
+    self.batch_reduce = _dev.env('GEECO_NO_BATCH_REDUCE') is None
     self.derived_version = -1
     # Only the FIRST training stack built on a store may rely on the post-Adam refresh of its derived
     # weight copies; eval / predict stacks and any later training stack (e.g. the model built for a
     # ragged final batch) share the parameters but not the copies, so they re-derive on every forward.
     self.lazy_refresh = (training and getattr(store, 'primary_stack', None) is None and
-                         os.environ.get('GEECO_EAGER_DERIVED') is None)
+                         _dev.env('GEECO_EAGER_DERIVED') is None)
     if self.lazy_refresh:
       store.primary_stack = self
     self.Cpad = -(-Cin // 4) * 4
@@ -129,23 +129,23 @@ class ConvEncoderStack:
     if training:
       # encoder bottom fused backward (conv2 dgrad + conv1 wgrad): the reference encoder's shapes, even sizes
       L0, L1 = self.layers[0], self.layers[1]
-      self.fused_bottom = (os.environ.get('GEECO_NO_FUSED_BOTTOM') is None and os.environ.get('GEECO_NO_HALO') is None
+      self.fused_bottom = (_dev.env('GEECO_NO_FUSED_BOTTOM') is None and _dev.env('GEECO_NO_HALO') is None
                            and self.Cpad == 4 and self.Cin in (3, 4) and L0['Cout'] == 32 and L0['stride'] == 1
                            and L1['Cout'] == 48 and L1['stride'] == 2 and L1['H'] % 2 == 0 and L1['W'] % 2 == 0)
       # the fused bottom only needs the SIGN of conv1's output (ReluGrad): conv1's forward writes one bit word per pixel
       # next to y1 and the backward reads those 25 MB instead of the 805 MB of y1 (GEECO_NO_RELU_BITS: read y1)
-      self.relu_bits = self.fused_bottom and os.environ.get('GEECO_NO_RELU_BITS') is None
+      self.relu_bits = self.fused_bottom and _dev.env('GEECO_NO_RELU_BITS') is None
       # with the fused bottom and the sign bits nothing reads the channel-padded copy of conv1's kernel any more: conv1's
       # forward takes the RGB variable itself (together with the gather GEMM reading HWIO kernels this leaves NO weight
       # copy to re-derive after Adam: one launch less per step)
-      if self.relu_bits and self.Cin == 3 and os.environ.get('GEECO_PAD1_COPY') is None:
+      if self.relu_bits and self.Cin == 3 and _dev.env('GEECO_PAD1_COPY') is None:
         self.pad1_copy = False
       if self.relu_bits:
         self.bits1 = torch.zeros(G, Nf, ops.relu_bits_rows(L0['H']), ops.relu_bits_pitch(L0['W']), dtype=torch.int32, device=dev)
       # the same one layer up: conv2's forward leaves 16-bit sign fields of y2 for conv3's input-gradient kernel
       L2 = self.layers[2]
-      self.relu_fields = (os.environ.get('GEECO_NO_RELU_BITS') is None and os.environ.get('GEECO_NO_HALO') is None
-                          and os.environ.get('GEECO_NO_HALO3') is None and os.environ.get('GEECO_HALO_WS') is None
+      self.relu_fields = (_dev.env('GEECO_NO_RELU_BITS') is None and _dev.env('GEECO_NO_HALO') is None
+                          and _dev.env('GEECO_NO_HALO3') is None and _dev.env('GEECO_HALO_WS') is None
                           and (L1['Cin'], L1['Cout'], L1['stride']) == (32, 48, 2)
                           and (L2['Cin'], L2['Cout'], L2['stride']) == (48, 64, 2)
                           and L1['H'] % 2 == 0 and L1['W'] % 2 == 0 and L2['H'] % 2 == 0 and L2['W'] % 2 == 0)
@@ -153,26 +153,32 @@ class ConvEncoderStack:
         self.fields2 = torch.zeros(G, ops.relu_fields_elems(Nf, L2['H'], L2['W']), dtype=torch.int16, device=dev)
       # ... and conv3's forward leaves byte sign fields of y3 for conv4's LDS-staged input-gradient kernel
       L3 = self.layers[3]
-      self.relu_fields3 = (self.relu_fields and os.environ.get('GEECO_NO_DGRAD_LDS') is None and os.environ.get('GEECO_NO_FIELDS3') is None and L3['Cin'] == 64
+      self.relu_fields3 = (self.relu_fields and _dev.env('GEECO_NO_DGRAD_LDS') is None and _dev.env('GEECO_NO_FIELDS3') is None and L3['Cin'] == 64
                            and L3['stride'] == 2 and ops.conv3x3_dgrad_relu_fields_supported(L3['H'], L3['W'], L3['Cin'], L3['Cout'], 2))
       if self.relu_fields3:
         self.fields3 = torch.zeros(G, Nf, L3['H'], L3['W'], L3['Cin'] // 8, dtype=torch.uint8, device=dev)
       # dz[0] (conv1's pre-activation gradient, the largest tensor of the step) never exists when the bottom is fused
       self.dz = [None if (i == 0 and self.fused_bottom) else
                  ([torch.empty_like(t) for t in a] if isinstance(a, list) else torch.empty_like(a)) for i, a in enumerate(self.acts)]
-      self.wt = [None] + [torch.empty(G, 3, 3, L['Cout'], L['Cin'], **f32) for L in self.layers[1:]]
+      # per-tap transposed kernel copies exist ONLY for the layers whose input-gradient kernel reads them (none in the bench
+      # shapes: the LDS-staged kernels and the gather GEMM read the HWIO kernel); every other layer passes wt = NULL, so
+      # a dispatcher that disagreed with geeco_conv3x3_dgrad_needs_wt would fail its null-pointer check, not read garbage
       self.needs_wt = [False] + [ops.conv3x3_dgrad_needs_wt(L['H'], L['W'], L['Cin'], L['Cout'], L['stride'])
                                  for L in self.layers[1:]]
+      self.wt = [None] + [torch.empty(G, 3, 3, L['Cout'], L['Cin'], **f32) if self.needs_wt[l] else None
+                          for l, L in enumerate(self.layers) if l >= 1]
       if self.split_top:
-        self.wt[7] = [torch.empty(3, 3, d, self.layers[7]['Cin'], **f32) for d in self.dim_outs]
+        L7 = self.layers[7]
+        self.needs_wt7 = [ops.conv3x3_dgrad_needs_wt(L7['H'], L7['W'], L7['Cin'], d, L7['stride']) for d in self.dim_outs]
+        self.wt[7] = [torch.empty(3, 3, d, L7['Cin'], **f32) if nw else None for d, nw in zip(self.dim_outs, self.needs_wt7)]
       if self.pad1:
         self.dw1p = torch.zeros(G, 3, 3, self.Cpad, self.layers[0]['Cout'], **f32)
       # wgrads of different layers may run concurrently (different streams): one split-K workspace each
-      nside = int(os.environ.get('GEECO_WGRAD_STREAMS', '2'))   # measured: 1 -> 2 streams +1.1 %, 3 slower
-      self.wgrad1_on_main = os.environ.get('GEECO_WGRAD1_SIDE') is None
+      nside = int(_dev.env('GEECO_WGRAD_STREAMS', '2'))   # measured: 1 -> 2 streams +1.1 %, 3 slower
+      self.wgrad1_on_main = _dev.env('GEECO_WGRAD1_SIDE') is None
       # the LDS-halo wgrad kernels of conv1 / conv2 want whole CUs: beside the dgrad chain they only slow it
       # down (measured: layers below 2 serial +0.8 %, below 3 +0.1 %, below 4 -0.5 %)
-      self.serial_below = int(os.environ.get('GEECO_SERIAL_BELOW', '2'))
+      self.serial_below = int(_dev.env('GEECO_SERIAL_BELOW', '2'))
       self.ws_l = [torch.empty(ops.conv3x3_wgrad_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) // 4 + 4,
                                **f32) for L in self.layers]
       self.ws = self.ws_l[0]
@@ -249,7 +255,8 @@ class ConvEncoderStack:
     if self.training and self.split_top:
       L7 = self.layers[7]
       for g in range(G):
-        ops.derive_conv_weights([self._w(7, g)], [self.wt[7][g].unsqueeze(0)], [L7['Cin']], [self.dim_outs[g]], 1, 0)
+        if self.wt[7][g] is not None:
+          ops.derive_conv_weights([self._w(7, g)], [self.wt[7][g].unsqueeze(0)], [L7['Cin']], [self.dim_outs[g]], 1, 0)
     pad = dict(pad_src=self._w(0), pad_dst=self.w1p, pad_cin=self.Cin, pad_cin_padded=self.Cpad,
                pad_cout=self.layers[0]['Cout']) if self.pad1_copy else {}
     if ls or pad:
@@ -349,8 +356,8 @@ class ConvEncoderStack:
       ops.conv3_dgrad_relu_fields_into(dx, dz, self._w(2), self.fields2, G, dz[0].numel(), self.gs_p, self.fields2[0].numel(),
                                        dx[0].numel(), Nf, L['H'], L['W'])
       return
-    ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel(), dx[0].numel(), Nf, L['H'], L['W'],
-                           L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
+    ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel() if wt is not None else 0, dx[0].numel(), Nf, L['H'],
+                           L['W'], L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
 
   def forward(self):
     if not self.lazy_refresh or self.derived_version != self.store.version:
@@ -529,9 +536,9 @@ class _ModelBase:
     # RGB-D: rgb || depth (estimator.py:36,169,172).  The dynimg branch of the goal model forms the concat inside its
     # input kernels (no packed copy of all N * K frames: 1.07 GB read + 1.43 GB written per step at K = 32); the other
     # graphs pack once per step.
-    self.last_from_dynimg = os.environ.get('GEECO_PACK_CURRENT') is None   # current frame's padded copy out of the buffer-image kernel
+    self.last_from_dynimg = _dev.env('GEECO_PACK_CURRENT') is None   # current frame's padded copy out of the buffer-image kernel
     self.split_rgbd = (self.C == 4 and goal and cfg.proc_obs == 'dynimg' and (H * W) % 4 == 0 and
-                       os.environ.get('GEECO_PACK_RGBD') is None)
+                       _dev.env('GEECO_PACK_RGBD') is None)
     if self.C == 4 and not self.split_rgbd:
       self.obs4 = torch.empty(N, K, H, W, 4, **f32)
       if goal:

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GEECO_DEV=1   # the product reads GEECO_* switches only under GEECO_DEV=1
 # A/B two env settings of bench.py (skip cpu leg)
 for i in 1 2; do
   for e in "$@"; do

@@ -1,7 +1,7 @@
 """Per-tile s_memtime timeline of the fused encoder-bottom backward kernel (conv2 dgrad + conv1 wgrad), waves 0 and 4
 of every block (needs the -DGEECO_STAMPS build: scripts/dev/build_stamps.sh)."""
 import os, sys, ctypes
-os.environ.setdefault('GEECO_LIB', 'libgeeco_hip_stamps.so')
+os.environ.setdefault('GEECO_DEV', '1'); os.environ.setdefault('GEECO_LIB', 'libgeeco_hip_stamps.so')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
 from geeco_amd import graph, ops, _native

@@ -1,6 +1,6 @@
 """Phase timeline (s_memtime) of the LDS heads/loss kernel; needs the -DGEECO_STAMPS build."""
 import os, sys
-os.environ.setdefault('GEECO_LIB', 'libgeeco_hip_stamps.so')
+os.environ.setdefault('GEECO_DEV', '1'); os.environ.setdefault('GEECO_LIB', 'libgeeco_hip_stamps.so')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from geeco_amd import graph

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GEECO_DEV=1   # the product reads GEECO_* switches only under GEECO_DEV=1
 # per-layer times under a list of env settings (same box, same build): layersweep.sh "A=1" "B=2" ...; prints rows 0-4 of the layer table
 mkdir -p gpurun_out/layersweep
 for e in "" "$@"; do

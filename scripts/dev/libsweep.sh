@@ -1,4 +1,5 @@
 #!/bin/bash
+export GEECO_DEV=1   # the product reads GEECO_* switches only under GEECO_DEV=1
 # same-box A/B of library builds: libsweep.sh "" _i0 ...  (suffixes of geeco_amd/libgeeco_hip<suffix>.so); prints the
 # bench value and the first four rows of the per-layer table, twice per build (alternating)
 mkdir -p gpurun_out/libsweep

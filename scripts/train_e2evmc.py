@@ -22,6 +22,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
+from geeco_amd import _dev                                               # noqa: E402
 from geeco_amd import dist as gdist                                      # noqa: E402
 from geeco_amd import estimator as est                                   # noqa: E402
 from geeco_amd.estimator import e2evmc_model_fn, goal_e2evmc_model_fn    # noqa: E402
@@ -132,7 +133,7 @@ def main(args):
                              save_checkpoints_steps=args.ckpt_steps, keep_checkpoint_max=args.num_last_ckpt,
                              # checkpoints are also written as TF-1.15 tensor bundles (model.ckpt-<step>.index / .data-*),
                              # the files the reference's predictor and snapshot tooling read
-                             save_tf_bundle=os.environ.get('GEECO_NO_TF_BUNDLE') is None)
+                             save_tf_bundle=_dev.env('GEECO_NO_TF_BUNDLE') is None)
   config_name = 'e2evmc_config'
   config_path = os.path.join(args.model_dir, '%s.json' % config_name)
   if os.path.exists(config_path):    # a previous run's config wins over the CLI (train_e2evmc.py:229-232)
@@ -178,7 +179,7 @@ def main(args):
         shuffle_buffer=args.shuffle_buffer, num_epochs=1, num_threads=args.num_threads,
         prefetch_size=args.prefetch_size,
         # episodes are uploaded once (to THIS rank's GPU) and windows are gathered in HBM unless GEECO_HOST_WINDOWS is set
-        device=None if os.environ.get('GEECO_HOST_WINDOWS') else dev, **kw)
+        device=None if _dev.env('GEECO_HOST_WINDOWS') else dev, **kw)
   train_input = lambda: input_fn(estimator_mode='train')
   eval_input = lambda: input_fn(estimator_mode='eval')
 

@@ -73,3 +73,25 @@ def test_stale_library_is_refused_by_version(tmp_path, monkeypatch):
   monkeypatch.setattr(_native, '_lib', None)
   with pytest.raises(_native.GeecoNativeError, match='ABI version mismatch'):
     _native.load()
+
+
+def test_dev_switches_are_ignored_without_geeco_dev(monkeypatch):
+  """GEECO_* A/B switches are development tooling: without GEECO_DEV=1 neither the Python side nor the library reads
+  them (a stray variable in a production environment must not change which kernels run)."""
+  from geeco_amd import _dev
+  monkeypatch.delenv('GEECO_DEV', raising=False)
+  monkeypatch.setenv('GEECO_NO_FUSED_BOTTOM', '1')
+  assert not _dev.enabled() and _dev.env('GEECO_NO_FUSED_BOTTOM') is None and _dev.env('GEECO_WGRAD_STREAMS', '2') == '2'
+  monkeypatch.setenv('GEECO_DEV', '1')
+  assert _dev.enabled() and _dev.env('GEECO_NO_FUSED_BOTTOM') == '1'
+  monkeypatch.setenv('GEECO_DEV', '0')
+  assert not _dev.enabled()
+  # the library: no getenv of a GEECO_ switch outside the one gate
+  import glob
+  for path in glob.glob(os.path.join(ROOT, 'geeco_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'geeco_amd', 'csrc', '*.cpp')):
+    src = open(path).read()
+    direct = re.findall(r'(?<![_a-z])getenv\("(GEECO_[A-Z0-9_]+)"', src)
+    assert direct in ([], ['GEECO_DEV']), (path, direct)
+  for path in glob.glob(os.path.join(ROOT, 'geeco_amd', '*.py')):
+    if not path.endswith('_dev.py'):
+      assert not re.findall(r"os\.environ\.get\('GEECO_", open(path).read()), path
