@@ -384,18 +384,19 @@ def check_losses(args, first_loss, final_loss, total_steps):
 
 # ======================================================================================================
 def device_identity(local):
-  """A string that is the same for two ranks exactly when they sit on the same physical GPU."""
+  """(identity, detail): `identity` is equal for two ranks exactly when they sit on the same physical GPU -- host name + PCI
+  address (domain:bus:device), which two devices cannot share; where this torch build does not expose the PCI address the
+  local device index stands in.  `detail` adds the UUID for the report only: it is NOT compared (a driver that reported one
+  placeholder UUID for every GPU must not make an honest 8-GPU run refuse itself)."""
   import torch
   pr = torch.cuda.get_device_properties(local)
-  parts = []
-  u = getattr(pr, 'uuid', None)
-  if u is not None:
-    parts.append('uuid=%s' % u)
+  host = socket.gethostname()
   if hasattr(pr, 'pci_bus_id'):
-    parts.append('pci=%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0)))
-  if not parts:
-    parts.append('index=%d' % local)
-  return '%s %s' % (socket.gethostname(), ' '.join(parts))
+    ident = '%s pci=%04x:%02x:%02x' % (host, getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0))
+  else:
+    ident = '%s index=%d' % (host, local)
+  u = getattr(pr, 'uuid', None)
+  return ident, ident + (' uuid=%s' % u if u is not None else '')
 
 
 def build_model(model_name, channels, seq_len, batch, dev):
@@ -535,7 +536,9 @@ def main():
   torch.cuda.set_device(local)
   dev = torch.device('cuda', local)
   # N ranks must sit on N distinct GPUs: two ranks on one device would report a number for the wrong machine
-  idents = gdist.gather_strings(device_identity(local), dev)
+  ident, detail = device_identity(local)
+  idents = gdist.gather_strings(ident, dev)
+  details = gdist.gather_strings(detail, dev, width=160)
   shared = len(set(idents)) < world
   if shared and not args.allow_shared_gpu:
     log('%d ranks but only %d distinct GPU(s): %s' % (world, len(set(idents)), idents))
@@ -573,7 +576,7 @@ def main():
         'final_loss': round(loss, 6),
     }
     if world > 1:
-      out['ranks'] = {'ms_per_step': [round(v, 4) for v in rank_ms], 'devices': idents, 'distinct_devices': len(set(idents))}
+      out['ranks'] = {'ms_per_step': [round(v, 4) for v in rank_ms], 'devices': details, 'distinct_devices': len(set(idents))}
     out['loss_check'], ok = check_losses(args, first_loss, loss, total_steps)
     if not ok:
       rc = 4

@@ -707,4 +707,3 @@ def test_conv1_rgb_kernel_variable(dev, G, N, H, W):
     ys.append(y); bs.append(bits)
   torch.cuda.synchronize()
   assert torch.equal(ys[0], ys[1]) and torch.equal(bs[0], bs[1])
-
