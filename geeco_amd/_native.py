@@ -85,6 +85,8 @@ SIGNATURES = {
     'geeco_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _P]),
     'geeco_lstm_gates_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'geeco_lstm_gates_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'geeco_lstm_step_bwd_ws_bytes': (_L, [_I, _I, _I]),
+    'geeco_lstm_step_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _P, _P]),
     'geeco_colsum': (_I, [_P, _L, _I, _I, _P, _I, _P]),
     'geeco_heads_ws_bytes': (_L, [_I, _I, _I]),
     'geeco_heads_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _PP, _PP, POINTER(_I), POINTER(_I), POINTER(_F), _PP,

@@ -141,13 +141,18 @@ struct GemmParams {
   int M, N, K, ta, tb, accumulate, S, k_per_split;
 };
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-  constexpr int BMg = 64, BNg = 64, BKg = 16, LD = 80;   // LD = 16 (mod 32): conflict-free ds_read_b32
-  __shared__ float sA[2][BKg * LD];
-  __shared__ float sB[2][BKg * LD];
+constexpr int GEMM_LD = 80, GEMM_BK = 16;   // LD = 16 (mod 32): conflict-free ds_read_b32
+
+// One 64 x 64 tile (bx = N tile, by = M tile, bz = K split) of C = op(A) op(B).  `store(gm, gn, value)` is called for
+// every element of an unsplit product (S == 1) after C has been written: the one-launch LSTM backward hangs the
+// state-concat scatter on it.
+template <class Store>
+__device__ __forceinline__ void gemm_block(const GemmParams& p, int bx, int by, int bz, float (*sA)[GEMM_BK * GEMM_LD],
+                                           float (*sB)[GEMM_BK * GEMM_LD], Store store) {
+  constexpr int BMg = 64, BNg = 64, BKg = GEMM_BK, LD = GEMM_LD;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int m0 = blockIdx.y * BMg, n0 = blockIdx.x * BNg;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int m0 = by * BMg, n0 = bx * BNg;
+  const int kbeg = bz * p.k_per_split;
   int kend = kbeg + p.k_per_split;
   if (kend > p.K) kend = p.K;
   const int r = lane & 15, q = lane >> 4;
@@ -230,12 +235,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         if (gm >= p.M) continue;
         if (p.S == 1) {
           float* c = p.C + (long long)gm * p.ldc + gn;
-          *c = p.accumulate ? *c + e[k] : e[k];
+          const float v = p.accumulate ? *c + e[k] : e[k];
+          *c = v;
+          store(gm, gn, v);
         } else {
-          p.part[((long long)blockIdx.z * p.M + gm) * p.N + gn] = e[k];
+          p.part[((long long)bz * p.M + gm) * p.N + gn] = e[k];
         }
       }
     }
+}
+
+struct NoStore {
+  __device__ __forceinline__ void operator()(int, int, float) const {}
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+  __shared__ float sA[2][GEMM_BK * GEMM_LD];
+  __shared__ float sB[2][GEMM_BK * GEMM_LD];
+  gemm_block(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB, NoStore());
 }
 
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmParams p) {
@@ -291,6 +308,121 @@ extern "C" int geeco_gemm_f32(const float* A, int64_t lda, int ta, const float* 
   GEECO_LAUNCH_CHECK();
   if (p.S > 1) {
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)cdiv64((long long)M * N, 256)), dim3(256), 0, s, p);
+    GEECO_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- one LSTM step's weight / input gradients in ONE launch --------------------------------------------------------
+// With one LSTM step (the goal model's dynimg branch: graph.py:405-407) everything after the gate gradients dz depends
+// on dz alone: dWx = X^T dz, db = column sums of dz, dX = dz Wx^T, and the scatter of dX into the encoders' feature
+// gradients (state concat backward + ReluGrad of conv8).  As separate launches that is gemm, colsum, gemm + split-K
+// reduce, concat_bwd = five dependent kernel boundaries of ~4.5 us each for ~0.2 GFLOP; here they are the blocks of one
+// two grids: (1) [0, nA) tiles of dWx, [nA, nA + nB) split-K tiles of dX (slabs; a K loop of this latency-bound GEMM costs
+// ~0.7 us per 16-deep step, so the 512-deep product keeps its 8-way split: unsplit it measured +22 us on the step), the
+// rest the bias column sums; (2) the slab sum of dX with the feature-gradient scatter in its epilogue.
+struct LstmBwdBatch {
+  GemmParams a, b;          // a: dWx (S == 1), b: dX (split-K into b.part)
+  int nA, nB, ax, bx, by;   // block counts and tile counts of the two products
+  const float* dz; long long ldz; int Mz, Nz; float* db;       // column sums
+  ConcatParams cc;          // scatter of dX (cc.dfeats[i] may be null); cc.nfeat == 0: no scatter
+};
+
+struct ConcatScatter {
+  const ConcatParams& c;
+  __device__ __forceinline__ void operator()(int n, int d, float v) const {
+    const int cell = d / c.Ctot, ch = d - cell * c.Ctot;
+    if (cell >= c.cells || (ch >= c.jnt_off && ch < c.jnt_off + c.J)) return;
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k)
+      if (k < c.nfeat && ch >= c.off[k]) f = k;
+    if (!c.dfeats[f]) return;
+    const long long i = ((long long)n * c.cells + cell) * c.ch[f] + (ch - c.off[f]);
+    c.dfeats[f][i] = c.feats[f][i] > 0.f ? v * c.scale : 0.f;       // ReluGrad of the encoder's last layer
+  }
+};
+
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const LstmBwdBatch q) {
+  __shared__ float sA[2][GEMM_BK * GEMM_LD];
+  __shared__ float sB[2][GEMM_BK * GEMM_LD];
+  const int blk = blockIdx.x;
+  if (blk < q.nA) {
+    gemm_block(q.a, blk % q.ax, blk / q.ax, 0, sA, sB, NoStore());
+  } else if (blk < q.nA + q.nB) {
+    const int l = blk - q.nA, t = l % (q.bx * q.by);
+    if (q.b.S == 1 && q.cc.nfeat > 0)
+      gemm_block(q.b, t % q.bx, t / q.bx, l / (q.bx * q.by), sA, sB, ConcatScatter{q.cc});
+    else
+      gemm_block(q.b, t % q.bx, t / q.bx, l / (q.bx * q.by), sA, sB, NoStore());
+  } else {
+    const int j = (blk - q.nA - q.nB) * 256 + threadIdx.x;
+    if (j >= q.Nz) return;
+    float s = 0.f;
+    for (int i = 0; i < q.Mz; ++i) s += q.dz[(long long)i * q.ldz + j];     // row order, as geeco_colsum
+    q.db[j] = s;
+  }
+}
+
+// slab sum of dX (fixed slab order, as gemm_reduce_kernel) + the state-concat scatter of the sums
+__global__ __launch_bounds__(256) void lstm_step_bwd_finish_kernel(const LstmBwdBatch q) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long MN = (long long)q.b.M * q.b.N;
+  if (i >= MN) return;
+  float s = 0.f;
+  const float* src = q.b.part + i;
+  int k = 0;
+  for (; k + 8 <= q.b.S; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(k + u) * MN];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < q.b.S; ++k) s += src[(long long)k * MN];
+  const int m = (int)(i / q.b.N), n = (int)(i - (long long)m * q.b.N);
+  q.b.C[(long long)m * q.b.ldc + n] = s;
+  if (q.cc.nfeat > 0) ConcatScatter{q.cc}(m, n, s);
+}
+
+extern "C" int64_t geeco_lstm_step_bwd_ws_bytes(int N, int D, int H4) { return geeco_gemm_ws_bytes(N, D, H4); }
+
+extern "C" int geeco_lstm_step_bwd(const float* x, int64_t ldx, const float* dz, int64_t ldz, const float* wx, int64_t ldw,
+                                   float* dwx, int64_t lddw, float* db, float* dx, int64_t lddx, int N, int D, int H4,
+                                   const float* const* feats_fwd, float* const* dfeats, const int* feat_ch, int nfeat,
+                                   int jnt_pos, int J, int cells, void* ws, void* stream) {
+  GEECO_CHECK_ARG(x && dz && wx && dwx && db && dx, "lstm_step_bwd: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && D >= 1 && H4 >= 1, "lstm_step_bwd: bad dims");
+  GEECO_CHECK_ARG(nfeat >= 0 && nfeat <= 3 && (nfeat == 0 || (feats_fwd && dfeats && feat_ch && jnt_pos >= 0 && jnt_pos <= nfeat)),
+                  "lstm_step_bwd: concat description");
+  LstmBwdBatch q = {};
+  // dWx [D][4H] = X^T dz: A = X [N][D] transposed, B = dz [N][4H]
+  q.a.A = x; q.a.lda = ldx; q.a.ta = 1; q.a.B = dz; q.a.ldb = ldz; q.a.tb = 0; q.a.C = dwx; q.a.ldc = lddw;
+  q.a.M = D; q.a.N = H4; q.a.K = N; q.a.S = 1; q.a.k_per_split = cdiv(N, 16) * 16;
+  // dX [N][D] = dz Wx^T: A = dz [N][4H], B = Wx [D][4H] transposed
+  q.b.A = dz; q.b.lda = ldz; q.b.ta = 0; q.b.B = wx; q.b.ldb = ldw; q.b.tb = 1; q.b.C = dx; q.b.ldc = lddx;
+  q.b.M = N; q.b.N = D; q.b.K = H4; q.b.part = (float*)ws;
+  gemm_plan(N, D, H4, &q.b.S, &q.b.k_per_split);
+  GEECO_CHECK_ARG(q.b.S == 1 || ws, "lstm_step_bwd: workspace required (geeco_lstm_step_bwd_ws_bytes)");
+  q.ax = cdiv(H4, 64); q.nA = q.ax * cdiv(D, 64);
+  q.bx = cdiv(D, 64); q.by = cdiv(N, 64); q.nB = q.bx * q.by * q.b.S;
+  q.dz = dz; q.ldz = ldz; q.Mz = N; q.Nz = H4; q.db = db;
+  if (nfeat > 0) {
+    const int ctot = fill_concat(&q.cc, feat_ch, nfeat, jnt_pos, J);
+    GEECO_CHECK_ARG((int64_t)cells * ctot <= D, "lstm_step_bwd: %d cells x %d channels exceed the state width %d", cells, ctot, D);
+    q.cc.N = N; q.cc.cells = cells; q.cc.scale = 1.f;
+    for (int i = 0; i < nfeat; ++i) {
+      GEECO_CHECK_ARG(!dfeats[i] || feats_fwd[i], "lstm_step_bwd: feats_fwd[%d] is null", i);
+      q.cc.feats[i] = feats_fwd[i];
+      q.cc.dfeats[i] = dfeats[i];
+    }
+  }
+  const int blocks = q.nA + q.nB + cdiv(H4, 256);
+  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, q);
+  GEECO_LAUNCH_CHECK();
+  if (q.b.S > 1) {
+    hipLaunchKernelGGL(lstm_step_bwd_finish_kernel, dim3((unsigned)cdiv64((long long)N * D, 256)), dim3(256), 0,
+                       (hipStream_t)stream, q);
     GEECO_LAUNCH_CHECK();
   }
   return 0;

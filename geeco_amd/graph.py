@@ -441,6 +441,9 @@ class LSTMDecoder:
     self.gemm_ws = torch.empty(max(ops.gemm_ws_bytes(*s) for s in gemm_shapes) // 4 + 4, **f32)
     self.targets, self.target_strides = None, None     # bound by the model
     self.loss_scale = 1.0
+    # one-step decoders: weight / bias / input gradients (+ the state-concat backward) as TWO launches instead of five
+    # dependent ones (GEECO_DEV=1 GEECO_NO_LSTM_BATCH: the separate launches)
+    self.one_launch_bwd = _dev.env('GEECO_NO_LSTM_BATCH') is None
 
   def _v(self, n):
     return self.store.var('%s/%s' % (self.scope, n))
@@ -470,12 +473,23 @@ class LSTMDecoder:
                         [h[2] for h in self.heads], [h[3] for h in self.heads], [h[4] for h in self.heads],
                         self.targets, self.target_strides, float(self.loss_scale), N, H, F, self.heads_ws, **kw)
 
-  def backward(self):
-    """After forward(backward_too=True): fills d(states) and the LSTM variable gradients."""
+  def backward(self, concat=None):
+    """After forward(backward_too=True): fills d(states) and the LSTM variable gradients.  ``concat`` (one-step decoders
+    only): dict(feats, dfeats, feat_ch, jnt_pos, J, cells) of the state concat that produced ``states``; its backward
+    (feature gradients + ReluGrad of conv8) then rides in the same launch as the weight / input gradients and the method
+    returns True (else the caller scatters ``dstates`` itself)."""
     N, T, D, H = self.N, self.T, self.D, self.H
     W = self._v('lstm_cell/kernel')
     Wx, Wh = W[:D], W[D:]
     dW = self._g('lstm_cell/kernel')
+    if T == 1 and self.one_launch_bwd:
+      # one step from a zero state: dWh = h_prev^T dz = 0 (the arena's rows stay zero); everything else in ONE launch
+      ops.lstm_gates_bwd_into(self.dz[0], None, self.gates[0], None, self.c[0], self.dh, None, N, H)
+      kw = dict(feats_fwd=concat['feats'], dfeats=concat['dfeats'], feat_ch=concat['feat_ch'], jnt_pos=concat['jnt_pos'],
+                J=concat['J'], cells=concat['cells']) if concat else {}
+      ops.lstm_step_bwd_into(dW[:D], self._g('lstm_cell/bias'), self.dstates[0], self.states[0], self.dz[0], Wx, N, D, 4 * H,
+                             4 * H, self.gemm_ws, **kw)
+      return concat is not None
     for t in range(T - 1, -1, -1):
       last = t == T - 1
       ops.lstm_gates_bwd_into(self.dz[t], self.dc if t > 0 else None, self.gates[t],
@@ -488,6 +502,7 @@ class LSTMDecoder:
       ops.gemm_into(dW[D:], self.h, self.dz[1:], H, 4 * H, (T - 1) * N, H, 4 * H, 4 * H, ta=True, ws=self.gemm_ws)
     ops.colsum_into(self._g('lstm_cell/bias'), self.dz, 4 * H, T * N, 4 * H)
     ops.gemm_into(self.dstates, self.dz, Wx, T * N, D, 4 * H, 4 * H, 4 * H, D, tb=True, ws=self.gemm_ws)
+    return False
 
 
 # ================================================================================================
@@ -743,12 +758,14 @@ class GoalE2EVMC(_ModelBase):
       return
     N, K, jn = self.N, self.K, self.cfg.dim_jnt_state
     d = self.decoder
-    d.backward()
     if self.mode == 'dynimg':
       feats, dfe = self.enc.features, self.enc.dfeatures
-      ops.state_concat_bwd_into([dfe[0], dfe[1], dfe[2]], d.dstates[0], d.D, [feats[0], feats[1], feats[2]],
-                                self.feat_ch, 2, jn, N, _CELLS)
+      cc = dict(feats=[feats[0], feats[1], feats[2]], dfeats=[dfe[0], dfe[1], dfe[2]], feat_ch=self.feat_ch, jnt_pos=2, J=jn,
+                cells=_CELLS)
+      if not d.backward(concat=cc):
+        ops.state_concat_bwd_into(cc['dfeats'], d.dstates[0], d.D, cc['feats'], self.feat_ch, 2, jn, N, _CELLS)
     elif self.mode in ('seq_constant', 'seq_residual'):
+      d.backward()
       ch = self.feat_ch[0]
       feats = self.enc.features[0].view(K + 1, N, _CELLS, ch)
       dfe = self.enc.dfeatures[0].view(K + 1, N, _CELLS, ch)
@@ -762,6 +779,7 @@ class GoalE2EVMC(_ModelBase):
           ops.state_concat_bwd_into([dfe[K]], d.dstates[t], d.D, [feats[K]], self.feat_ch, 1, jn, N, _CELLS,
                                     accumulate=t > 0, scale=1.0)
     else:
+      d.backward()
       f = [self.enc.features[g].view(K, N, _CELLS, self.feat_ch[g]) for g in range(2)]
       df = [self.enc.dfeatures[g].view(K, N, _CELLS, self.feat_ch[g]) for g in range(2)]
       for t in range(K):

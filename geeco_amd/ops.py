@@ -379,6 +379,21 @@ def lstm_gates_bwd_into(dz, dc_prev, gates, c_prev, c, dh, dc, N, H):
                                     _stream()), 'geeco_lstm_gates_bwd')
 
 
+def lstm_step_bwd_ws_bytes(N, D, H4):
+  return int(_lib().geeco_lstm_step_bwd_ws_bytes(N, D, H4))
+
+
+def lstm_step_bwd_into(dwx, db, dx, x, dz, wx, N, D, H4, ldw, ws, feats_fwd=None, dfeats=None, feat_ch=None, jnt_pos=0, J=0,
+                       cells=0):
+  """Two launches: dwx = x^T dz, db = colsum(dz), split-K partials of dx = dz wx^T side by side; then dx's slab sum with
+  the state-concat backward (``dfeats``) in its epilogue."""
+  nf = len(feats_fwd) if feats_fwd else 0
+  check(_lib().geeco_lstm_step_bwd(_p(x), D, _p(dz), H4, _p(wx), ldw, _p(dwx), ldw, _p(db), _p(dx), D, N, D, H4,
+                                   _parr(feats_fwd) if nf else None, _parr(dfeats) if nf else None,
+                                   _iarr(feat_ch) if nf else None, nf, jnt_pos, J, cells, _p(ws), _stream()),
+        'geeco_lstm_step_bwd')
+
+
 def colsum_into(out, a, lda, M, N, accumulate=False):
   check(_lib().geeco_colsum(_p(a), lda, M, N, _p(out), 1 if accumulate else 0, _stream()), 'geeco_colsum')
 

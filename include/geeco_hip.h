@@ -270,6 +270,18 @@ int geeco_lstm_gates_fwd(const float* z, const float* bias, const float* c_prev,
 /* dz [N][4H] from dh, dc (either may be NULL = 0); dc_prev (optional) out. */
 int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh,
                          const float* dc, float* dz, float* dc_prev, int N, int H, void* stream);
+/* TWO launches for everything a single LSTM step's backward needs after the gate gradients dz [N][4H] (the goal model's
+ * dynimg branch runs one step: graph.py:405-407; autodiff of :217-225 + :169-192): dwx [D][4H] = x^T dz, db [4H] = column
+ * sums of dz, dx [N][D] = dz wx^T and - if nfeat > 0 - the state-concat backward of dx (geeco_state_concat_bwd with
+ * scale 1, accumulate 0: dfeats[i][n][cell][c] = (feats_fwd[i] > 0) * dx[n][cell * Ctot + off_i + c]).  Grid 1: the
+ * tiles of dwx, the split-K tiles of dx and the column sums side by side; grid 2: dx's slab sum with the scatter in its
+ * epilogue.  Replaces the five launches geeco_gemm_f32 (ta) + geeco_colsum + geeco_gemm_f32 (tb: split-K + reduce) +
+ * geeco_state_concat_bwd; same K / slab order, so bitwise the same results.  ws: geeco_lstm_step_bwd_ws_bytes bytes. */
+int64_t geeco_lstm_step_bwd_ws_bytes(int N, int D, int H4);
+int geeco_lstm_step_bwd(const float* x, int64_t ldx, const float* dz, int64_t ldz, const float* wx, int64_t ldw, float* dwx,
+                        int64_t lddw, float* db, float* dx, int64_t lddx, int N, int D, int H4,
+                        const float* const* feats_fwd, float* const* dfeats, const int* feat_ch, int nfeat, int jnt_pos,
+                        int J, int cells, void* ws, void* stream);
 /* column sums: out[j] = sum_i a[i][j] (bias gradients). */
 int geeco_colsum(const float* a, int64_t lda, int M, int N, float* out, int accumulate, void* stream);
 

@@ -707,3 +707,54 @@ def test_conv1_rgb_kernel_variable(dev, G, N, H, W):
     ys.append(y); bs.append(bits)
   torch.cuda.synchronize()
   assert torch.equal(ys[0], ys[1]) and torch.equal(bs[0], bs[1])
+
+
+@pytest.mark.parametrize('N,chs,J', [(32, (256, 256, 256), 7), (5, (256, 128, 64), 7), (2, (256,), 7), (33, (64, 64), 3)])
+def test_lstm_step_bwd_one_launch(dev, N, chs, J):
+  """geeco_lstm_step_bwd (dWx tiles, dX split-K tiles and the bias sums as the blocks of one grid, then dX's slab sum with
+  the state-concat backward in its epilogue) against the five separate launches it replaces (gemm ta, colsum, gemm tb with
+  split-K + reduce, state_concat_bwd): bitwise (same tile code, same K and slab order), and against fp64; the
+  joint-state columns of dX are not scattered anywhere."""
+  from geeco_amd import ops
+  r = np.random.default_rng(71)
+  H4, cells = 512, 4
+  nf = len(chs)
+  Ctot = sum(chs) + J
+  D = cells * Ctot
+  x = torch.tensor(r.standard_normal([N, D]).astype(np.float32), device=dev)
+  dz = torch.tensor(r.standard_normal([N, H4]).astype(np.float32), device=dev)
+  w = torch.tensor((r.standard_normal([D + 128, H4]) / 30).astype(np.float32), device=dev)
+  wx = w[:D]
+  feats = [torch.tensor(r.standard_normal([N, cells, c]).astype(np.float32), device=dev) for c in chs]
+  jnt_pos = min(2, nf)
+  # separate launches
+  dw_ref = torch.zeros(D + 128, H4, device=dev)
+  db_ref = torch.empty(H4, device=dev)
+  dx_ref = torch.empty(N, D, device=dev)
+  ws = torch.empty(max(ops.gemm_ws_bytes(D, H4, N), ops.gemm_ws_bytes(N, D, H4)) // 4 + 4, device=dev)
+  ops.gemm_into(dw_ref[:D], x, dz, D, H4, N, D, H4, H4, ta=True, ws=ws)
+  ops.colsum_into(db_ref, dz, H4, N, H4)
+  ops.gemm_into(dx_ref, dz, wx, N, D, H4, H4, H4, D, tb=True, ws=ws)
+  df_ref = [torch.full_like(f, float('nan')) for f in feats]
+  ops.state_concat_bwd_into(df_ref, dx_ref, D, feats, list(chs), jnt_pos, J, N, cells)
+  # one launch
+  dw = torch.zeros(D + 128, H4, device=dev)
+  db = torch.full((H4,), float('nan'), device=dev)
+  dx = torch.full((N, D), float('nan'), device=dev)
+  df = [torch.full_like(f, float('nan')) for f in feats]
+  ws2 = torch.empty(ops.lstm_step_bwd_ws_bytes(N, D, H4) // 4 + 4, device=dev)
+  ops.lstm_step_bwd_into(dw[:D], db, dx, x, dz, wx, N, D, H4, H4, ws2, feats_fwd=feats, dfeats=df, feat_ch=list(chs),
+                         jnt_pos=jnt_pos, J=J, cells=cells)
+  torch.cuda.synchronize()
+  assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+  assert float(dw[D:].abs().max()) == 0.0                      # the recurrent rows are not touched
+  ref64 = dz.double().cpu() @ wx.double().cpu().T
+  _close(dx, ref64, 1e-5, 2e-5 * np.sqrt(H4), 'dX vs fp64')
+  assert torch.equal(dx, dx_ref)
+  for a, b in zip(df, df_ref):
+    assert not torch.isnan(a).any() and torch.equal(a, b)
+  # without a concat description only the three products are written
+  dx2 = torch.full((N, D), float('nan'), device=dev)
+  ops.lstm_step_bwd_into(dw[:D], db, dx2, x, dz, wx, N, D, H4, H4, ws2)
+  torch.cuda.synchronize()
+  assert torch.equal(dx2, dx)
