@@ -6,7 +6,7 @@ tag=${1:-prof}
 out=$R/gpurun_out/$tag
 rm -rf $out $R/gpurun_out/pmc; mkdir -p $out
 cd $R
-timeout -k 10 400 python bench.py --steps 100 --warmup 20 --skip-other-configs > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
+timeout -k 10 400 python bench.py --steps 100 --warmup 20 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
 bash scripts/dev/step_prof.sh $tag/sprof > $out/step_prof.log 2>&1; tail -3 $out/step_prof.log
 bash scripts/dev/pmc.sh > $out/pmc.log 2>&1; tail -5 $out/pmc.log
 python3 scripts/dev/pmc_report.py $R/gpurun_out/pmc > $out/pmc.txt 2>&1; tail -3 $out/pmc.txt
