@@ -672,10 +672,18 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
 // over through global memory (~1-2 us of store->load latency per phase, and an L2 round trip per
 // MFMA operand); here h, fc1/kernel, the packed head matrix and every intermediate live in LDS, so a
 // phase costs LDS latency only.  Gradients and predictions are written straight to their outputs.
-constexpr int HL_NMAX = 32, HL_DMAX = 128, HL_OMAX = 32;
-constexpr int HL_WP = HL_DMAX + 16;     // row pitch of fc1/kernel: q-th k-row starts 16 banks further
-constexpr int HL_RP = HL_DMAX + 1;      // row pitch of the [n][..] activations: rows on different banks
-constexpr int HL_LDS_FLOATS = HL_DMAX * HL_WP + 3 * HL_NMAX * HL_RP + HL_OMAX * HL_RP + 3 * HL_NMAX * (HL_OMAX + 1);
+// Row pitches of the LDS arrays.  Every array is an MFMA operand in two roles: "row-strided" (lane (r, q) reads element
+// [r][k0 + q]: bank r * P + q) and "k-strided" ([k0 + q][r]: bank q * P + r); ds_read_b32 serves 32 lanes (r = 0..15, q = 0..1)
+// per cycle over 32 banks.  P = 146 = 18 (mod 32): r * 18 takes 16 distinct even banks (row-strided: conflict free) and
+// q * 18 + r overlaps in 2 of 32 lanes only (k-strided: 1.06 cycles instead of 1).  Round 2's pitches (129 for the
+// activations: 2-way in both roles; 144 for fc1/kernel: conflict free k-strided but 8-way row-strided in the d(h) product)
+// made this one-workgroup kernel LDS-bandwidth bound: PMC 53 % conflict cycles, 2 b32 reads per MFMA.
+constexpr int HL_NMAX = 32, HL_DMAX = 128, HL_OMAX = 24;
+constexpr int HL_WP = 146;              // fc1/kernel [h][f]
+constexpr int HL_RP = 146;              // [n][..] activations and the packed head matrix [o][f]
+constexpr int HL_OP = 33;               // predictions / targets [n][o] (element-wise use only)
+constexpr int HL_OPD = 50;              // d(loss)/d(pred) [n][o]: MFMA operand in both roles (18 mod 32)
+constexpr int HL_LDS_FLOATS = HL_DMAX * HL_WP + 3 * HL_NMAX * HL_RP + HL_OMAX * HL_RP + 2 * HL_NMAX * HL_OP + HL_NMAX * HL_OPD;
 
 __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams p) {
   const int tid = threadIdx.x, NT = 1024;
@@ -687,9 +695,9 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
   float* sA1 = sH + HL_NMAX * HL_RP;             // [N][HL_RP]   relu(fc1)
   float* sDA = sA1 + HL_NMAX * HL_RP;            // [N][HL_RP]   d(loss)/d(fc1 pre-activation)
   float* sWh = sDA + HL_NMAX * HL_RP;            // [OT][HL_RP]  head kernels side by side, transposed
-  float* sPr = sWh + HL_OMAX * HL_RP;            // [N][HL_OMAX + 1] predictions
-  float* sDp = sPr + HL_NMAX * (HL_OMAX + 1);    // [N][HL_OMAX + 1] d(loss)/d(pred)
-  constexpr int OP = HL_OMAX + 1;
+  float* sPr = sWh + HL_OMAX * HL_RP;            // [N][OP] predictions
+  float* sDp = sPr + HL_NMAX * HL_OP;            // [N][OPD] d(loss)/d(pred)
+  constexpr int OP = HL_OP, OPD = HL_OPD;
   __shared__ float s_red[16][GEECO_MAX_HEADS];
   __shared__ float s_hb[32], s_b1[HL_DMAX];
   __shared__ int s_hd[32], s_hc[32];
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
 #else
 #define HSTAMP(i)
 #endif
-  float* sTg = sDp + HL_NMAX * (HL_OMAX + 1);    // [N][HL_OMAX + 1] targets (kind 1: the label in the head's first column)
+  float* sTg = sDp + HL_NMAX * HL_OPD;           // [N][OP] targets (kind 1: the label in the head's first column)
   HSTAMP(0);
   // P0: every global input is fetched up front (independent loads, issued together), then one barrier
   auto head_of = [&](int o) {
@@ -728,7 +736,12 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int e4 = tid + NT * i;
-      if (e4 < H * F4) *reinterpret_cast<f32x4*>(sW1 + (e4 / F4) * HL_WP + (e4 % F4) * 4) = wv[i];
+      if (e4 < H * F4) {      // the row pitch is even, not a multiple of 4 floats: two 8-byte stores
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2* d = reinterpret_cast<f32x2*>(sW1 + (e4 / F4) * HL_WP + (e4 % F4) * 4);
+        d[0] = f32x2{wv[i].x, wv[i].y};
+        d[1] = f32x2{wv[i].z, wv[i].w};
+      }
     }
     if (tid < (N * H >> 2)) {
       const int e = tid * 4;
@@ -774,10 +787,10 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
         M = N; Nn = OT; K = F; a = oA1; a_rs = HL_RP; a_ks = 1; b = oWh; b_ks = 1; b_cs = HL_RP; c = oPr; c_rs = OP; c_cs = 1;
         break;
       case 2:   // d(a1) = dpred Wh^T (ReluGrad applied after the loop body)
-        M = N; Nn = F; K = OT; a = oDp; a_rs = OP; a_ks = 1; b = oWh; b_ks = HL_RP; b_cs = 1; c = oDA; c_rs = HL_RP; c_cs = 1;
+        M = N; Nn = F; K = OT; a = oDp; a_rs = OPD; a_ks = 1; b = oWh; b_ks = HL_RP; b_cs = 1; c = oDA; c_rs = HL_RP; c_cs = 1;
         break;
       case 3:   // head kernel gradients [f][o] = a1^T dpred, into the (now free) packed head matrix as [o][f]
-        M = F; Nn = OT; K = N; a = oA1; a_rs = 1; a_ks = HL_RP; b = oDp; b_ks = OP; b_cs = 1; c = oWh; c_rs = 1; c_cs = HL_RP;
+        M = F; Nn = OT; K = N; a = oA1; a_rs = 1; a_ks = HL_RP; b = oDp; b_ks = OPD; b_cs = 1; c = oWh; c_rs = 1; c_cs = HL_RP;
         break;
       case 4:   // d(h) = d(a1) W1^T
         M = N; Nn = H; K = F; a = oDA; a_rs = HL_RP; a_ks = 1; b = oW1; b_ks = 1; b_cs = HL_WP; gc = p.dh; c_rs = H; c_cs = 1;
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
       const float invn = 1.f / N;
       for (int n = tid; n < N; n += NT) {
         const float* pr = sPr + n * OP;
-        float* dp = sDp + n * OP;
+        float* dp = sDp + n * OPD;
 #pragma unroll 1
         for (int hd = 0; hd < p.nheads; ++hd) {
           const int sz = sel5(p.size, hd), of = sel5(p.off, hd);
@@ -910,7 +923,7 @@ __global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams 
       }
       for (int o = tid; o < OT; o += NT) {
         float sum = 0.f;
-        for (int n = 0; n < N; ++n) sum += sDp[n * OP + o];
+        for (int n = 0; n < N; ++n) sum += sDp[n * OPD + o];
         sel5(p.dhb, s_hd[o])[s_hc[o]] = sum;
       }
       __syncthreads();
@@ -969,7 +982,7 @@ extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, cons
   p.OT = off;
   p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
   static const int no_lds = geeco_dev_getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
-  if (!no_lds && N <= HL_NMAX && H == HL_DMAX && Hfc == HL_DMAX) {
+  if (!no_lds && N <= HL_NMAX && H == HL_DMAX && Hfc == HL_DMAX && off <= HL_OMAX) {
     const size_t lds = (size_t)HL_LDS_FLOATS * 4;
     static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
     if (!attr_set) {
