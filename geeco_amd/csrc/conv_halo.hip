@@ -2298,6 +2298,11 @@ struct Conv1FwdParams {
   int N, H, W, tiles_x, tiles_y, relu, Wp, Hp, w_cin;
 };
 
+// PACK3 (RGB, w_cin == 3): the 27 real (tap, channel) products are packed into 7 MFMA k-steps (k = 3 tap + c = 4 s + q)
+// instead of 9 steps of (R, G, B, pad): 14 MFMAs and 7 fragment reads per 16-pixel strip instead of 18 / 9.  The dropped
+// terms are exact zeros (pad channel x zero weight), added in the same order before: y is bitwise unchanged.  The kernel
+// is issue bound, not only HBM bound (PMC: MFMA busy 51 %, 61 % of the wave time issuing), so the MFMAs saved show.
+template <bool PACK3>
 __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParams p) {
   // Persistent blocks: a block keeps the kernel fragments and bias of its encoder in registers and walks the
   // tiles t = blockIdx.x, + gridDim.x, ...; the next tile's halo is fetched into registers before the current
@@ -2318,11 +2323,26 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
   const float* xg0 = p.x + (long long)g * p.gs_x;
   // kernel fragments: lane (r = co, q = channel) of tap tp, co tile i
   const float* wg = p.w + (long long)g * p.gs_w;
-  float wf[9][2];
+  constexpr int NS = PACK3 ? 7 : 9;
+  float wf[NS][2];
+  int xo[NS];          // float offset of the lane's x operand of step s inside a strip's halo window (without the pixel r)
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+  for (int s = 0; s < NS; ++s) {
+    if (PACK3) {
+      const int kk = 4 * s + q;                    // = 3 tap + c
+      const bool v = kk < 27;
+      const int tap = v ? kk / 3 : 0, c = v ? kk - tap * 3 : 0;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      xo[s] = ((ky * HW_ + kx) << 2) + c;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) wf[tp][i] = q < p.w_cin ? wg[(tp * p.w_cin + q) * 32 + i * 16 + r] : 0.f;
+      for (int i = 0; i < 2; ++i) wf[s][i] = v ? wg[kk * 32 + i * 16 + r] : 0.f;      // w [9][3][32]
+    } else {
+      const int ky = s / 3, kx = s - ky * 3;
+      xo[s] = ((ky * HW_ + kx) << 2) + q;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[s][i] = q < p.w_cin ? wg[(s * p.w_cin + q) * 32 + i * 16 + r] : 0.f;
+    }
+  }
   f32x4 bias_r[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + i * 16 + 4 * q);
@@ -2368,17 +2388,19 @@ __global__ __launch_bounds__(256) void conv1_halo_fwd_kernel(const Conv1FwdParam
     // contiguous in NHWC memory: it is transposed through LDS so that each store instruction writes 1 KB
     // of consecutive bytes (lane l -> pixel l / 8 (+8), channel quad l % 8) instead of 16 separate 64 B pieces.
     unsigned myword = 0;
+    const float* xt[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) xt[s] = &sX[buf][((2 * wid * HW_ + r) << 2) + xo[s]];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int oyl = 2 * wid + (st >> 1), oxl0 = 16 * (st & 1);
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      const float* base = &sX[buf][((oyl * HW_ + oxl0 + r) << 2) + q];
+      // operand address = (per-lane part, formed once per tile) + (strip part: a compile-time immediate)
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int ky = tp / 3, kx = tp - ky * 3;
-        const float xv = base[(ky * HW_ + kx) << 2];
+      for (int s = 0; s < NS; ++s) {
+        const float xv = xt[s][(((st >> 1) * HW_ + 16 * (st & 1)) << 2)];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tp][i], xv, acc[i], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i], xv, acc[i], 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -2535,7 +2557,11 @@ static int launch_conv1_fwd(const float* x, const float* w, const float* b, floa
   static const int bpg = geeco_dev_getenv("GEECO_C1_BLOCKS") ? atoi(geeco_dev_getenv("GEECO_C1_BLOCKS")) : 768;   // blocks per encoder (256..2048 within 5 %)
   dim3 grid((unsigned)(ntiles < bpg ? ntiles : bpg), (unsigned)groups);
   geeco_note_kernel("conv1_halo_fwd_kernel");
-  hipLaunchKernelGGL(conv1_halo_fwd_kernel, grid, dim3(256), 0, stream, p);
+  static const int no_pack = geeco_dev_getenv("GEECO_C1_NO_PACK3") ? 1 : 0;
+  if (w_cin == 3 && !no_pack)
+    hipLaunchKernelGGL(conv1_halo_fwd_kernel<true>, grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(conv1_halo_fwd_kernel<false>, grid, dim3(256), 0, stream, p);
   GEECO_LAUNCH_CHECK();
   return 0;
 }
