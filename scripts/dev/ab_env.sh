@@ -11,9 +11,9 @@ import json, sys
 d = json.loads(open('gpurun_out/ab/b.json').read().strip().splitlines()[-1])
 rows = {(r['layer'], r['op']): r['us'] for r in d['layers']}
 hb = [r for r in d['hbm'] if r['piece'].startswith('goal inputs as in the step')]
-print('[%s] %.0f frames/s  step median %.4f ms  conv1 fwd %.1f us  conv2 fwd %.1f  fused bottom %.1f  input stage %s us' % (
+print('[%s] %.0f frames/s  step median %.4f ms  conv1 fwd %.1f us  conv2 fwd %.1f  fused bottom %.1f  input stage %s us  wgrad conv3..6 %s' % (
     sys.argv[1], d['value'], d['step_ms']['median'], rows[('conv1', 'fwd')], rows[('conv2', 'fwd')], rows[('conv2', 'dgrad+conv1_wgrad')],
-    hb[0]['us'] if hb else '-'))
+    hb[0]['us'] if hb else '-', [rows[('conv%d' % l, 'wgrad')] for l in (3, 4, 5, 6)]))
 PY
 done
 done
