@@ -38,6 +38,8 @@ class SlabReduce(Structure):
 SIGNATURES = {
     'geeco_abi_version': (_I, []),
     'geeco_last_error': (c_char_p, []),
+    'geeco_set_reserved_cus': (_I, [_I]),
+    'geeco_reserved_cus': (_I, []),
     'geeco_debug_kernel_trace_begin': (None, []),
     'geeco_debug_kernel_trace_end': (c_char_p, []),
     'geeco_dynimg_alpha': (None, [_I, _P]),

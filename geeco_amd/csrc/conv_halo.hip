@@ -1110,14 +1110,18 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
 void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
                                long long KC, int Cout, int groups, hipStream_t s);
 
-static int halo_wgrad_S(int groups) {
-  int S = 256 / groups;
+// Persistent one-block-per-CU kernels of the encoder bottom (conv2's filter gradient, the fused conv2-dgrad + conv1-wgrad):
+// slices per encoder.  geeco_set_reserved_cus(k) leaves k CUs free for a collective that runs beside them (data parallel:
+// the early gradient bucket is reduced while these two kernels run; a grid that occupies every CU would make the
+// collective's workgroups wait for - or delay - the persistent blocks).  The workspace is sized for k = 0.
+static int halo_wgrad_S(int groups, bool for_ws = false) {
+  int S = (256 - (for_ws ? 0 : geeco_reserved_cus())) / groups;
   return S < 1 ? 1 : S;
 }
 
 int64_t geeco_halo_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
   if (stride == 2 && Cin == 32 && Cout == 48 && H % 2 == 0 && W % 2 == 0)
-    return (int64_t)groups * halo_wgrad_S(groups) * (9ll * Cin * Cout + Cout) * 4;
+    return (int64_t)groups * halo_wgrad_S(groups, true) * (9ll * Cin * Cout + Cout) * 4;
   return 0;
 }
 
@@ -2114,13 +2118,13 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   }
 }
 
-static int fused_bottom_S(int groups) {
-  int S = 256 / groups;
+static int fused_bottom_S(int groups, bool for_ws = false) {
+  int S = (256 - (for_ws ? 0 : geeco_reserved_cus())) / groups;
   return S < 1 ? 1 : S;
 }
 
 extern "C" int64_t geeco_conv2_dgrad_conv1_wgrad_ws_bytes(int groups) {
-  return (int64_t)groups * fused_bottom_S(groups) * (9 * 4 * 32 + 32) * 4;
+  return (int64_t)groups * fused_bottom_S(groups, true) * (9 * 4 * 32 + 32) * 4;
 }
 
 template <int CREAL, bool BITS>

@@ -1,4 +1,5 @@
 #include "geeco_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,6 +19,17 @@ const char* geeco_dev_getenv(const char* name) {
   }();
   return dev ? getenv(name) : nullptr;
 }
+
+static std::atomic<int> g_reserved_cus{0};
+extern "C" int geeco_set_reserved_cus(int k) {
+  if (k < 0 || k > 128) {
+    geeco_set_error("set_reserved_cus: %d outside 0..128", k);
+    return GEECO_EINVAL;
+  }
+  g_reserved_cus = k;
+  return 0;
+}
+extern "C" int geeco_reserved_cus(void) { return g_reserved_cus.load(); }
 
 extern "C" const char* geeco_last_error(void) { return g_err; }
 extern "C" int geeco_abi_version(void) { return GEECO_ABI_VERSION; }

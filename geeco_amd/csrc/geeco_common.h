@@ -19,6 +19,9 @@ void geeco_set_pending_reduce(geeco_slab_reduce* p);
 // GEECO_DEV=1 is set; a production process ignores every GEECO_* variable and always runs the measured-best path.
 const char* geeco_dev_getenv(const char* name);
 
+// CUs the persistent bottom-of-the-backward kernels leave free (geeco_set_reserved_cus; 0 by default)
+extern "C" int geeco_reserved_cus(void);
+
 #define GEECO_CHECK_ARG(cond, ...)              \
   do {                                          \
     if (!(cond)) {                              \

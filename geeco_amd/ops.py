@@ -43,6 +43,15 @@ def _iarr(vals):
   return arr
 
 
+def set_reserved_cus(k: int):
+  """CUs the persistent bottom-of-the-backward kernels leave free for a collective running beside them (0 = none)."""
+  check(_lib().geeco_set_reserved_cus(int(k)), 'geeco_set_reserved_cus')
+
+
+def reserved_cus() -> int:
+  return int(_lib().geeco_reserved_cus())
+
+
 def same_out(size: int, stride: int) -> int:
   return -(-size // stride)
 

@@ -32,6 +32,14 @@ extern "C" {
 int geeco_abi_version(void);
 const char* geeco_last_error(void);
 
+/* Data parallel: the two persistent one-block-per-CU kernels at the bottom of the backward (conv2's filter gradient,
+ * geeco_conv2_dgrad_conv1_wgrad*) normally occupy every CU; the early gradient bucket is all-reduced while they run.
+ * geeco_set_reserved_cus(k), 0 <= k <= 128, makes their FUTURE launches leave k CUs free for the collective's workgroups
+ * (process-wide; takes effect at the next launch, so a captured hipGraph keeps the grid it was captured with; workspaces
+ * are sized for k = 0 and fit any k).  Default 0.  The reference has no counterpart (no distributed code: SURVEY.md 2). */
+int geeco_set_reserved_cus(int k);
+int geeco_reserved_cus(void);
+
 /* Diagnostics (bench.py's per-layer table): between _begin and _end on one host thread every
  * conv entry point records the names of the kernels it dispatched; _end returns them ';'-separated
  * (thread-local buffer, valid until the next _begin on that thread). */

@@ -69,5 +69,6 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   d = json.loads(line[0])
   assert d['n_gpus'] == 2 and 'REHEARSAL' in d['data'] and len(d['ranks']['ms_per_step']) == 2 and d['ranks']['distinct_devices'] == 1
   c = d['comm']
-  assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'no_exchange'} and all(v > 0 for v in c['step_ms'].values())
+  assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'no_exchange', 'overlap_reserve16'}
+  assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c
   assert c['buckets']['early_allreduce_calls'] == 1 and c['buckets']['late_written_in_place']

@@ -758,3 +758,46 @@ def test_lstm_step_bwd_one_launch(dev, N, chs, J):
   ops.lstm_step_bwd_into(dw[:D], db, dx2, x, dz, wx, N, D, H4, H4, ws2)
   torch.cuda.synchronize()
   assert torch.equal(dx2, dx)
+
+
+def test_reserved_cus_shrink_the_persistent_bottom_kernels(dev):
+  """geeco_set_reserved_cus(k): conv2's filter gradient and the fused bottom launch (256 - k) / groups blocks per encoder
+  (the workspace is sized for k = 0); results equal the k = 0 launches to fp32 summation-order differences (other slab
+  partition), and the setting is process-wide until reset."""
+  from geeco_amd import ops
+  G, N, H, W = 3, 4, 32, 128
+  r = np.random.default_rng(83)
+  y1 = torch.tensor(r.standard_normal([G, N, H, W, 32]).astype(np.float32), device=dev)
+  x4 = torch.tensor(r.standard_normal([G, N, H, W, 4]).astype(np.float32), device=dev)
+  x4[..., 3] = 0
+  dz2 = torch.tensor(r.standard_normal([G, N, H // 2, W // 2, 48]).astype(np.float32), device=dev)
+  w2 = torch.tensor((r.standard_normal([G, 3, 3, 32, 48]) / 17).astype(np.float32), device=dev)
+  wsf = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, device=dev)
+  wsw = torch.empty(ops.conv3x3_wgrad_ws_bytes(G, N, H, W, 32, 48, 2) // 4 + 4, device=dev)
+
+  def run():
+    dw1 = torch.full((G, 9, 3, 32), float('nan'), device=dev)
+    db1 = torch.full((G, 32), float('nan'), device=dev)
+    ops.conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x4, G, dz2[0].numel(), w2[0].numel(), y1[0].numel(), x4[0].numel(),
+                                     dw1[0].numel(), 32, N, H, W, wsf, real_channels=3)
+    dw2 = torch.full((G, 9 * 32 * 48), float('nan'), device=dev)
+    db2 = torch.full((G, 48), float('nan'), device=dev)
+    ops.conv3x3_wgrad_into(dw2, db2, y1, dz2, G, y1[0].numel(), dz2[0].numel(), dw2[0].numel(), 48, N, H, W, 32, 48, 2, wsw)
+    torch.cuda.synchronize()
+    return dw1, db1, dw2, db2
+
+  assert ops.reserved_cus() == 0
+  ref = run()
+  ops.set_reserved_cus(16)
+  try:
+    assert ops.reserved_cus() == 16
+    got = run()
+  finally:
+    ops.set_reserved_cus(0)
+  scale = np.sqrt(N * H * W)
+  for a, b, what in zip(got, ref, ('dw1', 'db1', 'dw2', 'db2')):
+    assert not torch.isnan(a).any()
+    _close(a, b.double(), 2e-5, 2e-5 * scale, what + ' with 16 CUs reserved')
+  assert torch.equal(run()[0], ref[0])            # back to the k = 0 partition: bitwise as before
+  with pytest.raises(Exception):
+    ops.set_reserved_cus(500)
