@@ -226,7 +226,11 @@ class ConvEncoderStack:
     """Data parallel (runtime.TrainStepRunner): the gradients of conv1 / conv2 -- the LATE bucket, written by the last
     launches of the backward -- go straight into ``staging`` (encoder g's block at g * len, same inner layout as the
     arena) instead of the gradient arena, so that the arena is not written while the early bucket is being reduced.
-    Returns False (nothing changed) if the late ranges are not the uniformly strided conv1 / conv2 blocks."""
+    Returns False if the late ranges are not the uniformly strided conv1 / conv2 blocks, or when called with
+    ``staging=None``, which ends a redirection (the gradients go to the arena again)."""
+    self.late = None
+    if staging is None:
+      return False
     off = self.store.offsets
     lo0 = off[self.scopes[0] + '/conv1/kernel']
     length = off[self.scopes[0] + '/conv%d/kernel' % (ConvEncoderStack.SPLIT + 1)] - lo0

@@ -91,6 +91,8 @@ class TrainStepRunner:
       # over the span of its ranges: the late variables' slots inside that span are dead (zero) until part 3 unpacks.
       redirect = getattr(model, 'redirect_late_gradients', None)
       self.redirected = bool(redirect and redirect(self.staging, self.late))
+    elif getattr(model, 'redirect_late_gradients', None):
+      model.redirect_late_gradients(None, None)           # a model that an earlier data-parallel runner had redirected
     if self.redirected and self.early:
       lo = min(off for off, _ in self.early)
       hi = max(off + n for off, n in self.early)

@@ -279,6 +279,11 @@ def test_bottom_backward_writes_only_the_late_bucket(dev):
     if redirect:
       assert torch.equal(before.view(torch.int32), after.view(torch.int32))        # the arena was not written at all
       outs.append(staging.clone())
+      # ending the redirection (what a later single-process runner on the same model does): the arena gets them again
+      assert model.redirect_late_gradients(None, None) is False
+      model.backward(part='bottom')
+      torch.cuda.synchronize()
+      assert torch.equal(torch.cat([model.store.grads[off:off + n] for off, n in late]), outs[-1])
     else:
       outs.append(torch.cat([after[off:off + n] for off, n in late]))
   assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])
