@@ -14,6 +14,10 @@ hb = [r for r in d['hbm'] if r['piece'].startswith('goal inputs as in the step')
 print('[%s] %.0f frames/s  step median %.4f ms  conv1 fwd %.1f us  conv2 fwd %.1f  fused bottom %.1f  input stage %s us  wgrad conv3..6 %s' % (
     sys.argv[1], d['value'], d['step_ms']['median'], rows[('conv1', 'fwd')], rows[('conv2', 'fwd')], rows[('conv2', 'dgrad+conv1_wgrad')],
     hb[0]['us'] if hb else '-', [rows[('conv%d' % l, 'wgrad')] for l in (3, 4, 5, 6)]))
+import os
+extra = os.environ.get('AB_ROWS', '').split()      # AB_ROWS="conv6:dgrad conv6:wgrad": further rows of the layer table
+if extra:
+  print('    ' + '  '.join('%s %.1f' % (e, rows[tuple(e.split(':'))]) for e in extra))
 PY
 done
 done
