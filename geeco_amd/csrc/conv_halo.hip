@@ -878,14 +878,16 @@ struct HaloWgradParams {
   int N, H, W, Ho, Wo;
   int tiles_x, tiles_y;
   int tiles_per_group;
-  int S;                     // blocks (slabs) per group
+  int S;                     // slabs per group (S0, + 1 with the remainder block)
+  int S0, per, groups;       // block b < S0 * groups: group b / S0, tiles [per * (b % S0), + per); block S0 * groups (if
+                             // launched): the remainder [S0 * per, tiles_per_group) of EVERY group, one after the other
 };
 
 #ifdef GEECO_STAMPS
 #define WSTAMP(i)                                                                                        \
   do {                                                                                                   \
-    if (lane == 0 && (wid & 3) == 0 && wid < 8 && blockIdx.y == 0 && p.stamps && (i) < 64)               \
-      p.stamps[((long long)blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();      \
+    if (lane == 0 && (wid & 3) == 0 && wid < 8 && g == 0 && p.stamps && (i) < 64)                        \
+      p.stamps[((long long)split * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();           \
   } while (0)
 #else
 #define WSTAMP(i)
@@ -927,12 +929,18 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int strip = wid & 3, cit = wid >> 2;
-  const int g = blockIdx.y, split = blockIdx.x;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-  const int per = (p.tiles_per_group + p.S - 1) / p.S;
-  int tile = split * per;
-  const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
+  // Regular blocks own `per` tiles of one encoder; the remainder block (at most one per launch) walks the tiles the
+  // regular blocks of every encoder leave over - one segment, one slab per encoder (bottom_slices() below).
+  const int nreg = p.S0 * p.groups;
+  const bool regular = (int)blockIdx.x < nreg;
+  const int nseg = regular ? 1 : p.groups;
+#pragma unroll 1
+  for (int seg = 0; seg < nseg; ++seg) {
+  const int g = regular ? (int)blockIdx.x / p.S0 : seg;
+  const int split = regular ? (int)blockIdx.x - g * p.S0 : p.S0;
+  int tile = regular ? split * p.per : p.S0 * p.per;
+  const int tend = regular && tile + p.per < p.tiles_per_group ? tile + p.per : p.tiles_per_group;
   const long long slab = 9ll * CIN * COUT + COUT;
   float* part = p.part + ((long long)g * p.S + split) * slab;
 
@@ -1105,6 +1113,8 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
     for (int px = 0; px < TH * TW; ++px) s1 += zf[px * COUT + tid];
     part[9ll * CIN * COUT + tid] = s1;
   }
+  __syncthreads();     // the next segment stages into the images this one's sums were just read from
+  }
 }
 
 void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long long gs_dw, long long gs_db, int S,
@@ -1114,14 +1124,34 @@ void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long lon
 // slices per encoder.  geeco_set_reserved_cus(k) leaves k CUs free for a collective that runs beside them (data parallel:
 // the early gradient bucket is reduced while these two kernels run; a grid that occupies every CU would make the
 // collective's workgroups wait for - or delay - the persistent blocks).  The workspace is sized for k = 0.
-static int halo_wgrad_S(int groups, bool for_ws = false) {
-  int S = (256 - (for_ws ? 0 : geeco_reserved_cus())) / groups;
-  return S < 1 ? 1 : S;
+struct BottomSlices {
+  int S0, per, S, blocks;
+};
+// S0 = CUs / groups regular blocks per encoder.  When that leaves CUs over (three encoders on 256 CUs: one) and the tiles
+// the regular blocks leave over (T mod S0 per encoder) fit ONE more block of the same length, that block takes them:
+// bench shape, fused bottom: 85 x 49 tiles with the last two blocks short or empty and the 256th CU idle becomes
+// 85 x 48 + 1 x (3 x 16); conv2's filter gradient 97 -> 96 tiles per block.  Otherwise ceil(T / S0) tiles per block.
+static BottomSlices bottom_slices(int groups, long long T, bool for_ws = false) {
+  static const int no_rem = geeco_dev_getenv("GEECO_NO_REMAINDER_BLOCK") ? 1 : 0;
+  const int cus = 256 - (for_ws ? 0 : geeco_reserved_cus());
+  BottomSlices b;
+  b.S0 = cus / groups < 1 ? 1 : cus / groups;
+  const long long fl = T / b.S0, rem = T - fl * b.S0;
+  if (for_ws) {                       // upper bound over all T
+    b.per = 0; b.S = b.S0 + 1; b.blocks = b.S0 * groups + 1;
+    return b;
+  }
+  if (!no_rem && rem > 0 && fl >= 1 && cus - b.S0 * groups >= 1 && rem * groups <= fl) {
+    b.per = (int)fl; b.S = b.S0 + 1; b.blocks = b.S0 * groups + 1;
+  } else {
+    b.per = (int)((T + b.S0 - 1) / b.S0); b.S = b.S0; b.blocks = b.S0 * groups;
+  }
+  return b;
 }
 
 int64_t geeco_halo_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
   if (stride == 2 && Cin == 32 && Cout == 48 && H % 2 == 0 && W % 2 == 0)
-    return (int64_t)groups * halo_wgrad_S(groups, true) * (9ll * Cin * Cout + Cout) * 4;
+    return (int64_t)groups * bottom_slices(groups, 0, true).S * (9ll * Cin * Cout + Cout) * 4;
   return 0;
 }
 
@@ -1137,7 +1167,8 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
     p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
     p.tiles_x = cdiv(p.Wo, 16); p.tiles_y = cdiv(p.Ho, 4);
     p.tiles_per_group = N * p.tiles_x * p.tiles_y;
-    p.S = halo_wgrad_S(groups);
+    const BottomSlices bs = bottom_slices(groups, p.tiles_per_group);
+    p.S = bs.S; p.S0 = bs.S0; p.per = bs.per; p.groups = groups;
 #ifdef GEECO_STAMPS
     if (!g_hstamps) (void)hipMalloc(&g_hstamps, 256 * 2 * 64 * 8);
     (void)hipMemset(g_hstamps, 0, 256 * 2 * 64 * 8);
@@ -1157,8 +1188,7 @@ int geeco_try_halo_wgrad(const float* x, const float* dz, float* dw, float* db, 
       attr_set = true;
     }
     geeco_note_kernel("conv_s2_halo_wgrad_kernel<32, 48>");
-    hipLaunchKernelGGL((conv_s2_halo_wgrad_kernel<32, 48>), dim3((unsigned)p.S, (unsigned)groups), dim3(512), lds,
-                       stream, p);
+    hipLaunchKernelGGL((conv_s2_halo_wgrad_kernel<32, 48>), dim3((unsigned)bs.blocks), dim3(512), lds, stream, p);
     GEECO_LAUNCH_CHECK();
     geeco_launch_wgrad_reduce((const float*)ws, dw, db, gs_dw, gs_db, p.S, 9ll * Cin * Cout, Cout, groups, stream);
     GEECO_LAUNCH_CHECK();
@@ -1648,6 +1678,7 @@ struct FusedBottomParams {
   long long gs_dz, gs_w, gs_y, gs_x;
   int N, H, W, Ho, Wo;
   int tiles_x, tiles_y, tiles_per_group, S;
+  int S0, per, groups;          // slicing as HaloWgradParams (bottom_slices())
   unsigned long long* stamps;   // -DGEECO_STAMPS builds only (scripts/dev/fused_stamps.py)
 };
 
@@ -1672,8 +1703,8 @@ constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 
 #ifdef GEECO_STAMPS
 #define FSTAMP(i)                                                                                        \
   do {                                                                                                   \
-    if (lane == 0 && (wid & 3) == 0 && blockIdx.y == 0 && p.stamps && (i) < 64)                          \
-      p.stamps[((long long)blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();      \
+    if (lane == 0 && (wid & 3) == 0 && g == 0 && p.stamps && (i) < 64)                                   \
+      p.stamps[((long long)split * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime();           \
   } while (0)
 #else
 #define FSTAMP(i)
@@ -1727,12 +1758,17 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int row = wid & 3, half = wid >> 2;
-  const int g = blockIdx.y, split = blockIdx.x;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-  const int per = (p.tiles_per_group + p.S - 1) / p.S;
-  int tile = split * per;
-  const int tend = tile + per < p.tiles_per_group ? tile + per : p.tiles_per_group;
+  // regular blocks: `per` tiles of one encoder; the remainder block: what they leave over, encoder after encoder
+  const int nreg = p.S0 * p.groups;
+  const bool regular = (int)blockIdx.x < nreg;
+  const int nseg = regular ? 1 : p.groups;
+#pragma unroll 1
+  for (int seg = 0; seg < nseg; ++seg) {
+  const int g = regular ? (int)blockIdx.x / p.S0 : seg;
+  const int split = regular ? (int)blockIdx.x - g * p.S0 : p.S0;
+  int tile = regular ? split * p.per : p.S0 * p.per;
+  const int tend = regular && tile + p.per < p.tiles_per_group ? tile + p.per : p.tiles_per_group;
   const long long slab = 9 * CREAL * 32 + 32;       // [tap][real channel][32] + bias
   float* part = p.part + ((long long)g * p.S + split) * slab;
   int n, ty, tx;
@@ -2116,15 +2152,12 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     for (int w = 0; w < 8; ++w) s1 += sD[w * 32 + tid];
     part[NCOL * 32 + tid] = s1;
   }
-}
-
-static int fused_bottom_S(int groups, bool for_ws = false) {
-  int S = (256 - (for_ws ? 0 : geeco_reserved_cus())) / groups;
-  return S < 1 ? 1 : S;
+  __syncthreads();     // the next segment stages into the area this one's sums were just read from
+  }
 }
 
 extern "C" int64_t geeco_conv2_dgrad_conv1_wgrad_ws_bytes(int groups) {
-  return (int64_t)groups * fused_bottom_S(groups, true) * (9 * 4 * 32 + 32) * 4;
+  return (int64_t)groups * bottom_slices(groups, 0, true).S * (9 * 4 * 32 + 32) * 4;
 }
 
 template <int CREAL, bool BITS>
@@ -2150,7 +2183,8 @@ static int fused_bottom_impl(const float* dz2, const float* w2, const float* y1,
   p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2;
   p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
   p.tiles_per_group = N * p.tiles_x * p.tiles_y;
-  p.S = fused_bottom_S(groups);
+  const BottomSlices bs = bottom_slices(groups, p.tiles_per_group);
+  p.S = bs.S; p.S0 = bs.S0; p.per = bs.per; p.groups = groups;
   const size_t lds = FB_LDS_BYTES;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
   if (!attr_set) {
@@ -2170,7 +2204,7 @@ static int fused_bottom_impl(const float* dz2, const float* w2, const float* y1,
   p.stamps = g_hstamps;
 #endif
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)p.S, (unsigned)groups);
+  const dim3 grid((unsigned)bs.blocks);
   const bool bits = y1_bits != nullptr;
   geeco_note_kernel("conv2_dgrad_conv1_wgrad_kernel<%d, %s>", real_channels == 3 ? 3 : 4, bits ? "true" : "false");
   if (real_channels == 3 && bits)

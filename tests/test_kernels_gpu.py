@@ -327,7 +327,10 @@ def test_conv3x3_grouped_halo_kernels(dev, Cin, Cout, Nf, Nd):
 # Fused encoder bottom backward (conv2 dgrad + conv1 wgrad, dz1 on chip) vs the oracle's conv1 -> ReLU -> conv2
 # differentiated by autograd in fp64; grouped, ragged tiles (H = 24 -> 3 tile rows, W = 72 -> 2 tile columns, the
 # second one partial) and a block whose tile range crosses an image boundary.
-@pytest.mark.parametrize('G,N,H,W,C', [(1, 2, 16, 64, 3), (3, 3, 24, 72, 3), (2, 40, 32, 64, 3), (2, 3, 24, 72, 4)])
+# (3, 8, 64, 256): 256 tiles per encoder = 85 blocks x 3 + 1: the launch takes the remainder-block form (one more block
+# walks the tile each encoder leaves over: three segments, three slabs)
+@pytest.mark.parametrize('G,N,H,W,C', [(1, 2, 16, 64, 3), (3, 3, 24, 72, 3), (2, 40, 32, 64, 3), (2, 3, 24, 72, 4),
+                                       (3, 8, 64, 256, 3)])
 def test_conv2_dgrad_conv1_wgrad_fused(dev, G, N, H, W, C):
   from geeco_amd import ops
   r = np.random.default_rng(31)
@@ -801,3 +804,40 @@ def test_reserved_cus_shrink_the_persistent_bottom_kernels(dev):
   assert torch.equal(run()[0], ref[0])            # back to the k = 0 partition: bitwise as before
   with pytest.raises(Exception):
     ops.set_reserved_cus(500)
+
+
+def test_conv2_wgrad_remainder_block(dev):
+  """conv2's filter gradient, three encoders, 512 tiles each = 85 blocks x 6 + 2: the 256th block walks the two tiles
+  every encoder leaves over (three segments, slab 85 of each encoder); every encoder's dw / db against the fp64 oracle,
+  and the same with CUs reserved (80 blocks per encoder, no CU over: plain ceil slices)."""
+  from geeco_amd import ops
+  G, Nf, H, W, Cin, Cout, stride = 3, 8, 64, 256, 32, 48, 2
+  Ho, Wo = H // 2, W // 2
+  r = np.random.default_rng(35)
+  x = r.standard_normal([G, Nf, H, W, Cin]).astype(np.float32)
+  dz = r.standard_normal([G, Nf, Ho, Wo, Cout]).astype(np.float32)
+  xd, dzd = torch.tensor(x, device=dev), torch.tensor(dz, device=dev)
+  gs_w, gs_b = 9 * Cin * Cout + 32, Cout + 16
+  ws = torch.empty(ops.conv3x3_wgrad_ws_bytes(G, Nf, H, W, Cin, Cout, stride) // 4 + 4, device=dev)
+  refs = []
+  for g in range(G):
+    wt = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = O.conv2d_same(torch.tensor(x[g], dtype=torch.float64), wt, bt, stride, relu=False)
+    y.backward(torch.tensor(dz[g], dtype=torch.float64))
+    refs.append((wt.grad, bt.grad))
+  scale = np.sqrt(Nf * Ho * Wo)
+  for reserved in (0, 16):
+    ops.set_reserved_cus(reserved)
+    try:
+      dw = torch.full((G, gs_w), float('nan'), device=dev)
+      db = torch.full((G, gs_b), float('nan'), device=dev)
+      names = ops.kernel_trace(lambda: ops.conv3x3_wgrad_into(dw, db, xd, dzd, G, xd[0].numel(), dzd[0].numel(), gs_w, gs_b,
+                                                              Nf, H, W, Cin, Cout, stride, ws))
+      torch.cuda.synchronize()
+    finally:
+      ops.set_reserved_cus(0)
+    assert names and names[0].startswith('conv_s2_halo_wgrad_kernel'), names
+    for g in range(G):
+      _close(dw[g, :9 * Cin * Cout].reshape(3, 3, Cin, Cout), refs[g][0], 2e-5, 2e-5 * scale, 'wgrad, encoder %d' % g)
+      _close(db[g, :Cout], refs[g][1], 2e-5, 2e-5 * scale, 'bias grad, encoder %d' % g)
