@@ -7,10 +7,19 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -amdgpu-mfma-vgpr-form: accumulators stay in VGPRs (unified file on gfx950); without it the allocator parks them in AGPRs in
 # some kernels and pays v_accvgpr_read/write copies, each of which costs MFMA issue time
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
+# per-file scheduler settings (same-box A/B of whole-library variants, per-layer table: profiles/r03/ab_compiler_flags.txt):
+# the gather GEMM gains 2-3 % from the max-ILP strategy (conv4-6 forward), the LDS-halo and LDS-staged input-gradient
+# kernels 0.5-1 % from the AMDGPU register-pressure trackers; every other combination measured was neutral or worse
+extra_flags() {
+  case $1 in
+    conv_gemm) echo "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
+    conv_halo|conv_dgrad_lds) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+  esac
+}
 rm -rf build && mkdir -p build
 pids=()
 for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
-  $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+  $HIPCC $FLAGS $(extra_flags $f) -c $f.hip -o build/$f.o &
   pids+=($!)
 done
 $HIPCC $FLAGS -x hip -c errors.cpp -o build/errors.o &

@@ -8,9 +8,16 @@ cd $ROOT/geeco_amd/csrc
 B=build$SUF
 rm -rf $B && mkdir -p $B
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form $*"
+extra_flags() {      # as geeco_amd/csrc/build.sh; PLAIN=1: none (to A/B the per-file settings themselves)
+  [ -n "${PLAIN:-}" ] && return
+  case $1 in
+    conv_gemm) echo "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
+    conv_halo|conv_dgrad_lds) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+  esac
+}
 pids=()
 for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
-  /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $B/$f.o &
+  /opt/rocm/bin/hipcc $FLAGS $(extra_flags $f) -c $f.hip -o $B/$f.o &
   pids+=($!)
 done
 /opt/rocm/bin/hipcc $FLAGS -x hip -c errors.cpp -o $B/errors.o &
