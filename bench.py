@@ -600,7 +600,7 @@ def main():
       rc = 4
     if comm:
       out['comm'] = comm
-    if world == 1 and not args.skip_layers:
+    if not args.skip_layers:      # rank 0's GPU alone, after the timed region (any N: the per-GPU work is the same)
       samples = max(30, min(args.steps, 50))
       rows = layer_table(model, samples)
       out['roofline'] = dominant_roofline(rows)

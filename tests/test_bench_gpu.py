@@ -72,3 +72,4 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'no_exchange', 'overlap_reserve16'}
   assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c
   assert c['buckets']['early_allreduce_calls'] == 1 and c['buckets']['late_written_in_place']
+  assert d['roofline']['kernel'] and d['roofline']['frac'] > 0 and len(d['layers']) >= 20      # rank 0's table, at any N
