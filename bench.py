@@ -53,6 +53,9 @@ def parse_args():
                   help='N > 1: run the gradient exchange AFTER the backward instead of beside its bottom part (the timed '
                        'region then measures the serial step; comm.step_ms always reports both)')
   ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
+  ap.add_argument('--skip-input-pipeline', action='store_true', help='skip the input_pipeline leg (on-disk dataset -> Estimator.train)')
+  ap.add_argument('--skip-inference', action='store_true', help='skip the inference leg (predictor latency, Estimator.evaluate)')
+  ap.add_argument('--pipeline-episodes', type=int, default=32, help='episode files of the generated on-disk dataset')
   ap.add_argument('--allow-shared-gpu', action='store_true',
                   help='REHEARSAL on a one-GPU box (tests/_dp_launch.py): do not refuse ranks that share a device')
   return ap.parse_args()
@@ -487,6 +490,168 @@ def other_configs(args, dev):
   return out, True
 
 
+# ======================================================================================================
+# real-data legs: on-disk dataset -> reader -> Estimator.train; predictor latency; Estimator.evaluate
+# ======================================================================================================
+DISTINCT_SCENES = 8        # episodes generated (in parallel threads); the rest of the files are byte copies under other names
+
+
+def make_dataset(root, episodes, threads):
+  """``episodes`` episode files of 100 x 256 x 256 frames in the reference's on-disk layout (input_fn.write_synthetic_dataset:
+  toy table-top scenes, zlib level 6 as TFRecordWriter's ZLIB option): DISTINCT_SCENES are generated, the others are byte
+  copies under their own names — every file is inflated, checked, parsed and uploaded on its own (the cache keys on the
+  path), only generating them is shortened."""
+  import shutil
+  from concurrent.futures import ThreadPoolExecutor
+  from geeco_amd import input_fn as I
+  n_gen = min(DISTINCT_SCENES, episodes)
+  parts = os.path.join(root, 'parts')
+  with ThreadPoolExecutor(max_workers=min(threads, n_gen)) as ex:
+    list(ex.map(lambda e: I.write_synthetic_dataset(os.path.join(parts, str(e)), 1, seed=100 + e), range(n_gen)))
+  meta = I.write_synthetic_dataset(root, 0)
+  names = []
+  for e in range(episodes):
+    name = 'ep%05d.tfrecord.zlib' % e
+    src = os.path.join(parts, str(e % n_gen), 'data', 'ep00000.tfrecord.zlib')
+    shutil.copy(src, os.path.join(root, 'data', name))
+    names.append(name)
+  shutil.rmtree(parts)
+  for split, mode, sel in (('default', 'train', names), ('default', 'eval', names), ('warmup', 'train', names[:1])):
+    os.makedirs(os.path.join(root, 'splits', split), exist_ok=True)
+    with open(os.path.join(root, 'splits', split, mode + '.txt'), 'w') as fp:
+      fp.write('\n'.join(sel) + '\n')
+  return meta, [os.path.join(root, 'data', n) for n in names]
+
+
+def input_pipeline_report(args, dev, synthetic_ms_per_step, workdir):
+  """Training from an ON-DISK dataset through the reference's call surface (pickplace_input_fn -> Estimator.train,
+  scripts/train_e2evmc.py:266-291; reader = geeco_gym.py:436-473): reader episodes/s (pure-Python reader, native reader
+  with 1 and ``threads`` threads) and end-to-end frames/s of epoch 1 (every episode inflated, parsed, uploaded) and of
+  epochs 2-3 (episodes resident in HBM: EPISODE_CACHE).  Not the headline: that one keeps its inputs in HBM by definition."""
+  import torch
+  from concurrent.futures import ThreadPoolExecutor
+  from geeco_amd import estimator as est
+  from geeco_amd import input_fn as I
+  from geeco_amd.params import create_e2evmc_config
+  threads, box, usable = host_cores()
+  root = os.path.join(workdir, 'dataset')
+  t0 = time.perf_counter()
+  meta, paths = make_dataset(root, args.pipeline_episodes, threads)
+  gen_s = time.perf_counter() - t0
+  K, B = args.seq_len, args.batch
+  windows = (meta.episode_length - 1) - K + 1
+  frames_per_episode = windows * K
+  log('input_pipeline: %d episode files (%.1f MB each) written in %.1f s' % (len(paths), os.path.getsize(paths[0]) / 1e6, gen_s))
+  out = {'dataset': '%d files x %d frames x %dx%d rgb(uint8 as float list)+depth(float32), zlib; %d distinct scenes, the rest '
+                    'byte copies; %.1f MB per file on disk, %.1f MB inflated' %
+                    (len(paths), meta.episode_length, meta.img_height, meta.img_width, min(DISTINCT_SCENES, len(paths)),
+                     os.path.getsize(paths[0]) / 1e6, 0.0),
+         'frames_per_episode': frames_per_episode, 'host_threads': threads}
+
+  def rate(fn, sel, nthreads):
+    t = time.perf_counter()
+    if nthreads == 1:
+      for p_ in sel:
+        fn(p_)
+    else:
+      with ThreadPoolExecutor(max_workers=nthreads) as ex:
+        list(ex.map(fn, sel))
+    return len(sel) / (time.perf_counter() - t)
+  from geeco_amd import tfrecord as T
+  with T.EpisodeReader(paths[0]) as rd:
+    out['dataset'] = out['dataset'].replace('0.0 MB inflated', '%.1f MB inflated' % (rd.inflated_bytes / 1e6))
+  native = lambda p_: I.load_episode(p_, meta, True, raw_rgb=True, image_keys=('rgb',))
+  native(paths[0])
+  out['reader_episodes_per_s'] = {
+      'python_reader_1_thread (round 3: tfrecord.py + numpy, holds the GIL)': round(rate(lambda p_: I.load_episode_py(p_, meta, True, raw_rgb=True), paths[:2], 1), 2),
+      'native_1_thread': round(rate(native, paths[:4], 1), 2),
+      'native_%d_threads' % threads: round(rate(native, paths, threads), 2)}
+  out['reader_frames_per_s_%d_threads' % threads] = round(out['reader_episodes_per_s']['native_%d_threads' % threads] * frames_per_episode, 1)
+  log('input_pipeline: reader %s' % out['reader_episodes_per_s'])
+
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=K, img_channels=3, batch_size=B))
+  params = {'e2evmc_config': cfg, 'log_steps': 1000, 'debug': False}
+  e = est.Estimator(est.goal_e2evmc_model_fn, os.path.join(workdir, 'model'), est.RunConfig(), params)
+  I.EPISODE_CACHE.clear()
+  kw = dict(window_size=K, fetch_target=True, batch_size=B, num_threads=threads, prefetch_size=4, device=dev, device_keys=('rgb',))
+  # untimed: model build, eager warm-up steps, hipGraph capture (one episode, not cached)
+  e.train(input_fn=lambda: I.pickplace_input_fn(root, 'warmup', 'train', seed=0, cache=False, **kw))
+  epochs = []
+  for ep in range(3):
+    hits0 = I.EPISODE_CACHE.hits
+    e.train(input_fn=lambda: I.pickplace_input_fn(root, 'default', 'train', seed=ep, **kw))
+    st = e.last_train_stats
+    fps = st['steps'] * B * K / st['loop_seconds']
+    epochs.append({'epoch': ep + 1, 'steps': st['steps'], 'seconds': round(st['loop_seconds'], 4), 'frames_per_s': round(fps, 1),
+                   'ms_per_step': round(st['loop_seconds'] / st['steps'] * 1e3, 3),
+                   'episodes_from_hbm_cache': I.EPISODE_CACHE.hits - hits0})
+    log('input_pipeline: epoch %d: %d steps in %.3f s = %.0f frames/s' % (ep + 1, st['steps'], st['loop_seconds'], fps))
+  out['estimator_train'] = {
+      'workload': 'geeco-f rgb 256x256 seq_len=%d batch=%d, Estimator.train(pickplace_input_fn(device=cuda, device_keys=(rgb,), '
+                  'num_threads=%d)); wall time of the input + step loop (checkpoint write excluded)' % (K, B, threads),
+      'epochs': epochs, 'synthetic_ms_per_step': round(synthetic_ms_per_step, 3),
+      'cached_epoch_vs_synthetic': round(synthetic_ms_per_step / epochs[-1]['ms_per_step'], 4),
+      'hbm_cache': {'episodes': len(I.EPISODE_CACHE), 'MB': round(I.EPISODE_CACHE.bytes_in_use / 1e6, 1)}}
+  return out, e, root, kw
+
+
+def inference_report(args, dev, estimator, dataset_root, input_kw, workdir):
+  """Predictor latency (reference predictor.py:148-200: one frame in, one command out, batch 1) and Estimator.evaluate
+  throughput (train_e2evmc.py:290) on the dataset of the input_pipeline leg (episodes resident in HBM)."""
+  import numpy as np
+  import torch
+  from geeco_amd import input_fn as I
+  from geeco_amd import estimator as est
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.predictor import E2EVMCPredictor, GoalE2EVMCPredictor
+  from geeco_amd.variables import VariableStore
+  out = {}
+  K, B = args.seq_len, args.batch
+  if estimator is not None:
+    estimator.evaluate(input_fn=lambda: I.pickplace_input_fn(dataset_root, 'warmup', 'train', seed=0, **input_kw))      # build + capture
+    t = time.perf_counter()
+    res = estimator.evaluate(input_fn=lambda: I.pickplace_input_fn(dataset_root, 'default', 'eval', **input_kw))
+    dt = time.perf_counter() - t
+    windows = args.pipeline_episodes * (100 - 1 - K + 1)
+    out['estimator_evaluate'] = {'workload': 'geeco-f rgb seq_len=%d batch=%d over %d windows (episodes resident in HBM)' % (K, B, windows),
+                                 'seconds': round(dt, 4), 'frames_per_s': round(windows * K / dt, 1),
+                                 'ms_per_batch': round(dt / -(-windows // B) * 1e3, 3), 'loss': round(res['loss'], 6)}
+    log('inference: Estimator.evaluate %.0f frames/s' % out['estimator_evaluate']['frames_per_s'])
+  r = np.random.default_rng(0)
+  for label, goal, kw, cls in (('GoalE2EVMCPredictor (geeco-f: dynimg + dyndiff)', True, dict(proc_obs='dynimg', proc_tgt='dyndiff'), GoalE2EVMCPredictor),
+                               ('E2EVMCPredictor (e2e_vmc: K encoder passes + K LSTM steps)', False, {}, E2EVMCPredictor)):
+    md = os.path.join(workdir, 'pred_%d' % goal)
+    os.makedirs(md, exist_ok=True)
+    cfg = create_e2evmc_config(dict(window_size=K, **kw))
+    with open(os.path.join(md, 'e2evmc_config.json'), 'w') as fp:
+      json.dump(cfg._asdict(), fp)
+    st = VariableStore(model_variable_shapes(cfg, goal), 'cpu')
+    st.initialize(seed=0)
+    est.save_checkpoint(st, md, keep_max=1)
+    pred = cls(md, memcap=None, device=dev)
+    frames = r.integers(0, 256, [8, 256, 256, 3]).astype(np.float32) / np.float32(255.0)
+    jnt = r.standard_normal([8, 7]).astype(np.float32)
+    if goal:
+      pred.set_goal(frames[7])
+    for i in range(20):
+      pred.predict(frames[i % 8], jnt[i % 8])
+    lat = []
+    for i in range(300):
+      t = time.perf_counter()
+      pred.predict(frames[i % 8], jnt[i % 8])
+      lat.append((time.perf_counter() - t) * 1e3)
+    lat.sort()
+    out[label] = {'calls': len(lat), 'window_size': K, 'p50_ms': round(percentile(lat, 0.5), 3), 'p90_ms': round(percentile(lat, 0.9), 3),
+                  'p99_ms': round(percentile(lat, 0.99), 3), 'min_ms': round(lat[0], 3),
+                  'includes': 'range check of the frame, 786 KB frame upload, window shift in HBM, forward hipGraph, '
+                              'predictions (+ dynbuff / dyndiff images for the goal model) copied back'}
+    log('inference: %s p50 %.3f ms p99 %.3f ms' % (label, out[label]['p50_ms'], out[label]['p99_ms']))
+    del pred
+    torch.cuda.empty_cache()
+  return out
+
+
 def comm_report(args, model, runner, dev, world, step_ms):
   """N > 1 (every rank takes part): the exchange alone, and the step in BOTH orders of the exchange plus without it, so
   that one multi-GPU call shows whether RCCL beside the persistent 255-block kernels of the bottom backward helps."""
@@ -618,6 +783,20 @@ def main():
       out['other_configs'], ok2 = other_configs(args, dev)
       if not ok2:
         rc = 4
+    if world == 1 and not (args.skip_input_pipeline and args.skip_inference) and args.model == 'geeco-f' and args.channels == 3:
+      import shutil
+      import tempfile
+      model = None
+      torch.cuda.empty_cache()
+      workdir = tempfile.mkdtemp(prefix='geeco_bench_')
+      try:
+        e = root = kw = None
+        if not args.skip_input_pipeline:
+          out['input_pipeline'], e, root, kw = input_pipeline_report(args, dev, ms_step, workdir)
+        if not args.skip_inference:
+          out['inference'] = inference_report(args, dev, e, root, kw, workdir)
+      finally:
+        shutil.rmtree(workdir, ignore_errors=True)
     if world == 1 and not args.skip_cpu:
       out['cpu_baseline'] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

@@ -248,6 +248,7 @@ class Estimator:
     self.config = config or RunConfig()
     self.params = dict(params or {})
     self._specs = {}          # (mode, N) -> (spec, feature buffers, label buffers)
+    self.last_train_stats = None
     self._store = None
     self._restored = False
     if model_dir and gdist.rank() == 0:
@@ -373,7 +374,8 @@ class Estimator:
     world, rank = gdist.world_size(), gdist.rank()
     t0, nsteps, step = time.time(), 0, None
     last_runner = None
-    for feats, labels, n, n_global in self._local_batches(input_fn(), world, rank):
+    source = input_fn()
+    for feats, labels, n, n_global in self._local_batches(source, world, rank):
       if n == 0:
         # this rank has no window in this step (ragged end of the epoch): it still takes part in the gradient
         # exchange, with zeros, and applies the same update as the others
@@ -400,8 +402,12 @@ class Estimator:
         break
       if max_steps is not None and step is not None and step >= max_steps:
         break
+    if hasattr(source, 'close'):
+      source.close()      # an epoch left early must not leave reader threads filling a queue nobody drains
     if nsteps and torch.cuda.is_available():
       torch.cuda.synchronize()
+    # wall time of the input + step loop alone (the checkpoint written below is not part of the data path)
+    self.last_train_stats = {'steps': nsteps, 'loop_seconds': time.time() - t0}
     if nsteps and rank == 0 and self.model_dir:
       path = save_checkpoint(self._store, self.model_dir, self.config.keep_checkpoint_max, self.config.save_tf_bundle,
                           self.params['e2evmc_config'].batch_size if 'e2evmc_config' in self.params else None)
@@ -412,7 +418,8 @@ class Estimator:
     """Streams the eval metrics of estimator.py:246-254; 'loss' = mean of per-batch losses [TF1.15]."""
     world, rank = gdist.world_size(), gdist.rank()
     sums, nb, loss_sum = {}, 0, None
-    for feats, labels, n, _ in self._local_batches(input_fn(), world, rank):
+    source = input_fn()
+    for feats, labels, n, _ in self._local_batches(source, world, rank):
       if n == 0:
         continue
       spec, fbuf, lbuf = self._get_spec(ModeKeys.EVAL, feats, labels, n)
@@ -429,6 +436,8 @@ class Estimator:
       nb += 1
       if steps is not None and nb >= steps:
         break
+    if hasattr(source, 'close'):
+      source.close()
     # metric keys are fixed by the control mode (estimator.py:246-258): a rank whose shard of the eval split is empty still
     # takes part in the reduction, with zeros, instead of leaving the others waiting
     cfg = self.params.get('e2evmc_config')

@@ -98,11 +98,24 @@ def load_target_frames(dataset_dir, tfrecord_name, load_depth=True):
   return [load_target_frame(dataset_dir, tfrecord_name, load_depth)]
 
 
-def load_episode(path, meta, fetch_target, raw_rgb=False):
-  """One episode -> dict of per-frame arrays after _parse_v4 + _preprocess_states_v4 +
-  _preprocess_targets_v3 (i.e. the last frame already dropped: T = episode_length - 1).
-  ``raw_rgb``: keep 'rgb' / 'target_rgb' as the recorded 0..255 values (the device path divides by
-  255 on the GPU)."""
+def _finish_episode(ex, fetch_target):
+  """_parse_v4's target (:313-315: LAST frame of the full episode) + _preprocess_targets_v3 (:598-613: next-frame
+  states as targets, then the last frame is dropped) on per-frame arrays of the whole episode."""
+  target = None
+  if fetch_target:
+    target = {'target_rgb': ex['rgb'][-1].copy(), 'target_depth': ex['depth'][-1].copy()}
+  ex['vel_target'] = np.roll(ex['vel_state'], -1, axis=0)
+  ex['ee_target'] = np.roll(ex['ee_state'], -1, axis=0)
+  ex['grp_target'] = np.roll(ex['grp_state'], -1, axis=0)
+  ex = {k: v[:-1] for k, v in ex.items()}
+  if target:
+    ex.update(target)
+  return ex
+
+
+def load_episode_py(path, meta, fetch_target, raw_rgb=False):
+  """``load_episode`` through the pure-Python TFRecord / protobuf reader of tfrecord.py (one thread, holds the GIL):
+  the independent restatement the native reader is tested against; not used by the pipeline."""
   H, W = meta.img_height, meta.img_width
   payload = next(iter(tfrecord.read_records(path, 'zlib')))
   _, fl = tfrecord.parse_sequence_example(payload)
@@ -127,22 +140,79 @@ def load_episode(path, meta, fetch_target, raw_rgb=False):
   ex['jnt_state'] = np.stack([stack('joint_qpos-robot0:%s' % j, ()) for j in _ARM_JOINTS], axis=1)
   ex['vel_state'] = np.stack([stack('joint_qvel-robot0:%s' % j, ()) for j in _ARM_JOINTS], axis=1)
   ex['grp_state'] = np.stack([stack('joint_qpos-robot0:%s' % j, ()) for j in _FINGER_JOINTS], axis=1)
-  target = None
-  if fetch_target:      # :313-315: target = LAST frame of the full episode
-    target = {'target_rgb': ex['rgb'][-1].copy(), 'target_depth': ex['depth'][-1].copy()}
-  # _preprocess_targets_v3 (:598-613): next-frame states as targets, then drop the last frame
-  ex['vel_target'] = np.roll(ex['vel_state'], -1, axis=0)
-  ex['ee_target'] = np.roll(ex['ee_state'], -1, axis=0)
-  ex['grp_target'] = np.roll(ex['grp_state'], -1, axis=0)
-  ex = {k: v[:-1] for k, v in ex.items()}
-  if target:
-    ex.update(target)
-  return ex
+  return _finish_episode(ex, fetch_target)
+
+
+def load_episode(path, meta, fetch_target, raw_rgb=False, image_keys=('rgb', 'depth'), alloc=None):
+  """One episode -> dict of per-frame arrays after _parse_v4 + _preprocess_states_v4 + _preprocess_targets_v3 (i.e.
+  the last frame already dropped: T = episode_length - 1), read by the native reader (inflate, CRC, SequenceExample
+  scan and the float -> array copies run without the GIL: ``num_threads`` of these calls proceed side by side).
+
+  ``raw_rgb``: 'rgb' / 'target_rgb' keep the recorded 0..255 values — as a uint8 array when every value is integral
+  (the recorder stores uint8 frames as float lists, tfrecord.py:73-74; the test runs inside the conversion pass), else
+  as float32; the device path divides by 255 on the GPU.  Otherwise float32 / 255 (:312).
+  ``image_keys``: which of the image streams to decode (an RGB-only model never reads 'depth': 26 MB per episode).
+  ``alloc(nbytes) -> uint8 array``: where the image arrays go (pinned staging memory of the device path)."""
+  H, W = meta.img_height, meta.img_width
+  with tfrecord.EpisodeReader(path, 'zlib') as rd:
+    T = rd.frames('step')
+    ex = {
+        'step': rd.i64('step', 1).reshape(T),
+        'ts': rd.f32('ts', 1).reshape(T),
+        'cmd': rd.f32('cmd', meta.dim_cmd),
+        'ctrl': rd.f32('ctrl', meta.dim_ctrl),
+        'ee_state': rd.f32('mocap_qpos-robot0:mocap', 7),
+        'goal_state': rd.f32('goal_qpos', 7),
+        'obj_state': rd.f32('obj_qpos', 7),
+        'jnt_state': np.concatenate([rd.f32('joint_qpos-robot0:%s' % j, 1) for j in _ARM_JOINTS], axis=1),
+        'vel_state': np.concatenate([rd.f32('joint_qvel-robot0:%s' % j, 1) for j in _ARM_JOINTS], axis=1),
+        'grp_state': np.concatenate([rd.f32('joint_qpos-robot0:%s' % j, 1) for j in _FINGER_JOINTS], axis=1),
+    }
+    new = (lambda n, dt: np.empty(n, dt)) if alloc is None else (lambda n, dt: alloc(n * np.dtype(dt).itemsize).view(dt))
+    if 'rgb' in image_keys:
+      n = H * W * 3
+      rgb, exact = rd.u8('rgb', n, out=new(T * n, np.uint8))
+      if not exact:
+        rgb = rd.f32('rgb', n, out=new(T * n, np.float32))
+      if not raw_rgb:
+        rgb = rgb.astype(np.float32) / np.float32(255.0)
+      ex['rgb'] = rgb.reshape(T, H, W, 3)
+    else:
+      rd.frames('rgb')
+      ex['rgb'] = _Omitted((T, H, W, 3), 'rgb')
+    if 'depth' in image_keys:
+      ex['depth'] = rd.f32('depth', H * W, out=new(T * H * W, np.float32)).reshape(T, H, W, 1)
+    else:
+      rd.frames('depth')
+      ex['depth'] = _Omitted((T, H, W, 1), 'depth')
+  return _finish_episode(ex, fetch_target)
+
+
+class _Omitted:
+  """Stands in for an image stream the caller chose not to decode (``image_keys``): has the shape, indexes like the
+  array would (frames, windows), refuses to produce values."""
+
+  def __init__(self, shape, key):
+    self.shape, self.key, self.dtype = tuple(shape), key, np.dtype(np.float32)
+
+  def __len__(self):
+    return self.shape[0]
+
+  def __getitem__(self, idx):
+    lead = np.empty(self.shape[:1], np.bool_)[idx].shape
+    return _Omitted(lead + self.shape[1:], self.key)
+
+  def copy(self):
+    return self
+
+  def __array__(self, *a, **k):
+    raise RuntimeError("feature '%s' was not decoded (image_keys / device_keys excluded it)" % self.key)
 
 
 _FEATURE_KEYS = ['step', 'ts', 'rgb', 'depth', 'jnt_state', 'vel_state', 'ee_state', 'grp_state', 'goal_state',
                  'obj_state', 'cmd', 'ctrl']
 _LABEL_KEYS = ['cmd', 'ctrl', 'vel_target', 'ee_target', 'grp_target']
+_IMAGE_KEYS = ('rgb', 'depth')
 
 
 class DeviceWindows:
@@ -171,6 +241,8 @@ class DeviceWindows:
 
   @staticmethod
   def concat(a, b):
+    if a.divisor != b.divisor:
+      raise ValueError('DeviceWindows.concat: segments with different divisors (%g, %g)' % (a.divisor, b.divisor))
     out = DeviceWindows(a.K, a.frame_shape, a.divisor, a.squeeze_k)
     out.segments = a.segments + b.segments
     out.n = a.n + b.n
@@ -183,10 +255,12 @@ class DeviceWindows:
     off = 0
     for frames_dev, starts in self.segments:
       n = len(starts)
+      if frames_dev is None:
+        raise RuntimeError('DeviceWindows: this image stream was not uploaded (device_keys excluded it)')
       if frames_dev.device != out.device:
         raise RuntimeError('DeviceWindows: episode frames live on %s but the batch buffer on %s (each rank must '
                            'upload to its own GPU)' % (frames_dev.device, out.device))
-      st = torch.as_tensor(starts, device=out.device)
+      st = torch.as_tensor(starts).to(out.device, non_blocking=True)
       ops.gather_windows_into(out[off:off + n], frames_dev, st, n, self.K, fe, self.divisor)
       off += n
 
@@ -204,34 +278,9 @@ class DeviceWindows:
 def _concat_feature(a, b):
   if isinstance(a, DeviceWindows):
     return DeviceWindows.concat(a, b)
+  if isinstance(a, _Omitted):
+    return _Omitted((a.shape[0] + b.shape[0],) + a.shape[1:], a.key)
   return np.concatenate([a, b], axis=0)
-
-
-def episode_to_device(ex, device):
-  """Uploads the image streams of one episode: RGB as uint8 when the recorded values are integral
-  (they are: the recorder stores uint8 frames as float lists), depth as float32."""
-  import torch
-  from .runtime import CAPTURE_LOCK
-  device = resolve_device(device)
-  T = ex['rgb'].shape[0]
-  dev = {}
-  rgb = ex['rgb'].reshape(T, -1)
-  as_u8 = bool(np.all(rgb == np.rint(rgb)) and rgb.min() >= 0 and rgb.max() <= 255)
-  host = {'rgb': torch.as_tensor(rgb.astype(np.uint8) if as_u8 else rgb / np.float32(255.0)),
-          'depth': torch.as_tensor(np.ascontiguousarray(ex['depth'].reshape(T, -1)))}
-  dev['rgb_div'] = 255.0 if as_u8 else 1.0
-  if 'target_rgb' in ex:
-    t = ex['target_rgb'].reshape(1, -1)
-    t_u8 = bool(np.all(t == np.rint(t)) and t.min() >= 0 and t.max() <= 255)
-    host['target_rgb'] = torch.as_tensor(t.astype(np.uint8) if t_u8 else t / np.float32(255.0))
-    dev['target_rgb_div'] = 255.0 if t_u8 else 1.0
-    host['target_depth'] = torch.as_tensor(np.ascontiguousarray(ex['target_depth'].reshape(1, -1)))
-  # allocations / synchronous copies from this (prefetch) thread must not fall into a hipGraph capture window of
-  # the training thread (runtime.CAPTURE_LOCK)
-  with CAPTURE_LOCK:
-    for k, v in host.items():
-      dev[k] = v.to(device)
-  return dev
 
 
 def resolve_device(device):
@@ -244,43 +293,175 @@ def resolve_device(device):
   return d
 
 
+# ------------------------------------------------------------------------------------------------
+# staging memory and the HBM-resident episode cache of the device path
+# ------------------------------------------------------------------------------------------------
+class _PinnedPool:
+  """Page-locked staging arrays for the reader threads (the native reader writes the uint8 frames straight into
+  them; the upload is then one DMA).  Blocks are recycled: pinning 20 MB costs more than reading it."""
+
+  def __init__(self):
+    self._free = collections.defaultdict(list)
+    self._lock = threading.Lock()
+
+  def take(self, nbytes):
+    import torch
+    from .runtime import CAPTURE_LOCK
+    with self._lock:
+      if self._free[nbytes]:
+        return self._free[nbytes].pop()
+    with CAPTURE_LOCK:       # hipHostMalloc must not fall into the training thread's capture window
+      return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+
+  def give(self, t):
+    with self._lock:
+      if len(self._free[t.numel()]) < 32:
+        self._free[t.numel()].append(t)
+
+
+_PINNED = _PinnedPool()
+
+
+class EpisodeCache:
+  """Episodes that stay in HBM across epochs: uint8 RGB frames (19.7 MB per 100-frame 256 x 256 episode; float32 depth
+  26 MB more when the model reads it) + the few KB of per-frame states on the host.  Keyed by (file identity, device,
+  streams held); filled first-come until ``budget_bytes`` of device memory are in use — no eviction: an epoch scans
+  the dataset cyclically, where evicting the least recently used entry would always evict the next one needed.
+  Epochs >= 2 then touch neither the disk nor PCIe for cached episodes (MI355X: 288 GB holds ~10 k RGB episodes)."""
+
+  def __init__(self, budget_bytes=None):
+    self.budget_bytes = budget_bytes      # None: 60 % of the device's memory, decided on first use
+    self._entries = {}
+    self._bytes = 0
+    self._lock = threading.Lock()
+    self.hits = self.misses = 0
+
+  @staticmethod
+  def key(path, device, fetch_target, image_keys):
+    st = os.stat(path)
+    return (os.path.realpath(path), st.st_size, st.st_mtime_ns, str(device), bool(fetch_target), tuple(sorted(image_keys)))
+
+  def get(self, key):
+    with self._lock:
+      e = self._entries.get(key)
+      if e is None:
+        self.misses += 1
+      else:
+        self.hits += 1
+      return e
+
+  def put(self, key, ex, dev, device):
+    import torch
+    nbytes = sum(v.numel() * v.element_size() for v in dev.values() if hasattr(v, 'numel'))
+    with self._lock:
+      if self.budget_bytes is None:
+        self.budget_bytes = int(0.6 * torch.cuda.get_device_properties(device).total_memory)
+      if key in self._entries or self._bytes + nbytes > self.budget_bytes:
+        return False
+      self._entries[key] = (ex, dev)
+      self._bytes += nbytes
+      return True
+
+  def clear(self):
+    with self._lock:
+      self._entries.clear()
+      self._bytes = 0
+      self.hits = self.misses = 0
+
+  @property
+  def bytes_in_use(self):
+    return self._bytes
+
+  def __len__(self):
+    return len(self._entries)
+
+
+EPISODE_CACHE = EpisodeCache()
+
+
+def episode_to_device(ex, device, image_keys=_IMAGE_KEYS):
+  """Uploads the image streams of one episode (``load_episode(raw_rgb=True)``): RGB as uint8 when the recorded
+  values were integral, depth as float32.  Returns (states, dev): ``states`` = ``ex`` without the image arrays (what
+  the cache keeps on the host), ``dev`` = device tensors + the divisors the window gather applies."""
+  import torch
+  from .runtime import CAPTURE_LOCK
+  device = resolve_device(device)
+  T = ex['step'].shape[0]
+  dev, host = {}, {}
+
+  def stage(arr, rows):
+    if arr.dtype == np.uint8:
+      return torch.from_numpy(arr.reshape(rows, -1)), 255.0
+    return torch.from_numpy(np.ascontiguousarray(arr.reshape(rows, -1) / np.float32(255.0))), 1.0
+
+  if 'rgb' in image_keys:
+    host['rgb'], dev['rgb_div'] = stage(ex['rgb'], T)
+    if 'target_rgb' in ex:
+      host['target_rgb'], dev['target_rgb_div'] = stage(ex['target_rgb'], 1)
+  if 'depth' in image_keys:
+    host['depth'] = torch.from_numpy(np.ascontiguousarray(ex['depth'].reshape(T, -1)))
+    if 'target_depth' in ex:
+      host['target_depth'] = torch.from_numpy(np.ascontiguousarray(ex['target_depth'].reshape(1, -1)))
+  # allocations / synchronous copies from this (prefetch) thread must not fall into a hipGraph capture window of
+  # the training thread (runtime.CAPTURE_LOCK)
+  with CAPTURE_LOCK:
+    for k, v in host.items():
+      dev[k] = v.to(device)
+  states = {k: v for k, v in ex.items() if k not in ('rgb', 'depth', 'target_rgb', 'target_depth')}
+  states['_hw'] = ex['rgb'].shape[1:3]
+  return states, dev
+
+
 def episode_windows(ex, window_size, starts, dev=None):
   """(features, labels) for the windows beginning at ``starts`` (_window_v3 :615-631, _prepare_v4 :373-399).
-  With ``dev`` (episode_to_device) the image features are DeviceWindows instead of host arrays."""
+  With ``dev`` (episode_to_device) the image features are DeviceWindows instead of host arrays and ``ex`` needs only
+  the per-frame states."""
   K = window_size
-  idx = np.asarray(starts)[:, None] + np.arange(K)[None, :]
+  starts = np.asarray(starts)
+  idx = starts[:, None] + np.arange(K)[None, :]
+  last = starts + K - 1
   if dev is not None:
-    feats = {k: ex[k][idx] for k in _FEATURE_KEYS if k not in ('rgb', 'depth')}
-    H, W = ex['rgb'].shape[1:3]
-    for key, shp, div in (('rgb', (H, W, 3), dev['rgb_div']), ('depth', (H, W, 1), 1.0)):
-      dw = DeviceWindows(K, shp, div)
-      dw.add(dev[key], starts)
+    feats = {k: ex[k][idx] for k in _FEATURE_KEYS if k not in _IMAGE_KEYS}
+    H, W = ex['_hw'] if '_hw' in ex else ex['rgb'].shape[1:3]
+    for key, shp in (('rgb', (H, W, 3)), ('depth', (H, W, 1))):
+      dw = DeviceWindows(K, shp, dev.get(key + '_div', 1.0))
+      dw.add(dev.get(key), starts)
       feats[key] = dw
-    if 'target_rgb' in dev:
-      for key, shp, div in (('target_rgb', (H, W, 3), dev['target_rgb_div']), ('target_depth', (H, W, 1), 1.0)):
-        dw = DeviceWindows(1, shp, div, squeeze_k=True)
-        dw.add(dev[key], np.zeros(len(starts), np.int32))
+    if 'target_rgb' in dev or 'target_depth' in dev:
+      for key, shp in (('target_rgb', (H, W, 3)), ('target_depth', (H, W, 1))):
+        dw = DeviceWindows(1, shp, dev.get(key + '_div', 1.0), squeeze_k=True)
+        dw.add(dev.get(key), np.zeros(len(starts), np.int32))
         feats[key] = dw
-    last = np.asarray(starts) + K - 1
     return feats, {k: ex[k][last] for k in _LABEL_KEYS}
   feats = {k: ex[k][idx] for k in _FEATURE_KEYS}
   if 'target_rgb' in ex:
     n = len(starts)
-    feats['target_rgb'] = np.broadcast_to(ex['target_rgb'], (n,) + ex['target_rgb'].shape).copy()
-    feats['target_depth'] = np.broadcast_to(ex['target_depth'], (n,) + ex['target_depth'].shape).copy()
-  last = np.asarray(starts) + K - 1
+    for k in ('target_rgb', 'target_depth'):
+      t = ex[k]
+      feats[k] = _Omitted((n,) + t.shape, t.key) if isinstance(t, _Omitted) else np.broadcast_to(t, (n,) + t.shape).copy()
   labels = {k: ex[k][last] for k in _LABEL_KEYS}
   return feats, labels
 
 
 class _Prefetcher:
-  """Runs an iterator factory in background threads (tf.data's num_parallel_calls / prefetch)."""
+  """Runs an iterator factory in a background thread (tf.data's prefetch); the episode readers it draws from are a
+  thread pool of their own (``_EpisodeSource``)."""
 
   def __init__(self, make_iter, depth, device=None):
     self._q = queue.Queue(maxsize=max(int(depth), 1))
     self._device = device
+    self._stop = threading.Event()
     self._t = threading.Thread(target=self._run, args=(make_iter,), daemon=True)
     self._t.start()
+
+  def _put(self, item):
+    while not self._stop.is_set():
+      try:
+        self._q.put(item, timeout=0.2)
+        return True
+      except queue.Full:
+        continue
+    return False
 
   def _run(self, make_iter):
     try:
@@ -288,10 +469,18 @@ class _Prefetcher:
         import torch
         torch.cuda.set_device(self._device)     # thread-local: a new thread starts on device 0 whatever LOCAL_RANK is
       for item in make_iter():
-        self._q.put(('item', item))
-      self._q.put(('end', None))
+        if not self._put(('item', item)):
+          return
+      self._put(('end', None))
     except BaseException as e:   # surfaced in the consumer
-      self._q.put(('error', e))
+      self._put(('error', e))
+
+  def close(self):
+    """Stops the producer (a consumer that leaves the epoch early, e.g. Estimator.train(steps=...))."""
+    self._stop.set()
+
+  def __del__(self):
+    self._stop.set()
 
   def __iter__(self):
     while True:
@@ -304,13 +493,83 @@ class _Prefetcher:
         raise val
 
 
+class _EpisodeSource:
+  """Episodes of ``paths`` in order, read ``num_threads`` at a time (tf.data's num_parallel_reads /
+  num_parallel_calls, geeco_gym.py:442-473: parallel and order-preserving): a window of reads runs ahead of the
+  consumer in a thread pool; the native reader holds no Python lock, so the threads really overlap.  On the device
+  path a cached episode (EPISODE_CACHE) is never read again."""
+
+  def __init__(self, paths, meta, fetch_target, num_threads, device, image_keys, cache):
+    from concurrent.futures import ThreadPoolExecutor
+    self.paths, self.meta, self.fetch_target = list(paths), meta, fetch_target
+    self.device, self.image_keys, self.cache = device, tuple(image_keys), cache
+    self.num_threads = max(int(num_threads or 1), 1)
+    self._pool = ThreadPoolExecutor(max_workers=self.num_threads, thread_name_prefix='geeco-reader')
+
+  def _read(self, path):
+    staged = []
+    def alloc(nbytes):
+      t = _PINNED.take(nbytes)
+      staged.append(t)
+      return t.numpy()
+    pinned = self.device is not None and self.device.type == 'cuda'
+    ex = load_episode(path, self.meta, self.fetch_target, raw_rgb=self.device is not None, image_keys=self.image_keys,
+                      alloc=alloc if pinned else None)
+    return ex, staged
+
+  def __iter__(self):
+    """Yields (states / ex, dev or None) per episode, in the order of ``paths``."""
+    ahead = self.num_threads + 1
+    pending = collections.deque()      # (path, key, cached entry or future)
+    it = iter(self.paths)
+
+    def submit():
+      for path in it:
+        key = entry = None
+        if self.device is not None and self.cache is not None:
+          key = self.cache.key(path, self.device, self.fetch_target, self.image_keys)
+          entry = self.cache.get(key)
+        pending.append((path, key, entry if entry is not None else self._pool.submit(self._read, path)))
+        return
+
+    try:
+      for _ in range(ahead):
+        submit()
+      while pending:
+        path, key, item = pending.popleft()
+        submit()
+        if isinstance(item, tuple):
+          yield item
+          continue
+        ex, staged = item.result()
+        if self.device is None:
+          yield ex, None
+          continue
+        states, dev = episode_to_device(ex, self.device, self.image_keys)
+        for t in staged:          # the copies above were synchronous: the staging blocks are free again
+          _PINNED.give(t)
+        if self.cache is not None:
+          self.cache.put(key, states, dev, self.device)
+        yield states, dev
+    finally:
+      for _, _, item in pending:
+        if not isinstance(item, tuple):
+          item.cancel()
+      self._pool.shutdown(wait=False)
+
+
 def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size=4, fetch_target=False,
                        shuffle_buffer=128, batch_size=1, num_epochs=1, num_threads=4, prefetch_size=4, seed=None,
-                       shard=None, device=None):
+                       shard=None, device=None, device_keys=None, cache=True):
   """Same signature as the reference's pickplace_input_fn (geeco_gym.py:234-279).  Returns an iterable of
-  (features, labels) numpy batches.  ``shard = (rank, world)`` makes each data-parallel rank read a
-  disjoint, rank-strided subset of the episodes.  ``device`` (e.g. 'cuda'): upload every episode's
-  frames once and hand out image features as DeviceWindows (windows are gathered in HBM)."""
+  (features, labels) numpy batches.  ``num_threads`` episodes are read in parallel, in order (num_parallel_reads /
+  num_parallel_calls of :442-473); ``prefetch_size`` batches are prepared ahead of the consumer (:473).
+  Extensions: ``shard = (rank, world)`` makes each data-parallel rank read a disjoint, rank-strided subset of the
+  episodes.  ``device`` (e.g. 'cuda'): upload every episode's frames once and hand out image features as DeviceWindows
+  (windows are gathered in HBM); ``device_keys``: which image streams the model reads (default both; ('rgb',) for an
+  RGB-only model skips decoding, uploading and caching 26 MB of depth per episode — the 'depth' features then refuse
+  to materialise); ``cache``: keep uploaded episodes in HBM across epochs (EPISODE_CACHE; True, False or an
+  EpisodeCache)."""
   if encoding != 'v4':
     # v1-v3 are dead code in the reference (undefined PickAndPlaceEncodingV1/2/3 -> NameError)
     raise KeyError(encoding)
@@ -336,33 +595,37 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
     paths = paths[rank::world]
   if device is not None:
     device = resolve_device(device)
+  image_keys = _IMAGE_KEYS if device_keys is None else tuple(device_keys)
+  if not set(image_keys) <= set(_IMAGE_KEYS):
+    raise ValueError('device_keys must be a subset of %s' % (_IMAGE_KEYS,))
+  ep_cache = None
+  if device is not None and device.type == 'cuda' and cache:
+    ep_cache = cache if isinstance(cache, EpisodeCache) else EPISODE_CACHE
   print('[pickplace_input_fn_v4] #tfrecords: %d' % len(paths))
 
   def batches():
     carry_f, carry_l = None, None   # windows left over from the previous episode (batch() spans episodes)
-    for _ in range(num_epochs):
-      for path in paths:
-        ex = load_episode(path, meta, fetch_target, raw_rgb=device is not None)
-        dev = episode_to_device(ex, device) if device is not None else None
-        T = ex['step'].shape[0]
-        if shard is not None and T != meta.episode_length - 1:
-          raise ValueError('%s holds %d frames, meta_info.json says %d: the data-parallel batch schedule assumes '
-                           'fixed-length episodes' % (path, T + 1, meta.episode_length))
-        nwin = T - K + 1
-        pos = 0
-        while pos < nwin:
-          need = batch_size - (0 if carry_f is None else len(carry_f['step']))
-          take = min(need, nwin - pos)
-          f, l = episode_windows(ex, K, np.arange(pos, pos + take), dev)
-          pos += take
-          if carry_f is not None:
-            f = {k: _concat_feature(carry_f[k], f[k]) for k in f}
-            l = {k: np.concatenate([carry_l[k], l[k]], axis=0) for k in l}
-            carry_f = carry_l = None
-          if len(f['step']) == batch_size:
-            yield f, l
-          else:
-            carry_f, carry_l = f, l
+    source = _EpisodeSource(paths * num_epochs, meta, fetch_target, num_threads, device, image_keys, ep_cache)
+    for ex, dev in source:
+      T = ex['step'].shape[0]
+      if shard is not None and T != meta.episode_length - 1:
+        raise ValueError('an episode holds %d frames, meta_info.json says %d: the data-parallel batch schedule assumes '
+                         'fixed-length episodes' % (T + 1, meta.episode_length))
+      nwin = T - K + 1
+      pos = 0
+      while pos < nwin:
+        need = batch_size - (0 if carry_f is None else len(carry_f['step']))
+        take = min(need, nwin - pos)
+        f, l = episode_windows(ex, K, np.arange(pos, pos + take), dev)
+        pos += take
+        if carry_f is not None:
+          f = {k: _concat_feature(carry_f[k], f[k]) for k in f}
+          l = {k: np.concatenate([carry_l[k], l[k]], axis=0) for k in l}
+          carry_f = carry_l = None
+        if len(f['step']) == batch_size:
+          yield f, l
+        else:
+          carry_f, carry_l = f, l
     if carry_f is not None:   # ragged final batch (dataset.batch without drop_remainder, :471)
       yield carry_f, carry_l
 
@@ -449,3 +712,67 @@ def write_episode(path, meta, frames_rgb_u8, depth, cmd, ctrl, joints_qpos, join
       fr['object_qpos-%s' % name] = obj_qpos[t].astype(np.float32)
     frames.append(fr)
   tfrecord.write_records(path, [tfrecord.encode_sequence_example(ctx, frames)], 'zlib')
+
+
+def synthetic_scene_frames(T, H, W, seed):
+  """uint8 RGB frames [T, H, W, 3] + float32 depth [T, H, W, 1] of a toy table-top scene (shaded background, a textured
+  table, a few boxes sliding between frames): flat and smooth regions with a little sensor-like noise, which is what
+  makes a rendered frame compress — uniform noise (test fixtures) would not.  Generator of on-disk datasets for the
+  input-pipeline benchmark; not part of training."""
+  r = np.random.default_rng(seed)
+  yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+  base = np.stack([90 + 60 * yy / H, 110 + 40 * xx / W, 140 - 50 * yy / H], axis=-1)            # wall gradient
+  table = yy > 0.55 * H
+  tex = r.integers(-6, 7, size=[H, W, 1]).astype(np.float32) * table[..., None]
+  base = np.where(table[..., None], np.float32([150, 120, 90]) + tex, base)
+  depth0 = (2.5 - 1.5 * yy / H + 0.02 * np.sin(xx / 9.0)).astype(np.float32)
+  nbox = 4
+  pos0, vel = r.random([nbox, 2]) * [0.4 * H, 0.8 * W] + [0.5 * H, 0.0], r.standard_normal([nbox, 2]) * 0.6
+  size = r.integers(H // 16, H // 6, size=[nbox, 2])
+  col = r.integers(20, 236, size=[nbox, 3]).astype(np.float32)
+  rgb = np.empty([T, H, W, 3], np.uint8)
+  depth = np.empty([T, H, W, 1], np.float32)
+  for t in range(T):
+    img, dep = base.copy(), depth0.copy()
+    for b in range(nbox):
+      y0, x0 = (pos0[b] + t * vel[b]).astype(int) % [H, W]
+      y1, x1 = min(H, y0 + size[b, 0]), min(W, x0 + size[b, 1])
+      shade = np.linspace(1.0, 0.8, max(x1 - x0, 1), dtype=np.float32)[None, :, None]
+      img[y0:y1, x0:x1] = col[b] * shade
+      dep[y0:y1, x0:x1] = 0.8 + 0.1 * b
+    noise = r.integers(-1, 2, size=[H, W, 3]) * (r.random([H, W, 1]) < 0.15)                   # sparse +-1 sensor noise
+    rgb[t] = np.clip(np.rint(img + noise), 0, 255).astype(np.uint8)
+    depth[t, :, :, 0] = dep + (1e-3 * r.standard_normal([H, W])).astype(np.float32)
+  return rgb, depth
+
+
+def write_synthetic_dataset(root, num_episodes, episode_length=100, img_hw=(256, 256), seed=0, eval_episodes=None):
+  """A dataset directory in the reference's layout (geeco_gym.py:249-264: meta/meta_info.json, data/*.tfrecord.zlib,
+  splits/default/{train,eval}.txt) filled with ``synthetic_scene_frames`` episodes.  ``eval_episodes``: how many of
+  the episodes the eval split lists (default: all).  Returns the meta tuple."""
+  H, W = img_hw
+  joints = ['robot0:%s' % j for j in _ARM_JOINTS + _FINGER_JOINTS]
+  meta = PickAndPlaceMetaV4(episode_length=episode_length, img_height=H, img_width=W, monitored_joints=joints,
+                            actuated_joints=joints[:2], monitored_mocaps=['robot0:mocap'],
+                            monitored_objects=['object0:joint'], dim_cmd=4, dim_ctrl=2)
+  for sub in ('meta', 'data', os.path.join('splits', 'default')):
+    os.makedirs(os.path.join(root, sub), exist_ok=True)
+  with open(os.path.join(root, 'meta', 'meta_info.json'), 'w') as fp:
+    json.dump(meta._asdict(), fp)
+  names = []
+  for e in range(num_episodes):
+    r = np.random.default_rng([seed, e])
+    T = episode_length
+    rgb, depth = synthetic_scene_frames(T, H, W, seed=[seed, e, 1])
+    cmd = np.concatenate([0.3 * r.standard_normal([T, 3]), r.integers(-1, 2, [T, 1])], 1).astype(np.float32)
+    name = 'ep%05d.tfrecord.zlib' % e
+    write_episode(os.path.join(root, 'data', name), meta, rgb, depth, cmd, r.standard_normal([T, 2]).astype(np.float32),
+                  r.standard_normal([T, 9]).astype(np.float32), r.standard_normal([T, 9]).astype(np.float32),
+                  (1.5 * r.random([T, 7])).astype(np.float32), (1.5 * r.random([T, 7])).astype(np.float32),
+                  (1.5 * r.random([T, 7])).astype(np.float32))
+    names.append(name)
+  n_eval = num_episodes if eval_episodes is None else eval_episodes
+  for mode, sel in (('train', names), ('eval', names[:n_eval])):
+    with open(os.path.join(root, 'splits', 'default', mode + '.txt'), 'w') as fp:
+      fp.write('\n'.join(sel) + '\n')
+  return meta

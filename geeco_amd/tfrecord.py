@@ -27,21 +27,138 @@ import zlib
 import numpy as np
 
 _HOST_LIB = None
+_HOST_ABI_VERSION = 2      # include/geeco_host.h: GEECO_HOST_ABI_VERSION
 
 
 def _host():
+  """ctypes binding of libgeeco_host.so (include/geeco_host.h).  ctypes releases the GIL around every call, which is
+  what lets the reader threads of input_fn.py run side by side."""
   global _HOST_LIB
   if _HOST_LIB is None:
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libgeeco_host.so')
     if not os.path.exists(path):
       raise RuntimeError('%s is missing: run geeco_amd/csrc/build.sh' % path)
     lib = ctypes.CDLL(path)
-    lib.geeco_masked_crc32c.restype = ctypes.c_uint32
-    lib.geeco_masked_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
-    lib.geeco_crc32c.restype = ctypes.c_uint32
-    lib.geeco_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    c = ctypes
+    if not hasattr(lib, 'geeco_host_abi_version') or lib.geeco_host_abi_version() != _HOST_ABI_VERSION:
+      raise RuntimeError('%s is stale (host ABI version differs from %d): run geeco_amd/csrc/build.sh'
+                         % (path, _HOST_ABI_VERSION))
+    lib.geeco_host_last_error.restype = c.c_char_p
+    lib.geeco_masked_crc32c.restype = c.c_uint32
+    lib.geeco_masked_crc32c.argtypes = [c.c_char_p, c.c_size_t]
+    lib.geeco_crc32c.restype = c.c_uint32
+    lib.geeco_crc32c.argtypes = [c.c_char_p, c.c_size_t, c.c_uint32]
+    lib.geeco_episode_open.restype = c.c_void_p
+    lib.geeco_episode_open.argtypes = [c.c_char_p, c.c_int, c.c_int]
+    lib.geeco_episode_close.restype = None
+    lib.geeco_episode_close.argtypes = [c.c_void_p]
+    lib.geeco_episode_num_records.restype = c.c_int64
+    lib.geeco_episode_num_records.argtypes = [c.c_void_p]
+    lib.geeco_episode_inflated_bytes.restype = c.c_int64
+    lib.geeco_episode_inflated_bytes.argtypes = [c.c_void_p]
+    lib.geeco_episode_num_lists.restype = c.c_int
+    lib.geeco_episode_num_lists.argtypes = [c.c_void_p]
+    lib.geeco_episode_list_name.restype = c.c_char_p
+    lib.geeco_episode_list_name.argtypes = [c.c_void_p, c.c_int]
+    lib.geeco_episode_list_frames.restype = c.c_int64
+    lib.geeco_episode_list_frames.argtypes = [c.c_void_p, c.c_char_p]
+    lib.geeco_episode_list_kind.restype = c.c_int
+    lib.geeco_episode_list_kind.argtypes = [c.c_void_p, c.c_char_p, c.POINTER(c.c_int64)]
+    for fn in ('geeco_episode_read_f32', 'geeco_episode_read_i64'):
+      getattr(lib, fn).restype = c.c_int
+      getattr(lib, fn).argtypes = [c.c_void_p, c.c_char_p, c.c_void_p, c.c_int64, c.c_int64]
+    lib.geeco_episode_read_u8.restype = c.c_int
+    lib.geeco_episode_read_u8.argtypes = [c.c_void_p, c.c_char_p, c.c_void_p, c.c_int64, c.c_int64, c.POINTER(c.c_int)]
+    lib.geeco_inflate.restype = c.c_int64
+    lib.geeco_inflate.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int]
     _HOST_LIB = lib
   return _HOST_LIB
+
+
+_COMPRESSION = {None: 0, '': 0, 'none': 0, 'zlib': 1, 'gzip': 2}
+
+
+class EpisodeReader:
+  """One episode file through the native reader (geeco_episode_* of include/geeco_host.h): inflate, record framing
+  with CRC check and the SequenceExample scan happen in ``__init__`` WITHOUT the GIL; ``f32`` / ``i64`` / ``u8`` copy
+  one feature list into a dense [frames, values] array (optionally one the caller owns, e.g. pinned memory).
+
+  The same bytes as ``parse_sequence_example(next(read_records(path)))`` (the pure-Python reader below, kept as the
+  independent restatement the tests compare against), two orders of magnitude faster on a 100-frame 256 x 256 episode."""
+
+  def __init__(self, path, compression='zlib', verify=True):
+    self._h = None
+    if compression not in _COMPRESSION:
+      raise ValueError('unknown compression %r' % (compression,))
+    self._lib = _host()
+    self.path = path
+    self._h = self._lib.geeco_episode_open(os.fsencode(path), _COMPRESSION[compression], 1 if verify else 0)
+    if not self._h:
+      raise IOError(self._lib.geeco_host_last_error().decode('utf-8', 'replace'))
+
+  def close(self):
+    if self._h:
+      self._lib.geeco_episode_close(self._h)
+      self._h = None
+
+  __del__ = close
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+
+  @property
+  def num_records(self):
+    return int(self._lib.geeco_episode_num_records(self._h))
+
+  @property
+  def inflated_bytes(self):
+    return int(self._lib.geeco_episode_inflated_bytes(self._h))
+
+  def names(self):
+    return [self._lib.geeco_episode_list_name(self._h, i).decode() for i in range(self._lib.geeco_episode_num_lists(self._h))]
+
+  def frames(self, name):
+    """Frame count of a feature list; KeyError when the record has no such list (tf.parse_single_sequence_example
+    raises for a missing sequence feature as well)."""
+    n = int(self._lib.geeco_episode_list_frames(self._h, name.encode()))
+    if n < 0:
+      raise KeyError("%s: feature list '%s' missing" % (self.path, name))
+    return n
+
+  def kind(self, name):
+    """(kind, values per frame) of frame 0: kind 1 bytes, 2 float, 3 int64, 0 empty."""
+    self.frames(name)
+    vals = ctypes.c_int64(0)
+    k = int(self._lib.geeco_episode_list_kind(self._h, name.encode(), ctypes.byref(vals)))
+    if k < 0:
+      raise IOError(self._lib.geeco_host_last_error().decode('utf-8', 'replace'))
+    return k, int(vals.value)
+
+  def _read(self, fn, name, values, dtype, out, *extra):
+    T = self.frames(name)
+    if out is None:
+      out = np.empty((T, values), dtype)
+    elif out.dtype != dtype or out.size != T * values or not out.flags['C_CONTIGUOUS']:
+      raise ValueError("'%s': destination must be a contiguous %s array of %d x %d" % (name, np.dtype(dtype).name, T, values))
+    if fn(self._h, name.encode(), ctypes.c_void_p(out.ctypes.data), T, values, *extra) != 0:
+      raise IOError('%s: %s' % (self.path, self._lib.geeco_host_last_error().decode('utf-8', 'replace')))
+    return out
+
+  def f32(self, name, values, out=None):
+    return self._read(self._lib.geeco_episode_read_f32, name, values, np.float32, out)
+
+  def i64(self, name, values, out=None):
+    return self._read(self._lib.geeco_episode_read_i64, name, values, np.int64, out)
+
+  def u8(self, name, values, out=None):
+    """(array, exact): the float list as uint8; ``exact`` is False when some value is not an integer in [0, 255]
+    (the array is then meaningless: read the list with f32 instead)."""
+    exact = ctypes.c_int(0)
+    arr = self._read(self._lib.geeco_episode_read_u8, name, values, np.uint8, out, ctypes.byref(exact))
+    return arr, bool(exact.value)
 
 
 def masked_crc32c(data: bytes) -> int:

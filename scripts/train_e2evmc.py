@@ -178,8 +178,10 @@ def main(args):
         window_size=e2evmc_config.window_size, fetch_target=(args.goal_condition == 'target'),
         shuffle_buffer=args.shuffle_buffer, num_epochs=1, num_threads=args.num_threads,
         prefetch_size=args.prefetch_size,
-        # episodes are uploaded once (to THIS rank's GPU) and windows are gathered in HBM unless GEECO_HOST_WINDOWS is set
-        device=None if _dev.env('GEECO_HOST_WINDOWS') else dev, **kw)
+        # episodes are uploaded once (to THIS rank's GPU), stay there across epochs (input_fn.EPISODE_CACHE) and windows are
+        # gathered in HBM unless GEECO_HOST_WINDOWS is set; an RGB model never reads the depth stream
+        device=None if _dev.env('GEECO_HOST_WINDOWS') else dev,
+        device_keys=('rgb',) if e2evmc_config.img_channels == 3 else ('rgb', 'depth'), **kw)
   train_input = lambda: input_fn(estimator_mode='train')
   eval_input = lambda: input_fn(estimator_mode='eval')
 

@@ -1,0 +1,244 @@
+"""The native episode reader (libgeeco_host.so: inflate, TFRecord framing + CRC-32C, SequenceExample scan, float -> array
+copies; include/geeco_host.h) against the pure-Python reader of geeco_amd/tfrecord.py, and the parallel, order-preserving
+episode source of the input pipeline (reference: src/data/geeco_gym.py:291-315, 436-473)."""
+import gzip
+import os
+import struct
+import sys
+import threading
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_host_logic_cpu import _crc32c_bitwise, _make_dataset    # noqa: E402
+
+
+def _paths(root):
+  return sorted(os.path.join(root, 'data', f) for f in os.listdir(os.path.join(root, 'data')))
+
+
+def test_native_reader_equals_python_reader(tmp_path):
+  from geeco_amd import input_fn as I
+  meta, eps = _make_dataset(str(tmp_path), n_eps=2, T=7, H=12, W=10)
+  for path, d in zip(_paths(str(tmp_path)), eps):
+    for fetch_target in (False, True):
+      for raw in (False, True):
+        a = I.load_episode(path, meta, fetch_target, raw_rgb=raw)
+        b = I.load_episode_py(path, meta, fetch_target, raw_rgb=raw)
+        assert sorted(a) == sorted(b)
+        for k in b:
+          if raw and k in ('rgb', 'target_rgb'):
+            assert a[k].dtype == np.uint8          # integral recorded values: kept as bytes
+          else:
+            assert a[k].dtype == b[k].dtype, k
+          np.testing.assert_array_equal(np.asarray(a[k], b[k].dtype), b[k], err_msg=k)
+    np.testing.assert_array_equal(I.load_episode(path, meta, True, raw_rgb=True)['target_rgb'], d['rgb'][-1])
+
+
+def test_native_reader_list_index_and_kinds(tmp_path):
+  from geeco_amd import tfrecord as T
+  meta, eps = _make_dataset(str(tmp_path), n_eps=1, T=5, H=8, W=8)
+  path = _paths(str(tmp_path))[0]
+  _, fl = T.parse_sequence_example(next(iter(T.read_records(path))))
+  with T.EpisodeReader(path) as rd:
+    assert rd.num_records == 1 and rd.inflated_bytes == len(zlib.decompress(open(path, 'rb').read()))
+    assert rd.names() == list(fl.keys())                       # same lists, file order
+    for name, frames in fl.items():
+      assert rd.frames(name) == len(frames) == 5
+      kind, vals = rd.kind(name)
+      assert vals == len(frames[0]) and kind == (3 if frames[0].dtype == np.int64 else 2), name
+      got = rd.i64(name, vals) if kind == 3 else rd.f32(name, vals)
+      np.testing.assert_array_equal(got, np.stack(frames), err_msg=name)
+    with pytest.raises(KeyError):
+      rd.frames('no_such_list')
+    with pytest.raises(IOError, match='value count'):
+      rd.f32('cmd', 3)
+    with pytest.raises(IOError, match='not a float list'):
+      rd.f32('step', 1)
+    with pytest.raises(IOError, match='not an int64 list'):
+      rd.i64('cmd', 4)
+    with pytest.raises(ValueError):
+      rd.f32('cmd', 4, out=np.empty((5, 4), np.float64))
+
+
+def test_native_reader_non_integral_rgb_falls_back_to_float(tmp_path):
+  """uint8 upload only when EVERY recorded value is an integer in [0, 255] (tfrecord.py:73-74 writes uint8 images as
+  floats; nothing stops a dataset from holding real floats): 0.5, -1, 256, NaN each break exactness."""
+  from geeco_amd import input_fn as I
+  from geeco_amd import tfrecord as T
+  meta, eps = _make_dataset(str(tmp_path), n_eps=1, T=4, H=8, W=8)
+  d = eps[0]
+  for bad in (0.5, -1.0, 256.0, float('nan'), 255.00002):
+    rgb = d['rgb'].astype(np.float32)
+    rgb[2, 3, 4, 1] = bad
+    p = str(tmp_path / 'bad.tfrecord.zlib')
+    frames = [{'step': np.array([t], np.int64), 'rgb': rgb[t]} for t in range(4)]
+    T.write_records(p, [T.encode_sequence_example({}, frames)])
+    with T.EpisodeReader(p) as rd:
+      _, exact = rd.u8('rgb', 8 * 8 * 3)
+      assert not exact, bad
+      np.testing.assert_array_equal(rd.f32('rgb', 8 * 8 * 3).reshape(rgb.shape), rgb)
+  # -0.0 and 255 are exact
+  rgb = d['rgb'].astype(np.float32)
+  rgb[0, 0, 0, 0], rgb[0, 0, 0, 1] = -0.0, 255.0
+  T.write_records(p, [T.encode_sequence_example({}, [{'step': np.array([0], np.int64), 'rgb': rgb[0]}])])
+  with T.EpisodeReader(p) as rd:
+    got, exact = rd.u8('rgb', 8 * 8 * 3)
+    assert exact and got[0, 0] == 0 and got[0, 1] == 255
+  # and load_episode(raw_rgb=True) hands float32 0..255 values to the device path, which divides on the host then
+  rgb[0, 0, 0, 0] = 0.25
+  joints = {('joint_qpos-%s' % j): np.zeros(1, np.float32) for j in meta.monitored_joints}
+  joints.update({('joint_qvel-%s' % j): np.zeros(1, np.float32) for j in meta.monitored_joints})
+  frames = [dict(step=np.array([t], np.int64), ts=np.zeros(1, np.float32), rgb=rgb[t], depth=d['depth'][t], cmd=d['cmd'][t],
+                 ctrl=d['ctrl'][t], goal_qpos=d['goal'][t], obj_qpos=d['obj'][t], **joints,
+                 **{'mocap_qpos-robot0:mocap': d['mocap'][t]}) for t in range(4)]
+  T.write_records(p, [T.encode_sequence_example({}, frames)])
+  ex = I.load_episode(p, meta, False, raw_rgb=True)
+  assert ex['rgb'].dtype == np.float32 and ex['rgb'][0, 0, 0, 0] == 0.25
+  np.testing.assert_array_equal(I.load_episode(p, meta, False)['rgb'], rgb[:-1] / np.float32(255.0))
+
+
+def test_native_reader_refuses_damaged_files(tmp_path):
+  from geeco_amd import tfrecord as T
+  meta, _ = _make_dataset(str(tmp_path), n_eps=1, T=4, H=8, W=8)
+  path = _paths(str(tmp_path))[0]
+  raw = bytearray(zlib.decompress(open(path, 'rb').read()))
+  bad = str(tmp_path / 'bad.tfrecord.zlib')
+
+  def opens(data, compressed=True, **kw):
+    open(bad, 'wb').write(zlib.compress(bytes(data)) if compressed else bytes(data))
+    return T.EpisodeReader(bad, **kw)
+
+  flipped = bytearray(raw); flipped[len(raw) // 2] ^= 0x10
+  with pytest.raises(IOError, match='corrupted record payload'):
+    opens(flipped)
+  assert opens(flipped, verify=False).num_records == 1          # as read_records(verify=False)
+  hdr = bytearray(raw); hdr[9] ^= 0x01
+  with pytest.raises(IOError, match='corrupted record length'):
+    opens(hdr)
+  with pytest.raises(IOError, match='truncated record'):
+    opens(raw[:-7])
+  with pytest.raises(IOError, match='truncated record header'):
+    opens(raw + b'\x01\x02\x03')
+  with pytest.raises(IOError, match='no record'):
+    opens(b'')
+  open(bad, 'wb').write(open(path, 'rb').read()[:-20])            # cut inside the zlib stream
+  with pytest.raises(IOError, match='inflate'):
+    T.EpisodeReader(bad)
+  open(bad, 'wb').write(b'not a zlib stream at all' * 10)
+  with pytest.raises(IOError, match='inflate'):
+    T.EpisodeReader(bad)
+  with pytest.raises(IOError):
+    T.EpisodeReader(str(tmp_path / 'missing.tfrecord.zlib'))
+  # a structurally broken SequenceExample inside a well-formed record
+  body = b'\x12\x05\x0a\x03\x0a\xff\xff'                          # feature_lists { entry { len runs past the end
+  rec = struct.pack('<Q', len(body)); rec += struct.pack('<I', T.masked_crc32c(rec)) + body + struct.pack('<I', T.masked_crc32c(body))
+  with pytest.raises(IOError, match='malformed SequenceExample'):
+    opens(rec)
+  # two records: both framings are checked, the first is parsed (data_recorder.py:134-156 writes one per file)
+  two = bytes(raw) + bytes(raw)
+  assert opens(two).num_records == 2
+  # uncompressed and gzip files
+  assert opens(raw, compressed=False, compression=None).num_records == 1
+  open(bad, 'wb').write(gzip.compress(bytes(raw)))
+  assert T.EpisodeReader(bad, compression='gzip').num_records == 1
+  with pytest.raises(ValueError):
+    T.EpisodeReader(bad, compression='lz4')
+
+
+def test_inflate_matches_zlib_and_crc32c_matches_bitwise():
+  from geeco_amd import tfrecord as T
+  lib = T._host()
+  r = np.random.default_rng(5)
+  cases = [b'', b'a', bytes(100000), r.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+           np.repeat(r.integers(0, 7, 4000, dtype=np.uint8), r.integers(1, 300, 4000)).tobytes(),
+           r.integers(0, 256, 3000, dtype=np.uint8).astype(np.float32).tobytes() * 9]
+  for data in cases:
+    for level in (0, 1, 6, 9):
+      for fmt, comp in ((1, zlib.compress(data, level)), (2, gzip.compress(data, compresslevel=level))):
+        dst = np.empty(len(data) + 8, np.uint8)
+        n = lib.geeco_inflate(comp, len(comp), dst.ctypes.data, len(data), fmt)        # exactly fitting destination
+        assert n == len(data) and dst[:n].tobytes() == data
+        if len(data) > 1:
+          assert lib.geeco_inflate(comp, len(comp), dst.ctypes.data, len(data) - 1, fmt) == -2      # too small
+        assert lib.geeco_inflate(comp[:-3], len(comp) - 3, dst.ctypes.data, len(data) + 8, fmt) == -1   # truncated
+    if len(data) > 100:
+      comp = bytearray(zlib.compress(data, 6)); comp[-2] ^= 0x40                       # Adler-32 mismatch
+      assert lib.geeco_inflate(bytes(comp), len(comp), dst.ctypes.data, len(data) + 8, 1) == -1
+  for n in (0, 1, 7, 8, 9, 31, 32, 33, 1000, 4099):
+    for off in (0, 1, 3):
+      data = r.integers(0, 256, n + off, dtype=np.uint8).tobytes()[off:]
+      assert lib.geeco_crc32c(data, len(data), 0) == _crc32c_bitwise(data), (n, off)
+  a, b = b'hello, ', b'world'
+  assert lib.geeco_crc32c(b, len(b), lib.geeco_crc32c(a, len(a), 0)) == _crc32c_bitwise(a + b)      # running value
+
+
+def test_episode_source_is_parallel_and_order_preserving(tmp_path, monkeypatch):
+  """num_threads readers at once (geeco_gym.py:442-473 num_parallel_reads / num_parallel_calls), episodes delivered in
+  list order whatever order the reads finish in, batches identical for every thread count."""
+  from geeco_amd import input_fn as I
+  meta, eps = _make_dataset(str(tmp_path), n_eps=7, T=9, H=8, W=8)
+  kw = dict(window_size=3, fetch_target=True, batch_size=5)
+  ref = list(I.pickplace_input_fn(str(tmp_path), 'default', 'eval', num_threads=1, **kw))
+  real = I.load_episode
+  state = {'now': 0, 'peak': 0}
+  lock = threading.Lock()
+
+  def slow(path, *a, **k):
+    with lock:
+      state['now'] += 1
+      state['peak'] = max(state['peak'], state['now'])
+    time.sleep(0.05 if path.endswith('ep000.tfrecord.zlib') or path.endswith('ep003.tfrecord.zlib') else 0.005)
+    try:
+      return real(path, *a, **k)
+    finally:
+      with lock:
+        state['now'] -= 1
+
+  monkeypatch.setattr(I, 'load_episode', slow)
+  for nt in (1, 3, 8):
+    state['peak'] = 0
+    got = list(I.pickplace_input_fn(str(tmp_path), 'default', 'eval', num_threads=nt, **kw))
+    assert state['peak'] == min(nt, 7) or (nt > 1 and 1 < state['peak'] <= nt), (nt, state['peak'])
+    assert len(got) == len(ref)
+    for (fa, la), (fb, lb) in zip(got, ref):
+      for k in fb:
+        np.testing.assert_array_equal(fa[k], fb[k], err_msg=k)
+      for k in lb:
+        np.testing.assert_array_equal(la[k], lb[k], err_msg=k)
+  assert state['peak'] > 1
+  # a reader error surfaces in the consumer, not in a worker thread
+  monkeypatch.setattr(I, 'load_episode', lambda path, *a, **k: (_ for _ in ()).throw(IOError('boom %s' % path)))
+  with pytest.raises(IOError, match='boom'):
+    list(I.pickplace_input_fn(str(tmp_path), 'default', 'eval', num_threads=2, **kw))
+
+
+def test_undecoded_image_stream_keeps_shapes_and_refuses_values(tmp_path):
+  from geeco_amd import input_fn as I
+  meta, _ = _make_dataset(str(tmp_path), n_eps=1, T=9, H=8, W=8)
+  path = _paths(str(tmp_path))[0]
+  ex = I.load_episode(path, meta, True, image_keys=('rgb',))
+  assert ex['depth'].shape == (8, 8, 8, 1) and ex['target_depth'].shape == (8, 8, 1) and ex['rgb'].dtype == np.float32
+  f, _ = I.episode_windows(ex, 3, np.arange(4))
+  assert f['depth'].shape == (4, 3, 8, 8, 1) and f['target_depth'].shape == (4, 8, 8, 1) and f['rgb'].shape == (4, 3, 8, 8, 3)
+  with pytest.raises(RuntimeError, match='not decoded'):
+    np.asarray(f['depth'])
+  with pytest.raises(ValueError):
+    I.pickplace_input_fn(str(tmp_path), 'default', 'eval', device_keys=('rgb', 'flow'))
+
+
+def test_synthetic_dataset_writer_round_trip(tmp_path):
+  from geeco_amd import input_fn as I
+  meta = I.write_synthetic_dataset(str(tmp_path), 3, episode_length=6, img_hw=(16, 24), seed=4, eval_episodes=1)
+  assert meta == I.get_meta_v4(str(tmp_path)) and meta.img_width == 24
+  assert len(I.collect_tfrecords(str(tmp_path), 'default', 'train')) == 3
+  assert len(I.collect_tfrecords(str(tmp_path), 'default', 'eval')) == 1
+  rgb, depth = I.synthetic_scene_frames(6, 16, 24, seed=[4, 1, 1])
+  ex = I.load_episode(I.collect_tfrecords(str(tmp_path), 'default', 'train')[1], meta, True, raw_rgb=True)
+  np.testing.assert_array_equal(ex['rgb'], rgb[:-1])
+  np.testing.assert_array_equal(ex['target_depth'], depth[-1])
+  batches = list(I.pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=2, batch_size=4, seed=0, num_threads=2))
+  assert sum(len(f['step']) for f, _ in batches) == 3 * 4
