@@ -218,7 +218,38 @@ def init_params(shapes, seed=0, dtype=np.float32):
 # --------------------------------------------------------------------------------------
 # graph pieces
 # --------------------------------------------------------------------------------------
-def conv_encoder(x, P, scope, collect=None, masks=None, force=False, stats=None):
+class ReluTap:
+  """Test instrumentation for the whole-graph restatements below (``e2e_vmc`` / ``goal_e2evmc``): SOMEBODY ELSE'S ReLU
+  decisions (and, optionally, conv1 inputs) for every ``conv_encoder`` call of one forward pass.
+
+  ``masks_fn(scope, call)`` -> eight bool tensors ``[n, h, w, c]`` (the device's ``y > 0`` of the frames which the
+  ``call``-th ``conv_encoder`` invocation under ``scope`` processes; calls are counted per scope in graph order:
+  graph.py:310-313, :354, :362-381, :390-402).  ``inputs_fn(scope, call)`` -> the frames the device fed its conv1 for
+  that call, or None to keep this restatement's own (only the dynamic images differ, by fp32 rounding).  With
+  ``force`` the activations are ``z * mask`` (see ``conv_encoder``); ``stats[scope][layer]`` =
+  [disagreements, max |z| there, elements] against this restatement's own ``z > 0``."""
+
+  def __init__(self, masks_fn, inputs_fn=None, force=True):
+    self.masks_fn, self.inputs_fn, self.force = masks_fn, inputs_fn, force
+    self.calls, self.stats = {}, {}
+    self.recorded = {}          # masks_fn None: (scope, call) -> this restatement's own eight decisions
+
+  def enter(self, scope, x):
+    call = self.calls.get(scope, 0)
+    self.calls[scope] = call + 1
+    st = self.stats.setdefault(scope, [[0, 0.0, 0] for _ in range(8)])
+    if self.inputs_fn is not None:
+      xi = self.inputs_fn(scope, call)
+      if xi is not None:
+        assert tuple(xi.shape) == tuple(x.shape), (scope, call, tuple(xi.shape), tuple(x.shape))
+        x = xi.to(x.dtype)
+    if self.masks_fn is None:
+      self.recorded[(scope, call)] = rec = []
+      return x, None, rec
+    return x, self.masks_fn(scope, call), st
+
+
+def conv_encoder(x, P, scope, collect=None, masks=None, force=False, stats=None, tap=None):
   """graph.py:61-117.
 
   Test instrumentation (the product of every other caller is unchanged): ``masks`` = per layer a bool tensor with
@@ -227,11 +258,16 @@ def conv_encoder(x, P, scope, collect=None, masks=None, force=False, stats=None)
   the forward changes only where the two disagree (|z| at rounding level, checked through ``stats``) and the
   backward is the gradient under the given decisions -- at z == 0 both are valid subgradients of ReLU, and which side
   of zero a pre-activation of 1e-8 lands on is rounding, not mathematics."""
+  if tap is not None:
+    x, masks, stats = tap.enter(scope, x)
+    force = tap.force
   net = x
   for i in range(8):
     w, b = P['%s/conv%d/kernel' % (scope, i + 1)], P['%s/conv%d/bias' % (scope, i + 1)]
     if masks is None:
       net = conv2d_same(net, w, b, ENC_STRIDES[i], relu=True)
+      if tap is not None:
+        stats.append((net > 0).detach())
     else:
       z = conv2d_same(net, w, b, ENC_STRIDES[i], relu=False)
       own = z > 0
@@ -301,23 +337,23 @@ def lstm_decoder(feat_list, P, scope, cfg: Config):
   return ep
 
 
-def e2e_vmc(frames, jnt_states, P, cfg: Config, collect=None):
+def e2e_vmc(frames, jnt_states, P, cfg: Config, collect=None, tap=None):
   """graph.py:268-319, scope 'VMC'."""
   K = cfg.window_size
   feats = []
   for k in range(K):
-    f = conv_encoder(frames[:, k], P, 'VMC/ConvEncoder', collect if k == K - 1 else None)
+    f = conv_encoder(frames[:, k], P, 'VMC/ConvEncoder', collect if k == K - 1 else None, tap=tap)
     feats.append(state_concatenation(f, jnt_states[:, k]))
   return lstm_decoder(feats, P, 'VMC/LSTMDecoder', cfg)
 
 
-def goal_e2evmc(frames, jnt_states, tgt_frame, P, cfg: Config, collect=None):
+def goal_e2evmc(frames, jnt_states, tgt_frame, P, cfg: Config, collect=None, tap=None):
   """graph.py:321-416, scope 'GoalVMC'."""
   root = 'GoalVMC'
   K = cfg.window_size
   ep = {}
   if cfg.proc_tgt in ('constant', 'residual'):
-    tgt_feat = conv_encoder(tgt_frame, P, root + '/ConvEncoder')                   # :354
+    tgt_feat = conv_encoder(tgt_frame, P, root + '/ConvEncoder', tap=tap)          # :354
   elif cfg.proc_tgt == 'dyndiff':
     pass
   else:
@@ -326,7 +362,7 @@ def goal_e2evmc(frames, jnt_states, tgt_frame, P, cfg: Config, collect=None):
   if cfg.proc_obs == 'sequence':
     for k in range(K):
       frame, jnt = frames[:, k], jnt_states[:, k]
-      feat = conv_encoder(frame, P, root + '/ConvEncoder')
+      feat = conv_encoder(frame, P, root + '/ConvEncoder', tap=tap)
       if cfg.proc_tgt == 'constant':
         st = representation_concatenation(feat, tgt_feat, jnt)
       elif cfg.proc_tgt == 'residual':
@@ -334,18 +370,18 @@ def goal_e2evmc(frames, jnt_states, tgt_frame, P, cfg: Config, collect=None):
       else:
         dd = dynimg(torch.stack([frame, tgt_frame], dim=1))                        # :373-376
         ep['dyndiff'] = dd
-        tf_ = conv_encoder(dd, P, root + '/DynDiffEncoder')
+        tf_ = conv_encoder(dd, P, root + '/DynDiffEncoder', tap=tap)
         st = representation_concatenation(feat, tf_, jnt)
       feats.append(st)
   elif cfg.proc_obs == 'dynimg':
     frame, jnt = frames[:, -1], jnt_states[:, -1]                                   # :387-388
-    feat = conv_encoder(frame, P, root + '/ConvEncoder', collect)                   # :390
+    feat = conv_encoder(frame, P, root + '/ConvEncoder', collect, tap=tap)          # :390
     db = dynimg(frames)                                                             # :392
     ep['dynbuff'] = db
-    dyn_feat = conv_encoder(db, P, root + '/DynBuffEncoder', collect)               # :394
+    dyn_feat = conv_encoder(db, P, root + '/DynBuffEncoder', collect, tap=tap)      # :394
     dd = dynimg(torch.stack([frame, tgt_frame], dim=1))                            # :397-400
     ep['dyndiff'] = dd
-    tf_ = conv_encoder(dd, P, root + '/DynDiffEncoder', collect)                    # :402
+    tf_ = conv_encoder(dd, P, root + '/DynDiffEncoder', collect, tap=tap)           # :402
     feats.append(representation_concatenation_v2(feat, dyn_feat, jnt, tf_))         # :405-407
   else:
     raise ValueError("Unknown processing mode for frame buffer: %s!" % (cfg.proc_obs,))
@@ -380,7 +416,7 @@ def build_targets(features, labels, cfg: Config):
           'pos_ee': features['ee_state'][:, -1, :3], 'pos_obj': features['obj_state'][:, -1, :3]}
 
 
-def model_forward(features, P, cfg: Config, goal: bool, collect=None):
+def model_forward(features, P, cfg: Config, goal: bool, collect=None, tap=None):
   """Feature decode + graph + predictions dict (estimator.py:28-61 / 159-197)."""
   if cfg.img_channels == 3:
     obs = features['rgb']
@@ -391,7 +427,7 @@ def model_forward(features, P, cfg: Config, goal: bool, collect=None):
   else:
     raise ValueError("Unsupported number of channels for input frame: %d!" % cfg.img_channels)
   jnt = features['jnt_state']
-  ep = goal_e2evmc(obs, jnt, tgt, P, cfg, collect) if goal else e2e_vmc(obs, jnt, P, cfg, collect)
+  ep = goal_e2evmc(obs, jnt, tgt, P, cfg, collect, tap) if goal else e2e_vmc(obs, jnt, P, cfg, collect, tap)
   if cfg.control_mode == 'cartesian':
     pred = {'cmd_ee': ep['pred_cmd_ee'], 'logits_cmd_grp': ep['logits_cmd_grp'],
             'pos_ee': ep['pred_aux_ee'], 'pos_obj': ep['pred_aux_obj']}
@@ -449,11 +485,14 @@ class OracleTrainer:
     return {k: (torch.as_tensor(np.asarray(v)).to(self.dtype) if torch.as_tensor(np.asarray(v)).is_floating_point()
                 else torch.as_tensor(np.asarray(v))) for k, v in d.items()}
 
-  def loss_and_grads(self, features, labels, collect=None):
+  def loss_and_grads(self, features, labels, collect=None, tap=None):
+    """``tap`` (a ``ReluTap``, test instrumentation): gradients under somebody else's ReLU decisions -- every
+    proc_obs x proc_tgt branch and the K-step e2e_vmc; ``tap.stats`` then says where those decisions differ from this
+    restatement's own.  Without it this is the plain restatement."""
     features, labels = self._cast(features), self._cast(labels)
     for p in self.P.values():
       p.requires_grad_(True); p.grad = None
-    pred, ep = model_forward(features, self.P, self.cfg, self.goal, collect)
+    pred, ep = model_forward(features, self.P, self.cfg, self.goal, collect, tap)
     loss, parts = model_loss(pred, build_targets(features, labels, self.cfg), self.P, self.cfg)
     loss.backward()
     grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in self.P.items()}
@@ -514,7 +553,8 @@ def _encoder_jobs(features, cfg: Config, goal: bool, dtype):
   if not goal:
     return [('VMC/ConvEncoder', obs.transpose(0, 1).reshape((K * N,) + tuple(obs.shape[2:])))], {}
   if cfg.proc_obs != 'dynimg':
-    raise NotImplementedError('chunked oracle: goal model only for proc_obs=dynimg')
+    raise NotImplementedError('chunked oracle: goal model only for proc_obs=dynimg (the sequence branches are small-shape '
+                              'cases: OracleTrainer.loss_and_grads(tap=ReluTap(...)) gives their mask-consistent gradients)')
   cur = obs[:, -1]
   db = dynimg(obs)
   dd = dynimg(torch.stack([cur, tgt], dim=1))
@@ -523,7 +563,7 @@ def _encoder_jobs(features, cfg: Config, goal: bool, dtype):
 
 
 def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16, enc_dtype=None, encoder_inputs=None,
-                           masks_fn=None):
+                           masks_fn=None, plain_grads=False, progress=None):
   """Same result as ``OracleTrainer.loss_and_grads`` (up to summation order) without holding the
   autograd graph of every frame at once: (1) encoder forward per chunk without graph -> conv8
   features; (2) decoder + loss with autograd on the features; (3) per chunk, encoder forward
@@ -537,7 +577,10 @@ def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16,
   where the device decided differently and how large |z| was there (``ep['relu_disagreements']``); pass (3) computes
   the gradient under the device's decisions (``conv_encoder(force=True)``), which removes the one effect that makes
   fp32 gradients of this graph incomparable at full size: a pre-activation of 1e-8 rounded to the other side of zero
-  moves a filter gradient by 1e-3 of its maximum in ANY fp32 implementation."""
+  moves a filter gradient by 1e-3 of its maximum in ANY fp32 implementation.  ``plain_grads`` (with ``masks_fn``): pass
+  (3) also runs the backward under this restatement's OWN decisions -> ``ep['plain_grads']`` (the loose, mask-independent
+  backstop of the full-size test).  ``ep['conv8']`` = the plain restatement's features of EVERY frame per encoder.
+  ``progress(text)`` is called once per chunk (long runs must show signs of life)."""
   cfg, goal, dt = trainer.cfg, trainer.goal, trainer.dtype
   edt = enc_dtype or dt
   features, labels = trainer._cast(features), trainer._cast(labels)
@@ -556,8 +599,11 @@ def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16,
         i1 = min(i + chunk, x.shape[0])
         kw = dict(masks=masks_fn(j, i, i1), stats=stats[j]) if masks_fn is not None else {}
         outs.append(conv_encoder(x[i:i1].to(edt), Pe, scope, **kw))
+        if progress is not None:
+          progress('forward %s frames %d-%d of %d' % (scope, i, i1, x.shape[0]))
       feats.append(torch.cat(outs, dim=0).to(dt))
   first_last = {scope: (f[0].clone(), f[-1].clone()) for (scope, _), f in zip(jobs, feats)}
+  conv8_all = {scope: f.detach().clone() for (scope, _), f in zip(jobs, feats)}
   for f in feats:
     f.requires_grad_(True)
   dec = {k: v for k, v in P.items() if '/conv' not in k}
@@ -585,18 +631,29 @@ def loss_and_grads_chunked(trainer: 'OracleTrainer', features, labels, chunk=16,
   grads = {k: p.grad.detach().clone() for k, p in dec.items()}
   for p in dec.values():
     p.requires_grad_(False)
+  plain = {} if (plain_grads and masks_fn is not None) else None
   for j, ((scope, x), f) in enumerate(zip(jobs, feats)):
     names = [k for k in P if k.startswith(scope + '/')]
     Pg = {k: P[k].detach().to(edt).requires_grad_(True) for k in names}
+    Pp = {k: P[k].detach().to(edt).requires_grad_(True) for k in names} if plain is not None else None
     for i in range(0, x.shape[0], chunk):
       i1 = min(i + chunk, x.shape[0])
       kw = dict(masks=masks_fn(j, i, i1), force=True) if masks_fn is not None else {}
       out = conv_encoder(x[i:i1].to(edt), Pg, scope, **kw)
       out.backward(f.grad[i:i1].to(edt))
+      if Pp is not None:
+        conv_encoder(x[i:i1].to(edt), Pp, scope).backward(f.grad[i:i1].to(edt))
+      if progress is not None:
+        progress('backward %s frames %d-%d of %d' % (scope, i, i1, x.shape[0]))
     for k in names:
       grads[k] = Pg[k].grad.detach().to(dt)
+      if Pp is not None:
+        plain[k] = Pp[k].grad.detach().to(dt)
   ep = dict(ep)
   ep['conv8_first_last'] = first_last
+  ep['conv8'] = conv8_all
+  if plain is not None:
+    ep['plain_grads'] = plain
   if stats is not None:
     ep['relu_disagreements'] = {scope: [tuple(s) for s in st] for (scope, _), st in zip(jobs, stats)}
   return (loss.detach(), {k: v.detach() for k, v in parts.items()}, grads, {k: v.detach() for k, v in pred.items()}, ep)

@@ -1,7 +1,9 @@
-"""Data-parallel path with world_size = 2 on CPU (gloo): the dist helpers shard the batch, SUM
+"""Data-parallel path with world_size = 2, 4 and 8 on CPU (gloo): the dist helpers shard the batch, SUM
 all-reduce the flat gradient arena and scale by 1/world; with equal shards this must equal the
 single-process gradient of the global batch (all losses are batch means).  The compute engine in
-this test is the CPU oracle (no GPU here); the exchange code is the product's geeco_amd.dist."""
+this test is the CPU oracle (no GPU here); the exchange code is the product's geeco_amd.dist.
+Also: the step runner's bucketed exchange at world 2 / 4 / 8 and the ragged end of an epoch at world 4 (ranks without a
+window take part through ``null_step``; unequal window counts are weighted by n_local * world / n_global)."""
 import os
 import sys
 
@@ -17,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, tmp, q):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-  torch.set_num_threads(2)
+  torch.set_num_threads(2 if world <= 2 else 1)
   from geeco_amd import dist as gdist
   from geeco_amd.graph import model_variable_shapes
   from geeco_amd.params import create_e2evmc_config
@@ -31,8 +33,10 @@ def _worker(rank, world, port, tmp, q):
     store.initialize(seed=5)              # other ranks start from zeros and must receive rank 0's weights
   gdist.broadcast_variables(store)
   P = store.to_numpy('params')
-  feats, labels = O.synthetic_batch(ocfg, False, 4, seed=9, H=136, W=136)
-  lo, hi = gdist.shard_bounds(4)
+  NB = max(4, world)
+  feats, labels = O.synthetic_batch(ocfg, False, NB, seed=9, H=136, W=136)
+  lo, hi = gdist.shard_bounds(NB)
+  assert hi - lo == NB // world
   sl = lambda d: {k: v[lo:hi] for k, v in d.items()}
   tr = O.OracleTrainer(ocfg, False, P, dtype=torch.float64)
   loss, _, grads, _, _ = tr.loss_and_grads(sl(feats), sl(labels))
@@ -43,19 +47,20 @@ def _worker(rank, world, port, tmp, q):
   gdist.allreduce_gradients(g64)
   g64 /= gdist.world_size()
   lmax = gdist.max_over_ranks(float(loss), 'cpu')
-  assert gdist.gather_floats(10.0 + rank, 'cpu') == [10.0, 11.0]                   # bench.py: per-rank ms/step
-  assert gdist.gather_strings('host gpu-%d' % rank, 'cpu') == ['host gpu-0', 'host gpu-1']   # ... and device identities
+  assert gdist.gather_floats(10.0 + rank, 'cpu') == [10.0 + r for r in range(world)]            # bench.py: per-rank ms/step
+  assert gdist.gather_strings('host gpu-%d' % rank, 'cpu') == ['host gpu-%d' % r for r in range(world)]   # ... and device identities
   q.put((rank, g64.numpy(), float(loss), lmax, float(np.abs(P['VMC/ConvEncoder/conv3/kernel']).sum())))
   dist.destroy_process_group()
 
 
-def test_dp_gradients_equal_global_batch(tmp_path):
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_dp_gradients_equal_global_batch(tmp_path, world):
   sys.path.insert(0, ROOT)
   from geeco_amd.graph import model_variable_shapes
   from geeco_amd.params import create_e2evmc_config
   from geeco_amd.variables import VariableStore
   from oracle import geeco_oracle as O
-  world, port = 2, 29500 + (os.getpid() % 2000)
+  port = 29500 + (os.getpid() % 2000) + world
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
@@ -72,16 +77,17 @@ def test_dp_gradients_equal_global_batch(tmp_path):
   store.initialize(seed=5)
   P = store.to_numpy('params')
   assert abs(res[1][4] - float(np.abs(P['VMC/ConvEncoder/conv3/kernel']).sum())) < 1e-3     # broadcast reached rank 1
-  feats, labels = O.synthetic_batch(ocfg, False, 4, seed=9, H=136, W=136)
+  feats, labels = O.synthetic_batch(ocfg, False, max(4, world), seed=9, H=136, W=136)
   loss, _, grads, _, _ = O.OracleTrainer(ocfg, False, P, dtype=torch.float64).loss_and_grads(feats, labels)
   ref = np.zeros(store.size)
   for k, g in grads.items():
     o = store.offsets[k]
     ref[o:o + g.numel()] = g.numpy().reshape(-1)
-  np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=0)                  # identical on both ranks
+  for r in range(1, world):
+    np.testing.assert_allclose(res[0][1], res[r][1], rtol=0, atol=0)                # identical on every rank
   np.testing.assert_allclose(res[0][1], ref, rtol=1e-9, atol=1e-12)                 # == global-batch gradient
-  assert abs(0.5 * (res[0][2] + res[1][2]) - float(loss)) < 1e-12                   # mean of shard means == global mean
-  assert res[0][3] == res[1][3] == max(res[0][2], res[1][2])
+  assert abs(sum(r[2] for r in res) / world - float(loss)) < 1e-12                  # mean of shard means == global mean
+  assert all(r[3] == max(q[2] for q in res) for r in res)
 
 
 def test_shard_bounds_errors():
@@ -156,11 +162,13 @@ def _bucket_worker(rank, world, port, q, can_redirect=False, overlap=True):
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('can_redirect,overlap', [(False, True), (True, True), (True, False)],
-                         ids=['packed-late', 'late-in-place', 'late-in-place-serial'])
-def test_bucketed_exchange_covers_the_arena(can_redirect, overlap):
+@pytest.mark.parametrize('world,can_redirect,overlap', [(2, False, True), (2, True, True), (2, True, False), (4, True, True),
+                                                        (4, False, True), (8, True, True)],
+                         ids=['packed-late', 'late-in-place', 'late-in-place-serial', 'world4-late-in-place', 'world4-packed-late',
+                              'world8-late-in-place'])
+def test_bucketed_exchange_covers_the_arena(world, can_redirect, overlap):
   sys.path.insert(0, ROOT)
-  world, port = 2, 31500 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap)
+  port = 31500 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap) + 10 * world
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, can_redirect, overlap)) for r in range(world)]
@@ -185,8 +193,87 @@ def test_bucketed_exchange_covers_the_arena(can_redirect, overlap):
   else:              # a model without redirect_late_gradients: one call per early range, late gradients packed
     assert info['early_allreduce_calls'] == info['early_ranges'] == 3 and not info['late_written_in_place']
   assert info['early_bytes'] + info['late_bytes'] == 4 * g0.size
-  # every element = mean over ranks of (rank + 1) * pattern = 1.5 * pattern, identical on both ranks
+  # every element = mean over ranks of (rank + 1) * pattern = (world + 1) / 2 * pattern, identical on every rank
   idx = np.arange(g0.size, dtype=np.float32)
-  want = 1.5 * (1.0 + 0.001 * (idx % 97))
+  want = 0.5 * (world + 1) * (1.0 + 0.001 * (idx % 97))
   np.testing.assert_allclose(g0, want, rtol=1e-6)
-  np.testing.assert_array_equal(res[0][1], res[1][1])
+  for r in range(1, world):
+    np.testing.assert_array_equal(res[0][1], res[r][1])
+
+
+# ----------------------------------------------------------------------------------------------------
+# ragged end of an epoch at world 4: dp_schedule -> loss scaling, null steps (geeco_amd/estimator.py train loop)
+# ----------------------------------------------------------------------------------------------------
+_SCHED = [(4, 4, 4, 4), (4, 4, 2, 0), (4, 0, 0, 0), (3, 1, 0, 0)]
+
+
+class _ScheduleSource:
+  """What ``pickplace_input_fn(shard=(rank, world))`` hands the Estimator: this rank's batches + every rank's counts."""
+
+  def __init__(self, rank):
+    self.dp_schedule = _SCHED
+    self.rank = rank
+
+  def __iter__(self):
+    for s, counts in enumerate(_SCHED):
+      if counts[self.rank]:
+        first = sum(counts[:self.rank])
+        yield {'step': torch.arange(first, first + counts[self.rank]) + 100 * s}, None
+
+
+def _ragged_worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.set_num_threads(1)
+  from geeco_amd import dist as gdist
+  from geeco_amd.estimator import Estimator
+  from geeco_amd.graph import model_variable_shapes
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import TrainStepRunner, gradient_buckets
+  from geeco_amd.variables import VariableStore
+  gdist.init_from_env('gloo')
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2))
+  store = VariableStore(model_variable_shapes(cfg, True), 'cpu')
+  early, late = gradient_buckets(store)
+  model = _FakeModel(store, rank, early, late, can_redirect=True)
+  runner = TrainStepRunner(model, use_graph=False, overlap=True)
+  idx = torch.arange(store.size, dtype=torch.float32)
+  pattern = 1.0 + 0.001 * (idx % 97)
+  applied = []
+  # the Estimator's own schedule walk (estimator.py: _local_batches), driven like Estimator.train drives it
+  for feats, labels, n, n_global in Estimator._local_batches(Estimator, _ScheduleSource(rank), world, rank):
+    if n == 0:
+      runner.null_step()
+    else:
+      # this rank's batch-mean gradient of per-window gradients (window id) * pattern, weighted like decoder.loss_scale
+      scale = n * world / float(n_global)
+      model.rank = float(feats['step'].double().mean()) * scale - 1.0        # _FakeModel writes (rank + 1) * pattern
+      runner.step()
+    applied.append(model.applied.clone().numpy())
+  q.put((rank, applied))
+  dist.destroy_process_group()
+
+
+def test_ragged_schedule_null_steps_world4():
+  """Four ranks walk a schedule whose last steps leave ranks with fewer or NO windows: every step's update must be the mean
+  over the GLOBAL batch on every rank, and the mixed ``step`` / ``null_step`` calls must pair up in the exchange (a
+  mismatch hangs: the queue read below times out)."""
+  sys.path.insert(0, ROOT)
+  world, port = 4, 33500 + (os.getpid() % 2000)
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  n = res[0][1][0].size
+  pattern = 1.0 + 0.001 * (np.arange(n, dtype=np.float32) % 97)
+  for s, counts in enumerate(_SCHED):
+    ids = np.arange(sum(counts)) + 100 * s
+    want = ids.mean() * pattern                                 # mean over the global batch of (window id) * pattern
+    for r in range(world):
+      np.testing.assert_allclose(res[r][1][s], want, rtol=2e-6, err_msg='step %d rank %d' % (s, r))
+      np.testing.assert_array_equal(res[r][1][s], res[0][1][s])

@@ -23,9 +23,16 @@ every activation the device wrote) on the device's conv1 inputs, and
       tests; a wrong tile edge, a mis-written slice or a systematic error in small entries cannot hide under it), and
   (b) every ReLU decision in which the device differs from the fp64 oracle sits on a pre-activation |z| <= 2e-5 -- the
       device never "decides" anything the forward tolerance does not already allow; the count per layer is printed.
+  (c) (round 4, mask-INDEPENDENT backstops) the device's conv8 features of EVERY frame equal the plain oracle's (2e-4 of
+      the maximum: a forward error that changes magnitudes but not signs cannot hide in the frames between the first and
+      the last); the decisions are copied out of the activation buffers BEFORE the device's backward runs (no buffer the
+      backward reuses can alias them); configs 2 and 5: every gradient also within PLAIN_TOL = 5e-3 of max |g| of the fp64
+      oracle under its OWN decisions (loose by necessity: a handful of rounding-level flips move a filter gradient by up to
+      1e-3, the measured worst being 5.8e-4, tests/golden/full_size_plain_oracle_r03.json); config 4 (oracle encoder in
+      fp32 for time): frames 0, 511, 512 and 1023 additionally through the fp64 encoder -- features 2e-5, decisions as (b).
 The achieved errors of every variable go to gpurun_out/full_size_achieved_<config>.json; the committed copy is
 tests/golden/full_size_achieved.json.  Mask-independent elementwise checks of every launch at these shapes:
-tests/test_bench_shapes_gpu.py.
+tests/test_bench_shapes_gpu.py.  The oracle appends a line per chunk to gpurun_out/full_size_progress.log (signs of life).
 """
 import json
 import os
@@ -36,12 +43,13 @@ import pytest
 import torch
 
 from oracle import geeco_oracle as O
+import _relu_taps as T
+from _relu_taps import GRAD_TOL, Z_TOL
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GRAD_TOL = 2e-5          # both norms, against the oracle under the device's ReLU decisions
-Z_TOL = 2e-5             # |pre-activation| wherever the device's ReLU decision differs from the fp64 oracle's
+PLAIN_TOL = 5e-3         # max-norm, against the fp64 oracle under its OWN decisions (backstop (c); configs 2 and 5)
 
 # Oracle precision: fp64 throughout for configs 2 and 5.  The 1024-frame config 4 runs the oracle's ENCODER in fp32 (decoder
 # and loss in fp64): in fp64 it takes 286 s on the GPU box's 16 host threads (measured; the achieved errors of that run are
@@ -84,27 +92,53 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
   model.store.load_numpy(P)
   model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
   model.forward(backward_too=True)
+  torch.cuda.synchronize()
+  enc, C = model.enc, ocfg.img_channels
+  masks = T.snapshot_masks(enc)             # bool copies, taken BEFORE the backward (0.3 / 3.4 GB of HBM at 96 / 1024 frames)
+  f8 = enc.features.cpu().numpy()           # [G][Nf][2][2][C]
   model.backward()
   torch.cuda.synchronize()
   t_hip = time.time() - t0
 
   # ---- the oracle: plain forward (its own ReLU decisions), backward under the device's decisions ----------------------
-  enc, C = model.enc, ocfg.img_channels
   enc_inputs = [enc.x_in[g][..., :C].cpu() for g in range(enc.G)]           # what the device fed its conv1 (fp32)
-  masks_fn = lambda g, i0, i1: [(enc.acts[l][g, i0:i1] > 0).cpu() for l in range(8)]
+  masks_fn = lambda g, i0, i1: [masks[l][g][i0:i1].cpu() for l in range(8)]
+  out_dir = os.path.join(ROOT, 'gpurun_out')
+  os.makedirs(out_dir, exist_ok=True)
   t0 = time.time()
+
+  def progress(text):
+    with open(os.path.join(out_dir, 'full_size_progress.log'), 'a') as f:
+      f.write('%s %6.1f s %s\n' % (name.split()[0], time.time() - t0, text))
+
+  plain_backstop = enc_dtype == torch.float64
   tr = O.OracleTrainer(ocfg, goal, P, dtype=torch.float64)
-  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(tr, feats, labels, chunk=16, enc_dtype=enc_dtype,
-                                                                            encoder_inputs=enc_inputs, masks_fn=masks_fn)
+  loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(
+      tr, feats, labels, chunk=16, enc_dtype=enc_dtype, encoder_inputs=enc_inputs, masks_fn=masks_fn, plain_grads=plain_backstop,
+      progress=progress)
   t_ora = time.time() - t0
 
-  # ---- conv8 features of the first and the last frame of every encoder ------------------------------
-  f8 = enc.features.cpu().numpy()                             # [G][Nf][2][2][C]
+  # ---- (c) conv8 features of EVERY frame of every encoder against the plain oracle ------------------------------
   for g, scope in enumerate(enc.scopes):
-    first, last = ep_ref['conv8_first_last'][scope]
-    scale = max(float(first.abs().max()), float(last.abs().max()), 1e-30)
-    assert np.abs(f8[g, 0] - first.numpy()).max() <= 2e-4 * scale, (scope, 'first frame')
-    assert np.abs(f8[g, -1] - last.numpy()).max() <= 2e-4 * scale, (scope, 'last frame')
+    ref8 = ep_ref['conv8'][scope].numpy()
+    assert ref8.shape == f8[g].shape, (scope, ref8.shape, f8[g].shape)
+    scale = max(float(np.abs(ref8).max()), 1e-30)
+    err = np.abs(f8[g] - ref8).reshape(ref8.shape[0], -1).max(axis=1)
+    assert err.max() <= 2e-4 * scale, (scope, 'frame %d' % int(err.argmax()), float(err.max()), scale)
+  fp64_subset = None
+  if enc_dtype != torch.float64:   # config 4: the frames at the ends and around the 2^31-element boundary through the fp64 encoder
+    Pe = {k: v for k, v in tr.P.items() if '/conv' in k}
+    fp64_subset = {}
+    for fr in sorted({0, enc.Nf // 2 - 1, enc.Nf // 2, enc.Nf - 1}):
+      st = [[0, 0.0, 0] for _ in range(8)]
+      with torch.no_grad():
+        out = O.conv_encoder(enc_inputs[0][fr:fr + 1].to(torch.float64), Pe, enc.scopes[0], masks=masks_fn(0, fr, fr + 1), stats=st)
+      e = float(np.abs(f8[0][fr] - out[0].numpy()).max() / max(float(out.abs().max()), 1e-30))
+      assert e <= 2e-5, ('fp64 encoder, frame %d' % fr, e)
+      T.check_decisions({'frame %d' % fr: st})
+      fp64_subset[fr] = {'conv8_err': float('%.3g' % e), 'decisions_differing': int(sum(s[0] for s in st)),
+                         'max_abs_preactivation_where_differing': float('%.3g' % max(s[1] for s in st))}
+      progress('fp64 encoder of frame %d' % fr)
   if goal:      # the device's dynamic images (fed to the oracle's encoders above) against the oracle's own fp64 ones
     ep = model.endpoints()
     for k in ('dynbuff', 'dyndiff'):
@@ -122,17 +156,13 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
 
   # ---- (b) the device's ReLU decisions: different from the fp64 oracle's only at rounding-level pre-activations ----------
   dis = ep_ref['relu_disagreements']
-  worst_z, n_dis, n_tot = 0.0, 0, 0
-  for scope, st in dis.items():
-    for l, (n, z, tot) in enumerate(st):
-      assert tot > 0
-      assert z <= Z_TOL, '%s conv%d: ReLU decision differs at |z| = %.3e (%d of %d decisions differ)' % (scope, l + 1, z, n, tot)
-      worst_z, n_dis, n_tot = max(worst_z, z), n_dis + n, n_tot + tot
+  n_dis, n_tot, worst_z = T.check_decisions(dis)
 
-  # ---- (a) every variable's gradient, max-norm and relative L2 -------------------------------------------------------------
+  # ---- (a) every variable's gradient, max-norm and relative L2; (c) the loose bound against the oracle's own decisions ---------
   grads = model.store.to_numpy('grads')
   achieved, failures = {}, []
   worst = ('', 0.0)
+  worst_plain = ('', 0.0)
   for k, g in grads_ref.items():
     g = g.numpy()
     assert np.isfinite(grads[k]).all(), k
@@ -142,14 +172,25 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
       failures.append((k, e_max, e_l2))
     if max(e_max, e_l2) > worst[1]:
       worst = (k, max(e_max, e_l2))
-  out_dir = os.path.join(ROOT, 'gpurun_out')
-  os.makedirs(out_dir, exist_ok=True)
+    gp = ep_ref.get('plain_grads', {}).get(k)
+    if gp is not None:
+      e_p = _rel_max(grads[k], gp.numpy())
+      achieved[k]['plain_oracle_max'] = float('%.3g' % e_p)
+      if e_p > PLAIN_TOL:
+        failures.append((k, 'plain oracle', e_p))
+      if e_p > worst_plain[1]:
+        worst_plain = (k, e_p)
   with open(os.path.join(out_dir, 'full_size_achieved_%s.json' % name.split()[0]), 'w') as f:
     json.dump({'case': name, 'bound': '%g of max|g| and %g relative L2, against the fp64 oracle under the device\'s ReLU decisions' % (GRAD_TOL, GRAD_TOL),
+               'oracle_encoder_dtype': str(enc_dtype).replace('torch.', ''),
+               'backstop': ('plain fp64 oracle (own decisions), %g of max|g|: worst %.3g at %s' % (PLAIN_TOL, worst_plain[1], worst_plain[0])
+                            if plain_backstop else 'fp64 encoder of frames %s' % sorted(fp64_subset)),
+               'fp64_frame_subset': fp64_subset,
                'relu_decisions': {'differing': n_dis, 'total': n_tot, 'max_abs_preactivation_where_differing': float('%.3g' % worst_z),
                                   'per_layer': {s: [[n, float('%.3g' % z), t] for n, z, t in st] for s, st in dis.items()}},
                'variables': achieved}, f, indent=1)
   print('%s: loss %.6f (oracle %.6f); worst gradient error %.2e (max-norm or rel. L2, bound %.0e) at %s; %d of %d ReLU decisions '
-        'differ from the fp64 oracle, all at |z| <= %.1e; hip %.1f s, oracle %.1f s'
-        % (name, parts['loss'], float(loss_ref), worst[1], GRAD_TOL, worst[0], n_dis, n_tot, worst_z, t_hip, t_ora))
+        'differ from the fp64 oracle, all at |z| <= %.1e; plain-oracle backstop %.2e at %s; hip %.1f s, oracle %.1f s'
+        % (name, parts['loss'], float(loss_ref), worst[1], GRAD_TOL, worst[0], n_dis, n_tot, worst_z, worst_plain[1], worst_plain[0],
+           t_hip, t_ora))
   assert not failures, failures

@@ -181,3 +181,59 @@ def test_chunked_mask_consistent_mode():
   assert float(ep3['relu_disagreements']['GoalVMC/ConvEncoder'][1][0]) == 0
   assert not torch.equal(grads3['GoalVMC/DynBuffEncoder/conv2/kernel'], grads['GoalVMC/DynBuffEncoder/conv2/kernel'])
   torch.testing.assert_close(grads3['GoalVMC/ConvEncoder/conv2/kernel'], grads['GoalVMC/ConvEncoder/conv2/kernel'], rtol=1e-12, atol=1e-15)
+
+
+def test_relu_tap_every_branch():
+  """``ReluTap`` (mask-consistent gradients of the PLAIN ``loss_and_grads``: the standard of tests/test_model_gpu.py) for
+  every proc_obs x proc_tgt branch, the K-step e2e_vmc, velocity heads and L2 > 0: (1) the recording pass names the
+  ``conv_encoder`` calls per scope in graph order (target frame first in the sequence branches, graph.py:354); (2) fed the
+  restatement's own decisions back, loss and every gradient are reproduced exactly with zero disagreements; (3) one flipped
+  decision is counted with its |z| and moves that encoder's gradients; (4) the chunked evaluation's ``plain_grads`` and
+  ``conv8`` outputs equal the plain restatement's."""
+  cases = [(True, dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2), {'ConvEncoder': 1, 'DynBuffEncoder': 1, 'DynDiffEncoder': 1}),
+           (True, dict(proc_obs='sequence', proc_tgt='constant', window_size=2), {'ConvEncoder': 3}),
+           (True, dict(proc_obs='sequence', proc_tgt='residual', window_size=2, l2_regularizer=1e-3), {'ConvEncoder': 3}),
+           (True, dict(proc_obs='sequence', proc_tgt='dyndiff', window_size=2), {'ConvEncoder': 2, 'DynDiffEncoder': 2}),
+           (False, dict(window_size=3, control_mode='velocity'), {'ConvEncoder': 3})]
+  for goal, kw, calls in cases:
+    cfg = O.make_config(img_height=136, img_width=136, batch_size=2, **kw)
+    P = O.init_params(O.model_param_shapes(cfg, goal), seed=3)
+    feats, labels = O.synthetic_batch(cfg, goal, 2, seed=5, H=136, W=136)
+    tr = O.OracleTrainer(cfg, goal, P, dtype=torch.float64)
+    loss, _, grads, _, _ = tr.loss_and_grads(feats, labels)
+    rec = O.ReluTap(None)
+    loss_r, _, grads_r, _, _ = tr.loss_and_grads(feats, labels, tap=rec)
+    assert float(loss_r) == float(loss)
+    assert {k.split('/')[-1]: v for k, v in rec.calls.items()} == calls, (kw, rec.calls)
+    assert all(len(v) == 8 and v[0].dtype == torch.bool for v in rec.recorded.values())
+    tap = O.ReluTap(lambda scope, call: rec.recorded[(scope, call)])
+    loss2, _, grads2, _, _ = tr.loss_and_grads(feats, labels, tap=tap)
+    assert float(loss2) == float(loss)
+    for k in grads:
+      torch.testing.assert_close(grads2[k], grads[k], rtol=1e-12, atol=1e-15, msg=k)
+    for scope, st in tap.stats.items():
+      assert all(n == 0 and z == 0.0 and tot > 0 for n, z, tot in st), (scope, st)
+    # flip one decision of conv2 in the LAST call of the first encoder
+    sc = next(iter(rec.calls))
+    m = rec.recorded[(sc, rec.calls[sc] - 1)][1]
+    m[(1, 5, 7, 3)] = ~m[(1, 5, 7, 3)]
+    tap3 = O.ReluTap(lambda scope, call: rec.recorded[(scope, call)])
+    _, _, grads3, _, _ = tr.loss_and_grads(feats, labels, tap=tap3)
+    # (forced forward: the flip is counted at its layer; layers above it see a changed input and may disagree too)
+    assert tap3.stats[sc][0][0] == 0 and tap3.stats[sc][1][0] == 1 and tap3.stats[sc][1][1] > 1e-6
+    assert not torch.equal(grads3[sc + '/conv2/kernel'], grads[sc + '/conv2/kernel'])
+  # (4)
+  cfg = O.make_config(img_height=136, img_width=136, batch_size=2, proc_obs='dynimg', proc_tgt='dyndiff', window_size=2)
+  P = O.init_params(O.model_param_shapes(cfg, True), seed=3)
+  feats, labels = O.synthetic_batch(cfg, True, 2, seed=5, H=136, W=136)
+  tr = O.OracleTrainer(cfg, True, P, dtype=torch.float64)
+  rec = O.ReluTap(None)
+  _, _, grads, _, _ = tr.loss_and_grads(feats, labels, tap=rec)
+  lines = []
+  _, _, g2, _, ep2 = O.loss_and_grads_chunked(tr, feats, labels, chunk=1, plain_grads=True, progress=lines.append,
+                                              masks_fn=lambda j, i0, i1: [m[i0:i1] for m in rec.recorded[(list(rec.calls)[j], 0)]])
+  assert len(lines) == 12 and lines[0].startswith('forward') and lines[-1].startswith('backward')
+  for k, g in ep2['plain_grads'].items():
+    torch.testing.assert_close(g, grads[k], rtol=1e-9, atol=1e-14, msg=k)
+    torch.testing.assert_close(g2[k], grads[k], rtol=1e-9, atol=1e-14, msg=k)
+  assert sorted(ep2['conv8']) == sorted(rec.calls) and all(v.shape == (2, 2, 2, 256) for v in ep2['conv8'].values())
