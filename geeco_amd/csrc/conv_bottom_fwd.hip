@@ -29,8 +29,6 @@
 #include "geeco_common.h"
 #include <atomic>
 
-namespace {
-
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -51,8 +49,35 @@ struct BottomFwdParams {
   long long ntiles;
 };
 
-__device__ __forceinline__ void nt_store(float* dst, const f32x4& v) {
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+// dev switches (scripts/dev/build_variant.sh): BF_PRIO 1 = producer waves at s_setprio 3, 2 = consumer waves; BF_ABL (WRONG results):
+// 1 = no y1 / sign-word stores, 2 = no conv1 MFMAs, 3 = producers only keep the barriers
+#ifndef BF_PRIO
+#define BF_PRIO 1
+#endif
+#ifndef BF_ABL
+#define BF_ABL 0
+#endif
+// who stores y1 (+ its sign words): 1 = the CONSUMER waves, from the halo image they are consuming (wave w = row w of the 8 owned
+// rows: 4 pieces of 1 KiB spread over its tap loop); 0 = the producer waves right after each strip (first form: the producers,
+// one wave per SIMD with dependent write -> read-back -> store chains, became the critical path: +78 us on the launch)
+#ifndef BF_CSTORE
+#define BF_CSTORE 2
+#endif
+// who forms y1's sign words when the consumers store y1: 1 = the producers from their accumulators (8 bits per lane, OR over
+// the four lanes of a pixel by two wave shuffles), 0 = the consumers by ballots on the pieces they store
+#ifndef BF_PBITS
+#define BF_PBITS 1
+#endif
+
+#ifndef BF_NT
+#define BF_NT 3      // bit 0: y1 stores non-temporal, bit 1: y2 stores
+#endif
+template <int SITE>
+__device__ __forceinline__ void out_store(float* dst, const f32x4& v) {
+  if constexpr ((BF_NT >> SITE) & 1)
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+  else
+    *reinterpret_cast<f32x4*>(dst) = v;
 }
 
 template <bool PACK3>
@@ -71,6 +96,7 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
   f32x4* sX = sH + 2 * HALO_F4;                     // 2 x halos
   f32x4* sR = sX + 2 * X_F4;                        // 2 K-half reduction buffers
   f32x4* sO = sR + 2 * RED_F4;                      // 4 strips x [16 pixels][OP]
+  f32x4* sB = sO + 4 * 16 * OP;                     // conv2's bias of encoder g at sB[(g & 1) * 12 ..]: 12 VGPRs less per consumer lane
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,6 +133,7 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
   if (wid >= 8) {
     // ===== producers: conv1 for the y1 halo of tile index i + 1 while the consumers run conv2 on tile i ==================
     const int pw = wid - 8;
+    if (BF_PRIO == 1) __builtin_amdgcn_s_setprio(3);
     constexpr int NS = PACK3 ? 7 : 9;
     float wf[NS][2];
     int xo[NS];              // float offset of the lane's x operand of k-step s relative to its pixel's halo position
@@ -162,6 +189,7 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
     const int x_lane = (2 * pw * XW + r) << 2;
 
     auto conv1_tile = [&](int rb, int xb, int g_, int n_, int ty_, int tx_) {
+      if (BF_ABL == 3) return;
       const float* sx = reinterpret_cast<const float*>(sX + xb * X_F4);
       f32x4* hb = sH + rb * HALO_F4;
       const int y0 = ty_ * (2 * TH), x0 = tx_ * (2 * TW);
@@ -178,25 +206,41 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
         for (int s = 0; s < NS; ++s) {
           const float xv = xt[s][((rowl * XW + 16 * hh) << 2)];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i], xv, acc[i], 0, 0, 0);
+          for (int i = 0; i < 2; ++i) {
+            if (BF_ABL == 2) acc[i].x += xv * wf[s][i];
+            else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i], xv, acc[i], 0, 0, 0);
+          }
         }
         const int gy = y0 + 2 * pw + rowl;
         const bool inside = gy < p.H && x0 + 16 * hh + r < p.W;    // outside the image y1 is conv2's zero padding
+        unsigned part = 0;       // this lane's 8 sign bits of pixel r: channel c = 16 i + 4 q + j <-> bit (c & 3) * 8 + (c >> 2) = 8 j + 4 i + q
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           f32x4 v = acc[i] + bias_r[i];
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           hb[wi[hh][i] + rowl * ROW] = inside ? v : zero4;
+          if (BF_CSTORE && BF_PBITS) {         // after the ReLU: > 0 <=> non-zero bits (as the sign fields of conv2's epilogue)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part |= min(__float_as_uint(v[j]), 1u) << (8 * j + 4 * i);
+          }
+        }
+        if (BF_CSTORE && BF_PBITS && BF_ABL != 1 && BF_ABL != 4 && p.bits) {
+          // the word of pixel r = OR over the four lanes q = 0..3 that hold its channel quads (lanes r, r + 16, r + 32, r + 48);
+          // strip st = (row half, column half) keeps it in the lanes of quad st: lane L <-> pixel (row L >> 5, column L & 31)
+          part <<= q;
+          part |= __shfl_xor(part, 16, 64);
+          part |= __shfl_xor(part, 32, 64);
+          if (q == st) myword = part;
         }
         // read the strip back in memory order (same wave: LDS operations of a wave complete in order) and store it:
         // lane l -> pair 8 hh + 4 h + (l >> 4), slot l & 15 = pixel 8 h + (l >> 3), channel quad l & 7: 1 KiB per instruction
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < (BF_CSTORE ? 0 : 2); ++h) {
           const int pair = 8 * hh + 4 * h + (lane >> 4);
           const f32x4 v = hb[(2 * pw + rowl) * ROW + pair * 16 + ((lane & 15) ^ (pair & 15))];
           const int gx = x0 + 16 * hh + 8 * h + (lane >> 3);
-          if (gy < p.H && gx < p.W) nt_store(yg + ((long long)gy * p.W + gx) * 32 + (lane & 7) * 4, v);
-          if (p.bits) {
+          if (BF_ABL != 1 && gy < p.H && gx < p.W) out_store<0>(yg + ((long long)gy * p.W + gx) * 32 + (lane & 7) * 4, v);
+          if (BF_ABL != 1 && p.bits) {
             // a compare IS a ballot (lane = 8 pixel + channel quad): byte `pixel` of the four masks holds the bits of channels
             // 4 c4 + {0, 1, 2, 3}; every lane assembles the word of pixel lane & 7 (bit (c & 3) * 8 + (c >> 2) <-> channel c)
             // and the lanes 8 (2 st + h) + j keep it: after the four strips lane L holds the word of pixel (row L >> 5, col L & 31)
@@ -229,7 +273,7 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
           }
         }
       }
-      if (p.bits) {           // one coalesced store per wave: 2 rows x 32 words
+      if ((!BF_CSTORE || BF_PBITS) && BF_ABL != 1 && BF_ABL != 4 && p.bits) {           // one coalesced store per wave: 2 rows x 32 words
         const int gy = y0 + 2 * pw + (lane >> 5), gx = x0 + (lane & 31);
         if (gy < p.H && gx < p.W) p.bits[(long long)g_ * p.gs_bits + ((long long)n_ * p.Hp + gy) * p.Wp + gx] = myword;
       }
@@ -258,53 +302,45 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
   }
 
   // ===== consumers: conv2 on the halo ring =====================================================================================
+  if (BF_PRIO == 2) __builtin_amdgcn_s_setprio(3);
   const int strip = wid & 3, khalf = (wid >> 2) & 1;
   // x halo DMA (K-half-1 waves): wave 4 + j issues pieces j and j + 4; slot sl = 64 piece + lane = halo pixel (sl / 35, sl % 35)
   const int xw = wid - 4;
-  int d_src[2];
-  short d_hy[2], d_hx[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int sl = ((khalf ? xw : 0) + 4 * k) * 64 + lane;
-    const int hy = sl / XW, hx = sl - hy * XW;
-    d_hy[k] = (short)(sl < XPX ? hy : 30000);         // out-of-range marker fails the per-tile bounds test
-    d_hx[k] = (short)hx;
-    d_src[k] = (hy * p.W + hx) * 4;
-  }
   auto dma_x = [&](int xb, int g_, int n_, int ty_, int tx_) {
     const int iy0 = ty_ * (2 * TH) - 1, ix0 = tx_ * (2 * TW) - 1;     // conv1: TF SAME, stride 1: pad 1 on every side
     const float* xg = p.x + (long long)g_ * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * 4;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                        // keeps the per-lane halo coordinates out of loop-invariant registers
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (xw + 4 * k < XPIECES) {                       // wave-uniform
-        const int iy = iy0 + d_hy[k], ix = ix0 + d_hx[k];
-        const bool v = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float* src = v ? xg + d_src[k] : g_zero_page_bf;
+        const int sl = (xw + 4 * k) * 64 + ln;          // formed per tile: held across the tile loop they spill the compute waves
+        const int hy = sl / XW, hx = sl - hy * XW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool v = sl < XPX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* src = v ? xg + (hy * p.W + hx) * 4 : g_zero_page_bf;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + xb * X_F4 + (xw + 4 * k) * 64), 16, 0, 0);
       }
     }
   };
-  int gd = g, nd = n, tyd = ty, txd = tx;                 // the tile whose x halo is fetched next (K-half-1 waves)
-  long long tile_d = tile;
   if (khalf) {
-    dma_x(0, gd, nd, tyd, txd);
+    dma_x(0, g, n, ty, tx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   asm volatile("s_barrier" ::: "memory");                 // (P0)
-  if (khalf) {
-    if (tile_d + 1 < tend) {
-      advance(gd, nd, tyd, txd);
-      ++tile_d;
-      dma_x(1, gd, nd, tyd, txd);
-    }
+  if (khalf && tile + 1 < tend) {
+    int g1 = g, n1 = n, ty1 = ty, tx1 = tx;
+    advance(g1, n1, ty1, tx1);
+    dma_x(1, g1, n1, ty1, tx1);
   }
   int g_w = g;
-  f32x4 bias_r[TI];
   const int cq_lane = khalf * 4 + q;       // this wave sums channels [16 khalf, 16 khalf + 16)
   f32x4 wreg[9][TI];
   // kernel fragments straight from the HWIO kernel: lane (r, q) of co tile i holds w[tap][4 cq_lane + s][16 i + r], s = 0..3
   auto load_wreg = [&](int g_) {
-    const float* wg = p.w2 + (long long)g_ * p.gs_w2 + (4 * cq_lane) * COUT + r;
+    int lofs = (4 * cq_lane) * COUT + r;
+    asm volatile("" : "+v"(lofs));            // encoder changes are rare: no registers held for them across the tile loop
+    const float* wg = p.w2 + (long long)g_ * p.gs_w2 + lofs;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -312,8 +348,11 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
         const float* w0 = wg + tap * CIN * COUT + 16 * i;
         wreg[tap][i] = f32x4{w0[0], w0[COUT], w0[2 * COUT], w0[3 * COUT]};
       }
-#pragma unroll
-    for (int i = 0; i < TI; ++i) bias_r[i] = *reinterpret_cast<const f32x4*>(p.b2 + (long long)g_ * p.gs_b2 + i * 16 + 4 * q);
+    // bias -> LDS (wave 0; two slots by encoder parity: the epilogues of the previous encoder's last tile may still be reading theirs)
+    int lb = lane;
+    asm volatile("" : "+v"(lb));
+    if (wid == 0 && lb < COUT / 4)
+      sB[(g_ & 1) * (COUT / 4) + lb] = *reinterpret_cast<const f32x4*>(p.b2 + (long long)g_ * p.gs_b2 + 4 * lb);
   };
   load_wreg(g);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,10 +362,10 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
     if (more) advance(g2, n2, ty2, tx2);
-    if (khalf && tile_d + 1 < tend) {                       // x halo of tile + 2 -> the x buffer tile + 1's producers are not reading
-      advance(gd, nd, tyd, txd);
-      ++tile_d;
-      dma_x(buf, gd, nd, tyd, txd);
+    if (khalf && tile + 2 < tend) {                         // x halo of tile + 2 -> the x buffer tile + 1's producers are not reading
+      int g3 = g2, n3 = n2, ty3 = ty2, tx3 = tx2;
+      advance(g3, n3, ty3, tx3);
+      dma_x(buf, g3, n3, ty3, tx3);
     }
     f32x4 acc[TI];
 #pragma unroll
@@ -339,9 +378,42 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
       a = hA[ky * ROW + pair * 16 + ((((kx & 1) << 3) | cq_lane) ^ (pair & 15))];
     };
     frag(0, a_cur);
+    // y1 of THIS tile's halo image -> HBM (the producers fill the image and write the sign words): wave w stores row w of the 8
+    // owned rows, 32 pixels = 4 KiB of consecutive NHWC bytes, as 4 pieces of 8 pixels (lane l -> pair 4 h + (l >> 4), slot l & 15
+    // = pixel 8 h + (l >> 3), channel quad l & 7).  BF_CSTORE 1: read before tap 2 h, stored after it; 2: all four behind the tap loop
+    f32x4 yv = zero4;
+    const int gy1 = ty * (2 * TH) + wid;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));           // per-tile address arithmetic of the stores below: held across the tile loop it spills
+    auto y1_read_to = [&](int h, f32x4& dst) {
+      const int pair = 4 * h + (ln >> 4);
+      dst = sH[buf * HALO_F4 + wid * ROW + pair * 16 + ((ln & 15) ^ (pair & 15))];
+    };
+    [[maybe_unused]] unsigned myword = 0;
+    auto y1_store_from = [&](int h, const f32x4& src) {
+      const int gx = tx * (2 * TW) + 8 * h + (ln >> 3);
+      float* yg = p.y1 + (long long)g * p.gs_y1 + (((long long)n * p.H + gy1) * p.W + gx) * 32 + (ln & 7) * 4;
+      if (BF_ABL != 1 && gy1 < p.H && gx < p.W) out_store<0>(yg, src);
+      if (!BF_PBITS && BF_ABL != 1 && BF_ABL != 4 && p.bits) {
+        // a compare IS a ballot (lane = 8 pixel + channel quad): byte `pixel` of the four masks holds the bits of channels
+        // 4 c4 + {0, 1, 2, 3}; every lane assembles the word of pixel lane & 7 (bit (c & 3) * 8 + (c >> 2) <-> channel c) and
+        // the lanes 8 h + j keep it: after the four pieces lane L < 32 holds the word of pixel (row w, column L)
+        const unsigned long long bx = __ballot(src.x > 0.f), by = __ballot(src.y > 0.f), bz = __ballot(src.z > 0.f),
+                                 bw = __ballot(src.w > 0.f);
+        const unsigned j = ln & 7;
+        const unsigned word = __builtin_amdgcn_perm((unsigned)(bx >> 32), (unsigned)bx, 0x0c0c0c00u | j) |
+                              __builtin_amdgcn_perm((unsigned)(by >> 32), (unsigned)by, 0x0c0c000cu | (j << 8)) |
+                              __builtin_amdgcn_perm((unsigned)(bz >> 32), (unsigned)bz, 0x0c000c0cu | (j << 16)) |
+                              __builtin_amdgcn_perm((unsigned)(bw >> 32), (unsigned)bw, 0x000c0c0cu | (j << 24));
+        if ((ln >> 3) == h) myword = word;
+      }
+    };
+    auto y1_read = [&](int h) { y1_read_to(h, yv); };
+    auto y1_store = [&](int h) { y1_store_from(h, yv); };
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) frag(tap + 1, a_nxt);
+      if (BF_CSTORE == 1 && tap < 8 && (tap & 1) == 0) y1_read(tap >> 1);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch read ABOVE this group's MFMAs
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -349,7 +421,32 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
         for (int i = 0; i < TI; ++i)
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][i][s], a_cur[s], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (BF_CSTORE == 1 && tap < 8 && (tap & 1) == 0) {
+        y1_store(tap >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       a_cur = a_nxt;
+    }
+    if (BF_CSTORE == 2) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        y1_read(h);
+        y1_store(h);
+      }
+    }
+    if (BF_CSTORE == 3) {       // two pieces in flight: the second read's latency hides behind the first store
+      f32x4 yw;
+#pragma unroll
+      for (int h = 0; h < 4; h += 2) {
+        y1_read_to(h, yv);
+        y1_read_to(h + 1, yw);
+        y1_store_from(h, yv);
+        y1_store_from(h + 1, yw);
+      }
+    }
+    if (BF_CSTORE && !BF_PBITS && BF_ABL != 1 && BF_ABL != 4 && p.bits && ln < 32) {
+      const int gx = tx * (2 * TW) + ln;
+      if (gy1 < p.H && gx < p.W) p.bits[(long long)g * p.gs_bits + ((long long)n * p.Hp + gy1) * p.Wp + gx] = myword;
     }
     f32x4* red = sR + (int)(tile & 1) * RED_F4;
     if (khalf == 1) {
@@ -365,7 +462,7 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
       unsigned field = 0;
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
-        f32x4 v = acc[i] + red[(strip * TI + i) * 64 + lane] + bias_r[i];
+        f32x4 v = acc[i] + red[(strip * TI + i) * 64 + lane] + sB[(g & 1) * (COUT / 4) + 4 * i + q];
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         so[r * OP + 4 * i + q] = v;
         if (p.fields) {
@@ -374,19 +471,19 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
         }
       }
       if (p.fields) {
-        const int fy = ty * TH + strip, fx = tx * TW + r;
+        const int fy = ty * TH + strip, fx = tx * TW + (ln & 15);
         if (fy < p.Ho && fx < p.Wo)
-          p.fields[(long long)g * p.gs_fields + (((long long)n * p.fHp + fy) * p.fWp + fx) * 4 + q] = (unsigned short)field;
+          p.fields[(long long)g * p.gs_fields + (((long long)n * p.fHp + fy) * p.fWp + fx) * 4 + (ln >> 4)] = (unsigned short)field;
       }
       const int oy = ty * TH + strip;
       float* yo = p.y2 + (long long)g * p.gs_y2 + (((long long)n * p.Ho + oy) * p.Wo + tx * TW) * COUT;
       constexpr int C4 = COUT / 4;
 #pragma unroll
       for (int jj = 0; jj < TI; ++jj) {          // 16 * C4 float4 = TI x 64 lanes
-        const int m = lane + 64 * jj;
+        const int m = ln + 64 * jj;
         const int px = m / C4, c4 = m - px * C4;
         const f32x4 v = so[px * OP + c4];
-        if (oy < p.Ho && tx * TW + px < p.Wo) nt_store(yo + m * 4, v);
+        if (oy < p.Ho && tx * TW + px < p.Wo) out_store<1>(yo + m * 4, v);
       }
     }
     if (!more) break;
@@ -399,8 +496,6 @@ __global__ __launch_bounds__(768) void conv1_conv2_fwd_kernel(const BottomFwdPar
     ++tile;
   }
 }
-
-}  // namespace
 
 extern "C" int geeco_conv1_conv2_fwd(const float* x, const float* w1, const float* b1, float* y1, uint32_t* bits,
                                      const float* w2, const float* b2, float* y2, uint16_t* fields, int groups, int64_t gs_x,
@@ -422,7 +517,7 @@ extern "C" int geeco_conv1_conv2_fwd(const float* x, const float* w1, const floa
   p.Hp = (int)geeco_relu_bits_rows(H); p.Wp = (int)geeco_relu_bits_pitch(W);
   p.fHp = (p.Ho + 7) / 8 * 8; p.fWp = (p.Wo + 63) / 64 * 64;
   p.w_cin = w_cin;
-  const size_t lds = (size_t)(2 * 9 * 17 * 16 + 2 * 7 * 64 + 2 * 4 * 3 * 64 + 4 * 16 * 13) * 16;
+  const size_t lds = (size_t)(2 * 9 * 17 * 16 + 2 * 7 * 64 + 2 * 4 * 3 * 64 + 4 * 16 * 13 + 2 * 12) * 16;
   static std::atomic<bool> attr_set{false};   // idempotent attribute calls: racing threads at worst repeat them
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_conv2_fwd_kernel<true>),

@@ -12,11 +12,11 @@ extra_flags() {      # as geeco_amd/csrc/build.sh; PLAIN=1: none (to A/B the per
   [ -n "${PLAIN:-}" ] && return
   case $1 in
     conv_gemm) echo "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
-    conv_halo|conv_dgrad_lds) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+    conv_halo|conv_dgrad_lds|conv_bottom_fwd) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
   esac
 }
 pids=()
-for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
+for f in conv_gemm conv_halo conv_bottom_fwd conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
   /opt/rocm/bin/hipcc $FLAGS $(extra_flags $f) -c $f.hip -o $B/$f.o &
   pids+=($!)
 done
