@@ -25,6 +25,13 @@ struct DynParams {
   float* part;   // [N][nblk][2]
   int nblk;
   float alpha[DYN_MAXK];
+  // DIFF (geeco_goal_dynimgs_fwd): the pair image alpha2[0] * last frame + alpha2[1] * target (graph.py:397-400) from the same pass:
+  // the last frame is in registers anyway, so the pair image costs one read of the target instead of a launch that reads both
+  const float* tgt;       // [N][HW][3]
+  const float* tgt_depth; // [N][HW] (DEPTH)
+  float* diff_out;        // [N][HW][4]
+  float* part2;           // [N][nblk][2]
+  float alpha2[2];
 };
 
 __device__ __forceinline__ const float* dyn_frame_ptr(const DynParams& p, int n, int t) {
@@ -48,17 +55,38 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float* ds
   }
 }
 
+__device__ __forceinline__ void block_minmax_store2(float mn, float mx, float* dst, float mn2, float mx2, float* dst2) {
+  __shared__ float s4[4][4];
+  mn = wave_reduce_min(mn);
+  mx = wave_reduce_max(mx);
+  mn2 = wave_reduce_min(mn2);
+  mx2 = wave_reduce_max(mx2);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s4[wid][0] = mn; s4[wid][1] = mx; s4[wid][2] = mn2; s4[wid][3] = mx2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dst[0] = fminf(fminf(s4[0][0], s4[1][0]), fminf(s4[2][0], s4[3][0]));
+    dst[1] = fmaxf(fmaxf(s4[0][1], s4[1][1]), fmaxf(s4[2][1], s4[3][1]));
+    dst2[0] = fminf(fminf(s4[0][2], s4[1][2]), fminf(s4[2][2], s4[3][2]));
+    dst2[1] = fmaxf(fmaxf(s4[0][3], s4[1][3]), fmaxf(s4[2][3], s4[3][3]));
+  }
+}
+
 // C == 3, Cpad == 4, HW % 4 == 0: one thread = 4 pixels = 3 float4 in, 4 float4 out.  DEPTH: a 4th channel comes from its
 // own tensor (one more float4 = the depth of the 4 pixels per frame): rgb || depth (estimator.py:169,172) is formed in
 // registers instead of packing all N * K frames to 4 channels first (1.07 GB read + 1.43 GB written per step at K = 32).
-template <bool DEPTH>
+template <bool DEPTH, bool DIFF = false>
 __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
   const int n = blockIdx.y;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;   // 4-pixel unit
   const long long U = p.HW >> 2;
   float mn = INFINITY, mx = -INFINITY;
+  [[maybe_unused]] float mn2 = INFINITY, mx2 = -INFINITY;
   if (u < U) {
     f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    [[maybe_unused]] f32x4 d0 = a0, d1 = a0, d2 = a0, d3 = a0;
 #pragma unroll 4
     for (int t = 0; t < p.K; ++t) {
       const f32x4* src = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t)) + u * 3;
@@ -81,6 +109,39 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
         lo[2] = f32x4{v1.z, v1.w, v2.x, v3.z};
         lo[3] = f32x4{v2.y, v2.z, v2.w, v3.w};
       }
+      if (DIFF && t == p.K - 1) {       // the pair image, summed in the order of the two-frame pass: 0 + alpha2[0] * current, + alpha2[1] * target
+        const f32x4* ts = reinterpret_cast<const f32x4*>(p.tgt + (long long)n * p.HW * 3) + u * 3;
+        const f32x4 t0 = ts[0], t1 = ts[1], t2 = ts[2];
+        const float w0 = p.alpha2[0], w1 = p.alpha2[1];
+        d0 += w0 * v0; d1 += w0 * v1; d2 += w0 * v2;
+        d0 += w1 * t0; d1 += w1 * t1; d2 += w1 * t2;
+        if (DEPTH) {
+          const f32x4 t3 = reinterpret_cast<const f32x4*>(p.tgt_depth + (long long)n * p.HW)[u];
+          d3 += w0 * v3;
+          d3 += w1 * t3;
+        }
+      }
+    }
+    if (DIFF) {
+      float e2[12] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w};
+      float q4[4] = {d3.x, d3.y, d3.z, d3.w};
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        mn2 = fminf(mn2, e2[i]);
+        mx2 = fmaxf(mx2, e2[i]);
+      }
+      if (DEPTH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          mn2 = fminf(mn2, q4[i]);
+          mx2 = fmaxf(mx2, q4[i]);
+        }
+      }
+      f32x4* dd = reinterpret_cast<f32x4*>(p.diff_out + ((long long)n * p.HW + u * 4) * 4);
+      dd[0] = f32x4{e2[0], e2[1], e2[2], DEPTH ? q4[0] : 0.f};
+      dd[1] = f32x4{e2[3], e2[4], e2[5], DEPTH ? q4[1] : 0.f};
+      dd[2] = f32x4{e2[6], e2[7], e2[8], DEPTH ? q4[2] : 0.f};
+      dd[3] = f32x4{e2[9], e2[10], e2[11], DEPTH ? q4[3] : 0.f};
     }
     float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
     float d4[4] = {a3.x, a3.y, a3.z, a3.w};
@@ -102,7 +163,11 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
     dst[2] = f32x4{e[6], e[7], e[8], DEPTH ? d4[2] : 0.f};
     dst[3] = f32x4{e[9], e[10], e[11], DEPTH ? d4[3] : 0.f};
   }
-  block_minmax_store(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2);
+  if (DIFF)
+    block_minmax_store2(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2, mn2, mx2,
+                        p.part2 + ((long long)n * p.nblk + blockIdx.x) * 2);
+  else
+    block_minmax_store(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2);
 }
 
 // Generic: one thread = one pixel, C <= Cpad <= 8 channels (C == 4: one float4 per frame).
@@ -314,8 +379,9 @@ static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_
   return 0;
 }
 
-// The goal model's three conv1 inputs (graph.py:386-401) in three launches instead of five: buffer image (+ the current
-// frame's padded copy), diff image of (current frame, target), and ONE normalisation launch for both images.
+// The goal model's three conv1 inputs (graph.py:386-401) in TWO launches (round 3: three; before: five): one pass over the window
+// writes the buffer image, the current frame's padded copy AND the pair image of (current frame, target); one normalisation
+// launch serves both images.
 extern "C" int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* tgt_rgb,
                                       const float* depth, int64_t dsample_stride, int64_t dframe_stride,
                                       const float* tgt_depth, const float* alpha_host, const float* alpha2_host, int N, int K,
@@ -336,19 +402,14 @@ extern "C" int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, i
   p.depth = depth; p.dsample_stride = dsample_stride; p.dframe_stride = dframe_stride;
   p.N = N; p.K = K; p.HW = HW; p.C = 3; p.Cpad = 4; p.out = buf_out; p.last = cur_out; p.part = part1; p.nblk = nblk;
   for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
-  DynParams d = {};
-  d.frames = rgb + (long long)(K - 1) * frame_stride; d.frames2 = tgt_rgb; d.sample_stride = sample_stride;
-  if (depth) { d.depth = depth + (long long)(K - 1) * dframe_stride; d.depth2 = tgt_depth; d.dsample_stride = dsample_stride; }
-  d.N = N; d.K = 2; d.HW = HW; d.C = 3; d.Cpad = 4; d.out = diff_out; d.part = part2; d.nblk = nblk;
-  d.alpha[0] = alpha2_host[0]; d.alpha[1] = alpha2_host[1];
+  // ONE pass for both images (round 4): the pair image needs the current frame, which this pass holds in registers at t = K - 1
+  p.tgt = tgt_rgb; p.tgt_depth = tgt_depth; p.diff_out = diff_out; p.part2 = part2;
+  p.alpha2[0] = alpha2_host[0]; p.alpha2[1] = alpha2_host[1];
   const dim3 grid((unsigned)nblk, (unsigned)N);
-  if (depth) {
-    hipLaunchKernelGGL(dynimg_wsum3_kernel<true>, grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(dynimg_wsum3_kernel<true>, grid, dim3(256), 0, s, d);
-  } else {
-    hipLaunchKernelGGL(dynimg_wsum3_kernel<false>, grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(dynimg_wsum3_kernel<false>, grid, dim3(256), 0, s, d);
-  }
+  if (depth)
+    hipLaunchKernelGGL((dynimg_wsum3_kernel<true, true>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((dynimg_wsum3_kernel<false, true>), grid, dim3(256), 0, s, p);
   GEECO_LAUNCH_CHECK();
   const int C = depth ? 4 : 3;
   dim3 g2((unsigned)cdiv64(HW * 4, 1024), (unsigned)N, 2);

@@ -111,7 +111,8 @@ def dynimg_rgbd_last_into(out, last, rgb, depth, K, N, HW, ws, sample_stride, fr
 
 def goal_dynimgs_into(cur_out, buf_out, diff_out, rgb, tgt_rgb, K, N, HW, ws, sample_stride, frame_stride, depth=None,
                       tgt_depth=None, dsample_stride=0, dframe_stride=0):
-  """The goal model's three conv1 inputs (current frame padded, buffer image, diff image) in three launches."""
+  """The goal model's three conv1 inputs (current frame padded, buffer image, diff image) in two launches: one pass over the
+  window for all three + one normalisation of both images."""
   check(_lib().geeco_goal_dynimgs_fwd(_p(rgb), sample_stride, frame_stride, _p(tgt_rgb), _p(depth), dsample_stride,
                                       dframe_stride, _p(tgt_depth), ctypes.cast(_alpha_buf(K), ctypes.c_void_p),
                                       ctypes.cast(_alpha_buf(2), ctypes.c_void_p), N, K, HW, _p(cur_out), _p(buf_out),

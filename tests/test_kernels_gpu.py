@@ -557,6 +557,46 @@ def test_dynimg_with_last_frame(dev, N, K, H, W, C):
   assert torch.equal(out, out_ref) and torch.equal(last, last_ref)
 
 
+@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (2, 2, 40, 36, 4)])
+def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
+  """The goal model's input stage (graph.py:386-401) as the step runs it: ONE pass over the window writes the buffer image, the
+  current frame's padded copy and the pair image of (current frame, target), one normalisation launch serves both images.
+  Bitwise equal to the separate launches (buffer image; two-frame image with the target as second frame), and both images
+  against the fp64 oracle; K = 1 (alpha = [0]: the buffer image is identically 0), rgb and rgb + depth."""
+  from geeco_amd import ops
+  r = np.random.default_rng(57)
+  HW = H * W
+  rgb = torch.tensor(r.random([N, K, H, W, 3]).astype(np.float32), device=dev)
+  tgt = torch.tensor(r.random([N, H, W, 3]).astype(np.float32), device=dev)
+  ws = ops.dynimg_ws(N, HW * 4, dev)
+  ws2 = torch.empty(2 * ws.numel(), dtype=torch.float32, device=dev)
+  cur, buf, dif = (torch.full((N, H, W, 4), float('nan'), device=dev) for _ in range(3))
+  buf_ref, dif_ref, cur_ref = (torch.empty(N, H, W, 4, device=dev) for _ in range(3))
+  if C == 3:
+    ops.dynimg_into(buf_ref, rgb, K, N, HW, 3, 4, ws, K * HW * 3, HW * 3)
+    ops.dynimg_into(dif_ref, rgb[:, K - 1], 2, N, HW, 3, 4, ws, K * HW * 3, 0, frames2=tgt)
+    ops.pack_pixels_into(cur_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4)
+    ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3)
+    frames64 = rgb.cpu().double()
+    tgt64 = tgt.cpu().double()
+  else:
+    dep = torch.tensor((0.5 + 2.5 * r.random([N, K, H, W, 1])).astype(np.float32), device=dev)
+    tdep = torch.tensor((0.5 + 2.5 * r.random([N, H, W, 1])).astype(np.float32), device=dev)
+    ops.dynimg_rgbd_into(buf_ref, rgb, dep, K, N, HW, ws, K * HW * 3, HW * 3, K * HW, HW)
+    ops.dynimg_rgbd_into(dif_ref, rgb[:, K - 1], dep[:, K - 1], 2, N, HW, ws, K * HW * 3, 0, K * HW, 0, rgb2=tgt, depth2=tdep)
+    ops.pack_pixels_into(cur_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4, dep[:, K - 1], K * HW, 1)
+    ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3, depth=dep, tgt_depth=tdep,
+                          dsample_stride=K * HW, dframe_stride=HW)
+    frames64 = torch.cat([rgb, dep], -1).cpu().double()
+    tgt64 = torch.cat([tgt, tdep], -1).cpu().double()
+  torch.cuda.synchronize()
+  assert torch.equal(cur, cur_ref)
+  assert torch.equal(buf, buf_ref)
+  assert torch.equal(dif, dif_ref)
+  _close(buf[..., :C], O.dynimg(frames64), 0, 5e-6, 'buffer image vs fp64')
+  _close(dif[..., :C], O.dynimg(torch.stack([frames64[:, K - 1], tgt64], 1)), 0, 5e-6, 'pair image vs fp64')
+
+
 @pytest.mark.parametrize('G,N,H,W', [(1, 2, 32, 64), (3, 2, 64, 64)])
 def test_conv3_relu_fields_and_conv4_dgrad_fields(dev, G, N, H, W):
   """conv3's forward with the byte sign fields of its output (byte (T >> 1) * 4 + q, bit 4 (T & 1) + j <-> channel
