@@ -300,11 +300,11 @@ def hbm_table(model, args, iters):
         lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
   if args.model == 'geeco-f' and getattr(model, 'last_from_dynimg', False) \
       and HW % 4 == 0 and (C == 3 or getattr(model, 'split_rgbd', False)):
-    # what the step really runs: both images + the current frame's padded copy in three launches (one shared
+    # what the step really runs: both images + the current frame's padded copy in two launches (one shared
     # normalisation launch); algorithmic bytes = the two dynimg figures of SURVEY 8(d)
     inp, x_in = model.inputs, model.enc.x_in
     kw = dict(depth=inp['depth'], tgt_depth=inp['target_depth'], dsample_stride=K * HW, dframe_stride=HW) if C == 4 else {}
-    add('goal inputs as in the step: buffer image (K=%d) + diff image (K=2) + current frame, 3 launches' % K,
+    add('goal inputs as in the step: buffer image (K=%d) + diff image (K=2) + current frame, 2 launches' % K,
         4.0 * N * HW * C * (K + 1 + 3),
         lambda: ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], inp['rgb'], inp['target_rgb'], K, N, HW, model.dyn_ws2,
                                       K * HW * 3, HW * 3, **kw))
@@ -389,17 +389,20 @@ def check_losses(args, first_loss, final_loss, total_steps):
 # ======================================================================================================
 def device_identity(local):
   """(identity, detail): `identity` is equal for two ranks exactly when they sit on the same physical GPU -- host name + PCI
-  address (domain:bus:device), which two devices cannot share; where this torch build does not expose the PCI address the
-  local device index stands in.  `detail` adds the UUID for the report only: it is NOT compared (a driver that reported one
-  placeholder UUID for every GPU must not make an honest 8-GPU run refuse itself)."""
+  address (domain:bus:device), which two devices cannot share.  Where this torch build does not expose the PCI address the
+  device UUID stands in; with neither, identity is None and the caller SKIPS the shared-GPU refusal with a warning (a
+  per-process local index is never compared: launchers that isolate ranks through HIP_VISIBLE_DEVICES give every rank
+  index 0, and an honest N-GPU run must not refuse itself).  `detail` adds the UUID for the report."""
   import torch
   pr = torch.cuda.get_device_properties(local)
   host = socket.gethostname()
+  u = getattr(pr, 'uuid', None)
   if hasattr(pr, 'pci_bus_id'):
     ident = '%s pci=%04x:%02x:%02x' % (host, getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0))
+  elif u is not None:
+    ident = '%s uuid=%s' % (host, u)
   else:
-    ident = '%s index=%d' % (host, local)
-  u = getattr(pr, 'uuid', None)
+    return None, '%s local index %d (no PCI address / UUID exposed by this torch build)' % (host, local)
   return ident, ident + (' uuid=%s' % u if u is not None else '')
 
 
@@ -676,22 +679,27 @@ def comm_report(args, model, runner, dev, world, step_ms):
     torch.distributed.barrier()
     modes[name] = round(gdist.max_over_ranks(time_region(runner.step, iters), dev), 4)
   runner.overlap, runner.skip_allreduce = main_mode, False
+  # the no_exchange probe applied Adam to UN-reduced per-rank gradients (the batches differ per rank): the replicas have diverged.
+  # Put them back in step before anything else runs on this model: parameters and optimiser state from rank 0.
+  torch.cuda.synchronize()
+  st = model.store
+  for buf in (st.params, st.adam_m, st.adam_v):
+    torch.distributed.broadcast(buf, src=0)
+  torch.distributed.broadcast(st.global_step, src=0)
+  torch.cuda.synchronize()
+  if getattr(model, 'enc', None) is not None:
+    model.enc.refresh_derived()
   # the same overlapped step with the two persistent bottom-of-the-backward kernels leaving RESERVE CUs free for RCCL's
   # workgroups (new graphs captured with the smaller grids; the timed region above always runs with 0 reserved)
-  from geeco_amd import ops
   from geeco_amd.runtime import TrainStepRunner
-  ops.set_reserved_cus(DP_RESERVE_PROBE)
-  try:
-    r2 = TrainStepRunner(model, use_graph=runner.use_graph, warmup=2, overlap=True)
-    r2.prepare()
-    for _ in range(3):
-      r2.step()
-    torch.cuda.synchronize()
-    torch.distributed.barrier()
-    modes['overlap_reserve%d' % DP_RESERVE_PROBE] = round(gdist.max_over_ranks(time_region(r2.step, iters), dev), 4)
-    del r2
-  finally:
-    ops.set_reserved_cus(0)
+  r2 = TrainStepRunner(model, use_graph=runner.use_graph, warmup=2, overlap=True, reserved_cus=DP_RESERVE_PROBE)
+  r2.prepare()
+  for _ in range(3):
+    r2.step()
+  torch.cuda.synchronize()
+  torch.distributed.barrier()
+  modes['overlap_reserve%d' % DP_RESERVE_PROBE] = round(gdist.max_over_ranks(time_region(r2.step, iters), dev), 4)
+  del r2
   wire = 4 * sum(n for _, n in runner.early_calls) + (runner.staging.numel() * 4 if runner.staging is not None else 0)
   return {'mode': 'overlap' if main_mode else 'serial', 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
           'allreduce_bytes_on_the_wire': int(wire),
@@ -720,9 +728,11 @@ def main():
   dev = torch.device('cuda', local)
   # N ranks must sit on N distinct GPUs: two ranks on one device would report a number for the wrong machine
   ident, detail = device_identity(local)
-  idents = gdist.gather_strings(ident, dev)
+  idents = gdist.gather_strings(ident if ident is not None else '?', dev)
   details = gdist.gather_strings(detail, dev, width=160)
-  shared = len(set(idents)) < world
+  if '?' in idents:
+    log('WARNING: no PCI address / UUID available for at least one rank: cannot verify that the %d ranks sit on distinct GPUs' % world)
+  shared = '?' not in idents and len(set(idents)) < world
   if shared and not args.allow_shared_gpu:
     log('%d ranks but only %d distinct GPU(s): %s' % (world, len(set(idents)), idents))
     sys.exit(3)

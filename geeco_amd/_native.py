@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, _dev.env('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_DEV=1 GEECO_LIB=...: A/B builds side by side
 
 
-ABI_VERSION = 3        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
+ABI_VERSION = 4        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
 
 
 class GeecoNativeError(RuntimeError):
@@ -38,8 +38,6 @@ class SlabReduce(Structure):
 SIGNATURES = {
     'geeco_abi_version': (_I, []),
     'geeco_last_error': (c_char_p, []),
-    'geeco_set_reserved_cus': (_I, [_I]),
-    'geeco_reserved_cus': (_I, []),
     'geeco_debug_kernel_trace_begin': (None, []),
     'geeco_debug_kernel_trace_end': (c_char_p, []),
     'geeco_dynimg_alpha': (None, [_I, _P]),
@@ -62,9 +60,9 @@ SIGNATURES = {
     'geeco_conv2_dgrad_conv1_wgrad_ws_bytes': (_L, [_I]),
     'geeco_conv2_dgrad_conv1_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P]),
     'geeco_conv3x3_wgrad_partial': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P,
-                                         POINTER(SlabReduce)]),
+                                         POINTER(SlabReduce), _I]),
     'geeco_conv2_dgrad_conv1_wgrad_partial': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I,
-                                                   _P, _P, POINTER(SlabReduce)]),
+                                                   _P, _P, POINTER(SlabReduce), _I]),
     'geeco_slab_reduce_batch': (_I, [POINTER(SlabReduce), _I, _P]),
     'geeco_relu_bits_pitch': (_L, [_I]),
     'geeco_conv3_fwd_relu_fields': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
@@ -77,7 +75,7 @@ SIGNATURES = {
     'geeco_conv1_fwd_relu_bits': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_conv1_fwd_relu_bits_rgb': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_conv2_dgrad_conv1_wgrad_bits': (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P,
-                                                POINTER(SlabReduce)]),
+                                                POINTER(SlabReduce), _I]),
     'geeco_transpose_hwio': (_I, [_P, _P, _I, _L, _L, _I, _I, _P]),
     'geeco_derive_conv_weights': (_I, [_I, _PP, _PP, POINTER(_I), POINTER(_I), POINTER(_L), _I, _L, _P, _P, _I, _I, _I, _L,
                                        _P]),

@@ -1156,7 +1156,7 @@ void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long lon
                                long long KC, int Cout, int groups, hipStream_t s);
 
 // Persistent one-block-per-CU kernels of the encoder bottom (conv2's filter gradient, the fused conv2-dgrad + conv1-wgrad):
-// slices per encoder.  geeco_set_reserved_cus(k) leaves k CUs free for a collective that runs beside them (data parallel:
+// slices per encoder.  The entry points' `reserved_cus` argument k leaves k CUs free for a collective that runs beside them (data parallel:
 // the early gradient bucket is reduced while these two kernels run; a grid that occupies every CU would make the
 // collective's workgroups wait for - or delay - the persistent blocks).  The workspace is sized for k = 0.
 struct BottomSlices {
@@ -1168,7 +1168,7 @@ struct BottomSlices {
 // 85 x 48 + 1 x (3 x 16); conv2's filter gradient 97 -> 96 tiles per block.  Otherwise ceil(T / S0) tiles per block.
 static BottomSlices bottom_slices(int groups, long long T, bool for_ws = false) {
   static const int no_rem = geeco_dev_getenv("GEECO_NO_REMAINDER_BLOCK") ? 1 : 0;
-  const int cus = 256 - (for_ws ? 0 : geeco_reserved_cus());
+  const int cus = 256 - (for_ws ? 0 : geeco_call_reserved_cus());
   BottomSlices b;
   b.S0 = cus / groups < 1 ? 1 : cus / groups;
   const long long fl = T / b.S0, rem = T - fl * b.S0;
@@ -2270,14 +2270,16 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const flo
                                                      float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
                                                      int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
                                                      int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
-                                                     void* stream, geeco_slab_reduce* pending) {
+                                                     void* stream, geeco_slab_reduce* pending, int reserved_cus) {
   GEECO_CHECK_ARG(pending && y1, "conv2_dgrad_conv1_wgrad_partial: null pending / y1");
+  if (int e = geeco_enter_reserved_cus(reserved_cus)) return e;
   geeco_slab_reduce none = {};
   *pending = none;
   geeco_set_pending_reduce(pending);
   const int rc = fused_bottom_impl(dz2, w2, y1, nullptr, x, dw1, db1, dz1, groups, gs_dz2, gs_w2, gs_y1, 0, gs_x, gs_dw1,
                                    gs_db1, N, H, W, real_channels, ws, stream);
   geeco_set_pending_reduce(nullptr);
+  geeco_leave_reserved_cus();
   return rc;
 }
 
@@ -2285,8 +2287,9 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float*
                                                   const float* x, float* dw1, float* db1, int groups, int64_t gs_dz2,
                                                   int64_t gs_w2, int64_t gs_bits, int64_t gs_x, int64_t gs_dw1,
                                                   int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
-                                                  void* stream, geeco_slab_reduce* pending) {
+                                                  void* stream, geeco_slab_reduce* pending, int reserved_cus) {
   GEECO_CHECK_ARG(y1_bits, "conv2_dgrad_conv1_wgrad_bits: null y1_bits");
+  if (int e = geeco_enter_reserved_cus(reserved_cus)) return e;
   if (pending) {
     geeco_slab_reduce none = {};
     *pending = none;
@@ -2295,6 +2298,7 @@ extern "C" int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float*
   const int rc = fused_bottom_impl(dz2, w2, nullptr, y1_bits, x, dw1, db1, nullptr, groups, gs_dz2, gs_w2, 0, gs_bits, gs_x,
                                    gs_dw1, gs_db1, N, H, W, real_channels, ws, stream);
   if (pending) geeco_set_pending_reduce(nullptr);
+  geeco_leave_reserved_cus();
   return rc;
 }
 

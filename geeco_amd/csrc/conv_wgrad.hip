@@ -444,13 +444,15 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
 extern "C" int geeco_conv3x3_wgrad_partial(const float* x, const float* dz, float* dw, float* db, int groups,
                                            int64_t gs_x, int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H,
                                            int W, int Cin, int Cout, int stride, void* ws, void* stream,
-                                           geeco_slab_reduce* pending) {
+                                           geeco_slab_reduce* pending, int reserved_cus) {
   GEECO_CHECK_ARG(pending, "conv3x3_wgrad_partial: null pending");
+  if (int e = geeco_enter_reserved_cus(reserved_cus)) return e;
   geeco_slab_reduce none = {};
   *pending = none;
   geeco_set_pending_reduce(pending);
   const int rc = geeco_conv3x3_wgrad(x, dz, dw, db, groups, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws,
                                      stream);
   geeco_set_pending_reduce(nullptr);
+  geeco_leave_reserved_cus();
   return rc;
 }

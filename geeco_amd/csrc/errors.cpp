@@ -20,16 +20,20 @@ const char* geeco_dev_getenv(const char* name) {
   return dev ? getenv(name) : nullptr;
 }
 
-static std::atomic<int> g_reserved_cus{0};
-extern "C" int geeco_set_reserved_cus(int k) {
+// CUs the persistent bottom-of-the-backward kernels leave free: an ARGUMENT of the entry points that launch them (round 4; a
+// process-wide setting before).  The dispatchers below those entry points read it from here; thread-local and set only for the
+// duration of one call, like the pending slab sum of conv_wgrad.hip: no state survives a call.
+static thread_local int g_call_reserved_cus = 0;
+int geeco_call_reserved_cus(void) { return g_call_reserved_cus; }
+int geeco_enter_reserved_cus(int k) {
   if (k < 0 || k > 128) {
-    geeco_set_error("set_reserved_cus: %d outside 0..128", k);
+    geeco_set_error("reserved_cus: %d outside 0..128", k);
     return GEECO_EINVAL;
   }
-  g_reserved_cus = k;
+  g_call_reserved_cus = k;
   return 0;
 }
-extern "C" int geeco_reserved_cus(void) { return g_reserved_cus.load(); }
+void geeco_leave_reserved_cus(void) { g_call_reserved_cus = 0; }
 
 extern "C" const char* geeco_last_error(void) { return g_err; }
 extern "C" int geeco_abi_version(void) { return GEECO_ABI_VERSION; }

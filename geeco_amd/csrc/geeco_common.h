@@ -19,8 +19,11 @@ void geeco_set_pending_reduce(geeco_slab_reduce* p);
 // GEECO_DEV=1 is set; a production process ignores every GEECO_* variable and always runs the measured-best path.
 const char* geeco_dev_getenv(const char* name);
 
-// CUs the persistent bottom-of-the-backward kernels leave free (geeco_set_reserved_cus; 0 by default)
-extern "C" int geeco_reserved_cus(void);
+// CUs the persistent bottom-of-the-backward kernels leave free: the `reserved_cus` argument of the entry point being served on this
+// thread (errors.cpp; 0 outside such a call)
+int geeco_call_reserved_cus(void);
+int geeco_enter_reserved_cus(int k);     // GEECO_EINVAL outside 0..128
+void geeco_leave_reserved_cus(void);
 
 #define GEECO_CHECK_ARG(cond, ...)              \
   do {                                          \

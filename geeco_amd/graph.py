@@ -71,6 +71,9 @@ class ConvEncoderStack:
     self.store, self.scopes, self.G, self.Nf = store, list(scopes), len(scopes), Nf
     self.H, self.W, self.Cin = H, W, Cin
     self.late = None       # (staging buffer, per-encoder length): see redirect_late_gradients
+    # CUs the two persistent bottom-of-the-backward launches leave to a collective running beside them: a launch argument
+    # (runtime.TrainStepRunner sets it around its own part 2, so every runner captures the grids it was built for)
+    self.reserved_cus = 0
     self.dim_outs = [int(d) for d in dim_out] if isinstance(dim_out, (list, tuple)) else [int(dim_out)] * len(self.scopes)
     self.split_top = len(set(self.dim_outs)) > 1
     dim_out = max(self.dim_outs)
@@ -345,7 +348,8 @@ class ConvEncoderStack:
     if l == 0 and self.pad1:
       pending = None     # the padded gradient is repacked right below
     ops.conv3x3_wgrad_into(dw, self._db(l), x, dz, G, x[0].numel(), dz[0].numel(), gs_dw, self._gs_g(l), Nf, L['H'],
-                           L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l], pending=pending)
+                           L['W'], L['Cin'], L['Cout'], L['stride'], self.ws_l[l], pending=pending,
+                           reserved_cus=self.reserved_cus if (l == 1 and pending is not None) else 0)
     if l == 0 and self.pad1:
       for g in range(G):
         ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
@@ -368,11 +372,12 @@ class ConvEncoderStack:
         ops.conv2_dgrad_conv1_wgrad_bits_into(self._dw(0), self._db(0), dz, self._w(1), self.bits1, self.x_in, G,
                                               dz[0].numel(), self.gs_p, self.bits1[0].numel(), self.x_in[0].numel(),
                                               self._gs_g(0), self._gs_g(0), Nf, L['H'], L['W'], self.fws_fused,
-                                              real_channels=self.Cin, pending=pending)
+                                              real_channels=self.Cin, pending=pending, reserved_cus=self.reserved_cus)
         return
       ops.conv2_dgrad_conv1_wgrad_into(self._dw(0), self._db(0), dz, self._w(1), x, self.x_in, G, dz[0].numel(), self.gs_p,
                                        x[0].numel(), self.x_in[0].numel(), self._gs_g(0), self._gs_g(0), Nf, L['H'], L['W'],
-                                       self.fws_fused, real_channels=self.Cin, pending=pending)
+                                       self.fws_fused, real_channels=self.Cin, pending=pending,
+                                       reserved_cus=self.reserved_cus if pending is not None else 0)
       return
     wt = self.wt[l]
     dx = self.dz[l - 1]
@@ -743,7 +748,7 @@ class GoalE2EVMC(_ModelBase):
       cur = frames[:, K - 1]                                  # rgb_frame_list[-1] (graph.py:387)
       # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)
       if C == 3 and HW % 4 == 0 and self.last_from_dynimg:
-        # three launches: the buffer-image kernel has the current frame in registers and writes its channel-padded copy
+        # two launches: the buffer-image pass has the current frame in registers and writes its channel-padded copy and the pair image
         # too; one normalisation launch serves both images
         ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, self.dyn_ws2, K * HW * C, HW * C)
       else:

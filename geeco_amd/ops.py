@@ -43,15 +43,6 @@ def _iarr(vals):
   return arr
 
 
-def set_reserved_cus(k: int):
-  """CUs the persistent bottom-of-the-backward kernels leave free for a collective running beside them (0 = none)."""
-  check(_lib().geeco_set_reserved_cus(int(k)), 'geeco_set_reserved_cus')
-
-
-def reserved_cus() -> int:
-  return int(_lib().geeco_reserved_cus())
-
-
 def same_out(size: int, stride: int) -> int:
   return -(-size // stride)
 
@@ -182,16 +173,20 @@ def conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride):
   return int(_lib().geeco_conv3x3_wgrad_ws_bytes(G, N, H, W, Cin, Cout, stride))
 
 
-def conv3x3_wgrad_into(dw, db, x, dz, G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws, pending=None):
+def conv3x3_wgrad_into(dw, db, x, dz, G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, stride, ws, pending=None,
+                       reserved_cus=0):
   """``pending`` (a list): the kernel's final slab sum is not launched but appended to it (``slab_reduce_batch``
-  finishes all of them in one launch; ``ws`` must stay untouched until then)."""
+  finishes all of them in one launch; ``ws`` must stay untouched until then).  ``reserved_cus`` (data parallel; needs
+  ``pending``): CUs conv2's persistent filter-gradient kernel leaves to a collective running beside it."""
   if pending is None:
+    if reserved_cus:
+      raise ValueError('reserved_cus is an argument of the deferred-slab-sum form: pass pending=[...]')
     check(_lib().geeco_conv3x3_wgrad(_p(x), _p(dz), _p(dw), _p(db), G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin,
                                      Cout, stride, _p(ws), _stream()), 'geeco_conv3x3_wgrad')
     return
   item = _native.SlabReduce()
   check(_lib().geeco_conv3x3_wgrad_partial(_p(x), _p(dz), _p(dw), _p(db), G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin,
-                                           Cout, stride, _p(ws), _stream(), ctypes.byref(item)),
+                                           Cout, stride, _p(ws), _stream(), ctypes.byref(item), int(reserved_cus)),
         'geeco_conv3x3_wgrad_partial')
   if item.S > 0:
     pending.append(item)
@@ -212,10 +207,12 @@ def conv2_dgrad_conv1_wgrad_ws_bytes(G):
 
 
 def conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x, G, gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, ws,
-                                 dz1=None, real_channels=3, pending=None):
+                                 dz1=None, real_channels=3, pending=None, reserved_cus=0):
   """Fused encoder bottom backward: conv2's input gradient + conv1's filter/bias gradient (dz1 stays on chip).
-  dw1 [G][3][3][real_channels][32]; ``pending`` as for ``conv3x3_wgrad_into``."""
+  dw1 [G][3][3][real_channels][32]; ``pending`` / ``reserved_cus`` as for ``conv3x3_wgrad_into``."""
   if pending is None:
+    if reserved_cus:
+      raise ValueError('reserved_cus is an argument of the deferred-slab-sum form: pass pending=[...]')
     check(_lib().geeco_conv2_dgrad_conv1_wgrad(_p(dz2), _p(w2), _p(y1), _p(x), _p(dw1), _p(db1), _p(dz1), G, gs_dz2,
                                                gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, real_channels, _p(ws),
                                                _stream()), 'geeco_conv2_dgrad_conv1_wgrad')
@@ -223,7 +220,7 @@ def conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x, G, gs_dz2, gs_w2, gs_
   item = _native.SlabReduce()
   check(_lib().geeco_conv2_dgrad_conv1_wgrad_partial(_p(dz2), _p(w2), _p(y1), _p(x), _p(dw1), _p(db1), _p(dz1), G,
                                                      gs_dz2, gs_w2, gs_y1, gs_x, gs_dw1, gs_db1, N, H, W, real_channels,
-                                                     _p(ws), _stream(), ctypes.byref(item)),
+                                                     _p(ws), _stream(), ctypes.byref(item), int(reserved_cus)),
         'geeco_conv2_dgrad_conv1_wgrad_partial')
   if item.S > 0:
     pending.append(item)
@@ -250,12 +247,12 @@ def conv1_fwd_relu_bits_rgb_into(y, bits, x, w3, b, G, gs_x, gs_w, gs_b, gs_y, g
 
 
 def conv2_dgrad_conv1_wgrad_bits_into(dw1, db1, dz2, w2, y1_bits, x, G, gs_dz2, gs_w2, gs_bits, gs_x, gs_dw1, gs_db1, N, H,
-                                      W, ws, real_channels=3, pending=None):
+                                      W, ws, real_channels=3, pending=None, reserved_cus=0):
   """Fused encoder bottom backward with the ReluGrad mask given as conv1's sign bits."""
   item = _native.SlabReduce() if pending is not None else None
   check(_lib().geeco_conv2_dgrad_conv1_wgrad_bits(_p(dz2), _p(w2), _p(y1_bits), _p(x), _p(dw1), _p(db1), G, gs_dz2, gs_w2,
                                                   gs_bits, gs_x, gs_dw1, gs_db1, N, H, W, real_channels, _p(ws), _stream(),
-                                                  ctypes.byref(item) if item is not None else None),
+                                                  ctypes.byref(item) if item is not None else None, int(reserved_cus)),
         'geeco_conv2_dgrad_conv1_wgrad_bits')
   if item is not None and item.S > 0:
     pending.append(item)

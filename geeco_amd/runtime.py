@@ -66,8 +66,11 @@ class TrainStepRunner:
   beside part 2 (default); False = both buckets after part 2 (``bench.py --dp-serial``: the difference between the two
   is what the overlap buys on a given node)."""
 
-  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True):
+  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True, reserved_cus=0):
+    """``reserved_cus``: CUs the two persistent kernels of part 2 leave to the collective that runs beside them (0 = none;
+    a launch argument of those kernels, applied around THIS runner's part 2 only)."""
     self.model = model
+    self.reserved_cus = int(reserved_cus)
     self.world = gdist.world_size()
     model.world = self.world
     self.dp = (self.world > 1) if dp is None else bool(dp)
@@ -89,10 +92,15 @@ class TrainStepRunner:
       # The bottom of the backward writes the conv1 / conv2 gradients STRAIGHT into the staging buffer (no pack copies),
       # so nothing touches the arena while the early bucket is in flight and the early bucket can be ONE all-reduce
       # over the span of its ranges: the late variables' slots inside that span are dead (zero) until part 3 unpacks.
+      # The redirection is OWNED by this runner: it is switched on around this runner's own part 2 only (eager run or capture;
+      # the pointers are baked into the captured graph) and off again right behind it, so no model-wide state outlives a
+      # call -- a second runner on the same model (another batch size, a non-dp probe) neither inherits nor undoes it.
+      # Between part 2 and part 3 ``store.grads`` is NOT authoritative for conv1 / conv2: their gradients sit in the
+      # staging buffer until part 3 has unpacked them (nothing reads those slots in between).
       redirect = getattr(model, 'redirect_late_gradients', None)
       self.redirected = bool(redirect and redirect(self.staging, self.late))
-    elif getattr(model, 'redirect_late_gradients', None):
-      model.redirect_late_gradients(None, None)           # a model that an earlier data-parallel runner had redirected
+      if self.redirected:
+        redirect(None, None)
     if self.redirected and self.early:
       lo = min(off for off, _ in self.early)
       hi = max(off + n for off, n in self.early)
@@ -115,7 +123,18 @@ class TrainStepRunner:
       self.model.backward()
 
   def _part2(self):
-    self.model.backward(part='bottom')
+    enc = getattr(self.model, 'enc', None)
+    if self.redirected:
+      self.model.redirect_late_gradients(self.staging, self.late)
+    if enc is not None and self.reserved_cus:
+      enc.reserved_cus = self.reserved_cus
+    try:
+      self.model.backward(part='bottom')
+    finally:
+      if enc is not None:
+        enc.reserved_cus = 0
+      if self.redirected:
+        self.model.redirect_late_gradients(None, None)
     if self.redirected or self.staging is None:
       return
     g, pos = self.model.store.grads, 0

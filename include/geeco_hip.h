@@ -24,21 +24,13 @@
 extern "C" {
 #endif
 
-#define GEECO_ABI_VERSION 3   /* = the build round that last changed the entry points or their calling conventions */
+#define GEECO_ABI_VERSION 4   /* = the build round that last changed the entry points or their calling conventions */
 
 #define GEECO_EINVAL  (-1)   /* bad shape / alignment / null pointer */
 #define GEECO_ENOSUP  (-2)   /* shape outside what the kernels were built for */
 
 int geeco_abi_version(void);
 const char* geeco_last_error(void);
-
-/* Data parallel: the two persistent one-block-per-CU kernels at the bottom of the backward (conv2's filter gradient,
- * geeco_conv2_dgrad_conv1_wgrad*) normally occupy every CU; the early gradient bucket is all-reduced while they run.
- * geeco_set_reserved_cus(k), 0 <= k <= 128, makes their FUTURE launches leave k CUs free for the collective's workgroups
- * (process-wide; takes effect at the next launch, so a captured hipGraph keeps the grid it was captured with; workspaces
- * are sized for k = 0 and fit any k).  Default 0.  The reference has no counterpart (no distributed code: SURVEY.md 2). */
-int geeco_set_reserved_cus(int k);
-int geeco_reserved_cus(void);
 
 /* Diagnostics (bench.py's per-layer table): between _begin and _end on one host thread every
  * conv entry point records the names of the kernels it dispatched; _end returns them ';'-separated
@@ -159,7 +151,13 @@ int geeco_conv2_dgrad_conv1_wgrad(const float* dz2, const float* w2, const float
  * kernel wrote dw/db itself, nothing is pending); geeco_slab_reduce_batch then finishes up to GEECO_SLAB_REDUCE_MAX
  * of them in ONE launch (a training step: one per part of the backward instead of one per layer).  The `ws` of a
  * pending item must stay untouched until the batch has run.  Results are bitwise those of the plain calls (same
- * summation order). */
+ * summation order).
+ * reserved_cus (0..128; the forms below and geeco_conv2_dgrad_conv1_wgrad_bits): data parallel -- the two persistent
+ * one-block-per-CU kernels at the bottom of the backward (conv2's filter gradient, the fused conv2-dgrad + conv1-wgrad)
+ * normally occupy every CU while the early gradient bucket is all-reduced beside them; k > 0 makes THIS launch leave k CUs
+ * to the collective's workgroups ((256 - k) / groups blocks per encoder; workspaces are sized for k = 0 and fit any k; other
+ * kernels ignore it).  A launch argument since ABI 4 (a process-wide setter before): nothing outlives the call.  The
+ * reference has no counterpart (no distributed code: SURVEY.md 2). */
 typedef struct geeco_slab_reduce {
   const float* part;      /* [groups][S][KC + Cout] partial slabs */
   float* dw;              /* [groups] x KC floats, group stride gs_dw */
@@ -171,12 +169,12 @@ typedef struct geeco_slab_reduce {
 int geeco_conv3x3_wgrad_partial(const float* x, const float* dz, float* dw, float* db, int groups,
                                 int64_t gs_x, int64_t gs_dz, int64_t gs_dw, int64_t gs_db, int N, int H,
                                 int W, int Cin, int Cout, int stride, void* ws, void* stream,
-                                geeco_slab_reduce* pending);
+                                geeco_slab_reduce* pending, int reserved_cus);
 int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, const float* y1, const float* x,
                                           float* dw1, float* db1, float* dz1, int groups, int64_t gs_dz2,
                                           int64_t gs_w2, int64_t gs_y1, int64_t gs_x, int64_t gs_dw1,
                                           int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
-                                          void* stream, geeco_slab_reduce* pending);
+                                          void* stream, geeco_slab_reduce* pending, int reserved_cus);
 int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream);
 
 /* ReLU sign bits as the ReluGrad mask of the encoder bottom.  conv1's output y1 (805 MB at the bench shape) is read by
@@ -233,7 +231,8 @@ int geeco_conv3x3_dgrad_relu_fields(const float* dz, const float* w, const uint8
 int geeco_conv2_dgrad_conv1_wgrad_bits(const float* dz2, const float* w2, const uint32_t* y1_bits, const float* x,
                                        float* dw1, float* db1, int groups, int64_t gs_dz2, int64_t gs_w2,
                                        int64_t gs_bits, int64_t gs_x, int64_t gs_dw1, int64_t gs_db1, int N, int H, int W,
-                                       int real_channels, void* ws, void* stream, geeco_slab_reduce* pending);
+                                       int real_channels, void* ws, void* stream, geeco_slab_reduce* pending,
+                                       int reserved_cus);
 
 /* [G][9][A][B] -> [G][9][B][A] per-tap transpose (HWIO -> HWOI) feeding geeco_conv3x3_dgrad. */
 int geeco_transpose_hwio(const float* w, float* wt, int groups, int64_t gs_w, int64_t gs_wt, int Cin,
@@ -293,7 +292,10 @@ int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c
  * scale 1, accumulate 0: dfeats[i][n][cell][c] = (feats_fwd[i] > 0) * dx[n][cell * Ctot + off_i + c]).  Grid 1: the
  * tiles of dwx, the split-K tiles of dx and the column sums side by side; grid 2: dx's slab sum with the scatter in its
  * epilogue.  Replaces the five launches geeco_gemm_f32 (ta) + geeco_colsum + geeco_gemm_f32 (tb: split-K + reduce) +
- * geeco_state_concat_bwd; same K / slab order, so bitwise the same results.  ws: geeco_lstm_step_bwd_ws_bytes bytes. */
+ * geeco_state_concat_bwd.  dx: same K / slab order as geeco_gemm_f32, bitwise the same for every N.  dwx: ONE K loop over
+ * the N rows (no split), bitwise equal to geeco_gemm_f32 where that does not split K either, i.e. N < 128 (the batch sizes
+ * of the reference: params.py:26); for N >= 128 geeco_gemm_f32 splits the batch dimension and the two differ in rounding
+ * (tests/test_kernels_gpu.py: tolerance there, bitwise below).  ws: geeco_lstm_step_bwd_ws_bytes bytes. */
 int64_t geeco_lstm_step_bwd_ws_bytes(int N, int D, int H4);
 int geeco_lstm_step_bwd(const float* x, int64_t ldx, const float* dz, int64_t ldz, const float* wx, int64_t ldw, float* dwx,
                         int64_t lddw, float* db, float* dx, int64_t lddx, int N, int D, int H4,

@@ -196,10 +196,23 @@ def _rccl_worker(port, overlap, q):
   runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap)
   info = runner.bucket_info()
   losses = []
-  for _ in range(5):
+  for i in range(5):
     runner.step()
     torch.cuda.synchronize()
     losses.append(float(model.loss))
+    # the redirection of the late gradients and the reserved-CU argument are the runner's, scoped to its own part 2: no
+    # model-wide state is left behind (a second runner on the same model neither inherits nor undoes anything)
+    assert model.enc.late is None and model.enc.reserved_cus == 0, i
+  if overlap:
+    # a second runner with CUs reserved for the collective on the SAME model (bench.py's probe): its own graphs, same results
+    r2 = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=True, reserved_cus=16)
+    before = model.store.params.clone()
+    for i in range(3):
+      r2.step()
+    torch.cuda.synchronize()
+    assert model.enc.late is None and model.enc.reserved_cus == 0 and np.isfinite(float(model.loss))
+    assert not torch.equal(before, model.store.params)
+    model.store.params.copy_(before)      # (the comparison below is about the first runner's five steps)
   q.put((model.store.params.detach().cpu().numpy(), losses, info, runner._graphs is not None and len(runner._graphs) == 3))
   torch.distributed.destroy_process_group()
 

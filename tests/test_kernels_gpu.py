@@ -811,12 +811,14 @@ def test_conv1_rgb_kernel_variable(dev, G, N, H, W):
   assert torch.equal(ys[0], ys[1]) and torch.equal(bs[0], bs[1])
 
 
-@pytest.mark.parametrize('N,chs,J', [(32, (256, 256, 256), 7), (5, (256, 128, 64), 7), (2, (256,), 7), (33, (64, 64), 3)])
+@pytest.mark.parametrize('N,chs,J', [(32, (256, 256, 256), 7), (5, (256, 128, 64), 7), (2, (256,), 7), (33, (64, 64), 3), (160, (256, 64), 7)])
 def test_lstm_step_bwd_one_launch(dev, N, chs, J):
   """geeco_lstm_step_bwd (dWx tiles, dX split-K tiles and the bias sums as the blocks of one grid, then dX's slab sum with
   the state-concat backward in its epilogue) against the five separate launches it replaces (gemm ta, colsum, gemm tb with
   split-K + reduce, state_concat_bwd): bitwise (same tile code, same K and slab order), and against fp64; the
-  joint-state columns of dX are not scattered anywhere."""
+  joint-state columns of dX are not scattered anywhere.  N = 160: geeco_gemm_f32 splits dWx's batch dimension from N = 128
+  on and the one-launch form does not (include/geeco_hip.h), so dWx is compared to fp64 / to the split form at fp32
+  tolerance there, everything else stays bitwise."""
   from geeco_amd import ops
   r = np.random.default_rng(71)
   H4, cells = 512, 4
@@ -848,7 +850,12 @@ def test_lstm_step_bwd_one_launch(dev, N, chs, J):
   ops.lstm_step_bwd_into(dw[:D], db, dx, x, dz, wx, N, D, H4, H4, ws2, feats_fwd=feats, dfeats=df, feat_ch=list(chs),
                          jnt_pos=jnt_pos, J=J, cells=cells)
   torch.cuda.synchronize()
-  assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+  if N < 128:
+    assert torch.equal(dw, dw_ref)
+  else:
+    _close(dw[:D], x.double().cpu().T @ dz.double().cpu(), 1e-5, 2e-5 * np.sqrt(N), 'dWx vs fp64 (unsplit K)')
+    _close(dw[:D], dw_ref[:D], 1e-5, 2e-5 * np.sqrt(N), 'dWx vs the split-K form')
+  assert torch.equal(db, db_ref)
   assert float(dw[D:].abs().max()) == 0.0                      # the recurrent rows are not touched
   ref64 = dz.double().cpu() @ wx.double().cpu().T
   _close(dx, ref64, 1e-5, 2e-5 * np.sqrt(H4), 'dX vs fp64')
@@ -863,9 +870,10 @@ def test_lstm_step_bwd_one_launch(dev, N, chs, J):
 
 
 def test_reserved_cus_shrink_the_persistent_bottom_kernels(dev):
-  """geeco_set_reserved_cus(k): conv2's filter gradient and the fused bottom launch (256 - k) / groups blocks per encoder
-  (the workspace is sized for k = 0); results equal the k = 0 launches to fp32 summation-order differences (other slab
-  partition), and the setting is process-wide until reset."""
+  """``reserved_cus`` = k (an ARGUMENT of the deferred-slab-sum entry points since ABI 4): conv2's filter gradient and the fused
+  bottom launch (256 - k) / groups blocks per encoder (the workspace is sized for k = 0); results equal the k = 0 launches to
+  fp32 summation-order differences (other slab partition); nothing outlives the call (the next plain call is bitwise the
+  k = 0 result); values outside 0..128 and the plain (no ``pending``) forms with k > 0 are refused."""
   from geeco_amd import ops
   G, N, H, W = 3, 4, 32, 128
   r = np.random.default_rng(83)
@@ -877,32 +885,35 @@ def test_reserved_cus_shrink_the_persistent_bottom_kernels(dev):
   wsf = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, device=dev)
   wsw = torch.empty(ops.conv3x3_wgrad_ws_bytes(G, N, H, W, 32, 48, 2) // 4 + 4, device=dev)
 
-  def run():
+  def run(k):
+    pending = []
     dw1 = torch.full((G, 9, 3, 32), float('nan'), device=dev)
     db1 = torch.full((G, 32), float('nan'), device=dev)
     ops.conv2_dgrad_conv1_wgrad_into(dw1, db1, dz2, w2, y1, x4, G, dz2[0].numel(), w2[0].numel(), y1[0].numel(), x4[0].numel(),
-                                     dw1[0].numel(), 32, N, H, W, wsf, real_channels=3)
+                                     dw1[0].numel(), 32, N, H, W, wsf, real_channels=3, pending=pending, reserved_cus=k)
     dw2 = torch.full((G, 9 * 32 * 48), float('nan'), device=dev)
     db2 = torch.full((G, 48), float('nan'), device=dev)
-    ops.conv3x3_wgrad_into(dw2, db2, y1, dz2, G, y1[0].numel(), dz2[0].numel(), dw2[0].numel(), 48, N, H, W, 32, 48, 2, wsw)
+    ops.conv3x3_wgrad_into(dw2, db2, y1, dz2, G, y1[0].numel(), dz2[0].numel(), dw2[0].numel(), 48, N, H, W, 32, 48, 2, wsw,
+                           pending=pending, reserved_cus=k)
+    slabs = [it.S for it in pending]
+    ops.slab_reduce_batch(pending)
     torch.cuda.synchronize()
-    return dw1, db1, dw2, db2
+    return (dw1, db1, dw2, db2), slabs
 
-  assert ops.reserved_cus() == 0
-  ref = run()
-  ops.set_reserved_cus(16)
-  try:
-    assert ops.reserved_cus() == 16
-    got = run()
-  finally:
-    ops.set_reserved_cus(0)
+  ref, slabs0 = run(0)
+  got, slabs16 = run(16)
+  assert slabs16 == [(256 - 16) // G] * 2 and all(a >= b for a, b in zip(slabs0, slabs16)), (slabs0, slabs16)
   scale = np.sqrt(N * H * W)
   for a, b, what in zip(got, ref, ('dw1', 'db1', 'dw2', 'db2')):
     assert not torch.isnan(a).any()
     _close(a, b.double(), 2e-5, 2e-5 * scale, what + ' with 16 CUs reserved')
-  assert torch.equal(run()[0], ref[0])            # back to the k = 0 partition: bitwise as before
+  again, slabs = run(0)
+  assert slabs == slabs0 and torch.equal(again[0], ref[0]) and torch.equal(again[2], ref[2])     # nothing outlives the call
   with pytest.raises(Exception):
-    ops.set_reserved_cus(500)
+    run(500)
+  with pytest.raises(ValueError):
+    ops.conv3x3_wgrad_into(torch.empty(G, 9 * 32 * 48, device=dev), torch.empty(G, 48, device=dev), y1, dz2, G, y1[0].numel(),
+                           dz2[0].numel(), 9 * 32 * 48, 48, N, H, W, 32, 48, 2, wsw, reserved_cus=16)
 
 
 def test_conv2_wgrad_remainder_block(dev):
@@ -927,15 +938,14 @@ def test_conv2_wgrad_remainder_block(dev):
     refs.append((wt.grad, bt.grad))
   scale = np.sqrt(Nf * Ho * Wo)
   for reserved in (0, 16):
-    ops.set_reserved_cus(reserved)
-    try:
-      dw = torch.full((G, gs_w), float('nan'), device=dev)
-      db = torch.full((G, gs_b), float('nan'), device=dev)
-      names = ops.kernel_trace(lambda: ops.conv3x3_wgrad_into(dw, db, xd, dzd, G, xd[0].numel(), dzd[0].numel(), gs_w, gs_b,
-                                                              Nf, H, W, Cin, Cout, stride, ws))
-      torch.cuda.synchronize()
-    finally:
-      ops.set_reserved_cus(0)
+    dw = torch.full((G, gs_w), float('nan'), device=dev)
+    db = torch.full((G, gs_b), float('nan'), device=dev)
+    pending = []
+    names = ops.kernel_trace(lambda: ops.conv3x3_wgrad_into(dw, db, xd, dzd, G, xd[0].numel(), dzd[0].numel(), gs_w, gs_b,
+                                                            Nf, H, W, Cin, Cout, stride, ws, pending=pending,
+                                                            reserved_cus=reserved))
+    ops.slab_reduce_batch(pending)
+    torch.cuda.synchronize()
     assert names and names[0].startswith('conv_s2_halo_wgrad_kernel'), names
     for g in range(G):
       _close(dw[g, :9 * Cin * Cout].reshape(3, 3, Cin, Cout), refs[g][0], 2e-5, 2e-5 * scale, 'wgrad, encoder %d' % g)
