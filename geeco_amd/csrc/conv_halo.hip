@@ -322,29 +322,6 @@ __device__ __forceinline__ void wait_vm_imm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// dev switches of the kernel below (scripts/dev/build_variant.sh): WS_ABL (WRONG results) 1 = no output stores, 2 = no sign fields,
-// 3 = no epilogue at all, 4 = no halo DMA (the compute waves read whatever the LDS holds); WS_PRIO 1 = the epilogue runs at s_setprio 3
-#ifndef WS_ABL
-#define WS_ABL 0
-#endif
-#ifndef WS_PRIO
-#define WS_PRIO 0
-#endif
-// WS_BAR2 1: a SECOND barrier per tile behind the epilogue: the K-half-1 waves start the next tile's MFMAs only after their K-half-0
-// partners have issued the tile's stores (hypothesis under test: a store with data cannot leave its SIMD while the partner wave
-// streams MFMAs -- in-kernel stamps show the first store of an epilogue held ~3 k cycles, until about the end of the partner's loop)
-#ifndef WS_BAR2
-#define WS_BAR2 0
-#endif
-// WS_BUBBLE: a deliberate gap in every wave's MFMA stream after each tap's 12 MFMAs (1: 16 cycles of s_nop, 2: s_sleep 1 = 64 cycles)
-#ifndef WS_BUBBLE
-#define WS_BUBBLE 0
-#endif
-// WS_SLEEP n: the K-half-1 waves wait n x 64 cycles behind the tile barrier before they start the next tile's MFMAs (their partners'
-// epilogue stores leave the SIMD meanwhile)
-#ifndef WS_SLEEP
-#define WS_SLEEP 0
-#endif
 template <int CIN, int COUT, int LW>
 __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(const HaloFwdParams p) {
   constexpr int TH = 4, TW = 16;
@@ -422,7 +399,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
         if (lw + LW * i < NDMA) {                         // wave-uniform
           const bool v = iy0 + d_hy[i] < p.H && ix0 + d_hx[i] < p.W;
           const float* src = v ? xg + d_src[i] : g_zero_page;
-          if (WS_ABL != 4) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (lw + LW * i) * 64 + buf * HALO_F4), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (lw + LW * i) * 64 + buf * HALO_F4), 16, 0, 0);
         }
       }
     };
@@ -458,7 +435,6 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
           wait_vm_imm<0>();
         }
         asm volatile("s_barrier" ::: "memory");
-        if (WS_BAR2) asm volatile("s_barrier" ::: "memory");
         if (!more1) break;
         ++tile;
       }
@@ -493,9 +469,9 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
   for (;;) {
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
-    HSTAMP(tcount < 6 ? 10 * tcount + 0 : 64);
+    HSTAMP(tcount < 10 ? 6 * tcount + 0 : 64);
     if (more) advance(g2, n2, ty2, tx2);
-    HSTAMP(tcount < 6 ? 10 * tcount + 1 : 64);
+    HSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
     f32x4 acc[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) acc[i] = zero4;
@@ -517,21 +493,18 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
         for (int i = 0; i < TI; ++i)
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][i][s], a_cur[s], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (WS_BUBBLE == 1) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
-      if (WS_BUBBLE == 2) { __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_sched_barrier(0); }
       a_cur = a_nxt;
     }
-    HSTAMP(tcount < 6 ? 10 * tcount + 2 : 64);
+    HSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
     f32x4* red = sR + (int)(tile & 1) * RED_F4;
     if (khalf == 1) {
 #pragma unroll
       for (int i = 0; i < TI; ++i) red[(strip * TI + i) * 64 + lane] = acc[i];
     }
-    HSTAMP(tcount < 6 ? 10 * tcount + 3 : 64);
+    HSTAMP(tcount < 10 ? 6 * tcount + 3 : 64);
     lds_barrier();
-    HSTAMP(tcount < 6 ? 10 * tcount + 4 : 64);   // tile barrier: partial sums visible; everyone is done with buf; the loaders' next halo landed
-    if (khalf == 0 && WS_ABL != 3) {
-      if (WS_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+    HSTAMP(tcount < 10 ? 6 * tcount + 4 : 64);   // tile barrier: partial sums visible; everyone is done with buf; the loaders' next halo landed
+    if (khalf == 0) {
       // epilogue: lane owns pixel (ty*4 + strip, tx*16 + r), channels 16 i + 4 q .. +3.  The strip's 16 x COUT
       // outputs are 3 KB of consecutive NHWC bytes: they are transposed through LDS so that every store instruction
       // writes 1 KiB of consecutive bytes instead of 16 separate 64-byte pieces (in-kernel timeline: the three
@@ -545,20 +518,18 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         so[r * OP + 4 * i + q] = v;
-        if (WS_ABL != 2 && p.fields) {
+        if (p.fields) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) field |= min(__float_as_uint(v[j]), 1u) << (4 * i + j);
         }
       }
-      HSTAMP(tcount < 6 ? 10 * tcount + 6 : 64);     // sums + ReLU + staging writes done
-      if (WS_ABL != 2 && p.fields) {
+      if (p.fields) {
         // the consumer (conv3's input-gradient kernel) holds the same (pixel r, quad q) layout in its accumulators, so
         // every lane stores its own 16-bit field: no cross-lane assembly; 16 pixels x 4 fields = 128 consecutive bytes
         const int fy = ty * TH + strip, fx = tx * TW + r;
         if (fy < p.Ho && fx < p.Wo)
           p.fields[(long long)g * p.gs_fields + (((long long)n * p.fHp + fy) * p.fWp + fx) * 4 + q] = (unsigned short)field;
       }
-      HSTAMP(tcount < 6 ? 10 * tcount + 7 : 64);     // sign fields stored
       // same-wave LDS round trip: the compiler's lgkmcnt wait orders the reads behind the writes
       const int oy = ty * TH + strip;
       float* yo = p.y + (long long)g * p.gs_y + (((long long)n * p.Ho + oy) * p.Wo + tx * TW) * COUT;
@@ -568,14 +539,10 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_s2_halo_fwd_ws_kernel(cons
         const int m = lane + 64 * jj;
         const int px = m / C4, c4 = m - px * C4;
         const f32x4 v = so[px * OP + c4];
-        if (WS_ABL != 1 && oy < p.Ho && tx * TW + px < p.Wo) stream_store<1>(yo + m * 4, v);
-        if (jj == 0) HSTAMP(tcount < 6 ? 10 * tcount + 8 : 64);   // first output store issued
+        if (oy < p.Ho && tx * TW + px < p.Wo) stream_store<1>(yo + m * 4, v);
       }
-      if (WS_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
-    if (WS_BAR2) asm volatile("s_barrier" ::: "memory");
-    if (WS_SLEEP > 0 && khalf == 1) __builtin_amdgcn_s_sleep(WS_SLEEP);
-    HSTAMP(tcount < 6 ? 10 * tcount + 5 : 64);
+    HSTAMP(tcount < 10 ? 6 * tcount + 5 : 64);
     ++tcount;
     if (!more) break;
     if (g2 != g_w) {             // the range crosses into the next encoder: new kernel fragments

@@ -20,17 +20,12 @@ lib = _native.load()
 lib.geeco_debug_dump_halo_stamps.argtypes = [ctypes.c_char_p]
 assert lib.geeco_debug_dump_halo_stamps(b'/tmp/hstamps.bin') == 0
 s = np.fromfile('/tmp/hstamps.bin', dtype=np.uint64).reshape(256, 2, 64).astype(np.int64)
-# stamps per tile (10 slots, 6 tiles): 0 top, 1 advanced, 2 MFMA loop done, 3 partial sums written, 4 barrier passed, 5 epilogue done;
-# inside the epilogue (K half 0 only): 6 sums + ReLU + staging writes, 7 sign fields stored, 8 first output store issued
-segs = [('issue next DMA / advance', 0, 1), ('MFMA loop (9 steps)', 1, 2), ('partial sums -> LDS', 2, 3), ('wait vmcnt + barrier', 3, 4),
-        ('epilogue', 4, 5), ('  epilogue: sums, ReLU, staging', 4, 6), ('  epilogue: sign fields', 6, 7), ('  epilogue: 1st read + store', 7, 8),
-        ('  epilogue: 2nd, 3rd read + store', 8, 5)]
+names = ['issue next DMA / advance', 'MFMA loop (9 steps)', 'partial sums -> LDS', 'wait vmcnt + barrier', 'epilogue']
 for kh in (0, 1):
   print('K half %d (wave %d):' % (kh, 4 * kh))
-  t = s[:, kh, :60].reshape(256, 6, 10)[:, 1:6]           # tiles 1..5 of every block
-  for nme, a, b in segs:
-    if kh == 1 and nme.startswith('  '): continue
-    d = (t[:, :, b] - t[:, :, a]).reshape(-1)
-    print('  %-34s mean %7.0f  p10 %7.0f  p90 %7.0f' % (nme, d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+  t = s[:, kh, :60].reshape(256, 10, 6)[:, 2:9]           # tiles 2..8 of every block (steady state)
+  for i, nme in enumerate(names):
+    d = (t[:, :, i + 1] - t[:, :, i]).reshape(-1)
+    print('  %-24s mean %7.0f  p10 %7.0f  p90 %7.0f' % (nme, d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
   per = (t[:, 1:, 0] - t[:, :-1, 0]).reshape(-1)
-  print('  %-34s mean %7.0f  p10 %7.0f  p90 %7.0f' % ('tile period', per.mean(), np.percentile(per, 10), np.percentile(per, 90)))
+  print('  %-24s mean %7.0f  p10 %7.0f  p90 %7.0f' % ('tile period', per.mean(), np.percentile(per, 10), np.percentile(per, 90)))
