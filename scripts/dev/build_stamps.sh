@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")/../../geeco_amd/csrc"
 T=$(mktemp -d)
 for f in conv_gemm conv_halo conv_bottom_fwd conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DGEECO_STAMPS $STAMP_FLAGS -c $f.hip -o $T/$f.o &
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DGEECO_STAMPS ${STAMP_FLAGS:-} -c $f.hip -o $T/$f.o &
 done
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -x hip -c errors.cpp -o $T/errors.o
 wait
