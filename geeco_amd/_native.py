@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, _dev.env('GEECO_LIB', 'libgeeco_hip.so'))   # GEECO_DEV=1 GEECO_LIB=...: A/B builds side by side
 
 
+GEECO_EINVAL, GEECO_ENOSUP = -1, -2      # include/geeco_hip.h
 ABI_VERSION = 4        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
 
 
@@ -64,6 +65,8 @@ SIGNATURES = {
     'geeco_conv2_dgrad_conv1_wgrad_partial': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I,
                                                    _P, _P, POINTER(SlabReduce), _I]),
     'geeco_slab_reduce_batch': (_I, [POINTER(SlabReduce), _I, _P]),
+    'geeco_conv3x3_wgrad_pair': (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P,
+                                      _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, POINTER(SlabReduce)]),
     'geeco_relu_bits_pitch': (_L, [_I]),
     'geeco_conv3_fwd_relu_fields': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_conv3x3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P]),

@@ -34,7 +34,7 @@ struct WgradParams {
 };
 
 template <int BR, int BC, int MK>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int g, const int by, const int split) {
   constexpr int LDA = (BR % 32 == 16) ? BR : BR + 16;
   constexpr int LDBZ = (BC % 32 == 16) ? BC : BC + 16;
   constexpr int BR4 = BR / 4, BC4 = BC / 4;
@@ -49,10 +49,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   float* sB = smem + 2 * MK * LDA;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int g = blockIdx.z;
-  const int rt = blockIdx.y / p.col_tiles;
-  const int ct = blockIdx.y - rt * p.col_tiles;
-  const int split = blockIdx.x;
+  const int rt = by / p.col_tiles;
+  const int ct = by - rt * p.col_tiles;
   const float* __restrict__ xg = p.x + (long long)g * p.gs_x;
   const float* __restrict__ zg = p.dz + (long long)g * p.gs_dz;
   const int Cin = p.Cin, C4 = Cin >> 2, Cout = p.Cout;
@@ -204,6 +202,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int m = 0; m < MK; ++m) s += sT[m * LDBZ + tid];
       bpart[co0 + tid] = s;
     }
+  }
+}
+
+template <int BR, int BC, int MK>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  conv_wgrad_body<BR, BC, MK>(p, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x);
+}
+
+// TWO independent filter-gradient problems of the same tile shape as ONE grid (round 4: conv7's and conv8's, both ready once
+// conv8's input gradient exists; each alone is 432 blocks on 256 CUs for 30 / 12 us: together the short blocks fill the long
+// ones' tail and one launch boundary goes).  Blocks [0, blocks0) serve problem 0 (put the longer one first), the rest problem 1;
+// inside a problem the linear index decodes as (split, tile, group) like the 3-D grid of the single launch: bitwise the same.
+struct WgradPairParams {
+  WgradParams q0, q1;
+  int blocks0;
+};
+template <int BR, int BC, int MK>
+__global__ __launch_bounds__(256) void conv_wgrad_pair_kernel(const WgradPairParams pp) {
+  const int b = (int)blockIdx.x;
+  if (b < pp.blocks0) {
+    const int tiles = pp.q0.row_tiles * pp.q0.col_tiles;
+    const int split = b % pp.q0.S, t = b / pp.q0.S;
+    conv_wgrad_body<BR, BC, MK>(pp.q0, t / tiles, t % tiles, split);
+  } else {
+    const int l = b - pp.blocks0;
+    const int tiles = pp.q1.row_tiles * pp.q1.col_tiles;
+    const int split = l % pp.q1.S, t = l / pp.q1.S;
+    conv_wgrad_body<BR, BC, MK>(pp.q1, t / tiles, t % tiles, split);
   }
 }
 
@@ -455,4 +481,59 @@ extern "C" int geeco_conv3x3_wgrad_partial(const float* x, const float* dz, floa
   geeco_set_pending_reduce(nullptr);
   geeco_leave_reserved_cus();
   return rc;
+}
+
+
+// conv7's + conv8's filter gradients in one launch (see conv_wgrad_pair_kernel).  Only the shapes the generic kernel serves with
+// 64 x 64 tiles (Cin = 256: the LDS-staged kernels take the layers below); anything else: GEECO_ENOSUP, the caller launches twice.
+extern "C" int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
+                                        int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
+                                        const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
+                                        int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
+                                        int groups, int stride, void* stream, geeco_slab_reduce* pending2) {
+  GEECO_CHECK_ARG(x0 && dz0 && dw0 && ws0 && x1 && dz1 && dw1 && ws1, "conv3x3_wgrad_pair: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N0 >= 1 && N1 >= 1 && H0 >= 1 && W0 >= 1 && H1 >= 1 && W1 >= 1, "conv3x3_wgrad_pair: bad dims");
+  if (!(stride == 2 && Cin0 == 256 && Cin1 == 256 && Cout0 % 64 == 0 && Cout1 % 64 == 0 && Cout0 >= 64 && Cout1 >= 64)) {
+    geeco_set_error("conv3x3_wgrad_pair: shapes outside the paired kernel (Cin = 256, Cout %% 64 == 0, stride 2)");
+    return GEECO_ENOSUP;
+  }
+  WgradPairParams pp = {};
+  int bc0, bc1;
+  wgrad_plan(groups, N0, H0, W0, Cin0, Cout0, stride, &pp.q0, &bc0);
+  wgrad_plan(groups, N1, H1, W1, Cin1, Cout1, stride, &pp.q1, &bc1);
+  if (bc0 != 64064 || bc1 != 64064) {
+    geeco_set_error("conv3x3_wgrad_pair: the two problems do not share the 64 x 64 tile kernel");
+    return GEECO_ENOSUP;
+  }
+  pp.q0.x = x0; pp.q0.dz = dz0; pp.q0.part = (float*)ws0; pp.q0.gs_x = gs_x0; pp.q0.gs_dz = gs_dz0;
+  pp.q0.dw = dw0; pp.q0.db = db0; pp.q0.gs_dw = gs_dw0; pp.q0.gs_db = gs_db0;
+  pp.q1.x = x1; pp.q1.dz = dz1; pp.q1.part = (float*)ws1; pp.q1.gs_x = gs_x1; pp.q1.gs_dz = gs_dz1;
+  pp.q1.dw = dw1; pp.q1.db = db1; pp.q1.gs_dw = gs_dw1; pp.q1.gs_db = gs_db1;
+  const long long b0 = (long long)pp.q0.S * pp.q0.row_tiles * pp.q0.col_tiles * groups;
+  const long long b1 = (long long)pp.q1.S * pp.q1.row_tiles * pp.q1.col_tiles * groups;
+  pp.blocks0 = (int)b0;
+  hipStream_t s = (hipStream_t)stream;
+  geeco_note_kernel("conv_wgrad_pair_kernel<64, 64, 32>");
+  hipLaunchKernelGGL((conv_wgrad_pair_kernel<64, 64, 32>), dim3((unsigned)(b0 + b1)), dim3(256), 0, s, pp);
+  GEECO_LAUNCH_CHECK();
+  const WgradParams* q[2] = {&pp.q0, &pp.q1};
+  float* dws[2] = {dw0, dw1};
+  float* dbs[2] = {db0, db1};
+  const int64_t gsw[2] = {gs_dw0, gs_dw1}, gsb[2] = {gs_db0, gs_db1};
+  void* wss[2] = {ws0, ws1};
+  const int couts[2] = {Cout0, Cout1};
+  for (int i = 0; i < 2; ++i) {
+    if (pending2) {
+      geeco_slab_reduce none = {};
+      pending2[i] = none;
+    }
+    if (q[i]->S > 1) {
+      if (pending2) geeco_set_pending_reduce(&pending2[i]);
+      geeco_launch_wgrad_reduce((const float*)wss[i], dws[i], dbs[i], gsw[i], gsb[i], q[i]->S, (long long)q[i]->Krows * couts[i],
+                                couts[i], groups, s);
+      if (pending2) geeco_set_pending_reduce(nullptr);
+      GEECO_LAUNCH_CHECK();
+    }
+  }
+  return 0;
 }

@@ -82,6 +82,8 @@ class ConvEncoderStack:
     # with the LDS-staged wgrad kernels every big launch fills the chip by itself and the two schedules measure the same
     # (3.717 vs 3.719 ms), so the simpler one is the default.  GEECO_MULTI_STREAM=1 restores the side streams.
     self.two_streams = _dev.env('GEECO_MULTI_STREAM') is not None
+    # conv7's + conv8's filter gradients in one launch (GEECO_NO_WGRAD_PAIR: two)
+    self.pair_top = _dev.env('GEECO_NO_WGRAD_PAIR') is None
     # the filter-gradient kernels' slab sums of a backward part go into one launch (GEECO_NO_BATCH_REDUCE: one per layer)
     self.batch_reduce = _dev.env('GEECO_NO_BATCH_REDUCE') is None
     self.derived_version = -1
@@ -354,6 +356,17 @@ class ConvEncoderStack:
       for g in range(G):
         ops.pad_mid_into(self._dw(0, g), self.dw1p[g], 9, self.Cpad, self.Cin, L['Cout'])
 
+  def _wgrad_args(self, l):
+    L = self.layers[l]
+    x, dz = self.acts[l - 1], self.dz[l]
+    return dict(dw=self._dw(l), db=self._db(l), x=x, dz=dz, gs_x=x[0].numel(), gs_dz=dz[0].numel(), gs_dw=self._gs_g(l),
+                gs_db=self._gs_g(l), N=self.Nf, H=L['H'], W=L['W'], Cin=L['Cin'], Cout=L['Cout'], ws=self.ws_l[l])
+
+  def launch_wgrad_top_pair(self, pending=None):
+    """conv7's and conv8's filter gradients as ONE launch (both are ready once conv8's input gradient exists; each alone is
+    432 blocks on 256 CUs): False when the shapes are outside the paired kernel (the caller launches them one by one)."""
+    return ops.conv3x3_wgrad_pair_into(self._wgrad_args(6), self._wgrad_args(7), self.G, self.layers[6]['stride'], pending=pending)
+
   def launch_dgrad(self, l, pending=None):
     """Input gradient of layer l >= 1 into dz[l-1] (ReluGrad of the layer below fused).  With the fused encoder
     bottom, l == 1 also produces conv1's filter / bias gradient: dz1 has no other consumer and stays on chip
@@ -408,7 +421,19 @@ class ConvEncoderStack:
     main = torch.cuda.current_stream()
     sides = self.sides if self.two_streams else []
     pending = [] if self.batch_reduce else None   # slab sums of all layers of this part: one launch at the end
+    # conv8's filter gradient waits for conv7's: one launch for both (independent work batched into one grid)
+    pair_top = (hi == 7 and lo <= 6 and not self.split_top and not sides and self.pair_top
+                and self.layers[6]['stride'] == self.layers[7]['stride'] == 2)
     for l in range(hi, lo - 1, -1):
+      if pair_top and l == 7:
+        self.launch_dgrad(7, pending)
+        continue
+      if pair_top and l == 6:
+        if not self.launch_wgrad_top_pair(pending):
+          self.launch_wgrad(7, pending)
+          self.launch_wgrad(6, pending)
+        self.launch_dgrad(6, pending)
+        continue
       # wgrad(l) of the upper layers is off the critical path (the dgrad chain on `main`): it goes to a side
       # stream; the bottom layers' (LDS-halo kernels, one or two blocks per CU) stay on `main`
       side = None

@@ -192,6 +192,29 @@ def conv3x3_wgrad_into(dw, db, x, dz, G, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin
     pending.append(item)
 
 
+def conv3x3_wgrad_pair_into(a, b, G, stride, pending=None):
+  """Two independent filter gradients in ONE launch (``geeco_conv3x3_wgrad_pair``).  ``a`` / ``b``: dicts with the arguments of
+  ``conv3x3_wgrad_into`` (dw, db, x, dz, gs_x, gs_dz, gs_dw, gs_db, N, H, W, Cin, Cout, ws); ``a`` = the longer problem.
+  Returns False (nothing launched) when the shapes are outside the paired kernel: the caller launches them one by one."""
+  lib = _lib()
+  items = (_native.SlabReduce * 2)() if pending is not None else None
+  rc = lib.geeco_conv3x3_wgrad_pair(
+      _p(a['x']), _p(a['dz']), _p(a['dw']), _p(a['db']), a['gs_x'], a['gs_dz'], a['gs_dw'], a['gs_db'], a['N'], a['H'], a['W'],
+      a['Cin'], a['Cout'], _p(a['ws']),
+      _p(b['x']), _p(b['dz']), _p(b['dw']), _p(b['db']), b['gs_x'], b['gs_dz'], b['gs_dw'], b['gs_db'], b['N'], b['H'], b['W'],
+      b['Cin'], b['Cout'], _p(b['ws']), G, stride, _stream(), items)
+  if rc == _native.GEECO_ENOSUP:
+    return False
+  check(rc, 'geeco_conv3x3_wgrad_pair')
+  if items is not None:
+    for it in items:
+      if it.S > 0:
+        c = _native.SlabReduce()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(it), ctypes.sizeof(c))
+        pending.append(c)
+  return True
+
+
 def slab_reduce_batch(pending):
   """Finishes the deferred slab sums of ``pending`` (<= 8 per launch) and empties the list."""
   MAX = 8

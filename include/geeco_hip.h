@@ -176,6 +176,16 @@ int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, con
                                           int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
                                           void* stream, geeco_slab_reduce* pending, int reserved_cus);
 int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream);
+/* TWO independent filter gradients of the 64 x 64-tile generic kernel as ONE grid (the model: conv7's + conv8's, both ready
+ * once conv8's input gradient exists; problem 0 = the longer one).  Arguments per problem as geeco_conv3x3_wgrad; common
+ * groups / stride; pending2: NULL or TWO items (deferred slab sums as geeco_conv3x3_wgrad_partial; S = 0 where the kernel wrote
+ * the gradient directly).  Bitwise the results of two geeco_conv3x3_wgrad calls.  GEECO_ENOSUP for shapes outside the paired
+ * kernel (Cin = 256, Cout % 64 == 0, stride 2): launch twice then. */
+int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
+                             int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
+                             const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
+                             int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
+                             int groups, int stride, void* stream, geeco_slab_reduce* pending2);
 
 /* ReLU sign bits as the ReluGrad mask of the encoder bottom.  conv1's output y1 (805 MB at the bench shape) is read by
  * the fused bottom backward only for its sign; geeco_conv1_fwd_relu_bits is conv1's forward (4 -> 32, stride 1, bias,

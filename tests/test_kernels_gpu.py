@@ -916,6 +916,41 @@ def test_reserved_cus_shrink_the_persistent_bottom_kernels(dev):
                            dz2[0].numel(), 9 * 32 * 48, 48, N, H, W, 32, 48, 2, wsw, reserved_cus=16)
 
 
+@pytest.mark.parametrize('G,N,dim_out', [(3, 32, 256), (1, 5, 256), (2, 3, 128)])
+def test_wgrad_pair_conv7_conv8_bitwise(dev, G, N, dim_out):
+  """conv7's and conv8's filter gradients as ONE grid (geeco_conv3x3_wgrad_pair) against the two separate launches: bitwise
+  (the same tile code on the same (split, tile, group) decomposition), both against fp64 in their own tests; the separate
+  launches really are the generic 64 x 64-tile kernel for these shapes; shapes outside the paired kernel report "launch twice"."""
+  from geeco_amd import ops
+  r = np.random.default_rng(89)
+  shapes = [(8, 256, 256), (4, 256, dim_out)]          # (H = W of the layer's input, Cin, Cout): conv7, conv8
+  probs, refs = [], []
+  for H, Cin, Cout in shapes:
+    x = torch.tensor(r.standard_normal([G, N, H, H, Cin]).astype(np.float32), device=dev)
+    dz = torch.tensor(r.standard_normal([G, N, H // 2, H // 2, Cout]).astype(np.float32), device=dev)
+    ws = torch.empty(ops.conv3x3_wgrad_ws_bytes(G, N, H, H, Cin, Cout, 2) // 4 + 4, device=dev)
+    dw_ref = torch.full((G, 9 * Cin * Cout), float('nan'), device=dev)
+    db_ref = torch.full((G, Cout), float('nan'), device=dev)
+    names = ops.kernel_trace(lambda: ops.conv3x3_wgrad_into(dw_ref, db_ref, x, dz, G, x[0].numel(), dz[0].numel(), dw_ref[0].numel(),
+                                                            Cout, N, H, H, Cin, Cout, 2, ws))
+    assert names[0] == 'conv_wgrad_kernel<64, 64, 32>', names
+    refs.append((dw_ref, db_ref))
+    probs.append(dict(dw=torch.full_like(dw_ref, float('nan')), db=torch.full_like(db_ref, float('nan')), x=x, dz=dz, gs_x=x[0].numel(),
+                      gs_dz=dz[0].numel(), gs_dw=dw_ref[0].numel(), gs_db=Cout, N=N, H=H, W=H, Cin=Cin, Cout=Cout,
+                      ws=torch.empty_like(ws)))
+  pending = []
+  names = ops.kernel_trace(lambda: probs.__setitem__(0, probs[0]) or ops.conv3x3_wgrad_pair_into(probs[0], probs[1], G, 2, pending=pending))
+  ops.slab_reduce_batch(pending)
+  torch.cuda.synchronize()
+  assert names[0] == 'conv_wgrad_pair_kernel<64, 64, 32>', names
+  for pr, (dw_ref, db_ref) in zip(probs, refs):
+    assert not torch.isnan(pr['dw']).any() and not torch.isnan(pr['db']).any()
+    assert torch.equal(pr['dw'], dw_ref) and torch.equal(pr['db'], db_ref)
+  # a layer the LDS-staged kernels serve (Cin = 192) is refused: nothing launched, the caller falls back
+  bad = dict(probs[0], Cin=192)
+  assert ops.conv3x3_wgrad_pair_into(bad, probs[1], G, 2) is False
+
+
 def test_conv2_wgrad_remainder_block(dev):
   """conv2's filter gradient, three encoders, 512 tiles each = 85 blocks x 6 + 2: the 256th block walks the two tiles
   every encoder leaves over (three segments, slab 85 of each encoder); every encoder's dw / db against the fp64 oracle,
