@@ -65,6 +65,9 @@ SIGNATURES = {
     'geeco_conv2_dgrad_conv1_wgrad_partial': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I,
                                                    _P, _P, POINTER(SlabReduce), _I]),
     'geeco_slab_reduce_batch': (_I, [POINTER(SlabReduce), _I, _P]),
+    'geeco_conv_top_bwd': (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P,
+                                _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P,
+                                _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, POINTER(SlabReduce)]),
     'geeco_conv3x3_wgrad_pair': (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P,
                                       _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, POINTER(SlabReduce)]),
     'geeco_relu_bits_pitch': (_L, [_I]),

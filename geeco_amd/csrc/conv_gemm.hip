@@ -22,6 +22,7 @@
 //   sB[k][BN + 4]: ds_read_b32, row pitch = 4 (mod 8) dwords => the two k-rows of a 32-lane half
 //       land in different bank halves (conflict free).
 #include "geeco_common.h"
+#include "conv_wgrad_body.h"
 #include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
@@ -89,11 +90,20 @@ struct ConvGemmParams {
 constexpr int GEMM_ZERO_PAGE = 4096;   // floats: a whole tap of the widest layer the uniform-tap path serves
 static __device__ float g_gemm_zero_page[GEMM_ZERO_PAGE + 64];
 
+// block coordinates of the 3-D launch grid (x = M tile, y = N tile x K split, z = encoder): the body takes them as arguments
+// so that it can also run as part of a heterogeneous grid (conv_top_bwd_kernel below)
+struct GemmBlock {
+  int x, y, z, gx, gy;
+};
+template <int BM, int BN, int BK>
+constexpr int conv_gemm_smem_floats() {
+  return 2 * (BM * BK + BK * (BN + 4)) + 60;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool UT>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+__device__ __forceinline__ void conv_gemm_body(const ConvGemmParams& p, const GemmBlock blk, float* smem) {
 #ifdef GEECO_STAMPS
-  unsigned long long* stamp_base =
-      p.stamps + ((long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64;
+  unsigned long long* stamp_base = p.stamps + ((long long)(blk.z * blk.gy + blk.y) * blk.gx + blk.x) * 64;
   STAMP(0);
   if (threadIdx.x == 0 && p.stamps) stamp_base[63] = (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
 #endif
@@ -111,7 +121,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   constexpr int KB = BK / 16;
   static_assert(PA >= 1 && TJ >= 1 && TI >= 1 && WM * WN == 4, "bad tile");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM * BK + BK * LDB) + 60];
   float* sA = smem;
   float* sB = smem + 2 * BM * BK;
   int* sTap = reinterpret_cast<int*>(smem + 2 * (BM * BK + BK * LDB));
@@ -119,15 +128,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int g = blockIdx.z;
+  const int g = blk.z;
   // Input gradients (ncls == 4 parity classes with 1 / 2 / 2 / 4 taps, i.e. K loops of unequal length): all blocks of a
   // launch are co-resident and dealt to the CUs in dispatch order, so blocks L, L + 256, L + 512 share a CU - and with
   // the M tile as the fastest grid index they would be tiles of the SAME class (conv7: three 4-tap blocks on one CU,
   // three 1-tap blocks on another).  p.rot rotates the M tile index by one class per 256 blocks.
-  int bx = blockIdx.x;
+  int bx = blk.x;
   if (p.rot) {
-    const int row = blockIdx.y + gridDim.y * blockIdx.z;
-    bx = (bx + (int)(((long long)row * gridDim.x) >> 8) * p.rot) % (int)gridDim.x;
+    const int row = blk.y + blk.gy * blk.z;
+    bx = (bx + (int)(((long long)row * blk.gx) >> 8) * p.rot) % blk.gx;
   }
   const float* __restrict__ xg = p.x + (long long)g * p.gs_x;
   const float* __restrict__ wg = p.w + (long long)g * p.gs_w;
@@ -139,8 +148,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const long long clsM = cl.M;
   const int clsHc = cl.Hc, clsWc = cl.Wc, ntaps = cl.ntaps;
   const long long m0 = (long long)(bx - cl.tile0) * BM;
-  const int ntile = blockIdx.y / p.ksplit;
-  const int split = blockIdx.y - ntile * p.ksplit;
+  const int ntile = blk.y / p.ksplit;
+  const int split = blk.y - ntile * p.ksplit;
   const int n0 = ntile * BN;
   const int C = p.C, C4 = p.C >> 2;
 
@@ -444,6 +453,35 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 }
 
 // Sums the split-K slabs and applies the epilogue (bias, ReLU, mask).  One thread = 4 channels.
+template <int BM, int BN, int BK, int WM, int WN, bool UT>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[conv_gemm_smem_floats<BM, BN, BK>()];
+  conv_gemm_body<BM, BN, BK, WM, WN, UT>(p, GemmBlock{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem);
+}
+
+// Heterogeneous top of the backward (round 4): conv7's input gradient (this file's gather GEMM, 64 x 64 x 16 tiles, split K) and
+// conv7's + conv8's filter gradients (conv_wgrad_body.h) all need only dz7 and each fills the 256 CUs badly on its own (768 / 432
+// / 432 short blocks, 26 / 30 / 12 us): ONE grid runs them side by side -- independent work, no graph branch.  The filter-gradient
+// blocks (the longest) come first; the rest decode to the input gradient's (M tile, N tile x split, encoder) grid.
+struct TopBwdParams {
+  ConvGemmParams d;
+  WgradPairParams w;
+  int wblocks, gx, gy;
+};
+template <bool UT>
+__global__ __launch_bounds__(256) void conv_top_bwd_kernel(const TopBwdParams pp) {
+  constexpr int SW = conv_wgrad_smem_floats<64, 64, 32>(), SG = conv_gemm_smem_floats<64, 64, 16>();
+  __shared__ __attribute__((aligned(16))) float smem[SW > SG ? SW : SG];
+  const int b = (int)blockIdx.x;
+  if (b < pp.wblocks) {
+    conv_wgrad_pair_body<64, 64, 32>(pp.w, b, smem);
+  } else {
+    const int l = b - pp.wblocks;
+    const int x = l % pp.gx, r = l / pp.gx;
+    conv_gemm_body<64, 64, 16, 2, 2, UT>(pp.d, GemmBlock{x, r % pp.gy, r / pp.gy, pp.gx, pp.gy}, smem);
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvGemmParams p) {
   const int g = blockIdx.y;
   const long long npix = (long long)p.N * p.Hd * p.Wd;
@@ -780,4 +818,85 @@ extern "C" int geeco_conv3x3_dgrad(const float* dz, const float* w, const float*
   GEECO_CHECK_ARG(p.w, "conv3x3_dgrad: this shape (Cout = %d) needs the per-tap transposed kernel wt", Cout);
   if (p.ncls == 0) return 0;
   return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
+}
+
+
+// conv7's input gradient + conv7's / conv8's filter gradients as ONE grid (conv_top_bwd_kernel).  The input gradient's arguments as
+// geeco_conv3x3_dgrad (stride 2), the two filter-gradient problems as geeco_conv3x3_wgrad_pair.  GEECO_ENOSUP when any of the three
+// is outside the kernels this launch combines (the caller then uses the separate entry points): nothing has been launched.
+extern "C" int geeco_conv_top_bwd(const float* dz, const float* w, const float* wt, const float* ymask, float* dx, int64_t gs_dz,
+                                  int64_t gs_w, int64_t gs_wt, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, void* ws,
+                                  const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
+                                  int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
+                                  const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
+                                  int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
+                                  int groups, int stride, void* stream, geeco_slab_reduce* pending2) {
+  GEECO_CHECK_ARG(dz && dx && (wt || w) && ws, "conv_top_bwd: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 1 && W >= 1 && Cout % 4 == 0 && Cin % 16 == 0, "conv_top_bwd: bad dims");
+  if (stride != 2 || geeco_halo_dgrad_handles(H, W, Cin, Cout, stride) || geeco_dgrad_lds_handles(H, W, Cin, Cout, stride)) {
+    geeco_set_error("conv_top_bwd: the input gradient of this shape is not the gather GEMM's");
+    return GEECO_ENOSUP;
+  }
+  TopBwdParams tp = {};
+  ConvGemmParams& p = tp.d;
+  fill_dgrad(&p, N, H, W, Cin, Cout, stride);
+  p.x = dz; p.w = wt; p.bias = nullptr; p.mask = ymask; p.out = dx;
+  p.gs_x = gs_dz; p.gs_w = gs_wt; p.gs_b = 0; p.gs_out = gs_dx;
+  if (w && dgrad_reads_hwio(Cout)) {
+    p.w = w; p.gs_w = gs_w; p.bt = 1;
+  }
+  if (!p.w || p.ncls == 0) {
+    geeco_set_error("conv_top_bwd: this input gradient needs the per-tap transposed kernel / is empty");
+    return GEECO_ENOSUP;
+  }
+  for (int c = 0; c < p.ncls; ++c)
+    if (p.cls[c].M + 256 >= (1ll << 31)) {
+      geeco_set_error("conv_top_bwd: %lld rows per launch exceed the 32-bit row index of the kernel", p.cls[c].M);
+      return GEECO_ENOSUP;
+    }
+  const ConvPlan pl = conv_plan(p, groups);
+  static const int bk32 = geeco_dev_getenv("GEECO_CONV_BK32") ? 1 : 0;
+  if (pl.bm != 64 || pl.bn != 64 || bk32) {
+    geeco_set_error("conv_top_bwd: the input gradient's plan is not the 64 x 64 x 16 tile kernel");
+    return GEECO_ENOSUP;
+  }
+  long long wblocks = 0;
+  if (int rc = geeco_wgrad_pair_fill(&tp.w, x0, dz0, dw0, db0, gs_x0, gs_dz0, gs_dw0, gs_db0, N0, H0, W0, Cin0, Cout0, ws0, x1, dz1,
+                                     dw1, db1, gs_x1, gs_dz1, gs_dw1, gs_db1, N1, H1, W1, Cin1, Cout1, ws1, groups, stride, &wblocks))
+    return rc;
+#ifdef GEECO_STAMPS
+  p.stamps = nullptr;
+#endif
+  p.ksplit = pl.ksplit; p.groups = groups; p.part = (float*)ws;
+  // grid and class rotation exactly as launch_cfg<64, 64, 16, 2, 2> would set them
+  int tiles = 0;
+  for (int c = 0; c < p.ncls; ++c) {
+    p.cls[c].tile0 = tiles;
+    tiles += (int)cdiv64(p.cls[c].M, 64);
+  }
+  {
+    static const int no_rot = geeco_dev_getenv("GEECO_CONV_NO_ROT") ? 1 : 0;
+    bool equal = p.ncls > 1;
+    for (int c = 1; c < p.ncls; ++c) equal = equal && cdiv64(p.cls[c].M, 64) == cdiv64(p.cls[0].M, 64);
+    p.rot = (equal && !no_rot) ? tiles / p.ncls : 0;
+  }
+  tp.wblocks = (int)wblocks; tp.gx = tiles; tp.gy = cdiv(p.Nout, 64) * p.ksplit;
+  static const int no_ut = geeco_dev_getenv("GEECO_CONV_NO_UT") ? 1 : 0;
+  const bool ut = p.C % 16 == 0 && p.C <= GEMM_ZERO_PAGE && !no_ut;
+  const long long blocks = wblocks + (long long)tp.gx * tp.gy * groups;
+  hipStream_t s = (hipStream_t)stream;
+  geeco_note_kernel("conv_top_bwd_kernel<%s>", ut ? "true" : "false");
+  if (ut)
+    hipLaunchKernelGGL(conv_top_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, tp);
+  else
+    hipLaunchKernelGGL(conv_top_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, tp);
+  GEECO_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    const long long total4 = (long long)p.N * p.Hd * p.Wd * p.Nout / 4;
+    dim3 grid((unsigned)cdiv64(total4, 256), (unsigned)groups);
+    geeco_note_kernel("conv_splitk_epilogue_kernel");
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, grid, dim3(256), 0, s, p);
+    GEECO_LAUNCH_CHECK();
+  }
+  return geeco_wgrad_pair_finish(tp.w, groups, s, pending2);
 }

@@ -17,220 +17,21 @@
 // different bank halves.
 #include "geeco_common.h"
 #include <stdlib.h>
-
-struct WgradParams {
-  const float* x;
-  const float* dz;
-  float* part;   // [G][S][Krows*Cout + Cout]
-  float* dw;     // S == 1: the block's tile is final and goes straight to dw / db (no slab, no reduce launch)
-  float* db;
-  long long gs_x, gs_dz, gs_dw, gs_db;
-  int N, H, W, Cin, Ho, Wo, Cout, stride, pt, pl;
-  long long M;          // N*Ho*Wo
-  long long m_per_split;
-  int S;
-  int Krows;            // 9*Cin
-  int row_tiles, col_tiles;
-};
-
-template <int BR, int BC, int MK>
-__device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int g, const int by, const int split) {
-  constexpr int LDA = (BR % 32 == 16) ? BR : BR + 16;
-  constexpr int LDBZ = (BC % 32 == 16) ? BC : BC + 16;
-  constexpr int BR4 = BR / 4, BC4 = BC / 4;
-  constexpr int NA4 = MK * BR4, NB4 = MK * BC4;
-  constexpr int PAS = (NA4 + 255) / 256, PBS = (NB4 + 255) / 256;
-  constexpr int TI = BC / 16;   // co tiles per wave
-  constexpr int TJW = BR / 64;  // 16-row k-strips per wave (wave w owns strips w*TJW .. +TJW-1)
-  static_assert(BR % 64 == 0, "whole strips per wave");
-
-  __shared__ __attribute__((aligned(16))) float smem[2 * MK * (LDA + LDBZ)];
-  float* sA = smem;
-  float* sB = smem + 2 * MK * LDA;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int rt = by / p.col_tiles;
-  const int ct = by - rt * p.col_tiles;
-  const float* __restrict__ xg = p.x + (long long)g * p.gs_x;
-  const float* __restrict__ zg = p.dz + (long long)g * p.gs_dz;
-  const int Cin = p.Cin, C4 = Cin >> 2, Cout = p.Cout;
-  const long long mbeg = (long long)split * p.m_per_split;
-  long long mend = mbeg + p.m_per_split;
-  if (mend > p.M) mend = p.M;
-
-  // ---- staging state: A (x gather) -------------------------------------------------------------
-  int a_ky[PAS], a_kx[PAS], a_coff[PAS], a_mrow[PAS], a_slot[PAS];
-  bool a_ok[PAS];
-  int a_n[PAS], a_oy[PAS], a_ox[PAS];
-  const long long HoWo = (long long)p.Ho * p.Wo;
-  const int adv_x = MK % p.Wo, adv_y = (MK / p.Wo) % p.Ho, adv_n = MK / (p.Wo * p.Ho);   // MK pixels as (columns, rows, frames)
-#pragma unroll
-  for (int i = 0; i < PAS; ++i) {
-    int idx = tid + i * 256;
-    a_mrow[i] = idx / BR4;
-    a_slot[i] = idx - a_mrow[i] * BR4;
-    int sg = rt * BR4 + a_slot[i];
-    int tap = sg / C4;
-    a_ok[i] = (idx < NA4) && (tap < 9);
-    if (tap > 8) tap = 8;
-    a_ky[i] = tap / 3 - p.pt;
-    a_kx[i] = tap % 3 - p.pl;
-    a_coff[i] = (sg - (sg / C4) * C4) * 4;
-    long long m = mbeg + a_mrow[i];
-    long long n = m / HoWo;
-    int rem = (int)(m - n * HoWo);
-    a_n[i] = (int)n;
-    a_oy[i] = rem / p.Wo;
-    a_ox[i] = rem - a_oy[i] * p.Wo;
-  }
-  // ---- staging state: B (dz rows) --------------------------------------------------------------
-  int b_mrow[PBS], b_c4[PBS];
-#pragma unroll
-  for (int i = 0; i < PBS; ++i) {
-    int idx = tid + i * 256;
-    b_mrow[i] = idx / BC4;
-    b_c4[i] = idx - b_mrow[i] * BC4;
-  }
-  const int co0 = ct * BC;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 ra[PAS], rz[PBS];
-  f32x4 dbsum[PBS];
-#pragma unroll
-  for (int i = 0; i < PBS; ++i) dbsum[i] = zero4;
-
-  auto load_tiles = [&](long long mb) {
-#pragma unroll
-    for (int i = 0; i < PAS; ++i) {
-      int iy = a_oy[i] * p.stride + a_ky[i];
-      int ix = a_ox[i] * p.stride + a_kx[i];
-      bool v = a_ok[i] && (mb + a_mrow[i] < mend) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      ra[i] = v ? *reinterpret_cast<const f32x4*>(xg + (((long long)a_n[i] * p.H + iy) * p.W + ix) * Cin + a_coff[i])
-                : zero4;
-      // advance this thread's pixel by MK for the next stage: carries instead of a wrap loop (conv8: Wo = 2, i.e. 16
-      // divergent loop trips per entry and stage - VALU work that the f32 MFMAs pay for)
-      a_ox[i] += adv_x;
-      const int cx = a_ox[i] >= p.Wo ? 1 : 0;
-      a_ox[i] -= cx * p.Wo;
-      a_oy[i] += adv_y + cx;
-      const int cy = a_oy[i] >= p.Ho ? 1 : 0;
-      a_oy[i] -= cy * p.Ho;
-      a_n[i] += adv_n + cy;
-    }
-#pragma unroll
-    for (int i = 0; i < PBS; ++i) {
-      long long m = mb + b_mrow[i];
-      bool v = (tid + i * 256 < NB4) && (m < mend) && (co0 + b_c4[i] * 4 < Cout);
-      rz[i] = v ? *reinterpret_cast<const f32x4*>(zg + m * Cout + co0 + b_c4[i] * 4) : zero4;
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    float* a = sA + buf * MK * LDA;
-    float* b = sB + buf * MK * LDBZ;
-#pragma unroll
-    for (int i = 0; i < PAS; ++i)
-      if (tid + i * 256 < NA4) *reinterpret_cast<f32x4*>(a + a_mrow[i] * LDA + a_slot[i] * 4) = ra[i];
-#pragma unroll
-    for (int i = 0; i < PBS; ++i)
-      if (tid + i * 256 < NB4) {
-        *reinterpret_cast<f32x4*>(b + b_mrow[i] * LDBZ + b_c4[i] * 4) = rz[i];
-        dbsum[i] += rz[i];
-      }
-  };
-
-  f32x4 acc[TJW][TI];
-#pragma unroll
-  for (int j = 0; j < TJW; ++j)
-#pragma unroll
-    for (int i = 0; i < TI; ++i) acc[j][i] = zero4;
-  const int r = lane & 15, q = lane >> 4;
-
-  const long long nchunk = (mend > mbeg) ? (mend - mbeg + MK - 1) / MK : 0;
-  if (nchunk > 0) {
-    load_tiles(mbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (long long c = 0; c < nchunk; ++c) {
-    const int buf = (int)(c & 1);
-    const bool more = c + 1 < nchunk;
-    if (more) load_tiles(mbeg + (c + 1) * MK);
-    const float* a = sA + buf * MK * LDA;
-    const float* b = sB + buf * MK * LDBZ;
-#pragma unroll
-    for (int blk = 0; blk < MK / 4; ++blk) {
-      float xv[TJW], zv[TI];
-#pragma unroll
-      for (int j = 0; j < TJW; ++j) xv[j] = a[(blk * 4 + q) * LDA + (wid * TJW + j) * 16 + r];
-#pragma unroll
-      for (int i = 0; i < TI; ++i) zv[i] = b[(blk * 4 + q) * LDBZ + i * 16 + r];
-#pragma unroll
-      for (int j = 0; j < TJW; ++j)
-#pragma unroll
-        for (int i = 0; i < TI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[i], xv[j], acc[j][i], 0, 0, 0);
-    }
-    if (more) store_tiles(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane owns k-row (lane & 15) of its wave's strip, co = 16 i + 4 q .. +3 ---------
-  const long long slab = (long long)p.Krows * Cout + Cout;
-  const bool direct = p.S == 1;
-  float* __restrict__ part = direct ? p.dw + (long long)g * p.gs_dw : p.part + ((long long)g * p.S + split) * slab;
-  float* __restrict__ bpart = direct ? (p.db ? p.db + (long long)g * p.gs_db : nullptr) : part + (long long)p.Krows * Cout;
-#pragma unroll
-  for (int j = 0; j < TJW; ++j) {
-    const int krow = rt * BR + (wid * TJW + j) * 16 + r;
-    if (krow < p.Krows) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        int co = co0 + i * 16 + 4 * q;
-        if (co < Cout) *reinterpret_cast<f32x4*>(part + (long long)krow * Cout + co) = acc[j][i];
-      }
-    }
-  }
-  if (rt == 0 && bpart) {
-    // bias gradient: per-thread dz sums -> LDS [pixel row][BC] -> fixed-order column sums
-    // (the main loop ended with a barrier, so sB is free to reuse)
-    float* sT = sB;
-#pragma unroll
-    for (int i = 0; i < PBS; ++i)
-      if (tid + i * 256 < NB4) *reinterpret_cast<f32x4*>(sT + b_mrow[i] * LDBZ + b_c4[i] * 4) = dbsum[i];
-    __syncthreads();
-    if (tid < BC && co0 + tid < Cout) {
-      float s = 0.f;
-#pragma unroll
-      for (int m = 0; m < MK; ++m) s += sT[m * LDBZ + tid];
-      bpart[co0 + tid] = s;
-    }
-  }
-}
+#include "conv_wgrad_body.h"
 
 template <int BR, int BC, int MK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  conv_wgrad_body<BR, BC, MK>(p, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float smem[conv_wgrad_smem_floats<BR, BC, MK>()];
+  conv_wgrad_body<BR, BC, MK>(p, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, smem);
 }
 
 // TWO independent filter-gradient problems of the same tile shape as ONE grid (round 4: conv7's and conv8's, both ready once
 // conv8's input gradient exists; each alone is 432 blocks on 256 CUs for 30 / 12 us: together the short blocks fill the long
-// ones' tail and one launch boundary goes).  Blocks [0, blocks0) serve problem 0 (put the longer one first), the rest problem 1;
-// inside a problem the linear index decodes as (split, tile, group) like the 3-D grid of the single launch: bitwise the same.
-struct WgradPairParams {
-  WgradParams q0, q1;
-  int blocks0;
-};
+// ones' tail and one launch boundary goes).  Bitwise the single launches.
 template <int BR, int BC, int MK>
 __global__ __launch_bounds__(256) void conv_wgrad_pair_kernel(const WgradPairParams pp) {
-  const int b = (int)blockIdx.x;
-  if (b < pp.blocks0) {
-    const int tiles = pp.q0.row_tiles * pp.q0.col_tiles;
-    const int split = b % pp.q0.S, t = b / pp.q0.S;
-    conv_wgrad_body<BR, BC, MK>(pp.q0, t / tiles, t % tiles, split);
-  } else {
-    const int l = b - pp.blocks0;
-    const int tiles = pp.q1.row_tiles * pp.q1.col_tiles;
-    const int split = l % pp.q1.S, t = l / pp.q1.S;
-    conv_wgrad_body<BR, BC, MK>(pp.q1, t / tiles, t % tiles, split);
-  }
+  __shared__ __attribute__((aligned(16))) float smem[conv_wgrad_smem_floats<BR, BC, MK>()];
+  conv_wgrad_pair_body<BR, BC, MK>(pp, (int)blockIdx.x, smem);
 }
 
 // Sums the S partial slabs in a fixed order (bitwise reproducible).  Streaming float4 kernel: a wave
@@ -381,7 +182,7 @@ int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, i
                         int64_t gs_dw, int64_t gs_db, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
                         hipStream_t stream, int* handled);
 
-static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride, WgradParams* p, int* bc) {
+void geeco_wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int stride, WgradParams* p, int* bc) {
   int Ho, Wo, pt, pl;
   same_pad(H, 3, stride, &Ho, &pt);
   same_pad(W, 3, stride, &Wo, &pl);
@@ -414,7 +215,7 @@ static void wgrad_plan(int groups, int N, int H, int W, int Cin, int Cout, int s
 extern "C" int64_t geeco_conv3x3_wgrad_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride) {
   WgradParams p = {};
   int bc;
-  wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &bc);
+  geeco_wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &bc);
   int64_t a = (int64_t)groups * p.S * ((int64_t)p.Krows * Cout + Cout) * 4;
   int64_t b = geeco_halo_wgrad_ws_bytes(groups, N, H, W, Cin, Cout, stride);
   int64_t c = geeco_conv1_wgrad_ws_bytes(groups, Cin, Cout, stride);
@@ -445,7 +246,7 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   }
   WgradParams p = {};
   int BC;
-  wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &BC);
+  geeco_wgrad_plan(groups, N, H, W, Cin, Cout, stride, &p, &BC);
   p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
   p.dw = dw; p.db = db; p.gs_dw = gs_dw; p.gs_db = gs_db;
   hipStream_t s = (hipStream_t)stream;
@@ -486,42 +287,38 @@ extern "C" int geeco_conv3x3_wgrad_partial(const float* x, const float* dz, floa
 
 // conv7's + conv8's filter gradients in one launch (see conv_wgrad_pair_kernel).  Only the shapes the generic kernel serves with
 // 64 x 64 tiles (Cin = 256: the LDS-staged kernels take the layers below); anything else: GEECO_ENOSUP, the caller launches twice.
-extern "C" int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
-                                        int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
-                                        const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
-                                        int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
-                                        int groups, int stride, void* stream, geeco_slab_reduce* pending2) {
+int geeco_wgrad_pair_fill(WgradPairParams* pp, const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0,
+                          int64_t gs_dz0, int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
+                          const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
+                          int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1, int groups,
+                          int stride, long long* blocks) {
   GEECO_CHECK_ARG(x0 && dz0 && dw0 && ws0 && x1 && dz1 && dw1 && ws1, "conv3x3_wgrad_pair: null pointer");
   GEECO_CHECK_ARG(groups >= 1 && N0 >= 1 && N1 >= 1 && H0 >= 1 && W0 >= 1 && H1 >= 1 && W1 >= 1, "conv3x3_wgrad_pair: bad dims");
   if (!(stride == 2 && Cin0 == 256 && Cin1 == 256 && Cout0 % 64 == 0 && Cout1 % 64 == 0 && Cout0 >= 64 && Cout1 >= 64)) {
     geeco_set_error("conv3x3_wgrad_pair: shapes outside the paired kernel (Cin = 256, Cout %% 64 == 0, stride 2)");
     return GEECO_ENOSUP;
   }
-  WgradPairParams pp = {};
   int bc0, bc1;
-  wgrad_plan(groups, N0, H0, W0, Cin0, Cout0, stride, &pp.q0, &bc0);
-  wgrad_plan(groups, N1, H1, W1, Cin1, Cout1, stride, &pp.q1, &bc1);
+  geeco_wgrad_plan(groups, N0, H0, W0, Cin0, Cout0, stride, &pp->q0, &bc0);
+  geeco_wgrad_plan(groups, N1, H1, W1, Cin1, Cout1, stride, &pp->q1, &bc1);
   if (bc0 != 64064 || bc1 != 64064) {
     geeco_set_error("conv3x3_wgrad_pair: the two problems do not share the 64 x 64 tile kernel");
     return GEECO_ENOSUP;
   }
-  pp.q0.x = x0; pp.q0.dz = dz0; pp.q0.part = (float*)ws0; pp.q0.gs_x = gs_x0; pp.q0.gs_dz = gs_dz0;
-  pp.q0.dw = dw0; pp.q0.db = db0; pp.q0.gs_dw = gs_dw0; pp.q0.gs_db = gs_db0;
-  pp.q1.x = x1; pp.q1.dz = dz1; pp.q1.part = (float*)ws1; pp.q1.gs_x = gs_x1; pp.q1.gs_dz = gs_dz1;
-  pp.q1.dw = dw1; pp.q1.db = db1; pp.q1.gs_dw = gs_dw1; pp.q1.gs_db = gs_db1;
-  const long long b0 = (long long)pp.q0.S * pp.q0.row_tiles * pp.q0.col_tiles * groups;
-  const long long b1 = (long long)pp.q1.S * pp.q1.row_tiles * pp.q1.col_tiles * groups;
-  pp.blocks0 = (int)b0;
-  hipStream_t s = (hipStream_t)stream;
-  geeco_note_kernel("conv_wgrad_pair_kernel<64, 64, 32>");
-  hipLaunchKernelGGL((conv_wgrad_pair_kernel<64, 64, 32>), dim3((unsigned)(b0 + b1)), dim3(256), 0, s, pp);
-  GEECO_LAUNCH_CHECK();
+  pp->q0.x = x0; pp->q0.dz = dz0; pp->q0.part = (float*)ws0; pp->q0.gs_x = gs_x0; pp->q0.gs_dz = gs_dz0;
+  pp->q0.dw = dw0; pp->q0.db = db0; pp->q0.gs_dw = gs_dw0; pp->q0.gs_db = gs_db0;
+  pp->q1.x = x1; pp->q1.dz = dz1; pp->q1.part = (float*)ws1; pp->q1.gs_x = gs_x1; pp->q1.gs_dz = gs_dz1;
+  pp->q1.dw = dw1; pp->q1.db = db1; pp->q1.gs_dw = gs_dw1; pp->q1.gs_db = gs_db1;
+  const long long b0 = (long long)pp->q0.S * pp->q0.row_tiles * pp->q0.col_tiles * groups;
+  const long long b1 = (long long)pp->q1.S * pp->q1.row_tiles * pp->q1.col_tiles * groups;
+  pp->blocks0 = (int)b0;
+  *blocks = b0 + b1;
+  return 0;
+}
+
+// the two problems' slab sums (launched, or recorded into pending2[0..1]; S == 1: the kernel wrote the gradient itself)
+int geeco_wgrad_pair_finish(const WgradPairParams& pp, int groups, hipStream_t s, geeco_slab_reduce* pending2) {
   const WgradParams* q[2] = {&pp.q0, &pp.q1};
-  float* dws[2] = {dw0, dw1};
-  float* dbs[2] = {db0, db1};
-  const int64_t gsw[2] = {gs_dw0, gs_dw1}, gsb[2] = {gs_db0, gs_db1};
-  void* wss[2] = {ws0, ws1};
-  const int couts[2] = {Cout0, Cout1};
   for (int i = 0; i < 2; ++i) {
     if (pending2) {
       geeco_slab_reduce none = {};
@@ -529,11 +326,28 @@ extern "C" int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float
     }
     if (q[i]->S > 1) {
       if (pending2) geeco_set_pending_reduce(&pending2[i]);
-      geeco_launch_wgrad_reduce((const float*)wss[i], dws[i], dbs[i], gsw[i], gsb[i], q[i]->S, (long long)q[i]->Krows * couts[i],
-                                couts[i], groups, s);
+      geeco_launch_wgrad_reduce(q[i]->part, q[i]->dw, q[i]->db, q[i]->gs_dw, q[i]->gs_db, q[i]->S,
+                                (long long)q[i]->Krows * q[i]->Cout, q[i]->Cout, groups, s);
       if (pending2) geeco_set_pending_reduce(nullptr);
       GEECO_LAUNCH_CHECK();
     }
   }
   return 0;
+}
+
+extern "C" int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
+                                        int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
+                                        const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
+                                        int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
+                                        int groups, int stride, void* stream, geeco_slab_reduce* pending2) {
+  WgradPairParams pp = {};
+  long long blocks = 0;
+  if (int rc = geeco_wgrad_pair_fill(&pp, x0, dz0, dw0, db0, gs_x0, gs_dz0, gs_dw0, gs_db0, N0, H0, W0, Cin0, Cout0, ws0, x1, dz1,
+                                     dw1, db1, gs_x1, gs_dz1, gs_dw1, gs_db1, N1, H1, W1, Cin1, Cout1, ws1, groups, stride, &blocks))
+    return rc;
+  hipStream_t s = (hipStream_t)stream;
+  geeco_note_kernel("conv_wgrad_pair_kernel<64, 64, 32>");
+  hipLaunchKernelGGL((conv_wgrad_pair_kernel<64, 64, 32>), dim3((unsigned)blocks), dim3(256), 0, s, pp);
+  GEECO_LAUNCH_CHECK();
+  return geeco_wgrad_pair_finish(pp, groups, s, pending2);
 }

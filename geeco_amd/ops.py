@@ -215,6 +215,29 @@ def conv3x3_wgrad_pair_into(a, b, G, stride, pending=None):
   return True
 
 
+def conv_top_bwd_into(d, a, b, G, stride, pending=None):
+  """conv7's input gradient + conv7's / conv8's filter gradients as ONE heterogeneous grid (``geeco_conv_top_bwd``).  ``d``: dict
+  with the arguments of ``conv3x3_dgrad_into`` (dx, dz, wt, ymask, w, gs_dz, gs_w, gs_wt, gs_dx, N, H, W, Cin, Cout, ws);
+  ``a`` / ``b`` as for ``conv3x3_wgrad_pair_into``.  Returns False (nothing launched) outside the combined kernels."""
+  lib = _lib()
+  items = (_native.SlabReduce * 2)() if pending is not None else None
+  wa = lambda q: (_p(q['x']), _p(q['dz']), _p(q['dw']), _p(q['db']), q['gs_x'], q['gs_dz'], q['gs_dw'], q['gs_db'], q['N'], q['H'],
+                  q['W'], q['Cin'], q['Cout'], _p(q['ws']))
+  rc = lib.geeco_conv_top_bwd(_p(d['dz']), _p(d['w']), _p(d['wt']), _p(d['ymask']), _p(d['dx']), d['gs_dz'], d['gs_w'], d['gs_wt'],
+                              d['gs_dx'], d['N'], d['H'], d['W'], d['Cin'], d['Cout'], _p(d['ws']), *wa(a), *wa(b), G, stride,
+                              _stream(), items)
+  if rc == _native.GEECO_ENOSUP:
+    return False
+  check(rc, 'geeco_conv_top_bwd')
+  if items is not None:
+    for it in items:
+      if it.S > 0:
+        c = _native.SlabReduce()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(it), ctypes.sizeof(c))
+        pending.append(c)
+  return True
+
+
 def slab_reduce_batch(pending):
   """Finishes the deferred slab sums of ``pending`` (<= 8 per launch) and empties the list."""
   MAX = 8

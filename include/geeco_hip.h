@@ -186,6 +186,18 @@ int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float* dw0, floa
                              const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
                              int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
                              int groups, int stride, void* stream, geeco_slab_reduce* pending2);
+/* ... and with conv7's INPUT gradient beside them (all three need only dz7; each alone fills the 256 CUs badly): ONE
+ * heterogeneous grid, the filter-gradient blocks first.  Leading arguments as geeco_conv3x3_dgrad (stride 2; ws = its split-K
+ * workspace, required), then the two problems of geeco_conv3x3_wgrad_pair.  Bitwise the separate calls.  GEECO_ENOSUP when
+ * any of the three is outside the kernels this launch combines (the gather GEMM's 64 x 64 x 16 tiles; the paired 64 x 64
+ * filter-gradient tiles): nothing has been launched, use the separate entry points. */
+int geeco_conv_top_bwd(const float* dz, const float* w, const float* wt, const float* ymask, float* dx, int64_t gs_dz,
+                       int64_t gs_w, int64_t gs_wt, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, void* ws,
+                       const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
+                       int64_t gs_dw0, int64_t gs_db0, int N0, int H0, int W0, int Cin0, int Cout0, void* ws0,
+                       const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
+                       int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
+                       int groups, int stride, void* stream, geeco_slab_reduce* pending2);
 
 /* ReLU sign bits as the ReluGrad mask of the encoder bottom.  conv1's output y1 (805 MB at the bench shape) is read by
  * the fused bottom backward only for its sign; geeco_conv1_fwd_relu_bits is conv1's forward (4 -> 32, stride 1, bias,

@@ -951,6 +951,49 @@ def test_wgrad_pair_conv7_conv8_bitwise(dev, G, N, dim_out):
   assert ops.conv3x3_wgrad_pair_into(bad, probs[1], G, 2) is False
 
 
+@pytest.mark.parametrize('G,N,dim_out', [(3, 32, 256), (1, 5, 256), (2, 3, 128)])
+def test_top_bwd_heterogeneous_grid_bitwise(dev, G, N, dim_out):
+  """conv7's input gradient + conv7's / conv8's filter gradients as ONE heterogeneous grid (geeco_conv_top_bwd) against the
+  separate launches (geeco_conv3x3_dgrad, 2 x geeco_conv3x3_wgrad): dx, both dw and both db bitwise; the separate input
+  gradient really is the gather GEMM with split K for this shape; a shape the LDS-staged kernels serve is refused."""
+  from geeco_amd import ops
+  r = np.random.default_rng(97)
+  # conv7: 8 x 8 x 256 -> 4 x 4 x 256; conv8: 4 x 4 x 256 -> 2 x 2 x dim_out
+  x6 = torch.tensor(r.standard_normal([G, N, 8, 8, 256]).astype(np.float32), device=dev)        # conv7's input (ReluGrad mask of dx)
+  dz7 = torch.tensor(r.standard_normal([G, N, 4, 4, 256]).astype(np.float32), device=dev)
+  x7 = torch.tensor(r.standard_normal([G, N, 4, 4, 256]).astype(np.float32), device=dev)        # conv8's input
+  dz8 = torch.tensor(r.standard_normal([G, N, 2, 2, dim_out]).astype(np.float32), device=dev)
+  w7 = torch.tensor((r.standard_normal([G, 3, 3, 256, 256]) / 48).astype(np.float32), device=dev)
+  dws = torch.empty(ops.conv3x3_dgrad_ws_bytes(G, N, 8, 8, 256, 256, 2) // 4 + 4, device=dev)
+  dx_ref = torch.full((G, N, 8, 8, 256), float('nan'), device=dev)
+  names = ops.kernel_trace(lambda: ops.conv3x3_dgrad_into(dx_ref, dz7, None, x6, G, dz7[0].numel(), 0, dx_ref[0].numel(), N, 8, 8, 256,
+                                                          256, 2, ws=dws, w=w7, gs_w=w7[0].numel()))
+  assert names[0].startswith('conv_gemm_kernel<64, 64, 16'), names
+  wg = []
+  for x, dz, H, Cout in ((x6, dz7, 8, 256), (x7, dz8, 4, dim_out)):
+    ws = torch.empty(ops.conv3x3_wgrad_ws_bytes(G, N, H, H, 256, Cout, 2) // 4 + 4, device=dev)
+    dw_ref = torch.full((G, 9 * 256 * Cout), float('nan'), device=dev)
+    db_ref = torch.full((G, Cout), float('nan'), device=dev)
+    ops.conv3x3_wgrad_into(dw_ref, db_ref, x, dz, G, x[0].numel(), dz[0].numel(), dw_ref[0].numel(), Cout, N, H, H, 256, Cout, 2, ws)
+    wg.append((dw_ref, db_ref, dict(dw=torch.full_like(dw_ref, float('nan')), db=torch.full_like(db_ref, float('nan')), x=x, dz=dz,
+                                    gs_x=x[0].numel(), gs_dz=dz[0].numel(), gs_dw=dw_ref[0].numel(), gs_db=Cout, N=N, H=H, W=H, Cin=256,
+                                    Cout=Cout, ws=torch.empty_like(ws))))
+  dx = torch.full_like(dx_ref, float('nan'))
+  d = dict(dx=dx, dz=dz7, wt=None, ymask=x6, w=w7, gs_dz=dz7[0].numel(), gs_w=w7[0].numel(), gs_wt=0, gs_dx=dx[0].numel(), N=N, H=8,
+           W=8, Cin=256, Cout=256, ws=torch.empty_like(dws))
+  pending = []
+  names = ops.kernel_trace(lambda: ops.conv_top_bwd_into(d, wg[0][2], wg[1][2], G, 2, pending=pending))
+  ops.slab_reduce_batch(pending)
+  torch.cuda.synchronize()
+  assert names[0] == 'conv_top_bwd_kernel<true>', names
+  assert not torch.isnan(dx).any() and torch.equal(dx, dx_ref)
+  for dw_ref, db_ref, pr in wg:
+    assert torch.equal(pr['dw'], dw_ref) and torch.equal(pr['db'], db_ref)
+  # conv6's input gradient (192 -> 256 at 16 x 16) belongs to the LDS-staged kernel: refused, nothing launched
+  bad = dict(d, Cin=192, H=16, W=16)
+  assert ops.conv_top_bwd_into(bad, wg[0][2], wg[1][2], G, 2) is False
+
+
 def test_conv2_wgrad_remainder_block(dev):
   """conv2's filter gradient, three encoders, 512 tiles each = 85 blocks x 6 + 2: the 256th block walks the two tiles
   every encoder leaves over (three segments, slab 85 of each encoder); every encoder's dw / db against the fp64 oracle,
