@@ -292,15 +292,17 @@ int geeco_wgrad_pair_fill(WgradPairParams* pp, const float* x0, const float* dz0
                           const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
                           int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1, int groups,
                           int stride, long long* blocks) {
-  GEECO_CHECK_ARG(x0 && dz0 && dw0 && ws0 && x1 && dz1 && dw1 && ws1, "conv3x3_wgrad_pair: null pointer");
-  GEECO_CHECK_ARG(groups >= 1 && N0 >= 1 && N1 >= 1 && H0 >= 1 && W0 >= 1 && H1 >= 1 && W1 >= 1, "conv3x3_wgrad_pair: bad dims");
-  if (!(stride == 2 && Cin0 == 256 && Cin1 == 256 && Cout0 % 64 == 0 && Cout1 % 64 == 0 && Cout0 >= 64 && Cout1 >= 64)) {
+  const bool two = x1 != nullptr;        // x1 == NULL: ONE problem (the heterogeneous launch with a single filter gradient)
+  GEECO_CHECK_ARG(x0 && dz0 && dw0 && ws0 && (!two || (dz1 && dw1 && ws1)), "conv3x3_wgrad_pair: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && N0 >= 1 && H0 >= 1 && W0 >= 1 && (!two || (N1 >= 1 && H1 >= 1 && W1 >= 1)),
+                  "conv3x3_wgrad_pair: bad dims");
+  if (!(stride == 2 && Cin0 == 256 && Cout0 % 64 == 0 && Cout0 >= 64 && (!two || (Cin1 == 256 && Cout1 % 64 == 0 && Cout1 >= 64)))) {
     geeco_set_error("conv3x3_wgrad_pair: shapes outside the paired kernel (Cin = 256, Cout %% 64 == 0, stride 2)");
     return GEECO_ENOSUP;
   }
-  int bc0, bc1;
+  int bc0, bc1 = 64064;
   geeco_wgrad_plan(groups, N0, H0, W0, Cin0, Cout0, stride, &pp->q0, &bc0);
-  geeco_wgrad_plan(groups, N1, H1, W1, Cin1, Cout1, stride, &pp->q1, &bc1);
+  if (two) geeco_wgrad_plan(groups, N1, H1, W1, Cin1, Cout1, stride, &pp->q1, &bc1);
   if (bc0 != 64064 || bc1 != 64064) {
     geeco_set_error("conv3x3_wgrad_pair: the two problems do not share the 64 x 64 tile kernel");
     return GEECO_ENOSUP;
@@ -310,7 +312,7 @@ int geeco_wgrad_pair_fill(WgradPairParams* pp, const float* x0, const float* dz0
   pp->q1.x = x1; pp->q1.dz = dz1; pp->q1.part = (float*)ws1; pp->q1.gs_x = gs_x1; pp->q1.gs_dz = gs_dz1;
   pp->q1.dw = dw1; pp->q1.db = db1; pp->q1.gs_dw = gs_dw1; pp->q1.gs_db = gs_db1;
   const long long b0 = (long long)pp->q0.S * pp->q0.row_tiles * pp->q0.col_tiles * groups;
-  const long long b1 = (long long)pp->q1.S * pp->q1.row_tiles * pp->q1.col_tiles * groups;
+  const long long b1 = two ? (long long)pp->q1.S * pp->q1.row_tiles * pp->q1.col_tiles * groups : 0;
   pp->blocks0 = (int)b0;
   *blocks = b0 + b1;
   return 0;
@@ -324,7 +326,7 @@ int geeco_wgrad_pair_finish(const WgradPairParams& pp, int groups, hipStream_t s
       geeco_slab_reduce none = {};
       pending2[i] = none;
     }
-    if (q[i]->S > 1) {
+    if (q[i]->x && q[i]->S > 1) {
       if (pending2) geeco_set_pending_reduce(&pending2[i]);
       geeco_launch_wgrad_reduce(q[i]->part, q[i]->dw, q[i]->db, q[i]->gs_dw, q[i]->gs_db, q[i]->S,
                                 (long long)q[i]->Krows * q[i]->Cout, q[i]->Cout, groups, s);
@@ -340,6 +342,7 @@ extern "C" int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float
                                         const float* x1, const float* dz1, float* dw1, float* db1, int64_t gs_x1, int64_t gs_dz1,
                                         int64_t gs_dw1, int64_t gs_db1, int N1, int H1, int W1, int Cin1, int Cout1, void* ws1,
                                         int groups, int stride, void* stream, geeco_slab_reduce* pending2) {
+  GEECO_CHECK_ARG(x1, "conv3x3_wgrad_pair: two problems");
   WgradPairParams pp = {};
   long long blocks = 0;
   if (int rc = geeco_wgrad_pair_fill(&pp, x0, dz0, dw0, db0, gs_x0, gs_dz0, gs_dw0, gs_db0, N0, H0, W0, Cin0, Cout0, ws0, x1, dz1,

@@ -85,7 +85,9 @@ class ConvEncoderStack:
     # conv7's + conv8's filter gradients in one launch (GEECO_NO_WGRAD_PAIR: two)
     self.pair_top = _dev.env('GEECO_NO_WGRAD_PAIR') is None
     # ... and conv7's input gradient in the same grid (GEECO_NO_TOP_BWD: its own launch)
-    self.hetero_top = _dev.env('GEECO_NO_TOP_BWD') is None
+    # (GEECO_TOP_BWD=2: two heterogeneous launches instead, conv8's pair then conv7's)
+    self.hetero_top = 0 if _dev.env('GEECO_NO_TOP_BWD') is not None else int(_dev.env('GEECO_TOP_BWD', '1'))
+    self.w8_done = False
     # the filter-gradient kernels' slab sums of a backward part go into one launch (GEECO_NO_BATCH_REDUCE: one per layer)
     self.batch_reduce = _dev.env('GEECO_NO_BATCH_REDUCE') is None
     self.derived_version = -1
@@ -369,14 +371,16 @@ class ConvEncoderStack:
     432 blocks on 256 CUs): False when the shapes are outside the paired kernel (the caller launches them one by one)."""
     return ops.conv3x3_wgrad_pair_into(self._wgrad_args(6), self._wgrad_args(7), self.G, self.layers[6]['stride'], pending=pending)
 
-  def launch_top_bwd(self, pending=None):
-    """conv7's input gradient AND conv7's / conv8's filter gradients as one heterogeneous launch (all need only dz7)."""
-    l, L = 6, self.layers[6]
+  def launch_top_bwd(self, l, wgrads, pending=None):
+    """Layer l's input gradient AND the filter gradients of layers ``wgrads`` as one heterogeneous launch (independent work
+    that needs only dz[l]): l = 6 with (6, 7), or l = 7 with (7,) followed by l = 6 with (6,)."""
+    L = self.layers[l]
     wt = self.wt[l]
     d = dict(dx=self.dz[l - 1], dz=self.dz[l], wt=wt, ymask=self.acts[l - 1], w=self._w(l), gs_dz=self.dz[l][0].numel(),
              gs_w=self.gs_p, gs_wt=wt[0].numel() if wt is not None else 0, gs_dx=self.dz[l - 1][0].numel(), N=self.Nf, H=L['H'],
              W=L['W'], Cin=L['Cin'], Cout=L['Cout'], ws=self.dws)
-    return ops.conv_top_bwd_into(d, self._wgrad_args(6), self._wgrad_args(7), self.G, L['stride'], pending=pending)
+    return ops.conv_top_bwd_into(d, self._wgrad_args(wgrads[0]), self._wgrad_args(wgrads[1]) if len(wgrads) > 1 else None, self.G,
+                                 L['stride'], pending=pending)
 
   def launch_dgrad(self, l, pending=None):
     """Input gradient of layer l >= 1 into dz[l-1] (ReluGrad of the layer below fused).  With the fused encoder
@@ -437,10 +441,17 @@ class ConvEncoderStack:
                 and self.layers[6]['stride'] == self.layers[7]['stride'] == 2)
     for l in range(hi, lo - 1, -1):
       if pair_top and l == 7:
-        self.launch_dgrad(7, pending)
+        self.w8_done = self.hetero_top == 2 and self.launch_top_bwd(7, (7,), pending)
+        if not self.w8_done:
+          self.launch_dgrad(7, pending)
+        continue
+      if pair_top and l == 6 and self.w8_done:
+        if not self.launch_top_bwd(6, (6,), pending):
+          self.launch_wgrad(6, pending)
+          self.launch_dgrad(6, pending)
         continue
       if pair_top and l == 6:
-        if self.hetero_top and self.launch_top_bwd(pending):
+        if self.hetero_top and self.launch_top_bwd(6, (6, 7), pending):
           continue
         if not self.launch_wgrad_top_pair(pending):
           self.launch_wgrad(7, pending)

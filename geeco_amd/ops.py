@@ -221,8 +221,9 @@ def conv_top_bwd_into(d, a, b, G, stride, pending=None):
   ``a`` / ``b`` as for ``conv3x3_wgrad_pair_into``.  Returns False (nothing launched) outside the combined kernels."""
   lib = _lib()
   items = (_native.SlabReduce * 2)() if pending is not None else None
-  wa = lambda q: (_p(q['x']), _p(q['dz']), _p(q['dw']), _p(q['db']), q['gs_x'], q['gs_dz'], q['gs_dw'], q['gs_db'], q['N'], q['H'],
-                  q['W'], q['Cin'], q['Cout'], _p(q['ws']))
+  none = (None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None)      # b is None: ONE filter gradient beside the input gradient
+  wa = lambda q: none if q is None else (_p(q['x']), _p(q['dz']), _p(q['dw']), _p(q['db']), q['gs_x'], q['gs_dz'], q['gs_dw'],
+                                         q['gs_db'], q['N'], q['H'], q['W'], q['Cin'], q['Cout'], _p(q['ws']))
   rc = lib.geeco_conv_top_bwd(_p(d['dz']), _p(d['w']), _p(d['wt']), _p(d['ymask']), _p(d['dx']), d['gs_dz'], d['gs_w'], d['gs_wt'],
                               d['gs_dx'], d['N'], d['H'], d['W'], d['Cin'], d['Cout'], _p(d['ws']), *wa(a), *wa(b), G, stride,
                               _stream(), items)

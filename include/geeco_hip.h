@@ -190,7 +190,8 @@ int geeco_conv3x3_wgrad_pair(const float* x0, const float* dz0, float* dw0, floa
  * heterogeneous grid, the filter-gradient blocks first.  Leading arguments as geeco_conv3x3_dgrad (stride 2; ws = its split-K
  * workspace, required), then the two problems of geeco_conv3x3_wgrad_pair.  Bitwise the separate calls.  GEECO_ENOSUP when
  * any of the three is outside the kernels this launch combines (the gather GEMM's 64 x 64 x 16 tiles; the paired 64 x 64
- * filter-gradient tiles): nothing has been launched, use the separate entry points. */
+ * filter-gradient tiles): nothing has been launched, use the separate entry points.  x1 == NULL: ONE filter gradient beside
+ * the input gradient (the model: conv8's pair, then conv7's). */
 int geeco_conv_top_bwd(const float* dz, const float* w, const float* wt, const float* ymask, float* dx, int64_t gs_dz,
                        int64_t gs_w, int64_t gs_wt, int64_t gs_dx, int N, int H, int W, int Cin, int Cout, void* ws,
                        const float* x0, const float* dz0, float* dw0, float* db0, int64_t gs_x0, int64_t gs_dz0,
