@@ -14,9 +14,15 @@ PEAK = 157.3
 SKIP = ('conv_splitk_epilogue', 'wgrad_reduce')
 
 
-def step_order():
+def step_order(layers):
   order = [('conv%d' % l, 'fwd') for l in range(1, 9)]
-  for l in range(8, 2, -1):
+  top = ('conv7+conv8', 'dgrad7+wgrad7+wgrad8')
+  if top in layers:     # round 4: conv7's input gradient + conv7's / conv8's filter gradients are ONE heterogeneous launch
+    order += [('conv8', 'dgrad'), top]
+    first = 6
+  else:
+    first = 8
+  for l in range(first, 2, -1):
     order += [('conv%d' % l, 'wgrad'), ('conv%d' % l, 'dgrad')]
   return order + [('conv2', 'wgrad'), ('conv2', 'dgrad+conv1_wgrad')]
 
@@ -36,7 +42,7 @@ def pmc_rows(path):
 def main(bench_path, pmc_path, tag):
   d = json.loads(open(bench_path).read().strip().splitlines()[-1])
   layers = {(r['layer'], r['op']): r for r in d['layers']}
-  order, pmc = step_order(), pmc_rows(pmc_path)
+  order, pmc = step_order(layers), pmc_rows(pmc_path)
   assert len(pmc) == len(order), (len(pmc), len(order))
   cfg = d['config']
   print('# Per-launch roofline table of one training step (set `%s_*`)\n' % tag)
