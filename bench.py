@@ -606,9 +606,14 @@ def input_pipeline_report(args, dev, synthetic_ms_per_step, workdir):
                    'ms_per_step': round(st['loop_seconds'] / st['steps'] * 1e3, 3),
                    'episodes_from_hbm_cache': I.EPISODE_CACHE.hits - hits0})
     log('input_pipeline: epoch %d: %d steps in %.3f s = %.0f frames/s' % (ep + 1, st['steps'], st['loop_seconds'], fps))
+  feeds = [f for (_, fbuf, _) in e._specs.values() for f in fbuf.values() if hasattr(f, 'pointers')]
+  by_address = bool(feeds) and all(f.table is not None and f.buffer is None for f in feeds)
   out['estimator_train'] = {
       'workload': 'geeco-f rgb 256x256 seq_len=%d batch=%d, Estimator.train(pickplace_input_fn(device=cuda, device_keys=(rgb,), '
                   'num_threads=%d)); wall time of the input + step loop (checkpoint write excluded)' % (K, B, threads),
+      'window_source': ('uint8 frames of the resident episodes, read by the input kernel through per-sample window addresses '
+                        '(geeco_goal_dynimgs_u8_fwd): no fp32 window tensor, no gather launch') if by_address else
+                       'float32 windows gathered per batch (geeco_gather_windows)',
       'epochs': epochs, 'synthetic_ms_per_step': round(synthetic_ms_per_step, 3),
       'cached_epoch_vs_synthetic': round(synthetic_ms_per_step / epochs[-1]['ms_per_step'], 4),
       'hbm_cache': {'episodes': len(I.EPISODE_CACHE), 'MB': round(I.EPISODE_CACHE.bytes_in_use / 1e6, 1)}}

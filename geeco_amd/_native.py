@@ -47,6 +47,7 @@ SIGNATURES = {
     'geeco_dynimg_fwd_last': (_I, [_P, _L, _L, _P, _I, _I, _L, _P, _P, _P, _P]),
     'geeco_dynimg_rgbd_fwd_last': (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P, _P]),
     'geeco_goal_dynimgs_fwd': (_I, [_P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
+    'geeco_goal_dynimgs_u8_fwd': (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
     'geeco_dynimg_rgbd_fwd': (_I, [_P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P]),
     'geeco_pack_pixels': (_I, [_P, _L, _P, _L, _I, _L, _I, _I, _I, _P, _P]),
     'geeco_gather_windows': (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),

@@ -32,6 +32,10 @@ struct DynParams {
   float* diff_out;        // [N][HW][4]
   float* part2;           // [N][nblk][2]
   float alpha2[2];
+  // U8 (geeco_goal_dynimgs_u8_fwd): the RGB frames are the recorder's uint8 values, still in the episode's resident frames:
+  // win[n] = address of the first frame of window n ([K][HW][3] bytes, consecutive frames), tgt_u8[n] = its target frame
+  const unsigned char* const* win;
+  const unsigned char* const* tgt_u8;
 };
 
 __device__ __forceinline__ const float* dyn_frame_ptr(const DynParams& p, int n, int t) {
@@ -74,12 +78,39 @@ __device__ __forceinline__ void block_minmax_store2(float mn, float mx, float* d
   }
 }
 
+// float(u8) / 255.0f (_parse_v4, geeco_gym.py:312) without the division sequence: one Newton correction of a * (1/255) is the
+// correctly rounded quotient for every a in 0..255 (tests/test_kernels_gpu.py::test_u8_unit_conversion_is_the_division checks all
+// 256 values bitwise against the division of geeco_gather_windows).
+__device__ __forceinline__ float u8_unit(float a) {
+  const float r = 1.0f / 255.0f;
+  const float q = a * r;
+  const float e = __builtin_fmaf(-255.0f, q, a);
+  return __builtin_fmaf(e, r, q);
+}
+
+__device__ __forceinline__ f32x4 u8x4_unit(unsigned int b) {
+  return f32x4{u8_unit((float)(b & 255u)), u8_unit((float)((b >> 8) & 255u)), u8_unit((float)((b >> 16) & 255u)),
+               u8_unit((float)(b >> 24))};
+}
+
+// 4 pixels = 12 bytes = three dwords of a uint8 RGB frame -> the three float4 the fp32 path loads
+__device__ __forceinline__ void load_u8_unit(const unsigned char* frame, long long u, f32x4& v0, f32x4& v1, f32x4& v2) {
+  const unsigned int* s = reinterpret_cast<const unsigned int*>(frame) + u * 3;
+  const unsigned int b0 = s[0], b1 = s[1], b2 = s[2];
+  v0 = u8x4_unit(b0);
+  v1 = u8x4_unit(b1);
+  v2 = u8x4_unit(b2);
+}
+
 // C == 3, Cpad == 4, HW % 4 == 0: one thread = 4 pixels = 3 float4 in, 4 float4 out.  DEPTH: a 4th channel comes from its
 // own tensor (one more float4 = the depth of the 4 pixels per frame): rgb || depth (estimator.py:169,172) is formed in
 // registers instead of packing all N * K frames to 4 channels first (1.07 GB read + 1.43 GB written per step at K = 32).
-template <bool DEPTH, bool DIFF = false>
+// U8: the RGB source is uint8 frames behind a per-sample address table (the window is never materialised as fp32: a quarter of
+// the bytes, and no gather launch in front); everything downstream of the load is the fp32 path, so the images are bitwise equal.
+template <bool DEPTH, bool DIFF = false, bool U8 = false>
 __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
   const int n = blockIdx.y;
+  [[maybe_unused]] const unsigned char* wbase = U8 ? p.win[n] : nullptr;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;   // 4-pixel unit
   const long long U = p.HW >> 2;
   float mn = INFINITY, mx = -INFINITY;
@@ -89,9 +120,14 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
     [[maybe_unused]] f32x4 d0 = a0, d1 = a0, d2 = a0, d3 = a0;
 #pragma unroll 4
     for (int t = 0; t < p.K; ++t) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t)) + u * 3;
       const float w = p.alpha[t];
-      f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
+      f32x4 v0, v1, v2;
+      if (U8) {
+        load_u8_unit(wbase + (long long)t * p.HW * 3, u, v0, v1, v2);
+      } else {
+        const f32x4* src = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t)) + u * 3;
+        v0 = src[0]; v1 = src[1]; v2 = src[2];
+      }
       a0 += w * v0;
       a1 += w * v1;
       a2 += w * v2;
@@ -110,8 +146,13 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
         lo[3] = f32x4{v2.y, v2.z, v2.w, v3.w};
       }
       if (DIFF && t == p.K - 1) {       // the pair image, summed in the order of the two-frame pass: 0 + alpha2[0] * current, + alpha2[1] * target
-        const f32x4* ts = reinterpret_cast<const f32x4*>(p.tgt + (long long)n * p.HW * 3) + u * 3;
-        const f32x4 t0 = ts[0], t1 = ts[1], t2 = ts[2];
+        f32x4 t0, t1, t2;
+        if (U8) {
+          load_u8_unit(p.tgt_u8[n], u, t0, t1, t2);
+        } else {
+          const f32x4* ts = reinterpret_cast<const f32x4*>(p.tgt + (long long)n * p.HW * 3) + u * 3;
+          t0 = ts[0]; t1 = ts[1]; t2 = ts[2];
+        }
         const float w0 = p.alpha2[0], w1 = p.alpha2[1];
         d0 += w0 * v0; d1 += w0 * v1; d2 += w0 * v2;
         d0 += w1 * t0; d1 += w1 * t1; d2 += w1 * t2;
@@ -382,6 +423,39 @@ static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_
 // The goal model's three conv1 inputs (graph.py:386-401) in TWO launches (round 3: three; before: five): one pass over the window
 // writes the buffer image, the current frame's padded copy AND the pair image of (current frame, target); one normalisation
 // launch serves both images.
+static int goal_dynimgs_launch(DynParams& p, const float* alpha_host, const float* alpha2_host, bool u8, float* cur_out,
+                               float* buf_out, float* diff_out, void* ws, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = dyn_nblk(p.HW, 3);
+  float* part1 = (float*)ws;
+  float* part2 = part1 + (long long)p.N * nblk * 2;
+  p.C = 3; p.Cpad = 4; p.out = buf_out; p.last = cur_out; p.part = part1; p.nblk = nblk;
+  for (int t = 0; t < p.K; ++t) p.alpha[t] = alpha_host[t];
+  // ONE pass for both images (round 4): the pair image needs the current frame, which this pass holds in registers at t = K - 1
+  p.diff_out = diff_out; p.part2 = part2;
+  p.alpha2[0] = alpha2_host[0]; p.alpha2[1] = alpha2_host[1];
+  const dim3 grid((unsigned)nblk, (unsigned)p.N);
+  const bool depth = p.depth != nullptr;
+  if (u8) {
+    if (depth)
+      hipLaunchKernelGGL((dynimg_wsum3_kernel<true, true, true>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((dynimg_wsum3_kernel<false, true, true>), grid, dim3(256), 0, s, p);
+  } else {
+    if (depth)
+      hipLaunchKernelGGL((dynimg_wsum3_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((dynimg_wsum3_kernel<false, true>), grid, dim3(256), 0, s, p);
+  }
+  GEECO_LAUNCH_CHECK();
+  const int C = depth ? 4 : 3;
+  dim3 g2((unsigned)cdiv64(p.HW * 4, 1024), (unsigned)p.N, 2);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, buf_out, (const float*)part1, nblk, p.HW, C, 4, diff_out,
+                     (const float*)part2);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* tgt_rgb,
                                       const float* depth, int64_t dsample_stride, int64_t dframe_stride,
                                       const float* tgt_depth, const float* alpha_host, const float* alpha2_host, int N, int K,
@@ -393,30 +467,36 @@ extern "C" int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, i
   GEECO_CHECK_ARG(N >= 1 && HW >= 4 && (HW & 3) == 0, "goal_dynimgs_fwd: HW=%lld must be a multiple of 4", (long long)HW);
   GEECO_CHECK_ARG(sample_stride % 4 == 0 && frame_stride % 4 == 0 && dsample_stride % 4 == 0 && dframe_stride % 4 == 0,
                   "goal_dynimgs_fwd: 16-byte aligned frames");
-  hipStream_t s = (hipStream_t)stream;
-  const int nblk = dyn_nblk(HW, 3);
-  float* part1 = (float*)ws;
-  float* part2 = part1 + (long long)N * nblk * 2;
   DynParams p = {};
   p.frames = rgb; p.sample_stride = sample_stride; p.frame_stride = frame_stride;
   p.depth = depth; p.dsample_stride = dsample_stride; p.dframe_stride = dframe_stride;
-  p.N = N; p.K = K; p.HW = HW; p.C = 3; p.Cpad = 4; p.out = buf_out; p.last = cur_out; p.part = part1; p.nblk = nblk;
-  for (int t = 0; t < K; ++t) p.alpha[t] = alpha_host[t];
-  // ONE pass for both images (round 4): the pair image needs the current frame, which this pass holds in registers at t = K - 1
-  p.tgt = tgt_rgb; p.tgt_depth = tgt_depth; p.diff_out = diff_out; p.part2 = part2;
-  p.alpha2[0] = alpha2_host[0]; p.alpha2[1] = alpha2_host[1];
-  const dim3 grid((unsigned)nblk, (unsigned)N);
-  if (depth)
-    hipLaunchKernelGGL((dynimg_wsum3_kernel<true, true>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((dynimg_wsum3_kernel<false, true>), grid, dim3(256), 0, s, p);
-  GEECO_LAUNCH_CHECK();
-  const int C = depth ? 4 : 3;
-  dim3 g2((unsigned)cdiv64(HW * 4, 1024), (unsigned)N, 2);
-  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, buf_out, (const float*)part1, nblk, (long long)HW, C, 4, diff_out,
-                     (const float*)part2);
-  GEECO_LAUNCH_CHECK();
-  return 0;
+  p.N = N; p.K = K; p.HW = HW;
+  p.tgt = tgt_rgb; p.tgt_depth = tgt_depth;
+  return goal_dynimgs_launch(p, alpha_host, alpha2_host, false, cur_out, buf_out, diff_out, ws, stream);
+}
+
+// The same input stage fed from the episodes' resident uint8 frames (the data path's "next" row: the window of
+// _window_v3, geeco_gym.py:615-631, and the / 255 of _parse_v4, :312, happen inside the load): win_ptrs_dev / tgt_ptrs_dev are
+// DEVICE arrays of N addresses (window n = K consecutive [HW][3] uint8 frames starting at win_ptrs_dev[n]; its target frame
+// at tgt_ptrs_dev[n]), so a captured graph keeps replaying while the host repoints the tables between steps.  Depth (float32)
+// stays a dense [N][K][HW] / [N][HW] tensor.  Outputs are bitwise those of geeco_gather_windows + geeco_goal_dynimgs_fwd.
+extern "C" int geeco_goal_dynimgs_u8_fwd(const void* const* win_ptrs_dev, const void* const* tgt_ptrs_dev, const float* depth,
+                                         int64_t dsample_stride, int64_t dframe_stride, const float* tgt_depth,
+                                         const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW,
+                                         float* cur_out, float* buf_out, float* diff_out, void* ws, void* stream) {
+  GEECO_CHECK_ARG(win_ptrs_dev && tgt_ptrs_dev && alpha_host && alpha2_host && cur_out && buf_out && diff_out && ws,
+                  "goal_dynimgs_u8_fwd: null pointer");
+  GEECO_CHECK_ARG((!depth) == (!tgt_depth), "goal_dynimgs_u8_fwd: depth and tgt_depth come together");
+  GEECO_CHECK_ARG(K >= 1 && K <= DYN_MAXK, "goal_dynimgs_u8_fwd: K=%d outside 1..%d", K, DYN_MAXK);
+  GEECO_CHECK_ARG(N >= 1 && HW >= 4 && (HW & 3) == 0, "goal_dynimgs_u8_fwd: HW=%lld must be a multiple of 4", (long long)HW);
+  GEECO_CHECK_ARG(dsample_stride % 4 == 0 && dframe_stride % 4 == 0, "goal_dynimgs_u8_fwd: 16-byte aligned depth frames");
+  DynParams p = {};
+  p.win = reinterpret_cast<const unsigned char* const*>(win_ptrs_dev);
+  p.tgt_u8 = reinterpret_cast<const unsigned char* const*>(tgt_ptrs_dev);
+  p.depth = depth; p.dsample_stride = dsample_stride; p.dframe_stride = dframe_stride;
+  p.N = N; p.K = K; p.HW = HW;
+  p.tgt_depth = tgt_depth;
+  return goal_dynimgs_launch(p, alpha_host, alpha2_host, true, cur_out, buf_out, diff_out, ws, stream);
 }
 
 // ---- pixel packing: [n][HW][C1] (+ [n][HW][C2]) -> [n][HW][Cpad] ---------------------------------

@@ -21,6 +21,7 @@ import os
 import re
 import time
 
+import numpy as np
 import torch
 
 from . import dist as gdist
@@ -167,20 +168,33 @@ def _model_fn(features, labels, mode, params, goal):
   if mode not in (ModeKeys.TRAIN, ModeKeys.EVAL, ModeKeys.PREDICT):
     raise RuntimeError("Unknown estimator mode: %s" % (mode,))
   rgb = features['rgb']
-  if not rgb.is_cuda:
+  if rgb.device.type != 'cuda':
     raise RuntimeError('geeco_amd needs a GPU: model_fn got features on %s (no CPU fallback)' % rgb.device)
   N = int(rgb.shape[0])
   training = mode == ModeKeys.TRAIN
   ctor = graph.GoalE2EVMC if goal else graph.E2EVMC
   model = ctor(cfg, N, rgb.device, training=training, store=params.get('_variable_store'))
   # adopt the caller's static buffers as the model inputs (placeholders)
+  source = lambda k: labels.get(k) if (labels is not None and k in model.label_keys) else features.get(k)
+  # all of the model's image inputs that CAN come as window addresses must, or none does
+  take_u8 = bool(model.u8_window_keys) and all(getattr(source(k), 'u8', False) for k in model.u8_window_keys)
   for k in list(model.inputs.keys()):
-    src = labels.get(k) if (labels is not None and k in model.label_keys) else features.get(k)
+    src = source(k)
     if src is None:
       if mode == ModeKeys.PREDICT and k in model.label_keys + ['ee_state', 'obj_state']:
         continue   # label-side inputs are not needed for predictions
       raise KeyError("model_fn: missing input '%s'" % k)
-    if (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and
+    if hasattr(src, 'pointers'):
+      # input_fn.WindowFeed (windows of HBM-resident episodes): a model whose input kernel follows window addresses takes the
+      # address table and the fp32 windows are never written; any other model gets the dense buffer the gather fills
+      if tuple(src.shape) != tuple(model.inputs[k].shape):
+        raise ValueError("model_fn: input '%s' must have shape %s, got %s" % (k, tuple(model.inputs[k].shape), tuple(src.shape)))
+      if take_u8 and k in model.u8_window_keys:
+        src.pointers()
+        model.inputs[k] = src
+      else:
+        model.inputs[k] = src.dense()
+    elif (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and
         tuple(src.shape) == tuple(model.inputs[k].shape)):
       model.inputs[k] = src
     else:
@@ -234,6 +248,14 @@ def _eval_metric_fn(model):
       out['cmd_grp'] = ((p['logits_cmd_grp'].argmax(dim=-1) == label).float().sum(), float(label.numel()))
     return out
   return batch_stats
+
+
+class _FeedDict(dict):
+  """name -> static buffer (a view of the spec's FeedArena, or an input_fn.WindowFeed) of the features or the labels."""
+
+  def __init__(self, arena, tag, items):
+    super().__init__(items)
+    self.arena, self.tag = arena, tag
 
 
 # ================================================================================================
@@ -309,20 +331,30 @@ class Estimator:
     n_global weights this rank's batch-mean loss so that the SUM all-reduce followed by 1/world is the mean over the
     GLOBAL batch also when the ranks hold different numbers of windows (ragged final batch); 1 for equal shards."""
     key = (mode, n) if loss_scale == 1.0 else (mode, n, round(float(loss_scale), 9))
+    # uint8 and float32 resident frames are read by different input kernels (a float32 episode = one whose recorded values
+    # were not integral): one model per frame type, sharing the variables
+    key += tuple(k for k, v in sorted(feats.items()) if hasattr(v, 'is_u8') and not v.is_u8())
     if key in self._specs:
       return self._specs[key]
     dev = self._device()
-    def to_dev(d):
+    # one arena for everything the host writes per batch (states, labels, window address tables): one H2D copy per step
+    from .input_fn import FeedArena, WindowFeed
+    arena = FeedArena(dev)
+    feeds = {}
+    for tag, d in (('features', feats), ('labels', labels)):
+      for k, v in (d or {}).items():
+        if hasattr(v, 'materialize_into'):      # input_fn.DeviceWindows: windows of HBM-resident episodes
+          feeds[tag, k] = WindowFeed(v, arena, (tag, k))
+        elif isinstance(v, np.ndarray) and v.nbytes <= self._ARENA_MAX_BYTES:
+          arena.reserve((tag, k), v.shape, v.dtype)
+        else:                                   # device tensors (synthetic inputs), dense host windows: a buffer and a copy of their own
+          feeds[tag, k] = torch.as_tensor(v).to(dev).contiguous()
+    arena.seal()
+    def to_dev(tag, d):
       if d is None:
         return None
-      out = {}
-      for k, v in d.items():
-        if hasattr(v, 'materialize_into'):      # input_fn.DeviceWindows: windows are gathered in HBM
-          out[k] = torch.empty(tuple(v.shape), dtype=torch.float32, device=dev)
-        else:
-          out[k] = torch.as_tensor(v).to(dev).contiguous()
-      return out
-    fbuf, lbuf = to_dev(feats), to_dev(labels)
+      return _FeedDict(arena, tag, {k: feeds[tag, k] if (tag, k) in feeds else arena.view((tag, k)) for k in d})
+    fbuf, lbuf = to_dev('features', feats), to_dev('labels', labels)
     params = dict(self.params)
     params['_variable_store'] = self._store
     params.setdefault('use_hipgraph', self.config.use_hipgraph)
@@ -334,8 +366,9 @@ class Estimator:
     self._restore_once()
     # only the buffers the model adopted are fed per batch
     used = {id(v) for v in spec.model.inputs.values()}
-    fbuf = {k: v for k, v in fbuf.items() if id(v) in used}
-    lbuf = {k: v for k, v in (lbuf or {}).items() if id(v) in used}
+    fbuf = _FeedDict(arena, 'features', {k: v for k, v in fbuf.items() if id(v) in used or
+                                         (getattr(v, 'buffer', None) is not None and id(v.buffer) in used)})
+    lbuf = _FeedDict(arena, 'labels', {k: v for k, v in (lbuf or {}).items() if id(v) in used})
     self._specs[key] = (spec, fbuf, lbuf)
     return self._specs[key]
 
@@ -349,16 +382,39 @@ class Estimator:
       print('INFO: restored parameters from %s' % ckpt)
     gdist.broadcast_variables(self._store)
 
+  _ARENA_MAX_BYTES = 1 << 20      # host arrays up to this size share the arena's one copy; larger ones (dense windows) go alone
+
   @staticmethod
   def _feed(bufs, batch):
+    """One dict of a batch into its static buffers; on its own, or inside a ``_feed_step`` that shares the arena's copy."""
     if batch is None:
       return
+    alone = not bufs.arena.is_open
+    if alone:
+      bufs.arena.begin()
     for k, buf in bufs.items():
       src = batch[k]
-      if hasattr(src, 'materialize_into'):
+      if hasattr(buf, 'feed'):                 # input_fn.WindowFeed: repoint the address table or gather into the dense buffer
+        buf.feed(src)
+      elif bufs.arena.has((bufs.tag, k)):
+        bufs.arena.write((bufs.tag, k), src.detach().cpu().numpy() if torch.is_tensor(src) else src)
+      elif hasattr(src, 'materialize_into'):
         src.materialize_into(buf.view((len(src), src.K) + src.frame_shape))
       else:
         buf.copy_(torch.as_tensor(src), non_blocking=True)
+    if alone:
+      bufs.arena.flush()
+
+  @classmethod
+  def _feed_step(cls, fbuf, lbuf, feats, labels):
+    """Features and labels of one step: every host array through the arena's ONE staging block and copy."""
+    fbuf.arena.begin()
+    try:
+      cls._feed(fbuf, feats)
+      if lbuf is not None and labels is not None:
+        cls._feed(lbuf, labels)
+    finally:
+      fbuf.arena.flush()
 
   # -- public API --------------------------------------------------------------------------------
   def latest_checkpoint(self):
@@ -385,8 +441,7 @@ class Estimator:
         spec = None
       else:
         spec, fbuf, lbuf = self._get_spec(ModeKeys.TRAIN, feats, labels, n, loss_scale=n * world / float(n_global))
-        self._feed(fbuf, feats)
-        self._feed(lbuf, labels)
+        self._feed_step(fbuf, lbuf, feats, labels)
         spec.train_op()
         last_runner = spec.train_op.__self__
       nsteps += 1
@@ -423,8 +478,7 @@ class Estimator:
       if n == 0:
         continue
       spec, fbuf, lbuf = self._get_spec(ModeKeys.EVAL, feats, labels, n)
-      self._feed(fbuf, feats)
-      self._feed(lbuf, labels)
+      self._feed_step(fbuf, lbuf, feats, labels)
       spec.train_op()
       loss_sum = spec.loss.clone() if loss_sum is None else loss_sum + spec.loss
       for k, (s, c) in spec.eval_metric_ops().items():
@@ -466,7 +520,7 @@ class Estimator:
       feats = batch[0] if isinstance(batch, tuple) else batch
       n = int(next(iter(feats.values())).shape[0])
       spec, fbuf, _ = self._get_spec(ModeKeys.PREDICT, feats, None, n)
-      self._feed(fbuf, feats)
+      self._feed_step(fbuf, None, feats, None)
       spec.train_op()
       torch.cuda.synchronize()
       yield {k: v.detach().cpu().numpy().copy() for k, v in spec.predictions.items()}

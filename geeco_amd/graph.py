@@ -645,9 +645,15 @@ class _ModelBase:
       if goal:
         self.tgt4 = torch.empty(N, H, W, 4, **f32)
 
+  # image inputs this model can read as uint8 frames behind window addresses (input_fn.WindowFeed.pointers()) instead of dense
+  # float32 windows; () = none
+  u8_window_keys = ()
+
   def load_batch(self, features, labels=None):
     """Copies one batch into the static input buffers (H2D or D2D; torch is plumbing here)."""
     for k, buf in self.inputs.items():
+      if hasattr(buf, 'pointers'):
+        raise RuntimeError("load_batch: input '%s' is fed through window addresses (input_fn.WindowFeed.feed)" % k)
       src = labels.get(k) if (labels is not None and k in self.label_keys) else features.get(k)
       if src is None:
         if k in self.label_keys:
@@ -765,6 +771,11 @@ class GoalE2EVMC(_ModelBase):
     self._bind_labels()
     self.dyn_ws = ops.dynimg_ws(N, H * W * 4, self.device)
     self.dyn_ws2 = torch.empty(2 * self.dyn_ws.numel(), dtype=torch.float32, device=self.device)   # partials of two images
+    # geeco-f reads its K-frame window ONCE, in the input kernel: that kernel can take the episodes' resident uint8 frames
+    # directly (RGB, or RGB of RGB-D with depth dense), see ops.goal_dynimgs_u8_into
+    if (self.mode == 'dynimg' and self.last_from_dynimg and (H * W) % 4 == 0 and (C == 3 or self.split_rgbd) and
+        _dev.env('GEECO_NO_U8_WINDOWS') is None):
+      self.u8_window_keys = ('rgb', 'target_rgb')
 
   def forward(self, backward_too=False):
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
@@ -773,10 +784,16 @@ class GoalE2EVMC(_ModelBase):
     jn = self.cfg.dim_jnt_state
     jnts = self.inputs['jnt_state']
     d = self.decoder
+    u8 = hasattr(self.inputs['rgb'], 'pointers')          # estimator: the Estimator bound window addresses (uint8 frames)
+    if u8 and not hasattr(self.inputs['target_rgb'], 'pointers'):
+      raise RuntimeError('GoalE2EVMC: rgb comes as window addresses but target_rgb as a dense tensor')
     if self.mode == 'dynimg' and self.split_rgbd:
       inp = self.inputs
       rgb, dep = inp['rgb'], inp['depth']
-      if self.last_from_dynimg:
+      if u8:
+        ops.goal_dynimgs_u8_into(x_in[0], x_in[1], x_in[2], rgb.table, inp['target_rgb'].table, K, N, HW, self.dyn_ws2,
+                                 depth=dep, tgt_depth=inp['target_depth'], dsample_stride=K * HW, dframe_stride=HW)
+      elif self.last_from_dynimg:
         ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], rgb, inp['target_rgb'], K, N, HW, self.dyn_ws2, K * HW * 3, HW * 3,
                               depth=dep, tgt_depth=inp['target_depth'], dsample_stride=K * HW, dframe_stride=HW)
       else:
@@ -792,11 +809,14 @@ class GoalE2EVMC(_ModelBase):
       d.forward(backward_too)
       self._finish_forward()
       return
-    frames, tgt = self._frames()
+    frames, tgt = (None, None) if u8 else self._frames()
     if self.mode == 'dynimg':
-      cur = frames[:, K - 1]                                  # rgb_frame_list[-1] (graph.py:387)
+      cur = None if u8 else frames[:, K - 1]                  # rgb_frame_list[-1] (graph.py:387)
       # g0: current frame;  g1: dynimg(buffer) (:392);  g2: dynimg([cur, tgt]) (:397-400)
-      if C == 3 and HW % 4 == 0 and self.last_from_dynimg:
+      if u8:
+        ops.goal_dynimgs_u8_into(x_in[0], x_in[1], x_in[2], self.inputs['rgb'].table, self.inputs['target_rgb'].table, K, N,
+                                 HW, self.dyn_ws2)
+      elif C == 3 and HW % 4 == 0 and self.last_from_dynimg:
         # two launches: the buffer-image pass has the current frame in registers and writes its channel-padded copy and the pair image
         # too; one normalisation launch serves both images
         ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, self.dyn_ws2, K * HW * C, HW * C)

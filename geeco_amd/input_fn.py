@@ -248,6 +248,29 @@ class DeviceWindows:
     out.n = a.n + b.n
     return out
 
+  def is_u8(self):
+    """Every segment is resident uint8 frames (the recorder's values; the consumer divides by 255)."""
+    import torch
+    return bool(self.segments) and self.divisor == 255.0 and all(
+        f is not None and f.dtype == torch.uint8 and f.is_contiguous() for f, _ in self.segments)
+
+  def addresses(self, device):
+    """int64 address of each window's first frame (WindowFeed.pointers(): the input kernel follows them)."""
+    fe = int(np.prod(self.frame_shape))
+    out = np.empty(self.n, np.int64)
+    off = 0
+    for frames_dev, starts in self.segments:
+      if frames_dev.device != device:
+        raise RuntimeError('DeviceWindows: episode frames live on %s but the model on %s (each rank must upload to its '
+                           'own GPU)' % (frames_dev.device, device))
+      T = frames_dev.shape[0]
+      if len(starts) and (int(starts.min()) < 0 or int(starts.max()) + self.K > T):
+        raise IndexError('DeviceWindows: window [%d, %d) outside the %d resident frames' %
+                         (int(starts.min()), int(starts.max()) + self.K, T))
+      out[off:off + len(starts)] = frames_dev.data_ptr() + starts.astype(np.int64) * fe
+      off += len(starts)
+    return out
+
   def materialize_into(self, out):
     import torch
     from . import ops
@@ -273,6 +296,132 @@ class DeviceWindows:
     torch.cuda.synchronize()
     arr = out.cpu().numpy()
     return arr[:, 0] if self.squeeze_k else arr
+
+
+class FeedArena:
+  """Every per-batch host array of a model's feed (states, labels, window address tables) in ONE device block, written
+  through ONE pinned staging block and ONE H2D copy per step: half a dozen small copies queued between two graph replays
+  cost the host ~70 us per step, one ~30.  ``reserve`` while building, then ``seal``; per batch ``begin`` / ``write``... /
+  ``flush``.  A ring of staging blocks lets the host run ahead: a block is rewritten only after its upload has finished.
+  (Measured and not kept: uploading on a side stream into device-side landing blocks and moving them into place with a
+  device-to-device copy - the ~30 us a fed step costs over a bare replay belong to ANY command queued between two graph
+  launches, not to the transfer.)"""
+
+  SLOTS = 4
+  ALIGN = 256
+
+  def __init__(self, device):
+    import torch
+    self.device = torch.device(device)
+    self._layout = {}       # key -> (offset, nbytes, np dtype, shape)
+    self._size = 0
+    self.block = None
+    self._open = False
+    self._turn = 0
+
+  def reserve(self, key, shape, dtype):
+    if self.block is not None:
+      raise RuntimeError('FeedArena.reserve after seal')
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    self._layout[key] = (self._size, nbytes, dt, tuple(shape))
+    self._size += -(-max(nbytes, 1) // self.ALIGN) * self.ALIGN
+
+  def seal(self):
+    import torch
+    self.block = torch.zeros(max(self._size, self.ALIGN), dtype=torch.uint8, device=self.device)
+    self._stage = [torch.zeros(self.block.numel(), dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS)]
+    self._events = [None] * self.SLOTS                       # upload of slot i finished (host may rewrite its staging block)
+    self._host = [{k: st.numpy()[off:off + nb].view(dt).reshape(shape) for k, (off, nb, dt, shape) in self._layout.items()}
+                  for st in self._stage]
+    return self
+
+  def view(self, key):
+    """The device tensor of one entry (a view of the block: static address, graph-safe)."""
+    import torch
+    off, nb, dt, shape = self._layout[key]
+    tdt = torch.from_numpy(np.empty(0, dt)).dtype
+    return self.block[off:off + nb].view(tdt).view(shape)
+
+  def has(self, key):
+    return key in self._layout
+
+  @property
+  def is_open(self):
+    return self._open
+
+  def begin(self):
+    i = self._turn % self.SLOTS
+    if self._events[i] is not None:
+      self._events[i].synchronize()
+    self._open = True
+
+  def write(self, key, values):
+    if not self._open:
+      raise RuntimeError('FeedArena.write outside begin() / flush()')
+    dst = self._host[self._turn % self.SLOTS][key]
+    values = np.asarray(values)
+    if values.shape != dst.shape:
+      raise ValueError("feed '%s': expected shape %s, got %s" % (key[-1], dst.shape, values.shape))
+    np.copyto(dst, values, casting='same_kind')
+
+  def flush(self):
+    import torch
+    i = self._turn % self.SLOTS
+    self.block.copy_(self._stage[i], non_blocking=True)
+    if self._events[i] is None:
+      self._events[i] = torch.cuda.Event()
+    self._events[i].record()
+    self._turn += 1
+    self._open = False
+
+
+class WindowFeed:
+  """The static feed slot of one DeviceWindows feature (what the Estimator hands the model_fn in place of a dense tensor).
+
+  The model picks ONE of two forms before its graph is captured:
+    * ``pointers()``: an int64 device table of per-sample window addresses (an entry of the step's FeedArena); the model's
+      input kernel reads the resident uint8 frames itself (ops.goal_dynimgs_u8_into), the fp32 windows are never written.
+      Only offered when ``u8`` (every segment of the first batch is uint8 frames with divisor 255).
+    * ``dense()``: a float32 [n, K, *frame_shape] buffer filled by geeco_gather_windows per batch.
+  ``feed(windows)`` then repoints / refills per batch; both are stream-ordered in front of the replay."""
+
+  def __init__(self, windows, arena, key):
+    self.n, self.K, self.frame_shape, self.squeeze_k = windows.n, windows.K, windows.frame_shape, windows.squeeze_k
+    self.arena, self.key, self.device = arena, key, arena.device
+    self.u8 = windows.is_u8()
+    self.shape = tuple(windows.shape)
+    self.table = self.buffer = None
+    self._want_table = False
+    self._live = collections.deque(maxlen=2)    # the batches whose frames a queued replay may still read
+    if self.u8:
+      arena.reserve(key, (self.n,), np.int64)
+
+  def pointers(self):
+    if not self.u8:
+      raise RuntimeError('WindowFeed.pointers(): the windows are not uint8 frames')
+    self._want_table = True
+    if self.arena.block is not None:
+      self.table = self.arena.view(self.key)
+    return self
+
+  def dense(self):
+    import torch
+    if self.buffer is None:
+      self.buffer = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+    return self.buffer
+
+  def feed(self, windows):
+    if (windows.n, windows.K, windows.frame_shape) != (self.n, self.K, self.frame_shape):
+      raise ValueError('WindowFeed: batch of %s windows does not fit the slot %s' % (tuple(windows.shape), self.shape))
+    if self.buffer is not None:
+      windows.materialize_into(self.buffer.view((self.n, self.K) + self.frame_shape))
+    if self._want_table:
+      if not windows.is_u8():
+        raise RuntimeError('WindowFeed: float32 frames in a slot whose model reads uint8 frames (the Estimator keys its '
+                           'models by the frame type)')
+      self.arena.write(self.key, windows.addresses(self.device))
+      self._live.append(windows)
 
 
 def _concat_feature(a, b):

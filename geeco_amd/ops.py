@@ -110,6 +110,20 @@ def goal_dynimgs_into(cur_out, buf_out, diff_out, rgb, tgt_rgb, K, N, HW, ws, sa
                                       _p(diff_out), _p(ws), _stream()), 'geeco_goal_dynimgs_fwd')
 
 
+def goal_dynimgs_u8_into(cur_out, buf_out, diff_out, win_ptrs, tgt_ptrs, K, N, HW, ws, depth=None, tgt_depth=None,
+                         dsample_stride=0, dframe_stride=0):
+  """goal_dynimgs_into fed from resident uint8 frames: win_ptrs / tgt_ptrs are int64 DEVICE tensors of N addresses (window n =
+  K consecutive [HW][3] uint8 frames; its target frame).  Bitwise the images of gather_windows_into(divisor 255) +
+  goal_dynimgs_into, without the fp32 window tensor in between."""
+  for t in (win_ptrs, tgt_ptrs):
+    if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == N and t.device == buf_out.device):
+      raise ValueError('goal_dynimgs_u8: address tables must be contiguous int64 tensors of N=%d entries on %s' % (N, buf_out.device))
+  check(_lib().geeco_goal_dynimgs_u8_fwd(ctypes.c_void_p(win_ptrs.data_ptr()), ctypes.c_void_p(tgt_ptrs.data_ptr()), _p(depth),
+                                         dsample_stride, dframe_stride, _p(tgt_depth), ctypes.cast(_alpha_buf(K), ctypes.c_void_p),
+                                         ctypes.cast(_alpha_buf(2), ctypes.c_void_p), N, K, HW, _p(cur_out), _p(buf_out),
+                                         _p(diff_out), _p(ws), _stream()), 'geeco_goal_dynimgs_u8_fwd')
+
+
 def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
   """frames [N,K,H,W,C] contiguous -> [N,H,W,Cpad]."""
   N, K, H, W, C = frames.shape

@@ -70,7 +70,7 @@ int geeco_dynimg_rgbd_fwd_last(const float* rgb, int64_t sample_stride, int64_t 
                                int64_t dsample_stride, int64_t dframe_stride, const float* alpha_host, int N, int K,
                                int64_t HW, float* out, float* last, void* ws, void* stream);
 
-/* All three conv1 inputs of the goal model's dynimg branch (graph.py:386-401) in three launches: buf_out = dynimg of the
+/* All three conv1 inputs of the goal model's dynimg branch (graph.py:386-401) in two launches: buf_out = dynimg of the
  * K-frame stack, diff_out = dynimg of (last frame, target) with the 2-frame coefficients alpha2, cur_out = the last
  * frame channel-padded; both images are normalised by ONE launch.  depth / tgt_depth NULL: RGB ((R, G, B, 0) pixels),
  * else RGB-D from separate tensors.  ws: 2 x geeco_dynimg_ws_bytes(N, HW * 4) bytes. */
@@ -78,6 +78,17 @@ int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t fram
                            const float* depth, int64_t dsample_stride, int64_t dframe_stride, const float* tgt_depth,
                            const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW, float* cur_out,
                            float* buf_out, float* diff_out, void* ws, void* stream);
+/* The same stage read straight from the episodes' resident uint8 frames: replaces the host-side window + division of the
+ * reference's input pipeline (_window_v3, src/data/geeco_gym.py:615-631; rgb / 255.0, _parse_v4 :312) AND the fp32 window
+ * tensor they produce.  win_ptrs_dev / tgt_ptrs_dev: DEVICE arrays of N addresses; window n = K consecutive [HW][3] uint8
+ * frames starting at win_ptrs_dev[n] (4-byte aligned), its target frame [HW][3] uint8 at tgt_ptrs_dev[n].  The tables are
+ * read when the kernel RUNS, so a captured graph follows the host repointing them between replays; the frames they point
+ * at must stay allocated until that run has finished.  depth / tgt_depth: dense float32 [N][K][HW] / [N][HW] or NULL.
+ * Outputs are bitwise those of geeco_gather_windows(divisor 255) followed by geeco_goal_dynimgs_fwd. */
+int geeco_goal_dynimgs_u8_fwd(const void* const* win_ptrs_dev, const void* const* tgt_ptrs_dev, const float* depth,
+                              int64_t dsample_stride, int64_t dframe_stride, const float* tgt_depth, const float* alpha_host,
+                              const float* alpha2_host, int N, int K, int64_t HW, float* cur_out, float* buf_out,
+                              float* diff_out, void* ws, void* stream);
 
 
 /* Copy [npix][C] -> [npix][Cpad] (zero-filled tail).  Used for the "current frame" view

@@ -127,6 +127,51 @@ def test_device_windows_match_host_pipeline(dev, tmp_path):
   np.testing.assert_allclose(res[0]['loss'], res[1]['loss'], rtol=1e-6)
 
 
+def test_u8_window_addresses_equal_dense_windows(dev, tmp_path):
+  """geeco-f on HBM-resident episodes: the model's input kernel follows window addresses into the uint8 frames
+  (input_fn.WindowFeed.pointers(), no fp32 window tensor, no gather launch); training and evaluation are BITWISE what the
+  dense path (geeco_gather_windows into a float32 buffer, GEECO_NO_U8_WINDOWS) computes - RGB and RGB-D, batches that span
+  two episodes, a ragged last batch, graph replay across repointed tables."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_host_logic_cpu import _make_dataset
+  from geeco_amd import estimator as est, _dev
+  from geeco_amd.input_fn import EPISODE_CACHE, WindowFeed, pickplace_input_fn
+  from geeco_amd.params import create_e2evmc_config
+  root = str(tmp_path / 'ds')
+  os.makedirs(root)
+  _make_dataset(root, n_eps=3, T=9, H=136, W=136)
+  kw = dict(window_size=3, fetch_target=True, batch_size=5, device='cuda')
+  for channels in (3, 4):
+    params = {'e2evmc_config': create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136,
+                                                         img_width=136, img_channels=channels, batch_size=5)),
+              'log_steps': 1000, 'debug': False}
+    res = []
+    for dense in (False, True):
+      EPISODE_CACHE.clear()
+      old = dict(os.environ)
+      if dense:
+        os.environ.update(GEECO_DEV='1', GEECO_NO_U8_WINDOWS='1')
+      try:
+        e = est.Estimator(est.goal_e2evmc_model_fn, None, est.RunConfig(init_seed=5), params)
+        for _ in range(2):          # epoch 2 comes from the episode cache
+          e.train(input_fn=lambda: pickplace_input_fn(root, 'default', 'train', seed=3, **kw))
+        ev = e.evaluate(input_fn=lambda: pickplace_input_fn(root, 'default', 'eval', **kw))
+      finally:
+        os.environ.clear()
+        os.environ.update(old)
+      feeds = [f for (spec, fbuf, lbuf) in e._specs.values() for f in fbuf.values() if isinstance(f, WindowFeed)]
+      took = {(f.table is not None, f.buffer is not None) for f in feeds if f.frame_shape[-1] == 3}
+      assert took == ({(False, True)} if dense else {(True, False)}), took
+      assert all(f.buffer is not None for f in feeds if f.frame_shape[-1] == 1)        # depth stays dense float32
+      res.append((ev, {n: e.get_variable_value(n) for n in e.get_variable_names()}))
+    (ev_a, var_a), (ev_b, var_b) = res
+    assert ev_a == ev_b, (ev_a, ev_b)
+    assert ev_a['global_step'] > 2
+    for n in var_a:
+      np.testing.assert_array_equal(var_a[n], var_b[n], err_msg=n)
+
+
 def test_ragged_final_batch_and_shared_store(dev, tmp_path):
   """dataset.batch() keeps a ragged final batch (geeco_gym.py:471); the Estimator builds a second graph for
   it on the SAME variables.  A 4+4+2 epoch followed by a full batch must equal the same four steps taken through one-off models."""

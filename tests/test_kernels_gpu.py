@@ -597,6 +597,54 @@ def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
   _close(dif[..., :C], O.dynimg(torch.stack([frames64[:, K - 1], tgt64], 1)), 0, 5e-6, 'pair image vs fp64')
 
 
+@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (4, 2, 40, 36, 4)])
+def test_goal_dynimgs_from_resident_u8_frames(dev, N, K, H, W, C):
+  """The input stage fed from the episodes' resident uint8 frames through per-sample window addresses
+  (geeco_goal_dynimgs_u8_fwd): bitwise the three images of geeco_gather_windows (/ 255, geeco_gym.py:312) followed by
+  geeco_goal_dynimgs_fwd, for overlapping windows of two 'episodes' of different length, every byte value present."""
+  from geeco_amd import ops
+  r = np.random.default_rng(61)
+  HW = H * W
+  fe = HW * 3
+  eps = []
+  for T in (K + 5, K + 2):
+    f = r.integers(0, 256, size=(T, fe), dtype=np.uint8)
+    f.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    f.reshape(-1)[-256:] = np.arange(255, -1, -1).astype(np.uint8)
+    eps.append(torch.tensor(f, device=dev))
+  tgts = [torch.tensor(r.integers(0, 256, size=(1, fe), dtype=np.uint8), device=dev) for _ in eps]
+  pick = [(n % 2, [0, 2, 5, 1][n % 4] % (eps[n % 2].shape[0] - K + 1)) for n in range(N)]
+  pick[-1] = (0, eps[0].shape[0] - K)                      # the last window an episode has
+  # dense path: gather (u8 -> float / 255) then the fp32 input stage
+  rgb = torch.empty(N, K, H, W, 3, device=dev)
+  tgt = torch.empty(N, H, W, 3, device=dev)
+  for n, (e, st) in enumerate(pick):
+    ops.gather_windows_into(rgb[n:n + 1], eps[e], torch.tensor([st], dtype=torch.int32, device=dev), 1, K, fe, 255.0)
+    ops.gather_windows_into(tgt[n:n + 1].view(1, 1, H, W, 3), tgts[e], torch.zeros(1, dtype=torch.int32, device=dev), 1, 1, fe, 255.0)
+  win = torch.tensor([eps[e].data_ptr() + st * fe for e, st in pick], dtype=torch.int64, device=dev)
+  tpt = torch.tensor([tgts[e].data_ptr() for e, _ in pick], dtype=torch.int64, device=dev)
+  ws = ops.dynimg_ws(N, HW * 4, dev)
+  ws2 = torch.empty(2 * ws.numel(), dtype=torch.float32, device=dev)
+  ref = [torch.empty(N, H, W, 4, device=dev) for _ in range(3)]
+  got = [torch.full((N, H, W, 4), float('nan'), device=dev) for _ in range(3)]
+  kw = {}
+  if C == 4:
+    dep = torch.tensor((0.5 + 2.5 * r.random([N, K, H, W, 1])).astype(np.float32), device=dev)
+    tdep = torch.tensor((0.5 + 2.5 * r.random([N, H, W, 1])).astype(np.float32), device=dev)
+    kw = dict(depth=dep, tgt_depth=tdep, dsample_stride=K * HW, dframe_stride=HW)
+  ops.goal_dynimgs_into(ref[0], ref[1], ref[2], rgb, tgt, K, N, HW, ws2, K * fe, fe, **kw)
+  ops.goal_dynimgs_u8_into(got[0], got[1], got[2], win, tpt, K, N, HW, ws2, **kw)
+  torch.cuda.synchronize()
+  # the dense windows themselves are the reference's values: float32(u8) / float32(255)
+  e, st = pick[0]
+  np.testing.assert_array_equal(rgb[0].cpu().numpy().reshape(K, fe),
+                                eps[e][st:st + K].cpu().numpy().astype(np.float32) / np.float32(255.0))
+  for name, a, b in zip(('current frame', 'buffer image', 'pair image'), got, ref):
+    assert torch.equal(a, b), name
+  with pytest.raises(ValueError):
+    ops.goal_dynimgs_u8_into(got[0], got[1], got[2], win.int(), tpt, K, N, HW, ws2, **kw)
+
+
 @pytest.mark.parametrize('G,N,H,W', [(1, 2, 32, 64), (3, 2, 64, 64)])
 def test_conv3_relu_fields_and_conv4_dgrad_fields(dev, G, N, H, W):
   """conv3's forward with the byte sign fields of its output (byte (T >> 1) * 4 + q, bit 4 (T & 1) + j <-> channel
