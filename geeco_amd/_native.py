@@ -52,6 +52,7 @@ SIGNATURES = {
     'geeco_pack_pixels': (_I, [_P, _L, _P, _L, _I, _L, _I, _I, _I, _P, _P]),
     'geeco_gather_windows': (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),
     'geeco_conv3x3_fwd': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'geeco_conv3x3_fwd_state': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _L, _I, _I, _P, _L, _P]),
     'geeco_conv3x3_fwd_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'geeco_conv3x3_dgrad': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
     'geeco_conv3x3_dgrad_ws_bytes': (_L, [_I, _I, _I, _I, _I, _I, _I]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     'geeco_gemm_ws_bytes': (_L, [_I, _I, _I]),
     'geeco_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _P]),
     'geeco_lstm_gates_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'geeco_lstm_input_step_fwd': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'geeco_lstm_gates_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'geeco_lstm_step_bwd_ws_bytes': (_L, [_I, _I, _I]),
     'geeco_lstm_step_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _P, _P]),

@@ -514,6 +514,59 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvGem
   *reinterpret_cast<f32x4*>(p.out + (long long)g * p.gs_out + e) = v;
 }
 
+// The top layer's epilogue with the state concat of the one-step decoder in it (graph.py:169-192): besides out[g][n][cell][c]
+// the ReLU'd features go to state[n][cell * Ctot + off[g] + c], and the blocks behind the epilogue's copy the joint state into
+// every cell's columns [jnt_off, jnt_off + J) -- geeco_state_concat_fwd's values, one dependent launch fewer.
+struct StateScatter {
+  float* state;
+  const float* jnt;
+  long long state_stride, jnt_stride;
+  int off[4];
+  int Ctot, jnt_off, J, cells, epi_blocks;
+};
+
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_state_kernel(const ConvGemmParams p, const StateScatter sc) {
+  const int g = blockIdx.y;
+  if ((int)blockIdx.x >= sc.epi_blocks) {
+    if (g != 0) return;
+    const long long i = (long long)((int)blockIdx.x - sc.epi_blocks) * 256 + threadIdx.x;
+    const long long per = (long long)sc.cells * sc.J;
+    if (i >= per * p.N) return;
+    const int n = (int)(i / per);
+    const int rem = (int)(i - (long long)n * per);
+    const int cell = rem / sc.J, j = rem - cell * sc.J;
+    sc.state[(long long)n * sc.state_stride + cell * sc.Ctot + sc.jnt_off + j] = sc.jnt[(long long)n * sc.jnt_stride + j];
+    return;
+  }
+  const long long npix = (long long)p.N * p.Hd * p.Wd;
+  const long long total4 = npix * p.Nout / 4;
+  const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= total4) return;
+  const long long e = i4 * 4;
+  const int co = (int)(e % p.Nout);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const float* src = p.part + (long long)g * npix * p.Nout + e;
+  const long long slab = (long long)p.groups * npix * p.Nout;
+  int s = 0;
+  for (; s + 4 <= p.ksplit; s += 4) {     // same slab order as conv_splitk_epilogue_kernel
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (s + u) * slab);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += t[u];
+  }
+  for (; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(src + s * slab);
+  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + (long long)g * p.gs_b + co);
+  if (p.relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  *reinterpret_cast<f32x4*>(p.out + (long long)g * p.gs_out + e) = v;
+  const long long pix = e / p.Nout;
+  const int n = (int)(pix / sc.cells), cell = (int)(pix - (long long)n * sc.cells);
+  float* st = sc.state + (long long)n * sc.state_stride + cell * sc.Ctot + sc.off[g] + co;   // Ctot is odd in general: scalar stores
+  st[0] = v.x; st[1] = v.y; st[2] = v.z; st[3] = v.w;
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 static void launch_cfg(ConvGemmParams& p, int groups, hipStream_t s) {
   int tiles = 0;
@@ -627,7 +680,7 @@ extern "C" int geeco_debug_dump_stamps(const char* path) {
 }
 #endif
 
-static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t s) {
+static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t s, const StateScatter* scatter = nullptr) {
   for (int c = 0; c < p.ncls; ++c)
     if (p.cls[c].M + 256 >= (1ll << 31)) {
       geeco_set_error("conv3x3: %lld rows per launch exceed the 32-bit row index of the kernel", p.cls[c].M);
@@ -638,6 +691,7 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
 #endif
   ConvPlan pl = conv_plan(p, groups);
   if (!ws) pl.ksplit = 1;
+  if (scatter && pl.ksplit <= 1) return GEECO_ENOSUP;      // no epilogue launch to carry the concat: the caller launches it
   p.ksplit = pl.ksplit;
   p.groups = groups;
   p.part = (float*)ws;
@@ -675,8 +729,16 @@ static int launch_conv_gemm(ConvGemmParams& p, int groups, void* ws, hipStream_t
   if (p.ksplit > 1) {
     const long long total4 = (long long)p.N * p.Hd * p.Wd * p.Nout / 4;
     dim3 grid((unsigned)cdiv64(total4, 256), (unsigned)groups);
-    geeco_note_kernel("conv_splitk_epilogue_kernel");
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, grid, dim3(256), 0, s, p);
+    if (scatter) {
+      StateScatter sc = *scatter;
+      sc.epi_blocks = (int)grid.x;
+      grid.x += (unsigned)cdiv64((long long)p.N * sc.cells * sc.J, 256);
+      geeco_note_kernel("conv_splitk_epilogue_state_kernel");
+      hipLaunchKernelGGL(conv_splitk_epilogue_state_kernel, grid, dim3(256), 0, s, p, sc);
+    } else {
+      geeco_note_kernel("conv_splitk_epilogue_kernel");
+      hipLaunchKernelGGL(conv_splitk_epilogue_kernel, grid, dim3(256), 0, s, p);
+    }
     GEECO_LAUNCH_CHECK();
   }
   return 0;
@@ -774,6 +836,35 @@ extern "C" int geeco_conv3x3_fwd(const float* x, const float* w, const float* b,
   p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_out = gs_y;
   p.relu = relu;
   return launch_conv_gemm(p, groups, ws, (hipStream_t)stream);
+}
+
+// conv8 + bias + ReLU of all encoders AND the one-step decoder's state concat (the epilogue of the split-K sum carries it).
+// GEECO_ENOSUP (nothing launched) when this shape does not go through the split-K gather GEMM: the caller then runs
+// geeco_conv3x3_fwd and geeco_state_concat_fwd.
+extern "C" int geeco_conv3x3_fwd_state(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
+                                       int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout,
+                                       int stride, void* ws, const int* feat_off, int Ctot, const float* jnt, int64_t jnt_stride,
+                                       int jnt_off, int J, float* state, int64_t state_stride, void* stream) {
+  GEECO_CHECK_ARG(x && w && y && feat_off && jnt && state, "conv3x3_fwd_state: null pointer");
+  GEECO_CHECK_ARG(groups >= 1 && groups <= 4 && N >= 1 && H >= 1 && W >= 1, "conv3x3_fwd_state: bad dims");
+  GEECO_CHECK_ARG(Cin % 4 == 0 && Cin >= 4 && Cout % 16 == 0 && stride >= 1 && stride <= 4, "conv3x3_fwd_state: Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+  ConvGemmParams p = {};
+  fill_fwd(&p, N, H, W, Cin, Cout, stride);
+  const int cells = p.Hd * p.Wd;
+  GEECO_CHECK_ARG(J >= 1 && jnt_off >= 0 && jnt_off + J <= Ctot && state_stride >= (int64_t)cells * Ctot, "conv3x3_fwd_state: joint columns / state_stride");
+  for (int g = 0; g < groups; ++g) {
+    GEECO_CHECK_ARG(feat_off[g] >= 0 && feat_off[g] + Cout <= Ctot && (feat_off[g] + Cout <= jnt_off || feat_off[g] >= jnt_off + J),
+                    "conv3x3_fwd_state: feature columns of encoder %d", g);
+  }
+  if (!ws || Cin <= 48) return GEECO_ENOSUP;      // (Cin <= 48: the shapes of the halo kernels, conv1..3 -- never a top layer)
+  p.x = x; p.w = w; p.bias = b; p.mask = nullptr; p.out = y;
+  p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_out = gs_y;
+  p.relu = 1;
+  StateScatter sc = {};
+  sc.state = state; sc.jnt = jnt; sc.state_stride = state_stride; sc.jnt_stride = jnt_stride;
+  for (int g = 0; g < groups; ++g) sc.off[g] = feat_off[g];
+  sc.Ctot = Ctot; sc.jnt_off = jnt_off; sc.J = J; sc.cells = cells;
+  return launch_conv_gemm(p, groups, ws, (hipStream_t)stream, &sc);
 }
 
 int geeco_halo_dgrad_handles(int H, int W, int Cin, int Cout, int stride);

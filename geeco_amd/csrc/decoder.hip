@@ -474,6 +474,68 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
   if (dc_prev) dc_prev[i] = dct * sf;
 }
 
+// The first LSTM step (zero state: z = X Wx alone) with the split-K slab sum of the input projection INSIDE the gate kernel: one
+// dependent launch fewer (~5 us of a step whose decoder is pure launch latency).  Block = 64 (sample, unit) pairs x 4 gates:
+// wave g sums gate g's slabs in the slab order of gemm_reduce_kernel (bitwise the same z), LDS hands the four sums to wave 0.
+__global__ __launch_bounds__(256) void lstm_gates_fwd_slabs_kernel(const float* __restrict__ part, int S,
+                                                                   const float* __restrict__ bias, float* __restrict__ z,
+                                                                   float* __restrict__ c, float* __restrict__ h,
+                                                                   float* __restrict__ gates, int N, int H) {
+  __shared__ float sz[4][64];
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < N * H;
+  const int n = live ? i / H : 0, u = live ? i - n * H : 0;
+  const long long MN = (long long)N * 4 * H;
+  const long long col = (long long)n * 4 * H + g * H + u;
+  float s = 0.f;
+  if (live) {
+    const float* src = part + col;
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[(long long)(k + q) * MN];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; k < S; ++k) s += src[(long long)k * MN];
+    z[col] = s;
+  }
+  sz[g][lane] = s + (live ? bias[g * H + u] : 0.f);
+  __syncthreads();
+  if (g != 0 || !live) return;
+  const float zi = sz[0][lane], zj = sz[1][lane], zf = sz[2][lane], zo = sz[3][lane];
+  const float si = sigmoidf_(zi), tj = tanhf(zj), sf = sigmoidf_(zf + 1.0f), so = sigmoidf_(zo);
+  const float cn = sf * 0.f + si * tj;
+  c[i] = cn;
+  h[i] = so * tanhf(cn);
+  float* gr = gates + (long long)n * 4 * H;
+  gr[u] = si; gr[H + u] = tj; gr[2 * H + u] = sf; gr[3 * H + u] = so;
+}
+
+extern "C" int geeco_lstm_input_step_fwd(const float* x, int64_t ldx, const float* wx, int64_t ldw, const float* bias, float* z,
+                                         float* c, float* h, float* gates, int N, int H, int D, void* ws, void* stream) {
+  GEECO_CHECK_ARG(x && wx && bias && z && c && h && gates, "lstm_input_step_fwd: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && H >= 1 && D >= 1 && ldx >= D && ldw >= 4 * (int64_t)H, "lstm_input_step_fwd: bad dims");
+  GemmParams p = {};
+  p.A = x; p.B = wx; p.C = z; p.part = (float*)ws; p.lda = ldx; p.ldb = ldw; p.ldc = 4 * H;
+  p.M = N; p.N = 4 * H; p.K = D;
+  gemm_plan(p.M, p.N, p.K, &p.S, &p.k_per_split);
+  GEECO_CHECK_ARG(p.S == 1 || ws, "lstm_input_step_fwd: workspace required for split-K (geeco_gemm_ws_bytes(N, 4H, D))");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), (unsigned)p.S), dim3(256), 0, s, p);
+  GEECO_LAUNCH_CHECK();
+  if (p.S > 1)
+    hipLaunchKernelGGL(lstm_gates_fwd_slabs_kernel, dim3((unsigned)cdiv(N * H, 64)), dim3(256), 0, s, (const float*)p.part, p.S,
+                       bias, z, c, h, gates, N, H);
+  else
+    hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3((unsigned)cdiv(N * H, 256)), dim3(256), 0, s, (const float*)z, bias,
+                       (const float*)nullptr, c, h, gates, N, H);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int geeco_lstm_gates_fwd(const float* z, const float* bias, const float* c_prev, float* c, float* h,
                                     float* gates, int N, int H, void* stream) {
   GEECO_CHECK_ARG(z && bias && c && h && gates && N >= 1 && H >= 1, "lstm_gates_fwd: bad arguments");

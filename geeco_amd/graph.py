@@ -288,6 +288,9 @@ class ConvEncoderStack:
     self.derived_version = self.store.version
 
   # -- single launches (also timed one by one by bench.py's per-layer table) ---------------------------
+  # the state concat of a one-step decoder inside conv8's split-K epilogue (GEECO_NO_CONCAT_IN_TOP: its own launch)
+  concat_in_top = _dev.env('GEECO_NO_CONCAT_IN_TOP') is None
+
   def launch_fwd(self, l):
     G, Nf, L = self.G, self.Nf, self.layers[l]
     if l == 7 and self.split_top:
@@ -420,15 +423,27 @@ class ConvEncoderStack:
     ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel() if wt is not None else 0, dx[0].numel(), Nf, L['H'],
                            L['W'], L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)
 
-  def forward(self):
+  def forward(self, state=None):
+    """``state`` (one-step decoders): dict(state, state_stride, feat_off, Ctot, jnt, jnt_stride, jnt_off, J) of the state
+    concat that consumes the features; it then rides in the epilogue of the top layer's split-K sum where that exists.
+    Returns True if it did (else the caller launches the concat)."""
     if not self.lazy_refresh or self.derived_version != self.store.version:
       self.refresh_derived()
     first = 0
     if self.fused_fwd:
       self.launch_fwd_bottom()
       first = 2
-    for l in range(first, len(self.layers)):
+    top = len(self.layers) - 1
+    for l in range(first, top):
       self.launch_fwd(l)
+    if state is not None and self.concat_in_top and not self.split_top:
+      G, Nf, L = self.G, self.Nf, self.layers[top]
+      x, y = self.acts[top - 1], self.acts[top]
+      if ops.conv3x3_fwd_state_into(y, x, self._w(top), self._b(top), G, x[0].numel(), self.gs_p, self.gs_p, y[0].numel(), Nf,
+                                    L['H'], L['W'], L['Cin'], L['Cout'], L['stride'], self.fws, **state):
+        return True
+    self.launch_fwd(top)
+    return False
 
   def backward(self, hi=7, lo=0):
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied).  Runs layers
@@ -530,6 +545,7 @@ class LSTMDecoder:
     # one-step decoders: weight / bias / input gradients (+ the state-concat backward) as TWO launches instead of five
     # dependent ones (GEECO_DEV=1 GEECO_NO_LSTM_BATCH: the separate launches)
     self.one_launch_bwd = _dev.env('GEECO_NO_LSTM_BATCH') is None
+    self.one_launch_fwd = _dev.env('GEECO_NO_LSTM_FWD_FUSE') is None   # ... and the forward's slab sum inside the gate kernel
 
   def _v(self, n):
     return self.store.var('%s/%s' % (self.scope, n))
@@ -542,8 +558,14 @@ class LSTMDecoder:
     W = self._v('lstm_cell/kernel')            # [D + H][4H]: rows 0..D-1 multiply x, D.. multiply h
     Wx, Wh = W[:D], W[D:]
     bias = self._v('lstm_cell/bias')
-    # hoisted input projection for all steps: Z = X Wx
-    ops.gemm_into(self.z, self.states, Wx, T * N, 4 * H, D, D, 4 * H, 4 * H, ws=self.gemm_ws)
+    if T == 1 and self.one_launch_fwd:
+      # one step from a zero state: the slab sum of the gate GEMM rides in the gate kernel (bitwise the same)
+      ops.lstm_input_step_fwd_into(self.z[0], self.c[0], self.h[0], self.gates[0], self.states[0], Wx, bias, N, H, D, D, 4 * H,
+                                   self.gemm_ws)
+      T = 0
+    else:
+      # hoisted input projection for all steps: Z = X Wx
+      ops.gemm_into(self.z, self.states, Wx, T * N, 4 * H, D, D, 4 * H, 4 * H, ws=self.gemm_ws)
     for t in range(T):
       if t > 0:
         ops.gemm_into(self.z[t], self.h[t - 1], Wh, N, 4 * H, H, H, 4 * H, 4 * H, accumulate=True, ws=self.gemm_ws)
@@ -554,7 +576,7 @@ class LSTMDecoder:
     if backward_too:
       kw = dict(dh=self.dh, d_fc1_w=self._g('fc1/kernel'), d_fc1_b=self._g('fc1/bias'),
                 d_heads_w=[self._g(n + '/kernel') for n in names], d_heads_b=[self._g(n + '/bias') for n in names])
-    ops.heads_loss_into(self.preds, self.losses, self.h[T - 1], self._v('fc1/kernel'), self._v('fc1/bias'),
+    ops.heads_loss_into(self.preds, self.losses, self.h[self.T - 1], self._v('fc1/kernel'), self._v('fc1/bias'),
                         [self._v(n + '/kernel') for n in names], [self._v(n + '/bias') for n in names],
                         [h[2] for h in self.heads], [h[3] for h in self.heads], [h[4] for h in self.heads],
                         self.targets, self.target_strides, float(self.loss_scale), N, H, F, self.heads_ws, **kw)
@@ -777,6 +799,19 @@ class GoalE2EVMC(_ModelBase):
         _dev.env('GEECO_NO_U8_WINDOWS') is None):
       self.u8_window_keys = ('rgb', 'target_rgb')
 
+  def _encode_dynimg_state(self):
+    """The three encoders and representation_concatenation_v2: [obs | dyn | jnt | tgt] (graph.py:169-192) of the current
+    step's joint state, jnt_state_list[-1] (:388); the concat rides in conv8's split-K epilogue where that exists."""
+    N, K, jn, d = self.N, self.K, self.cfg.dim_jnt_state, self.decoder
+    jnt = self.inputs['jnt_state'][:, K - 1]
+    ch = self.feat_ch
+    Ctot = sum(ch) + jn
+    state = dict(state=d.states[0], state_stride=d.D, feat_off=[0, ch[0], ch[0] + ch[1] + jn], Ctot=Ctot, jnt=jnt,
+                 jnt_stride=K * jn, jnt_off=ch[0] + ch[1], J=jn)
+    if not self.enc.forward(state if len(set(ch)) == 1 else None):
+      feats = self.enc.features                               # [3][N][2][2][256]
+      ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], ch, 2, jnt, K * jn, jn, N, _CELLS, d.D)
+
   def forward(self, backward_too=False):
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
     HW = H * W
@@ -802,10 +837,7 @@ class GoalE2EVMC(_ModelBase):
         ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, self.dyn_ws, K * HW * 3, HW * 3, K * HW, HW)
         ops.dynimg_rgbd_into(x_in[2], cur_rgb, cur_dep, 2, N, HW, self.dyn_ws, K * HW * 3, 0, K * HW, 0,
                              rgb2=inp['target_rgb'], depth2=inp['target_depth'])
-      self.enc.forward()
-      feats = self.enc.features
-      ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], self.feat_ch, 2, jnts[:, K - 1], K * jn,
-                                jn, N, _CELLS, d.D)
+      self._encode_dynimg_state()
       d.forward(backward_too)
       self._finish_forward()
       return
@@ -824,11 +856,7 @@ class GoalE2EVMC(_ModelBase):
         ops.pack_pixels_into(x_in[0], cur, K * HW * C, N, HW, C, 4)
         ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, self.dyn_ws, K * HW * C, HW * C)
         ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, self.dyn_ws, K * HW * C, 0, frames2=tgt)
-      self.enc.forward()
-      feats = self.enc.features                               # [3][N][2][2][256]
-      # representation_concatenation_v2: [obs | dyn | jnt | tgt] (graph.py:169-192); jnt_state_list[-1] (:388)
-      ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], self.feat_ch, 2, jnts[:, K - 1], K * jn,
-                                jn, N, _CELLS, d.D)
+      self._encode_dynimg_state()
     elif self.mode in ('seq_constant', 'seq_residual'):
       xs = x_in[0].view(K + 1, N, H, W, 4)                    # time-major; slot K = target frame
       for t in range(K):

@@ -158,6 +158,18 @@ def conv3x3_fwd_into(y, x, w, b, G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, 
                                  stride, 1 if relu else 0, _p(ws), _stream()), 'geeco_conv3x3_fwd')
 
 
+def conv3x3_fwd_state_into(y, x, w, b, G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, stride, ws, state, state_stride, feat_off,
+                           Ctot, jnt, jnt_stride, jnt_off, J):
+  """The top layer's forward with the one-step decoder's state concat in the split-K epilogue (``geeco_conv3x3_fwd_state``).
+  Returns False (nothing launched) when the shape has no such epilogue: run conv3x3_fwd_into + state_concat_fwd_into."""
+  rc = _lib().geeco_conv3x3_fwd_state(_p(x), _p(w), _p(b), _p(y), G, gs_x, gs_w, gs_b, gs_y, N, H, W, Cin, Cout, stride, _p(ws),
+                                      _iarr(feat_off), Ctot, _p(jnt), jnt_stride, jnt_off, J, _p(state), state_stride, _stream())
+  if rc == _native.GEECO_ENOSUP:
+    return False
+  check(rc, 'geeco_conv3x3_fwd_state')
+  return True
+
+
 def conv3x3_fwd_ws_bytes(G, N, H, W, Cin, Cout, stride):
   return int(_lib().geeco_conv3x3_fwd_ws_bytes(G, N, H, W, Cin, Cout, stride))
 
@@ -448,6 +460,12 @@ def gemm(A, B, ta=False, tb=False):
 def lstm_gates_fwd_into(c, h, gates, z, bias, c_prev, N, H):
   check(_lib().geeco_lstm_gates_fwd(_p(z), _p(bias), _p(c_prev), _p(c), _p(h), _p(gates), N, H, _stream()),
         'geeco_lstm_gates_fwd')
+
+
+def lstm_input_step_fwd_into(z, c, h, gates, x, wx, bias, N, H, D, ldx, ldw, ws):
+  """The cell's first step (zero state): gate GEMM + gate math, the split-K slab sum inside the gate kernel (two launches)."""
+  check(_lib().geeco_lstm_input_step_fwd(_p(x), ldx, _p(wx), ldw, _p(bias), _p(z), _p(c), _p(h), _p(gates), N, H, D, _p(ws),
+                                         _stream()), 'geeco_lstm_input_step_fwd')
 
 
 def lstm_gates_bwd_into(dz, dc_prev, gates, c_prev, c, dh, dc, N, H):

@@ -111,6 +111,17 @@ int geeco_gather_windows(const void* src, int src_is_u8, const int* starts_dev, 
 int geeco_conv3x3_fwd(const float* x, const float* w, const float* b, float* y, int groups,
                       int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W,
                       int Cin, int Cout, int stride, int relu, void* ws, void* stream);
+/* The encoders' TOP layer (conv8 + bias + ReLU, all `groups` encoders over the same N frames) together with the one-step
+ * decoder's state concat (representation_concatenation_v2, graph.py:169-192; jnt_state_list[-1], :388): the launch that sums
+ * the split-K slabs also writes state[n][cell * Ctot + feat_off[g] + c] = y[g][n][cell][c] and copies jnt[n][0..J) into the
+ * columns [jnt_off, jnt_off + J) of every cell -- the values of geeco_conv3x3_fwd + geeco_state_concat_fwd, one dependent launch
+ * fewer.  Returns GEECO_ENOSUP, having launched nothing, when the shape does not take the split-K path (ws NULL, no split for
+ * this M, a halo-kernel shape): the caller then runs the two entry points. */
+int geeco_conv3x3_fwd_state(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x, int64_t gs_w,
+                            int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride, void* ws,
+                            const int* feat_off, int Ctot, const float* jnt, int64_t jnt_stride, int jnt_off, int J,
+                            float* state, int64_t state_stride, void* stream);
+
 /* `ws` (may be NULL): device workspace of geeco_conv3x3_fwd_ws_bytes(...) bytes; layers whose
  * output is too small to fill 256 CUs (conv6..8) split their K loop over blocks through it. */
 int64_t geeco_conv3x3_fwd_ws_bytes(int groups, int N, int H, int W, int Cin, int Cout, int stride);
@@ -317,6 +328,12 @@ int geeco_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t 
  * c_prev may be NULL (zero state, graph.py:218-220). */
 int geeco_lstm_gates_fwd(const float* z, const float* bias, const float* c_prev, float* c, float* h,
                          float* gates, int N, int H, void* stream);
+/* The FIRST step of the cell (zero state, graph.py:218-220: z = x wx alone) as two launches instead of three: the gate GEMM
+ * (geeco_gemm_f32's kernel and K split) and the gate math with the split-K slab sum inside it.  x [N][D] (ldx), wx [D][4H]
+ * (ldw); z, c, h, gates as geeco_lstm_gates_fwd; ws: geeco_gemm_ws_bytes(N, 4H, D).  Bitwise equal to geeco_gemm_f32 +
+ * geeco_lstm_gates_fwd(c_prev = NULL). */
+int geeco_lstm_input_step_fwd(const float* x, int64_t ldx, const float* wx, int64_t ldw, const float* bias, float* z, float* c,
+                              float* h, float* gates, int N, int H, int D, void* ws, void* stream);
 /* dz [N][4H] from dh, dc (either may be NULL = 0); dc_prev (optional) out. */
 int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh,
                          const float* dc, float* dz, float* dc_prev, int N, int H, void* stream);

@@ -917,6 +917,78 @@ def test_lstm_step_bwd_one_launch(dev, N, chs, J):
   assert torch.equal(dx2, dx)
 
 
+@pytest.mark.parametrize('N,H,D', [(32, 128, 3100), (5, 128, 1052), (1, 64, 40), (33, 96, 3100), (64, 128, 3100)])
+def test_lstm_input_step_fwd_two_launches(dev, N, H, D):
+  """geeco_lstm_input_step_fwd (the cell's first step: gate GEMM, then the gate math with the split-K slab sum inside) against
+  geeco_gemm_f32 + geeco_lstm_gates_fwd(c_prev = NULL): bitwise z, c, h, gates (same tile code, K split and slab order), split
+  (D = 3100: 39 slabs at N = 32) and unsplit (D = 40) products, row counts that do not fill a tile; z against fp64."""
+  from geeco_amd import ops
+  r = np.random.default_rng(83)
+  x = torch.tensor(r.standard_normal([N, D]).astype(np.float32), device=dev)
+  w = torch.tensor((r.standard_normal([D + H, 4 * H]) / np.sqrt(D)).astype(np.float32), device=dev)
+  bias = torch.tensor(r.standard_normal([4 * H]).astype(np.float32), device=dev)
+  ws = torch.empty(ops.gemm_ws_bytes(N, 4 * H, D) // 4 + 4, device=dev)
+  ref = [torch.empty(N, 4 * H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, 4 * H, device=dev)]
+  got = [torch.full_like(t, float('nan')) for t in ref]
+  ops.gemm_into(ref[0], x, w[:D], N, 4 * H, D, D, 4 * H, 4 * H, ws=ws)
+  ops.lstm_gates_fwd_into(ref[1], ref[2], ref[3], ref[0], bias, None, N, H)
+  ops.lstm_input_step_fwd_into(got[0], got[1], got[2], got[3], x, w[:D], bias, N, H, D, D, 4 * H, ws)
+  torch.cuda.synchronize()
+  for name, a, b in zip(('z', 'c', 'h', 'gates'), got, ref):
+    assert not torch.isnan(a).any() and torch.equal(a, b), name
+  _close(got[0], x.double().cpu() @ w[:D].double().cpu(), 1e-5, 2e-5, 'z vs fp64')
+
+
+@pytest.mark.parametrize('G,N,C,J', [(3, 32, 256, 7), (3, 5, 256, 7), (1, 2, 64, 3), (2, 33, 128, 7)])
+def test_top_layer_forward_carries_the_state_concat(dev, G, N, C, J):
+  """geeco_conv3x3_fwd_state (conv8 + bias + ReLU of all encoders, the one-step decoder's state concat in the epilogue of the
+  split-K sum) against geeco_conv3x3_fwd + geeco_state_concat_fwd: features and state bitwise, no state element left
+  unwritten; a shape without a split-K epilogue is declined (False, nothing written)."""
+  from geeco_amd import ops
+  r = np.random.default_rng(97)
+  H = W = 4
+  cells = 4
+  x = torch.tensor(r.standard_normal([G, N, H, W, 256]).astype(np.float32), device=dev)
+  w = torch.tensor((r.standard_normal([G, 3, 3, 256, C]) / 48).astype(np.float32), device=dev)
+  b = torch.tensor(r.standard_normal([G, C]).astype(np.float32), device=dev)
+  K = 3
+  jnts = torch.tensor(r.standard_normal([N, K, J]).astype(np.float32), device=dev)
+  jnt = jnts[:, K - 1]
+  ch = [C] * G
+  jnt_pos = min(2, G)
+  Ctot = G * C + J
+  off, o = [], 0
+  for g in range(G):
+    if g == jnt_pos:
+      o += J
+    off.append(o)
+    o += C
+  jnt_off = sum(ch[:jnt_pos])
+  ws = torch.empty(ops.conv3x3_fwd_ws_bytes(G, N, H, W, 256, C, 2) // 4 + 4, device=dev)
+  y_ref = torch.empty(G, N, 2, 2, C, device=dev)
+  st_ref = torch.full((N, cells * Ctot), float('nan'), device=dev)
+  ops.conv3x3_fwd_into(y_ref, x, w, b, G, x[0].numel(), w[0].numel(), C, y_ref[0].numel(), N, H, W, 256, C, 2, relu=True, ws=ws)
+  ops.state_concat_fwd_into(st_ref, [y_ref[g] for g in range(G)], ch, jnt_pos, jnt, K * J, J, N, cells, cells * Ctot)
+  y = torch.full_like(y_ref, float('nan'))
+  st = torch.full_like(st_ref, float('nan'))
+  did = ops.conv3x3_fwd_state_into(y, x, w, b, G, x[0].numel(), w[0].numel(), C, y[0].numel(), N, H, W, 256, C, 2, ws, state=st,
+                                   state_stride=cells * Ctot, feat_off=off, Ctot=Ctot, jnt=jnt, jnt_stride=K * J, jnt_off=jnt_off, J=J)
+  torch.cuda.synchronize()
+  assert did
+  assert not torch.isnan(st_ref).any()
+  assert torch.equal(y, y_ref)
+  assert torch.equal(st, st_ref)
+  # no workspace = no split-K epilogue: declined, nothing launched
+  st2 = torch.full_like(st_ref, float('nan'))
+  assert not ops.conv3x3_fwd_state_into(y, x, w, b, G, x[0].numel(), w[0].numel(), C, y[0].numel(), N, H, W, 256, C, 2, None, state=st2,
+                                        state_stride=cells * Ctot, feat_off=off, Ctot=Ctot, jnt=jnt, jnt_stride=K * J, jnt_off=jnt_off, J=J)
+  torch.cuda.synchronize()
+  assert torch.isnan(st2).all()
+  with pytest.raises(RuntimeError):      # overlapping feature / joint columns
+    ops.conv3x3_fwd_state_into(y, x, w, b, G, x[0].numel(), w[0].numel(), C, y[0].numel(), N, H, W, 256, C, 2, ws, state=st2,
+                               state_stride=cells * Ctot, feat_off=off, Ctot=Ctot, jnt=jnt, jnt_stride=K * J, jnt_off=0, J=J)
+
+
 def test_reserved_cus_shrink_the_persistent_bottom_kernels(dev):
   """``reserved_cus`` = k (an ARGUMENT of the deferred-slab-sum entry points since ABI 4): conv2's filter gradient and the fused
   bottom launch (256 - k) / groups blocks per encoder (the workspace is sized for k = 0); results equal the k = 0 launches to
