@@ -304,8 +304,8 @@ class FeedArena:
   cost the host ~70 us per step, one ~30.  ``reserve`` while building, then ``seal``; per batch ``begin`` / ``write``... /
   ``flush``.  A ring of staging blocks lets the host run ahead: a block is rewritten only after its upload has finished.
   (Measured and not kept: uploading on a side stream into device-side landing blocks and moving them into place with a
-  device-to-device copy - the ~30 us a fed step costs over a bare replay belong to ANY command queued between two graph
-  launches, not to the transfer.)"""
+  device-to-device copy - no gain; one small command between two replays of the step costs 6-10 us whatever it is,
+  scripts/dev/between_graphs.py.)"""
 
   SLOTS = 4
   ALIGN = 256
