@@ -582,8 +582,13 @@ def input_pipeline_report(args, dev, synthetic_ms_per_step, workdir):
     out['dataset'] = out['dataset'].replace('0.0 MB inflated', '%.1f MB inflated' % (rd.inflated_bytes / 1e6))
   native = lambda p_: I.load_episode(p_, meta, True, raw_rgb=True, image_keys=('rgb',))
   native(paths[0])
+  host = T._host()
+  host.geeco_host_set_fast_inflate(0)
+  zlib_1 = round(rate(native, paths[:4], 1), 2)
+  host.geeco_host_set_fast_inflate(1)
   out['reader_episodes_per_s'] = {
       'python_reader_1_thread (round 3: tfrecord.py + numpy, holds the GIL)': round(rate(lambda p_: I.load_episode_py(p_, meta, True, raw_rgb=True), paths[:2], 1), 2),
+      'native_1_thread_system_zlib': zlib_1,
       'native_1_thread': round(rate(native, paths[:4], 1), 2),
       'native_%d_threads' % threads: round(rate(native, paths, threads), 2)}
   out['reader_frames_per_s_%d_threads' % threads] = round(out['reader_episodes_per_s']['native_%d_threads' % threads] * frames_per_episode, 1)

@@ -26,5 +26,5 @@ $HIPCC $FLAGS -x hip -c errors.cpp -o build/errors.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
-g++ -O3 -std=c++17 -Wall -fPIC -shared -o ../libgeeco_host.so host_io.cpp -lz -lpthread
+g++ -O3 -std=c++17 -Wall -fPIC -shared -o ../libgeeco_host.so host_io.cpp host_inflate.cpp -lz -lpthread
 echo "built $(realpath $OUT) and $(realpath ../libgeeco_host.so)"

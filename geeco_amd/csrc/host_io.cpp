@@ -7,8 +7,10 @@
 // The writer of the format is src/data/data_recorder.py:37-59,134-156 + src/data/utils/tfrecord.py:42-81
 // (uint8 images stored as FLOAT lists: an RGB frame is 196 608 floats).
 #include "../../include/geeco_host.h"
+#include "host_inflate.h"
 
 #include <errno.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -147,8 +149,26 @@ struct Buf {
   }
 };
 
-// zlib / gzip stream -> growable buffer
-static int inflate_into(const uint8_t* src, size_t n, int format, Buf* out, size_t fixed_cap) {
+static int g_fast_inflate = 1;          // geeco_host_set_fast_inflate(0): zlib only (A/B, tests)
+extern "C" void geeco_host_set_fast_inflate(int on) { __atomic_store_n(&g_fast_inflate, on ? 1 : 0, __ATOMIC_RELAXED); }
+
+static uint8_t* grow_buf(void* ctx, size_t want) {
+  Buf* b = (Buf*)ctx;
+  return b->reserve(want) ? b->p : nullptr;
+}
+
+// zlib / gzip stream -> growable buffer.  `padded`: src is readable for GEECO_FI_PAD bytes past n, so a zlib stream goes through
+// the table-driven decoder of host_inflate.cpp first; whatever that declines (and every gzip stream) is zlib's.
+static int inflate_into(const uint8_t* src, size_t n, int format, Buf* out, size_t fixed_cap, bool padded = false) {
+  if (padded && format == 1 && !fixed_cap && __atomic_load_n(&g_fast_inflate, __ATOMIC_RELAXED)) {
+    if (out->reserve(n * 5 + (1u << 20))) {
+      int64_t got = geeco_fast_inflate(src, n, grow_buf, out, out->p, out->cap);
+      if (got >= 0) {
+        out->n = (size_t)got;
+        return 0;
+      }
+    }
+  }
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, format == 2 ? 16 + MAX_WBITS : MAX_WBITS) != Z_OK) {
@@ -206,6 +226,32 @@ static int inflate_into(const uint8_t* src, size_t n, int format, Buf* out, size
   return 0;
 }
 
+// The table-driven decoder alone (tests, benchmarks): zlib stream -> dst; -2 = dst too small, -3 = declined (host_inflate.h).
+extern "C" int64_t geeco_inflate_fast(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  if (!src || (!dst && cap)) {
+    set_err("geeco_inflate_fast: bad arguments");
+    return -1;
+  }
+  Buf in, out;
+  if (!in.reserve(n + GEECO_FI_PAD) || !out.reserve(n * 5 + (1u << 20))) {
+    set_err("geeco_inflate_fast: out of memory");
+    return -1;
+  }
+  memcpy(in.p, src, n);
+  memset(in.p + n, 0, GEECO_FI_PAD);
+  int64_t got = geeco_fast_inflate(in.p, n, grow_buf, &out, out.p, out.cap);
+  if (got < 0) {
+    set_err("geeco_inflate_fast: the stream is not one the table-driven decoder takes (zlib decides what is wrong with it)");
+    return GEECO_FI_FALLBACK;
+  }
+  if ((size_t)got > cap) {
+    set_err("geeco_inflate_fast: destination too small (%zu bytes for %lld)", cap, (long long)got);
+    return -2;
+  }
+  memcpy(dst, out.p, (size_t)got);
+  return got;
+}
+
 extern "C" int64_t geeco_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int format) {
   if (!src || !dst || (format != 1 && format != 2)) {
     set_err("geeco_inflate: bad arguments");
@@ -238,8 +284,58 @@ struct FeatureList {
   std::vector<Span> frames;    // the Feature message of every frame
 };
 
+// Spare output buffers of closed episodes.  An inflated episode is ~105 MB: beyond glibc's mmap threshold, so every malloc of one is
+// a fresh mapping whose 26 k pages fault in one by one while the decoder writes (~40 ms per episode, 10 % of reading it); a buffer a
+// closed episode hands back is already mapped.  Bounded: at most kSpareMax buffers / kSpareBytes bytes are kept.
+static const size_t kSpareMax = 32, kSpareBytes = (size_t)6 << 30;
+static pthread_mutex_t g_spare_mu = PTHREAD_MUTEX_INITIALIZER;
+static std::vector<std::pair<uint8_t*, size_t>> g_spare;
+static size_t g_spare_bytes = 0;
+
+static void take_spare(Buf* b, size_t want) {
+  pthread_mutex_lock(&g_spare_mu);
+  int best = -1;
+  for (int i = 0; i < (int)g_spare.size(); ++i)
+    if (g_spare[i].second >= want && (best < 0 || g_spare[i].second < g_spare[best].second)) best = i;
+  if (best < 0 && !g_spare.empty()) {       // none is large enough: the largest one grows by mremap, most of it already mapped
+    best = 0;
+    for (int i = 1; i < (int)g_spare.size(); ++i)
+      if (g_spare[i].second > g_spare[best].second) best = i;
+  }
+  if (best >= 0) {
+    free(b->p);
+    b->p = g_spare[best].first;
+    b->cap = g_spare[best].second;
+    b->n = 0;
+    g_spare_bytes -= b->cap;
+    g_spare.erase(g_spare.begin() + best);
+  }
+  pthread_mutex_unlock(&g_spare_mu);
+}
+
+static void give_spare(Buf* b) {
+  if (!b->p) return;
+  pthread_mutex_lock(&g_spare_mu);
+  if (g_spare.size() < kSpareMax && g_spare_bytes + b->cap <= kSpareBytes) {
+    g_spare.emplace_back(b->p, b->cap);
+    g_spare_bytes += b->cap;
+    b->p = nullptr;
+    b->cap = b->n = 0;
+  }
+  pthread_mutex_unlock(&g_spare_mu);
+}
+
+extern "C" void geeco_host_release_buffers(void) {
+  pthread_mutex_lock(&g_spare_mu);
+  for (auto& s : g_spare) free(s.first);
+  g_spare.clear();
+  g_spare_bytes = 0;
+  pthread_mutex_unlock(&g_spare_mu);
+}
+
 struct geeco_episode {
   Buf raw;                                // inflated stream (or the file itself)
+  ~geeco_episode() { give_spare(&raw); }
   int64_t num_records = 0;
   std::vector<FeatureList> lists;
   const FeatureList* find(const char* name) const {
@@ -413,9 +509,10 @@ static bool read_file(const char* path, Buf* out) {
   bool ok = false;
   if (fseek(f, 0, SEEK_END) == 0) {
     long sz = ftell(f);
-    if (sz >= 0 && fseek(f, 0, SEEK_SET) == 0 && out->reserve((size_t)sz + 1)) {
+    if (sz >= 0 && fseek(f, 0, SEEK_SET) == 0 && out->reserve((size_t)sz + GEECO_FI_PAD)) {
       out->n = fread(out->p, 1, (size_t)sz, f);
       ok = out->n == (size_t)sz;
+      if (ok) memset(out->p + out->n, 0, GEECO_FI_PAD);      // the inflate's bit buffer refills 8 bytes at a time
     }
   }
   if (!ok) set_err("%s: read failed", path);
@@ -435,7 +532,8 @@ extern "C" geeco_episode* geeco_episode_open(const char* path, int compression, 
       delete ep;
       return nullptr;
     }
-    if (compression && inflate_into(file.p, file.n, compression, &ep->raw, 0) != 0) {
+    if (compression) take_spare(&ep->raw, file.n * 4);
+    if (compression && inflate_into(file.p, file.n, compression, &ep->raw, 0, /*padded=*/true) != 0) {
       std::string why = t_err;
       set_err("%s: %s", path, why.c_str());
       delete ep;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GEECO_HOST_ABI_VERSION 2
+#define GEECO_HOST_ABI_VERSION 3
 
 int geeco_host_abi_version(void);
 const char* geeco_host_last_error(void);
@@ -67,6 +67,14 @@ int geeco_episode_read_u8(const geeco_episode* ep, const char* name, uint8_t* ds
  * inflates `src` into `dst` (capacity `cap`); returns the number of bytes produced, -1 on a malformed stream,
  * -2 when `cap` is too small.  format: 1 zlib (RFC 1950, Adler-32 checked), 2 gzip (RFC 1952, CRC-32 checked). */
 int64_t geeco_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int format);
+/* The reader's own table-driven zlib decoder alone (csrc/host_inflate.cpp; geeco_episode_open tries it first and hands whatever
+ * it declines to zlib): same result as geeco_inflate(format 1) for every stream it accepts, -2 when `cap` is too small,
+ * -3 when it declines the stream (malformed, truncated, checksum mismatch, preset dictionary). */
+int64_t geeco_inflate_fast(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+/* 0: geeco_episode_open inflates with zlib only (A/B measurements, tests); 1 (default): table-driven decoder first. */
+void geeco_host_set_fast_inflate(int on);
+/* geeco_episode_close keeps up to 32 inflate buffers (<= 6 GiB) mapped for the next geeco_episode_open; this frees them. */
+void geeco_host_release_buffers(void);
 
 #ifdef __cplusplus
 }

@@ -176,6 +176,73 @@ def test_inflate_matches_zlib_and_crc32c_matches_bitwise():
   assert lib.geeco_crc32c(b, len(b), lib.geeco_crc32c(a, len(a), 0)) == _crc32c_bitwise(a + b)      # running value
 
 
+def test_table_driven_inflate_equals_zlib(tmp_path):
+  """csrc/host_inflate.cpp (the decoder geeco_episode_open tries first): every stream it accepts is bit-identical to zlib's
+  output - stored / fixed / dynamic blocks, overlapping copies at every short distance, long codes with subtables, the
+  recorder's uint8-as-float lists, 24 MB outputs that outgrow the first buffer; damaged streams are declined (and zlib, which
+  the reader then asks, reports them); an episode decodes to the same arrays with the decoder on and off."""
+  from geeco_amd import tfrecord as T, input_fn as I
+  lib = T._host()
+  r = np.random.default_rng(11)
+  big = r.integers(0, 256, 6_000_000, dtype=np.uint8).astype(np.float32).tobytes()          # 24 MB
+  cases = [b'', b'a', b'ab' * 5, bytes(100000), r.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+           np.repeat(r.integers(0, 7, 4000, dtype=np.uint8), r.integers(1, 300, 4000)).tobytes(),
+           b'abc' * 30000, b'abcde' * 20000, b'abcdef' * 20000, b'abcdefg' * 20000, b'abcdefghijk' * 9000,
+           bytes((i * 7) & 255 if r.random() < 0.97 else int(r.integers(0, 256)) for i in range(120000)), big]
+  for data in cases:
+    for level in ((0, 1, 6, 9) if len(data) < 1_000_000 else (6,)):
+      comp = zlib.compress(data, level)
+      dst = np.empty(len(data) + 8, np.uint8)
+      n = lib.geeco_inflate_fast(comp, len(comp), dst.ctypes.data, len(data))
+      assert n == len(data) and dst[:n].tobytes() == data, (len(data), level, n)
+      if len(data) > 1:
+        assert lib.geeco_inflate_fast(comp, len(comp), dst.ctypes.data, len(data) - 1) == -2          # destination too small
+      for cut in (1, 3, 5, len(comp) // 2):
+        if cut < len(comp):
+          assert lib.geeco_inflate_fast(comp[:-cut], len(comp) - cut, dst.ctypes.data, len(data) + 8) == -3   # truncated: declined
+          assert lib.geeco_inflate(comp[:-cut], len(comp) - cut, dst.ctypes.data, len(data) + 8, 1) == -1     # ... and zlib says why
+    if len(data) > 100:
+      comp = bytearray(zlib.compress(data, 6)); comp[-2] ^= 0x40                                       # Adler-32 mismatch
+      assert lib.geeco_inflate_fast(bytes(comp), len(comp), dst.ctypes.data, len(data) + 8) == -3
+  # not zlib streams at all: gzip, raw deflate, a preset dictionary header, garbage
+  co = zlib.compressobj(6, zlib.DEFLATED, -15)
+  raw_deflate = co.compress(b'hello' * 100) + co.flush()
+  cd = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_DEFAULT_STRATEGY, b'hello')
+  with_dict = cd.compress(b'hello' * 100) + cd.flush()
+  dst = np.empty(4096, np.uint8)
+  for bad in (gzip.compress(b'hello' * 100), raw_deflate, with_dict, b'not a zlib stream at all' * 10, b'\x78'):
+    assert lib.geeco_inflate_fast(bad, len(bad), dst.ctypes.data, 4096) == -3
+  # the reader: same episode with the decoder on and off (and the spare-buffer pool in between)
+  meta, _ = _make_dataset(str(tmp_path), n_eps=2, T=5, H=16, W=16)
+  got = []
+  for on in (1, 0, 1):
+    lib.geeco_host_set_fast_inflate(on)
+    got.append([I.load_episode(p, meta, True, raw_rgb=True) for p in _paths(str(tmp_path))])
+  lib.geeco_host_set_fast_inflate(1)
+  lib.geeco_host_release_buffers()
+  for a, b in zip(got[0] + got[0], got[1] + got[2]):
+    for k in a:
+      np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+
+
+def test_inflate_under_address_sanitizer(tmp_path):
+  """tests/native/fuzz_inflate.cpp: the decoder built with -fsanitize=address,undefined against 40 valid and ~3 900 damaged
+  streams (bit flips, truncations, overwritten stretches, damaged block headers): no access outside the buffers, nothing
+  accepted that zlib rejects or decodes differently.  (Sanitizers run on the CPU build only.)"""
+  import shutil, subprocess
+  if shutil.which('g++') is None:
+    pytest.skip('no g++')
+  here = os.path.dirname(os.path.abspath(__file__))
+  csrc = os.path.join(here, '..', 'geeco_amd', 'csrc')
+  exe = str(tmp_path / 'fuzz_inflate')
+  subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-I' + csrc,
+                  os.path.join(here, 'native', 'fuzz_inflate.cpp'), os.path.join(csrc, 'host_inflate.cpp'), '-lz', '-o', exe],
+                 check=True, timeout=300)
+  res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0, res.stdout + res.stderr
+  assert res.stdout.startswith('ok:'), res.stdout
+
+
 def test_episode_source_is_parallel_and_order_preserving(tmp_path, monkeypatch):
   """num_threads readers at once (geeco_gym.py:442-473 num_parallel_reads / num_parallel_calls), episodes delivered in
   list order whatever order the reads finish in, batches identical for every thread count."""
