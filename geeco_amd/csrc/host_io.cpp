@@ -21,6 +21,7 @@
 #include <vector>
 
 #if defined(__x86_64__)
+#include <immintrin.h>
 #include <nmmintrin.h>
 #endif
 
@@ -697,7 +698,7 @@ extern "C" int geeco_episode_read_i64(const geeco_episode* ep, const char* name,
 }
 
 // floats -> uint8 with the integrality test in the same pass; returns 1 iff every value was an integer in [0, 255]
-static int floats_to_u8(const uint8_t* src, uint8_t* dst, int64_t n) {
+static int floats_to_u8_scalar(const uint8_t* src, uint8_t* dst, int64_t n) {
   uint32_t bad = 0;
   for (int64_t i = 0; i < n; ++i) {
     float v;
@@ -709,6 +710,38 @@ static int floats_to_u8(const uint8_t* src, uint8_t* dst, int64_t n) {
     dst[i] = (uint8_t)k;
   }
   return bad ? 0 : 1;
+}
+
+#if defined(__x86_64__)
+// 32 floats -> 32 bytes per step (the scalar loop runs at 1.6 GB/s of floats: 48 ms of an episode's 0.27 s)
+__attribute__((target("avx2"))) static int floats_to_u8_avx2(const uint8_t* src, uint8_t* dst, int64_t n) {
+  const __m256i lanes = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7), hi = _mm256_set1_epi32(~255);
+  __m256i bad = _mm256_setzero_si256();
+  int64_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    __m256i k[4];
+    for (int j = 0; j < 4; ++j) {
+      const __m256 v = _mm256_loadu_ps(reinterpret_cast<const float*>(src + 4 * (i + 8 * j)));
+      k[j] = _mm256_cvttps_epi32(v);                                       // NaN / out of int range -> 0x80000000
+      const __m256 same = _mm256_cmp_ps(_mm256_cvtepi32_ps(k[j]), v, _CMP_EQ_OQ);
+      bad = _mm256_or_si256(bad, _mm256_or_si256(_mm256_and_si256(k[j], hi), _mm256_xor_si256(_mm256_castps_si256(same), _mm256_set1_epi32(-1))));
+    }
+    const __m256i w0 = _mm256_packus_epi32(k[0], k[1]), w1 = _mm256_packus_epi32(k[2], k[3]);   // saturating: < 0 -> 0, > 65535 -> 65535
+    const __m256i b = _mm256_permutevar8x32_epi32(_mm256_packus_epi16(w0, w1), lanes);
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), b);
+  }
+  int ok = _mm256_testz_si256(bad, bad);
+  if (i < n) ok &= floats_to_u8_scalar(src + 4 * i, dst + i, n - i);
+  return ok;
+}
+#endif
+
+static int floats_to_u8(const uint8_t* src, uint8_t* dst, int64_t n) {
+#if defined(__x86_64__)
+  static const int avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return floats_to_u8_avx2(src, dst, n);
+#endif
+  return floats_to_u8_scalar(src, dst, n);
 }
 
 extern "C" int geeco_episode_read_u8(const geeco_episode* ep, const char* name, uint8_t* dst, int64_t frames, int64_t vpf,

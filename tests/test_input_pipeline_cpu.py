@@ -71,7 +71,7 @@ def test_native_reader_non_integral_rgb_falls_back_to_float(tmp_path):
   from geeco_amd import tfrecord as T
   meta, eps = _make_dataset(str(tmp_path), n_eps=1, T=4, H=8, W=8)
   d = eps[0]
-  for bad in (0.5, -1.0, 256.0, float('nan'), 255.00002):
+  for bad in (0.5, -1.0, 256.0, float('nan'), 255.00002, float('inf'), 1e10, -1e10, 65536.0, 4294967296.0):
     rgb = d['rgb'].astype(np.float32)
     rgb[2, 3, 4, 1] = bad
     p = str(tmp_path / 'bad.tfrecord.zlib')
