@@ -55,7 +55,7 @@ def parse_args():
   ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
   ap.add_argument('--skip-input-pipeline', action='store_true', help='skip the input_pipeline leg (on-disk dataset -> Estimator.train)')
   ap.add_argument('--skip-inference', action='store_true', help='skip the inference leg (predictor latency, Estimator.evaluate)')
-  ap.add_argument('--pipeline-episodes', type=int, default=32, help='episode files of the generated on-disk dataset')
+  ap.add_argument('--pipeline-episodes', type=int, default=64, help='episode files of the generated on-disk dataset')
   ap.add_argument('--allow-shared-gpu', action='store_true',
                   help='REHEARSAL on a one-GPU box (tests/_dp_launch.py): do not refuse ranks that share a device')
   return ap.parse_args()
