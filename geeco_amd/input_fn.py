@@ -330,7 +330,7 @@ class FeedArena:
   def seal(self):
     import torch
     self.block = torch.zeros(max(self._size, self.ALIGN), dtype=torch.uint8, device=self.device)
-    self._stage = [torch.zeros(self.block.numel(), dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS)]
+    self._stage = [torch.zeros(self.block.numel(), dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS if self._layout else 0)]
     self._events = [None] * self.SLOTS                       # upload of slot i finished (host may rewrite its staging block)
     self._host = [{k: st.numpy()[off:off + nb].view(dt).reshape(shape) for k, (off, nb, dt, shape) in self._layout.items()}
                   for st in self._stage]
@@ -352,7 +352,7 @@ class FeedArena:
 
   def begin(self):
     i = self._turn % self.SLOTS
-    if self._events[i] is not None:
+    if self._layout and self._events[i] is not None:
       self._events[i].synchronize()
     self._open = True
 
@@ -367,6 +367,9 @@ class FeedArena:
 
   def flush(self):
     import torch
+    self._open = False
+    if not self._layout:          # nothing is fed through the arena (e.g. every input is a device tensor): no copy to queue
+      return
     i = self._turn % self.SLOTS
     self.block.copy_(self._stage[i], non_blocking=True)
     if self._events[i] is None:
