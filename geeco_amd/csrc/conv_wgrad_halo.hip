@@ -41,6 +41,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 struct WgradHaloParams {
   const float* x;
   const float* dz;
+  const float* zero;         // g_zero_page (its address as a kernel argument: no GOT load inside the tile loop)
   float* part;               // [G][S][9*Cin*Cout + Cout]
   long long gs_x, gs_dz;
   int N, H, W, Ho, Wo, Cin, Cout;
@@ -139,25 +140,30 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
       d_src[i] = (zr * p.Wo + zc) * Cout + co0 + quad * 4;
     }
   }
-  // one DMA piece (slot i of this wave) of tile (n_, ty_, tx_) into buffer buf
-  auto dma_piece = [&](int i, int buf, int n_, int ty_, int tx_) {
-    const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
-    const int k = wid + NW * i;                            // wave-uniform
-    if (k < NXP) {
-      const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * Cin;
-      const bool v = iy0 + d_a[i] < p.H && ix0 + d_b[i] < p.W;
-      const float* src = v ? xg + d_src[i] : g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sX + buf * X_F4 + k * 64), 16, 0, 0);
-    } else if (k < NXP + NZP) {
-      const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * Cout;
-      const bool v = ty_ * TH + d_a[i] < p.Ho && tx_ * TW + d_b[i] < p.Wo;
-      const float* src = v ? zg + d_src[i] : g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * Z_F4 + (k - NXP) * 64), 16, 0, 0);
-    }
-  };
+  // The DMA pieces of tile (n_, ty_, tx_) into buffer buf.  Everything that depends on the tile only - the two tile base
+  // addresses, the distances to the image edges, the zero page's offset from either base - is formed ONCE per tile in scalar
+  // registers; a piece is then two compares, a 64-bit select and an add per lane.  (Until round 4 every piece recomputed its
+  // 64-bit base from the kernel arguments and fetched the zero page's address through the GOT behind an s_waitcnt lgkmcnt(0):
+  // ~80 instructions and an SMEM round trip per piece, issued by all waves at the same point of the tile.)
   auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
+    const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
+    const float* xt = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * Cin;
+    const float* zt = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * Cout;
+    const long long zero_x = p.zero - xt, zero_z = p.zero - zt;            // element offsets of the zero page from the bases
+    const int hy = p.H - iy0, hx_ = p.W - ix0, zy = p.Ho - ty_ * TH, zx = p.Wo - tx_ * TW;
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) dma_piece(i, buf, n_, ty_, tx_);
+    for (int i = 0; i < NSLOT; ++i) {
+      const int k = wid + NW * i;                            // wave-uniform
+      if (k < NXP) {
+        const bool v = d_a[i] < hy && d_b[i] < hx_;
+        const long long off = v ? (long long)d_src[i] : zero_x;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xt + off), (lptr_t)(sX + buf * X_F4 + k * 64), 16, 0, 0);
+      } else if (k < NXP + NZP) {
+        const bool v = d_a[i] < zy && d_b[i] < zx;
+        const long long off = v ? (long long)d_src[i] : zero_z;
+        __builtin_amdgcn_global_load_lds((gptr_t)(zt + off), (lptr_t)(sZ + buf * Z_F4 + (k - NXP) * 64), 16, 0, 0);
+      }
+    }
   };
   auto advance = [&](int& n_, int& ty_, int& tx_) {
     if (++tx_ == p.tiles_x) {
@@ -380,6 +386,21 @@ int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, i
   if (!pl.variant) return 0;
   WgradHaloParams p = {};
   p.x = x; p.dz = dz; p.part = (float*)ws; p.gs_x = gs_x; p.gs_dz = gs_dz;
+  {
+    static const float* zero_page = nullptr;      // resolved once (idempotent: racing threads store the same address)
+    const float* z = __atomic_load_n(&zero_page, __ATOMIC_ACQUIRE);
+    if (!z) {
+      void* sym = nullptr;
+      hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_zero_page));
+      if (e != hipSuccess || !sym) {
+        geeco_set_error("hipGetSymbolAddress(g_zero_page) failed: %s", hipGetErrorString(e));
+        return (int)(e != hipSuccess ? e : hipErrorInvalidSymbol);
+      }
+      z = (const float*)sym;
+      __atomic_store_n(&zero_page, z, __ATOMIC_RELEASE);
+    }
+    p.zero = z;
+  }
   p.N = N; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2; p.Cin = Cin; p.Cout = Cout;
   p.tiles_x = cdiv(p.Wo, pl.TW); p.tiles_y = cdiv(p.Ho, pl.TH);
   p.tiles_per_group = N * p.tiles_x * p.tiles_y;
