@@ -688,15 +688,19 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
     d_hx[i] = (short)hx;
     d_src[i] = (rw * p.W + hx) * CIN + cq4 * 4;
   }
+  const float* zero_page = g_zero_page;             // its address ONCE, in scalar registers: referenced inside the tile loop the
+  asm volatile("" : "+s"(zero_page));              // compiler re-fetches it through the GOT (s_getpc + s_load + s_waitcnt lgkmcnt(0)) per DMA piece
   auto dma_chunk = [&](int buf, int g_, int n_, int ty_, int tx_, int chunk) {
     const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;      // TF SAME, stride 2, even input: pad_before = 0
     const float* xg = p.x + (long long)g_ * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN + chunk * 16;
+    const long long zero_x = zero_page - xg;             // tile-only values in scalar registers (as conv_wgrad_halo.hip)
+    const int hy = p.H - iy0, hx = p.W - ix0;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       if (wid + 8 * i < NPIECE) {                       // wave-uniform
-        const bool v = iy0 + d_hy[i] < p.H && ix0 + d_hx[i] < p.W;
-        const float* src = v ? xg + d_src[i] : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * BUF_F4 + (wid + 8 * i) * 64), 16, 0, 0);
+        const bool v = d_hy[i] < hy && d_hx[i] < hx;
+        const long long off = v ? (long long)d_src[i] : zero_x;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xg + off), (lptr_t)(sH + buf * BUF_F4 + (wid + 8 * i) * 64), 16, 0, 0);
       }
     }
   };
@@ -987,21 +991,27 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
       d_src[i] = ((px >> 4) * p.Wo + (px & 15)) * COUT + c4 * 4;
     }
   }
+  const float* zero_page = g_zero_page;             // its address ONCE, in scalar registers: referenced inside the tile loop the
+  asm volatile("" : "+s"(zero_page));              // compiler re-fetches it through the GOT (s_getpc + s_load + s_waitcnt lgkmcnt(0)) per DMA piece
   auto dma_tile = [&](int buf, int n_, int ty_, int tx_) {
     const int iy0 = ty_ * TH * 2, ix0 = tx_ * TW * 2;
     const float* xg = p.x + (long long)g * p.gs_x + (((long long)n_ * p.H + iy0) * p.W + ix0) * CIN;
     const float* zg = p.dz + (long long)g * p.gs_dz + (((long long)n_ * p.Ho + ty_ * TH) * p.Wo + tx_ * TW) * COUT;
+    // everything that depends on the tile only in scalar registers, once per tile; a piece is then two compares, a select
+    // between its own offset and the zero page's, and one 64-bit add (as conv_wgrad_halo.hip)
+    const long long zero_x = zero_page - xg, zero_z = zero_page - zg;
+    const int hy = p.H - iy0, hx = p.W - ix0, zy = p.Ho - ty_ * TH, zx = p.Wo - tx_ * TW;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const int k = wid + 8 * i;                          // wave-uniform
       if (k < NHP) {
-        const bool v = iy0 + d_a[i] < p.H && ix0 + d_b[i] < p.W;
-        const float* src = v ? xg + d_src[i] : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * HALO_F4 + k * 64), 16, 0, 0);
+        const bool v = d_a[i] < hy && d_b[i] < hx;
+        const long long off = v ? (long long)d_src[i] : zero_x;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xg + off), (lptr_t)(sH + buf * HALO_F4 + k * 64), 16, 0, 0);
       } else if (k < NHP + NZP) {
-        const bool v = ty_ * TH + d_a[i] < p.Ho && tx_ * TW + d_b[i] < p.Wo;
-        const float* src = v ? zg + d_src[i] : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sZ + buf * DZ_F4 + (k - NHP) * 64), 16, 0, 0);
+        const bool v = d_a[i] < zy && d_b[i] < zx;
+        const long long off = v ? (long long)d_src[i] : zero_z;
+        __builtin_amdgcn_global_load_lds((gptr_t)(zg + off), (lptr_t)(sZ + buf * DZ_F4 + (k - NHP) * 64), 16, 0, 0);
       }
     }
   };
