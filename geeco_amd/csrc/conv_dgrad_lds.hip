@@ -71,7 +71,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
   constexpr int CIB = 16 * NCIT;
   constexpr int W_F4 = 9 * NCIT * 64;               // [tap][ci tile][q 4][ci row 16]
   constexpr int NWP = 9 * NCIT;                     // one piece per (tap, ci tile)
-  constexpr int NSLOT = (NWP + NZP + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f32x4* sW = reinterpret_cast<f32x4*>(smem);       // 2 weight chunks
   f32x4* sZ = sW + 2 * W_F4;                        // 2 dz halo chunks
@@ -86,29 +85,34 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
   const int item_step = gridDim.x;
   if (item >= p.items) return;
 
-  // ---- DMA pieces of this wave: k = wid + 8 i; k < NWP: weight granules [64 k, +64), else dz granules ---------------
-  int d_off[NSLOT];
-  short d_a[NSLOT], d_b[NSLOT];      // dz pieces: frame-local row / col (-1 based) ; d_f: frame of the tile
-  signed char d_f[NSLOT];
+  // ---- DMA pieces of this wave.  Weight pieces kw = wid + NW i (i < NSW) and dz pieces kz = wid + NW j (j < NSZ) are numbered
+  // separately, so that a slot has ONE role for every wave and only the last slot of each kind needs a (wave-uniform) range test:
+  // with the combined numbering of rounds 2-4 every slot carried two scalar branches and the pointer of each piece travelled
+  // through v_mov chains between their arms (94 branches, 118 v_mov per 72 MFMAs in the chunk loop).
+  constexpr int NSW = (NWP + NW - 1) / NW, NSZ = (NZP + NW - 1) / NW;
+  __builtin_assume(wid >= 0 && wid < NW);
+  unsigned w_off[NSW];               // byte offset of this lane's granule from the chunk's weight base (uniform base + 32-bit lane offset)
+  int d_off[NSZ];
+  short d_a[NSZ], d_b[NSZ];          // dz pieces: frame-local row / col (-1 based) ; d_f: frame of the tile
+  signed char d_f[NSZ];
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) {
-    const int k = wid + NW * i;
-    if (k < NWP) {
-      // piece k = (tap, ci tile): lane = q * 16 + ci row
-      const int tap = k / NCIT, cit = k - tap * NCIT;
-      d_off[i] = (tap * Cin + cit * 16 + (lane & 15)) * Cout + (lane >> 4) * 4;
-      d_a[i] = 0; d_b[i] = 0; d_f[i] = 0;
-    } else {
-      const int sl = (k - NWP) * 64 + lane;         // granule index inside the dz image: q * NPIXP + pixel
-      const int qq = sl / NPIXP, px = sl - qq * NPIXP;
-      const int f = px / (IR * IC), rem = px - f * (IR * IC);
-      const int ir = rem / IC, ic = rem - ir * IC;
-      const bool ok = k < NWP + NZP && sl < Z_F4 && px < NPIX;
-      d_f[i] = (signed char)(ok ? f : 100);
-      d_a[i] = (short)(ir - 1);
-      d_b[i] = (short)(ic - 1);
-      d_off[i] = ((ir - 1) * p.Wo + (ic - 1)) * Cout + qq * 4;
-    }
+  for (int i = 0; i < NSW; ++i) {
+    const int k = wid + NW * i;       // piece k = (tap, ci tile): lane = q * 16 + ci row
+    const int tap = k / NCIT, cit = k - tap * NCIT;
+    w_off[i] = (unsigned)(((tap * Cin + cit * 16 + (lane & 15)) * Cout + (lane >> 4) * 4) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NSZ; ++j) {
+    const int k = wid + NW * j;
+    const int sl = k * 64 + lane;                   // granule index inside the dz image: q * NPIXP + pixel
+    const int qq = sl / NPIXP, px = sl - qq * NPIXP;
+    const int f = px / (IR * IC), rem = px - f * (IR * IC);
+    const int ir = rem / IC, ic = rem - ir * IC;
+    const bool ok = k < NZP && sl < Z_F4 && px < NPIX;
+    d_f[j] = (signed char)(ok ? f : 100);
+    d_a[j] = (short)(ir - 1);
+    d_b[j] = (short)(ic - 1);
+    d_off[j] = ((ir - 1) * p.Wo + (ic - 1)) * Cout + qq * 4;
   }
   // item -> (encoder g, ci block, frame n0, class-pixel origin Y0, X0)
   auto decode = [&](int it, int& g_, int& cib_, int& n0_, int& y0_, int& x0_) {
@@ -124,40 +128,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (NCIT == 4 ? 2 : 4)) void co
     y0_ = ty * (GPF * PR);
     x0_ = (tt - ty * p.tiles_x) * PC;
   };
-  // Source pointers of this wave's pieces for the NEXT chunk to fetch, set once per item (bounds tests, frame offsets:
-  // ~12 VALU instructions per piece) and then advanced by 16 channels per chunk (one 64-bit add per piece): address
-  // work inside the chunk loop is VALU work next to the MFMAs.  Lanes outside the image stay on the zero page (step 0).
-  const float* d_ptr[NSLOT];
-  int d_step[NSLOT];
+  // Sources of this wave's pieces for the NEXT chunk to fetch, set once per item and advanced by 16 channels per chunk: the
+  // weights as ONE uniform base (scalar add per chunk; lane offsets never change), the dz pieces as per-lane pointers (bounds
+  // tests, frame offsets: ~12 VALU instructions per piece and item; lanes outside the image stay on the zero page, step 0).
+  const float* w_next = nullptr;
+  const float* d_ptr[NSZ];
+  int d_step[NSZ];
   auto setup_item = [&](int g_, int cib_, int n0_, int y0_, int x0_) {
-    const float* wg = p.w + (long long)g_ * p.gs_w + (long long)cib_ * CIB * Cout;
+    w_next = p.w + (long long)g_ * p.gs_w + (long long)cib_ * CIB * Cout;
     const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n0_ * p.Ho + y0_) * p.Wo + x0_) * Cout;
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const int k = wid + NW * i;                   // wave-uniform
-      if (k < NWP) {
-        d_ptr[i] = wg + d_off[i];
-        d_step[i] = 16;
-      } else if (k < NWP + NZP) {
-        const int f = d_f[i];
-        const bool v = n0_ + f < p.N && (unsigned)(y0_ + d_a[i]) < (unsigned)p.Ho && (unsigned)(x0_ + d_b[i]) < (unsigned)p.Wo;
-        d_ptr[i] = v ? zg + (long long)f * p.Ho * p.Wo * Cout + d_off[i] : g_zero_page;
-        d_step[i] = v ? 16 : 0;
-      }
+    for (int j = 0; j < NSZ; ++j) {
+      const int f = d_f[j];
+      const bool v = n0_ + f < p.N && (unsigned)(y0_ + d_a[j]) < (unsigned)p.Ho && (unsigned)(x0_ + d_b[j]) < (unsigned)p.Wo;
+      d_ptr[j] = v ? zg + (long long)f * p.Ho * p.Wo * Cout + d_off[j] : g_zero_page;
+      d_step[j] = v ? 16 : 0;
     }
   };
-  auto dma_next = [&](int buf) {                    // the chunk d_ptr points at -> LDS buffer buf; then one chunk further
+  auto dma_next = [&](int buf) {                    // the chunk the sources point at -> LDS buffer buf; then one chunk further
+    const char* wb = reinterpret_cast<const char*>(w_next);
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const int k = wid + NW * i;                   // wave-uniform
-      if (k < NWP) {
-        __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[i], (lptr_t)(sW + buf * W_F4 + k * 64), 16, 0, 0);
-        d_ptr[i] += d_step[i];
-      } else if (k < NWP + NZP) {
-        __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[i], (lptr_t)(sZ + buf * ZP_F4 + (k - NWP) * 64), 16, 0, 0);
-        d_ptr[i] += d_step[i];
+    for (int i = 0; i < NSW; ++i)
+      if (NW * (i + 1) <= NWP || wid + NW * i < NWP)      // compile-time true except in the last slot
+        __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[i]), (lptr_t)(sW + buf * W_F4 + (wid + NW * i) * 64), 16, 0, 0);
+    w_next += 16;
+#pragma unroll
+    for (int j = 0; j < NSZ; ++j)
+      if (NW * (j + 1) <= NZP || wid + NW * j < NZP) {
+        __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[j], (lptr_t)(sZ + buf * ZP_F4 + (wid + NW * j) * 64), 16, 0, 0);
+        d_ptr[j] += d_step[j];
       }
-    }
   };
 
   // ---- this wave's pixel group and fragment offsets (in float4 granules) ----------------------------------------------
@@ -300,7 +300,7 @@ int geeco_dgrad_lds_handles(int H, int W, int Cin, int Cout, int stride) {
   if (disabled || stride != 2 || (H & 1) || (W & 1) || Cin % 64 != 0 || Cout % 16 != 0 || Cout < 32) return 0;
   const int Ho = H / 2, Wo = W / 2;
   if (!((Ho % 8 == 0 && Wo % 16 == 0) || (Ho == 8 && Wo == 8))) return 0;
-  if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 31)) return 0;
+  if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 30)) return 0;      // (weight granules are addressed by 32-bit BYTE offsets)
   return 1;
 }
 
@@ -346,7 +346,7 @@ static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* yma
   if (Ho % 8 == 0 && Wo % 16 == 0) variant = 1;          // 8 groups of 1 x 16 class pixels: a 16 x 32 input-pixel tile
   else if (Ho == 8 && Wo == 8) variant = 2;               // 2 x 8 groups: a tile = two whole frames
   if (!variant) return 0;
-  if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 31)) return 0;
+  if ((long long)H * W * Cin >= (1ll << 31) || (long long)Ho * Wo * Cout >= (1ll << 31) || 9ll * Cin * Cout >= (1ll << 30)) return 0;      // (weight granules are addressed by 32-bit BYTE offsets)
   DgradLdsParams p = {};
   p.dz = dz; p.w = w_hwio; p.mask = ymask; p.fields = fields; p.gs_fields = gs_fields; p.dx = dx; p.gs_dz = gs_dz; p.gs_w = gs_w; p.gs_dx = gs_dx;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cin = Cin; p.Cout = Cout;
