@@ -71,7 +71,6 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
   constexpr int COB = 16 * NCO * COT, ZQ = COB / 4;      // co block and its float4 granules per pixel
   constexpr int Z_F4 = TH * TW * ZQ;                     // dz tile: [pixel][ZQ granules]
   constexpr int NZP = Z_F4 / 64;
-  constexpr int NSLOT = (NXP + NZP + NW - 1) / NW;       // DMA pieces per wave and tile
   constexpr int KG = TW / 4;                             // k-groups (4 consecutive pixels) per tile row
   static_assert((ZQ == 16 || ZQ == 24 || ZQ == 32) && TW % 4 == 0 && Z_F4 % 64 == 0, "co block = 64, 96 or 128 channels");
   static_assert(XPQ >= CQ && (SWZ ? (XPQ == 16 && CQ == 16) : (XPQ % 4 == 2)), "x pixel pitch must be 8 (mod 16) floats or swizzled");
@@ -115,30 +114,33 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
     tx = rem - ty * p.tiles_x;
   }
 
-  // ---- this wave's DMA pieces k = wid + NW i: k < NXP -> halo granules [64 k, +64), else dz granules --------------
-  int d_src[NSLOT];
-  short d_a[NSLOT], d_b[NSLOT];       // halo: (row, column); dz: (tile row, tile column); 30000 = never valid
+  // ---- this wave's DMA pieces: halo pieces kx = wid + NW i (i < NSX, granules [64 kx, +64) of the x image) and dz pieces
+  // kz = wid + NW j (j < NSZ), numbered separately so that a slot has ONE role for every wave and only the last slot of each kind
+  // needs a (wave-uniform) range test (as conv_dgrad_lds.hip) -----------------------------------------------------------------
+  constexpr int NSX = (NXP + NW - 1) / NW, NSZ = (NZP + NW - 1) / NW;
+  __builtin_assume(wid >= 0 && wid < NW);
+  int x_src[NSX], z_src[NSZ];
+  short x_a[NSX], x_b[NSX], z_a[NSZ], z_b[NSZ];       // halo: (row, column); dz: (tile row, tile column); 30000 = never valid
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) {
-    const int k = wid + NW * i;
-    if (k < NXP) {
-      const int sl = k * 64 + lane;
-      const int rw = sl / (HX * XPQ), rem = sl - rw * (HX * XPQ);
-      const int hx = rem / XPQ, qs = rem - hx * XPQ;
-      const int quad = SWZ ? (qs ^ (((hx >> 1) & 1) << 2)) : qs;
-      const bool ok = sl < X_USED && quad < CQ;
-      d_a[i] = (short)(ok ? rw : 30000);
-      d_b[i] = (short)hx;
-      d_src[i] = (rw * p.W + hx) * Cin + ci0 + quad * 4;
-    } else {
-      const int f = (k - NXP) * 64 + lane;
-      const int px = f / ZQ, qs = f - px * ZQ;
-      const int zr = px / TW, zc = px - zr * TW;
-      const int quad = qs ^ ((zc & 1) << 2);
-      d_a[i] = (short)(k < NXP + NZP ? zr : 30000);
-      d_b[i] = (short)zc;
-      d_src[i] = (zr * p.Wo + zc) * Cout + co0 + quad * 4;
-    }
+  for (int i = 0; i < NSX; ++i) {
+    const int sl = (wid + NW * i) * 64 + lane;
+    const int rw = sl / (HX * XPQ), rem = sl - rw * (HX * XPQ);
+    const int hx = rem / XPQ, qs = rem - hx * XPQ;
+    const int quad = SWZ ? (qs ^ (((hx >> 1) & 1) << 2)) : qs;
+    const bool ok = sl < X_USED && quad < CQ;
+    x_a[i] = (short)(ok ? rw : 30000);
+    x_b[i] = (short)hx;
+    x_src[i] = (rw * p.W + hx) * Cin + ci0 + quad * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < NSZ; ++j) {
+    const int f = (wid + NW * j) * 64 + lane;
+    const int px = f / ZQ, qs = f - px * ZQ;
+    const int zr = px / TW, zc = px - zr * TW;
+    const int quad = qs ^ ((zc & 1) << 2);
+    z_a[j] = (short)zr;
+    z_b[j] = (short)zc;
+    z_src[j] = (zr * p.Wo + zc) * Cout + co0 + quad * 4;
   }
   // The DMA pieces of tile (n_, ty_, tx_) into buffer buf.  Everything that depends on the tile only - the two tile base
   // addresses, the distances to the image edges, the zero page's offset from either base - is formed ONCE per tile in scalar
@@ -152,18 +154,19 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
     const long long zero_x = p.zero - xt, zero_z = p.zero - zt;            // element offsets of the zero page from the bases
     const int hy = p.H - iy0, hx_ = p.W - ix0, zy = p.Ho - ty_ * TH, zx = p.Wo - tx_ * TW;
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const int k = wid + NW * i;                            // wave-uniform
-      if (k < NXP) {
-        const bool v = d_a[i] < hy && d_b[i] < hx_;
-        const long long off = v ? (long long)d_src[i] : zero_x;
-        __builtin_amdgcn_global_load_lds((gptr_t)(xt + off), (lptr_t)(sX + buf * X_F4 + k * 64), 16, 0, 0);
-      } else if (k < NXP + NZP) {
-        const bool v = d_a[i] < zy && d_b[i] < zx;
-        const long long off = v ? (long long)d_src[i] : zero_z;
-        __builtin_amdgcn_global_load_lds((gptr_t)(zt + off), (lptr_t)(sZ + buf * Z_F4 + (k - NXP) * 64), 16, 0, 0);
+    for (int i = 0; i < NSX; ++i)
+      if (NW * (i + 1) <= NXP || wid + NW * i < NXP) {      // compile-time true except in the last slot
+        const bool v = x_a[i] < hy && x_b[i] < hx_;
+        const long long off = v ? (long long)x_src[i] : zero_x;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xt + off), (lptr_t)(sX + buf * X_F4 + (wid + NW * i) * 64), 16, 0, 0);
       }
-    }
+#pragma unroll
+    for (int j = 0; j < NSZ; ++j)
+      if (NW * (j + 1) <= NZP || wid + NW * j < NZP) {
+        const bool v = z_a[j] < zy && z_b[j] < zx;
+        const long long off = v ? (long long)z_src[j] : zero_z;
+        __builtin_amdgcn_global_load_lds((gptr_t)(zt + off), (lptr_t)(sZ + buf * Z_F4 + (wid + NW * j) * 64), 16, 0, 0);
+      }
   };
   auto advance = [&](int& n_, int& ty_, int& tx_) {
     if (++tx_ == p.tiles_x) {
