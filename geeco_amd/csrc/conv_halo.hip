@@ -165,6 +165,7 @@ __global__ __launch_bounds__(512, RW ? 1 : 2) void conv_s2_halo_fwd_kernel(const
   };
 
   // this wave's LDS-DMA pieces: piece k = wid + 8 i covers halo slots [64 k, 64 k + 64); lane -> (hy, hx, cq)
+  __builtin_assume(wid >= 0 && wid < 8);
   int d_src[NSLOT];
   short d_hy[NSLOT], d_hx[NSLOT];
 #pragma unroll
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
     }
   };
 
+  __builtin_assume(wid >= 0 && wid < 8);
   int d_src[NSLOT];
   short d_hy[NSLOT], d_hx[NSLOT];
 #pragma unroll
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_fwd_chunked_kernel(const Hal
     const int hy = p.H - iy0, hx = p.W - ix0;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-      if (wid + 8 * i < NPIECE) {                       // wave-uniform
+      if (8 * (i + 1) <= NPIECE || wid + 8 * i < NPIECE) {      // compile-time true except in the last slot (wid < 8)
         const bool v = d_hy[i] < hy && d_hx[i] < hx;
         const long long off = v ? (long long)d_src[i] : zero_x;
         __builtin_amdgcn_global_load_lds((gptr_t)(xg + off), (lptr_t)(sH + buf * BUF_F4 + (wid + 8 * i) * 64), 16, 0, 0);
@@ -968,28 +970,31 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
     }
   };
 
-  // this wave's DMA pieces k = wid + 8 i: k < NHP -> halo slots [64 k, +64), else dz float4 [64 (k - NHP), +64)
-  int d_src[NSLOT];
-  short d_a[NSLOT], d_b[NSLOT];       // halo: (row, hx); dz: (tile row, tile column)
+  // this wave's DMA pieces: halo pieces kh = wid + 8 i (slots [64 kh, +64) of the halo image) and dz pieces kz = wid + 8 j
+  // (float4 [64 kz, +64) of the dz tile), numbered separately: one role per slot for every wave, a (wave-uniform) range test only
+  // in the last slot of each kind (as conv_wgrad_halo.hip / conv_dgrad_lds.hip)
+  constexpr int NSH = (NHP + 7) / 8, NSZ = (NZP + 7) / 8;
+  __builtin_assume(wid >= 0 && wid < 8);
+  int h_src[NSH], z_src[NSZ];
+  short h_a[NSH], h_b[NSH], z_a[NSZ], z_b[NSZ];       // halo: (row, hx); dz: (tile row, tile column)
 #pragma unroll
-  for (int i = 0; i < NSLOT; ++i) {
-    const int k = wid + 8 * i;
-    if (k < NHP) {
-      const int sl = k * 64 + lane;
-      const int rw = sl / ROW, rem = sl - rw * ROW;
-      const int pair = rem >> 4, u = (rem & 15) ^ ((pair & 3) << 2);
-      const int hx = 2 * pair + (u >> 3), cq = u & 7;
-      const bool ok = sl < HALO_USED && hx <= 2 * TW;
-      d_a[i] = (short)(ok ? rw : 30000);                 // out-of-range marker fails the per-tile bounds test
-      d_b[i] = (short)hx;
-      d_src[i] = (rw * p.W + hx) * CIN + cq * 4;
-    } else {
-      const int f = (k - NHP) * 64 + lane;
-      const int px = f / C4, c4 = f - px * C4;
-      d_a[i] = (short)(k < NHP + NZP ? (px >> 4) : 30000);
-      d_b[i] = (short)(px & 15);
-      d_src[i] = ((px >> 4) * p.Wo + (px & 15)) * COUT + c4 * 4;
-    }
+  for (int i = 0; i < NSH; ++i) {
+    const int sl = (wid + 8 * i) * 64 + lane;
+    const int rw = sl / ROW, rem = sl - rw * ROW;
+    const int pair = rem >> 4, u = (rem & 15) ^ ((pair & 3) << 2);
+    const int hx = 2 * pair + (u >> 3), cq = u & 7;
+    const bool ok = sl < HALO_USED && hx <= 2 * TW;
+    h_a[i] = (short)(ok ? rw : 30000);                 // out-of-range marker fails the per-tile bounds test
+    h_b[i] = (short)hx;
+    h_src[i] = (rw * p.W + hx) * CIN + cq * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < NSZ; ++j) {
+    const int f = (wid + 8 * j) * 64 + lane;
+    const int px = f / C4, c4 = f - px * C4;
+    z_a[j] = (short)(px >> 4);
+    z_b[j] = (short)(px & 15);
+    z_src[j] = ((px >> 4) * p.Wo + (px & 15)) * COUT + c4 * 4;
   }
   const float* zero_page = g_zero_page;             // its address ONCE, in scalar registers: referenced inside the tile loop the
   asm volatile("" : "+s"(zero_page));              // compiler re-fetches it through the GOT (s_getpc + s_load + s_waitcnt lgkmcnt(0)) per DMA piece
@@ -1002,18 +1007,19 @@ __global__ __launch_bounds__(512) void conv_s2_halo_wgrad_kernel(const HaloWgrad
     const long long zero_x = zero_page - xg, zero_z = zero_page - zg;
     const int hy = p.H - iy0, hx = p.W - ix0, zy = p.Ho - ty_ * TH, zx = p.Wo - tx_ * TW;
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      const int k = wid + 8 * i;                          // wave-uniform
-      if (k < NHP) {
-        const bool v = d_a[i] < hy && d_b[i] < hx;
-        const long long off = v ? (long long)d_src[i] : zero_x;
-        __builtin_amdgcn_global_load_lds((gptr_t)(xg + off), (lptr_t)(sH + buf * HALO_F4 + k * 64), 16, 0, 0);
-      } else if (k < NHP + NZP) {
-        const bool v = d_a[i] < zy && d_b[i] < zx;
-        const long long off = v ? (long long)d_src[i] : zero_z;
-        __builtin_amdgcn_global_load_lds((gptr_t)(zg + off), (lptr_t)(sZ + buf * DZ_F4 + (k - NHP) * 64), 16, 0, 0);
+    for (int i = 0; i < NSH; ++i)
+      if (8 * (i + 1) <= NHP || wid + 8 * i < NHP) {       // compile-time true except in the last slot
+        const bool v = h_a[i] < hy && h_b[i] < hx;
+        const long long off = v ? (long long)h_src[i] : zero_x;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xg + off), (lptr_t)(sH + buf * HALO_F4 + (wid + 8 * i) * 64), 16, 0, 0);
       }
-    }
+#pragma unroll
+    for (int j = 0; j < NSZ; ++j)
+      if (8 * (j + 1) <= NZP || wid + 8 * j < NZP) {
+        const bool v = z_a[j] < zy && z_b[j] < zx;
+        const long long off = v ? (long long)z_src[j] : zero_z;
+        __builtin_amdgcn_global_load_lds((gptr_t)(zg + off), (lptr_t)(sZ + buf * DZ_F4 + (wid + 8 * j) * 64), 16, 0, 0);
+      }
   };
 
   f32x4 dbsum[NDZ];
@@ -1490,6 +1496,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
   };
 
   // this wave's DMA pieces: piece k = wid + 8 i covers image slots [64 k, 64 k + 64); lane -> (hy, hx, quad)
+  __builtin_assume(wid >= 0 && wid < 8);
   int d_src[NSLOT];
   short d_hy[NSLOT], d_hx[NSLOT];
 #pragma unroll
@@ -1506,7 +1513,7 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
     const float* zg = p.dz + (long long)g_ * p.gs_dz + (((long long)n_ * p.Ho + oy0) * p.Wo + ox0) * COUT + chunk * 16;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-      if (wid + 8 * i < NPIECE) {                       // wave-uniform
+      if (8 * (i + 1) <= NPIECE || wid + 8 * i < NPIECE) {      // compile-time true except in the last slot (wid < 8)
         const int oy = oy0 + d_hy[i], ox = ox0 + d_hx[i];
         const bool v = (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
         const float* src = v ? zg + d_src[i] : g_zero_page;
