@@ -602,8 +602,10 @@ def input_pipeline_report(args, dev, synthetic_ms_per_step, workdir):
   # untimed: model build, eager warm-up steps, hipGraph capture (one episode, not cached)
   e.train(input_fn=lambda: I.pickplace_input_fn(root, 'warmup', 'train', seed=0, cache=False, **kw))
   epochs = []
+  import gc
   for ep in range(3):
     hits0 = I.EPISODE_CACHE.hits
+    gc.collect()        # a full collection now rather than in the middle of a 0.5 s epoch (the timed loop itself is untouched)
     e.train(input_fn=lambda: I.pickplace_input_fn(root, 'default', 'train', seed=ep, **kw))
     st = e.last_train_stats
     fps = st['steps'] * B * K / st['loop_seconds']
