@@ -52,10 +52,13 @@ def parse_args():
   ap.add_argument('--dp-serial', action='store_true',
                   help='N > 1: run the gradient exchange AFTER the backward instead of beside its bottom part (the timed '
                        'region then measures the serial step; comm.step_ms always reports both)')
+  ap.add_argument('--dp-three-graphs', action='store_true',
+                  help='N > 1: launch the exchange between three captured graphs (round 4) instead of capturing it into ONE step graph')
   ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
   ap.add_argument('--skip-input-pipeline', action='store_true', help='skip the input_pipeline leg (on-disk dataset -> Estimator.train)')
   ap.add_argument('--skip-inference', action='store_true', help='skip the inference leg (predictor latency, Estimator.evaluate)')
   ap.add_argument('--pipeline-episodes', type=int, default=64, help='episode files of the generated on-disk dataset')
+  ap.add_argument('--skip-dp-one-rank', action='store_true', help='skip the dp_one_rank leg (N = 1: three-graph step over a one-rank RCCL group)')
   ap.add_argument('--allow-shared-gpu', action='store_true',
                   help='REHEARSAL on a one-GPU box (tests/_dp_launch.py): do not refuse ranks that share a device')
   return ap.parse_args()
@@ -434,13 +437,13 @@ def build_model(model_name, channels, seq_len, batch, dev):
   return cfg, graph.E2EVMC(cfg, batch, dev, training=True)
 
 
-def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=True):
+def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=True, capture_exchange=None):
   """First optimiser step eager (its loss is the one checked against the oracle), second eager step + hipGraph capture,
   `warmup` untimed replays, then EXACTLY `steps` steps between barrier + synchronize on both sides."""
   import torch
   from geeco_amd import dist as gdist
   from geeco_amd.runtime import TrainStepRunner
-  runner = TrainStepRunner(model, use_graph=use_graph, warmup=2, overlap=overlap)
+  runner = TrainStepRunner(model, use_graph=use_graph, warmup=2, overlap=overlap, capture_exchange=capture_exchange)
   runner.step()
   torch.cuda.synchronize()
   first_loss = float(model.loss)
@@ -684,13 +687,47 @@ def inference_report(args, dev, estimator, dataset_root, input_kw, workdir):
   return out
 
 
+DP_MODES = (   # name, TrainStepRunner arguments, skip the exchange
+    ('overlap', dict(overlap=True), False),                                   # the default form: ONE graph, exchange captured
+    ('serial', dict(overlap=False), False),
+    ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # exchange launched between three graphs
+    ('three_graphs_serial', dict(overlap=False, capture_exchange=False), False),
+    ('overlap_reserve%d' % DP_RESERVE_PROBE, dict(overlap=True, reserved_cus=DP_RESERVE_PROBE), False),
+    ('no_exchange', dict(overlap=True, capture_exchange=False), True),        # three graphs, no all-reduce: the graph gaps alone
+)
+
+
+def dp_step_modes(args, model, timer):
+  """ms per step of the data-parallel step in every form the runner has (each one its own runner and its own captured
+  graphs on the same model and batch).  ``timer(fn)`` -> (ms, p10, p90).  The no_exchange form runs LAST: at N > 1 it
+  applies Adam to un-reduced gradients and the caller must put the replicas back in step afterwards."""
+  import torch
+  from geeco_amd.runtime import TrainStepRunner
+  modes, forms, info = {}, {}, None
+  for name, kw, skip in DP_MODES:
+    r = TrainStepRunner(model, use_graph=not args.no_graph, warmup=2, dp=True, **kw)
+    r.skip_allreduce = skip
+    r.prepare()
+    for _ in range(3):
+      r.step()
+    torch.cuda.synchronize()
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+      torch.distributed.barrier()
+    modes[name] = timer(r.step)
+    forms[name] = r.bucket_info()['graphs_per_step']
+    if name == 'overlap':
+      info = r.bucket_info()
+    del r
+  return modes, forms, info
+
+
 def comm_report(args, model, runner, dev, world, step_ms):
-  """N > 1 (every rank takes part): the exchange alone, and the step in BOTH orders of the exchange plus without it, so
-  that one multi-GPU call shows whether RCCL beside the persistent 255-block kernels of the bottom backward helps."""
+  """N > 1 (every rank takes part): the exchange alone, and the step in every form of the exchange (one graph with the
+  exchange captured / three graphs with the exchange between them, each overlapped and serial), with CUs reserved for RCCL
+  and without any exchange, so that one multi-GPU call shows what each choice is worth on that node."""
   import torch
   from geeco_amd import dist as gdist
   iters = max(5, min(args.steps, 20))
-  g = model.store.grads
 
   def exchange():
     for w in runner._exchange_early() + runner._exchange_late():
@@ -698,16 +735,8 @@ def comm_report(args, model, runner, dev, world, step_ms):
   exchange()
   torch.distributed.barrier()
   ar_ms = gdist.max_over_ranks(time_region(exchange, iters), dev)
-  modes = {}
-  main_mode = runner.overlap
-  for name, overlap, skip in (('overlap', True, False), ('serial', False, False), ('no_exchange', True, True)):
-    runner.overlap, runner.skip_allreduce = overlap, skip
-    for _ in range(3):
-      runner.step()
-    torch.cuda.synchronize()
-    torch.distributed.barrier()
-    modes[name] = round(gdist.max_over_ranks(time_region(runner.step, iters), dev), 4)
-  runner.overlap, runner.skip_allreduce = main_mode, False
+  modes, forms, _ = dp_step_modes(args, model, lambda fn: (gdist.max_over_ranks(time_region(fn, iters), dev), None, None))
+  modes = {k: round(v[0], 4) for k, v in modes.items()}
   # the no_exchange probe applied Adam to UN-reduced per-rank gradients (the batches differ per rank): the replicas have diverged.
   # Put them back in step before anything else runs on this model: parameters and optimiser state from rank 0.
   torch.cuda.synchronize()
@@ -718,25 +747,90 @@ def comm_report(args, model, runner, dev, world, step_ms):
   torch.cuda.synchronize()
   if getattr(model, 'enc', None) is not None:
     model.enc.refresh_derived()
-  # the same overlapped step with the two persistent bottom-of-the-backward kernels leaving RESERVE CUs free for RCCL's
-  # workgroups (new graphs captured with the smaller grids; the timed region above always runs with 0 reserved)
-  from geeco_amd.runtime import TrainStepRunner
-  r2 = TrainStepRunner(model, use_graph=runner.use_graph, warmup=2, overlap=True, reserved_cus=DP_RESERVE_PROBE)
-  r2.prepare()
-  for _ in range(3):
-    r2.step()
-  torch.cuda.synchronize()
-  torch.distributed.barrier()
-  modes['overlap_reserve%d' % DP_RESERVE_PROBE] = round(gdist.max_over_ranks(time_region(r2.step, iters), dev), 4)
-  del r2
   wire = 4 * sum(n for _, n in runner.early_calls) + (runner.staging.numel() * 4 if runner.staging is not None else 0)
-  return {'mode': 'overlap' if main_mode else 'serial', 'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(g.numel() * 4),
+  timed = ('overlap' if runner.overlap else 'serial') if runner.capture_exchange else \
+          ('three_graphs_overlap' if runner.overlap else 'three_graphs_serial')
+  rk = 'overlap_reserve%d' % DP_RESERVE_PROBE
+  return {'mode': 'overlap' if runner.overlap else 'serial', 'timed_form': timed, 'graphs_per_step': forms,
+          'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(model.store.grads.numel() * 4),
           'allreduce_bytes_on_the_wire': int(wire),
           'bus_GB/s': round(2.0 * (world - 1) / world * wire / (ar_ms * 1e-3) / 1e9, 1),
           'step_ms': modes, 'step_ms_without_allreduce': modes['no_exchange'],
           'allreduce_exposed_ms': round(max(step_ms - modes['no_exchange'], 0.0), 4),
           'overlap_gain_ms': round(modes['serial'] - modes['overlap'], 4),
-          'reserve_gain_ms': round(modes['overlap'] - modes['overlap_reserve%d' % DP_RESERVE_PROBE], 4), 'buckets': runner.bucket_info()}
+          'one_graph_gain_ms': round(modes['three_graphs_overlap'] - modes['overlap'], 4),
+          'reserve_gain_ms': round(modes['overlap'] - modes[rk], 4), 'buckets': runner.bucket_info()}
+
+
+def dp_one_rank_report(args, model, runner, dev):
+  """world == 1: the FIXED cost of the data-parallel form of the step, on this GPU, in this process.  A ONE-rank RCCL group
+  is formed in-process (the sum over one rank is the identity), and the SAME batch goes through the step exactly as every
+  rank of an N-GPU run executes it (runtime.TrainStepRunner(dp=True)): the 30.2 MB early bucket and the 177 KB late bucket as
+  real RCCL all-reduce launches, in every form the runner has -- ONE graph with the exchange captured (what an N > 1 run
+  times; exchange overlapped with part 2 / serial), three graphs with the exchange launched between them (round 4's form),
+  and three graphs with no exchange (what the two inter-graph gaps alone cost).  ``delta_vs_single_graph_us`` is everything
+  an N-GPU step pays on top of the single-GPU step EXCEPT wire time, so single / (dp step + exposed wire time) bounds the
+  scaling efficiency.  Every number is the median of `samples` HIP-event pairs, each around 5 back-to-back steps."""
+  import torch
+  from geeco_amd import dist as gdist
+  if gdist.group_active():
+    return {'status': 'skipped: a process group is already active'}
+  samples = max(10, min(args.steps, 30))
+  with socket.socket() as s_:
+    s_.bind(('127.0.0.1', 0))
+    port = s_.getsockname()[1]
+  saved = {k: os.environ.get(k) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK=str(dev.index or 0), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  out = {}
+  try:
+    for _ in range(3):
+      runner.step()
+    single = time_launches(runner.step, samples)
+    assert gdist.init_from_env('nccl', device_index=dev.index or 0, single_rank_group=True) == 1 and gdist.group_active()
+    out['backend'] = torch.distributed.get_backend()
+    modes, forms, info = dp_step_modes(args, model, lambda fn: time_launches(fn, samples))
+    single2 = time_launches(runner.step, samples)           # the single graph again, now with RCCL's threads alive
+    from geeco_amd.runtime import TrainStepRunner
+    r_dp = TrainStepRunner(model, use_graph=False, dp=True)
+
+    def early():
+      for w in r_dp._exchange_early():
+        w.wait()
+
+    def late():
+      for w in r_dp._exchange_late():
+        w.wait()
+    early(), late()
+    ar_early, ar_late = time_launches(early, samples), time_launches(late, samples)
+    us = lambda t: round(t[0] * 1e3, 1)
+    one = min(single[0], single2[0])
+    out.update({
+        'status': 'ok', 'graphs_per_step': forms, 'buckets': info,
+        'single_graph_ms': round(single[0], 4), 'single_graph_ms_with_rccl_threads': round(single2[0], 4),
+        'ms_per_step': {k: round(v[0], 4) for k, v in modes.items()},
+        'ms_per_step_p10_p90': {k: [round(v[1], 4), round(v[2], 4)] for k, v in modes.items()},
+        'delta_vs_single_graph_us': {k: round((v[0] - one) * 1e3, 1) for k, v in modes.items()},
+        'allreduce_us_one_rank': {'early_%d_bytes' % (4 * sum(n for _, n in r_dp.early_calls)): us(ar_early),
+                                  'late_%d_bytes' % (4 * r_dp.staging.numel() if r_dp.staging is not None else 0): us(ar_late)},
+        'efficiency_bound_wire_hidden': round(one / modes['overlap'][0], 4),
+        'note': 'one rank: RCCL launches both all-reduces for real (launch floor) but moves no bytes over xGMI; at N > 1 add the '
+                'exposed wire time of the late bucket (and of the early one if it outlasts part 2, ~0.85 ms of kernels)'})
+    del r_dp
+  except Exception as e:        # this leg must never take the headline line with it
+    out.update({'status': 'failed: %s: %s' % (type(e).__name__, str(e)[:300])})
+  finally:
+    try:
+      torch.cuda.synchronize()
+      if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    except Exception as e:
+      out['destroy'] = 'failed: %s' % str(e)[:200]
+    for k, v in saved.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
+  return out
 
 
 def main():
@@ -746,6 +840,12 @@ def main():
 
   import torch
   from geeco_amd import dist as gdist
+
+  # stdout carries exactly ONE line, the JSON: libraries that print to fd 1 on their own (RCCL writes its version banner
+  # there when a communicator is created) go to stderr for the rest of the run
+  sys.stdout.flush()
+  json_fd = os.dup(1)
+  os.dup2(2, 1)
 
   world = gdist.init_from_env('nccl')      # a launcher that formed the group already (tests/_dp_launch.py) is respected
   rank = gdist.rank()
@@ -772,7 +872,8 @@ def main():
   synthetic_batch(model, 1234 + rank)
   log('model built: %d parameters, batch %d/GPU, world %d' % (model.store.count_parameters(), args.batch, world))
 
-  r = timed_steps(model, args.steps, args.warmup, not args.no_graph, not args.dp_serial, world, dev)
+  r = timed_steps(model, args.steps, args.warmup, not args.no_graph, not args.dp_serial, world, dev,
+                  capture_exchange=False if args.dp_three_graphs else None)
   runner, dt, per_step = r['runner'], r['dt'], r['per_step']
   first_loss, loss, total_steps = r['first_loss'], r['final_loss'], r['total_steps']
   log('timed region: %d steps in %.3f s' % (args.steps, dt))
@@ -792,7 +893,7 @@ def main():
         'config': {'workload': '%s %s %dx%d seq_len=%d batch=%d/GPU (global %d), fwd+bwd+allreduce+Adam' %
                                (args.model, 'rgb' if args.channels == 3 else 'rgbd', cfg.img_height, cfg.img_width,
                                 args.seq_len, args.batch, world * args.batch),
-                   'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, 'params': model.store.count_parameters()},
+                   'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, 'graphs_per_step': runner.bucket_info()['graphs_per_step'], 'params': model.store.count_parameters()},
         'step_ms': {'median': round(percentile(per_step, 0.5), 4), 'p10': round(percentile(per_step, 0.1), 4),
                     'p90': round(percentile(per_step, 0.9), 4), 'timer': 'HIP events per step, rank 0'},
         'final_loss': round(loss, 6),
@@ -817,6 +918,9 @@ def main():
                                 'ms': round(ms_enc, 3), 'frames': model.enc.G * model.enc.Nf}
       out['step_frac_of_f32_mfma_peak'] = round(step_flop(args.channels, model.enc.G * model.enc.Nf) / (ms_step * 1e-3) / 1e12
                                                 / PEAK_F32_MFMA_TFLOPS, 4)
+    if world == 1 and not args.skip_dp_one_rank:
+      out['dp_one_rank'] = dp_one_rank_report(args, model, runner, dev)
+      log('dp_one_rank: %s' % json.dumps({k: out['dp_one_rank'].get(k) for k in ('status', 'single_graph_ms', 'ms_per_step', 'delta_vs_single_graph_us', 'allreduce_us_one_rank')}))
     if world == 1 and not args.skip_other_configs:
       del runner, r
       out['other_configs'], ok2 = other_configs(args, dev)
@@ -838,8 +942,14 @@ def main():
         shutil.rmtree(workdir, ignore_errors=True)
     if world == 1 and not args.skip_cpu:
       out['cpu_baseline'] = cpu_baseline(args)
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
+  # N > 1: ranks 1..N-1 have nothing to do after the timed region and the comm report; they wait here ON THE HOST (no
+  # collective pending, GPUs idle) until rank 0 has finished its tables and printed the line, then all ranks leave together
+  gdist.host_rendezvous('bench_done')
   if torch.distributed.is_available() and torch.distributed.is_initialized():
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
     torch.distributed.destroy_process_group()
   sys.exit(rc)
 

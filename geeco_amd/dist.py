@@ -49,6 +49,10 @@ def init_from_env(backend=None, device_index=None, single_rank_group=False):
   return ws
 
 
+def backend() -> str:
+  return dist.get_backend() if dist.is_available() and dist.is_initialized() else ''
+
+
 def group_active() -> bool:
   """True when collectives go through a backend (also for a one-rank group)."""
   return dist.is_available() and dist.is_initialized()
@@ -128,6 +132,26 @@ def gather_strings(value: str, device, width=96):
   out = [torch.zeros_like(t) for _ in range(world_size())]
   dist.all_gather(out, t)
   return [bytes(o.cpu().tolist()).rstrip(b'\0').decode(errors='replace') for o in out]
+
+
+def host_rendezvous(tag: str, timeout_s: float = 3600.0, poll_s: float = 0.05):
+  """Every rank blocks ON THE HOST until all ranks have arrived at `tag` -- a counter in the rendezvous store the group was
+  formed through (no collective is enqueued, so a rank that waits here for tens of seconds while another finishes its
+  GPU-side post-processing keeps its GPU idle and RCCL's watchdog has nothing pending to time out on).  One-rank groups
+  and processes without a group return at once.  Falls back to a backend barrier if the store is not reachable."""
+  if world_size() == 1:
+    return
+  import time
+  try:
+    store = dist.distributed_c10d._get_default_store()
+    store.add(tag, 1)
+    t0 = time.monotonic()
+    while int(store.add(tag, 0)) < world_size():
+      if time.monotonic() - t0 > timeout_s:
+        raise TimeoutError('host_rendezvous(%r): %d of %d ranks after %.0f s' % (tag, int(store.add(tag, 0)), world_size(), timeout_s))
+      time.sleep(poll_s)
+  except (AttributeError, RuntimeError):
+    dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:

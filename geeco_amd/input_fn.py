@@ -224,12 +224,15 @@ class DeviceWindows:
 
   def __init__(self, K, frame_shape, divisor, squeeze_k=False):
     self.K, self.frame_shape, self.divisor, self.squeeze_k = K, tuple(frame_shape), float(divisor), squeeze_k
-    self.segments = []      # (device tensor [T, frame_elems], np.int32 starts)
+    self.segments = []      # (device tensor [T, frame_elems], np.int32 starts, divisor of THIS segment's frames)
     self.n = 0
 
-  def add(self, frames_dev, starts):
+  def add(self, frames_dev, starts, divisor=None):
+    """``divisor``: what the gather divides this segment's frames by (default: the constructor's).  One batch can hold
+    episodes stored as uint8 (255) next to episodes kept as float32 (1): a batch that straddles two such episodes is
+    gathered segment by segment with each one's own divisor (and is then not ``is_u8()``: dense path)."""
     starts = np.asarray(starts, np.int32)
-    self.segments.append((frames_dev, starts))
+    self.segments.append((frames_dev, starts, self.divisor if divisor is None else float(divisor)))
     self.n += len(starts)
 
   @property
@@ -241,8 +244,8 @@ class DeviceWindows:
 
   @staticmethod
   def concat(a, b):
-    if a.divisor != b.divisor:
-      raise ValueError('DeviceWindows.concat: segments with different divisors (%g, %g)' % (a.divisor, b.divisor))
+    if (a.K, a.frame_shape, a.squeeze_k) != (b.K, b.frame_shape, b.squeeze_k):
+      raise ValueError('DeviceWindows.concat: windows of different shapes (%s, %s)' % (a.shape[1:], b.shape[1:]))
     out = DeviceWindows(a.K, a.frame_shape, a.divisor, a.squeeze_k)
     out.segments = a.segments + b.segments
     out.n = a.n + b.n
@@ -251,15 +254,16 @@ class DeviceWindows:
   def is_u8(self):
     """Every segment is resident uint8 frames (the recorder's values; the consumer divides by 255)."""
     import torch
-    return bool(self.segments) and self.divisor == 255.0 and all(
-        f is not None and f.dtype == torch.uint8 and f.is_contiguous() for f, _ in self.segments)
+    return bool(self.segments) and all(
+        f is not None and d == 255.0 and f.dtype == torch.uint8 and f.is_contiguous() for f, _, d in self.segments)
 
   def addresses(self, device):
     """int64 address of each window's first frame (WindowFeed.pointers(): the input kernel follows them)."""
     fe = int(np.prod(self.frame_shape))
     out = np.empty(self.n, np.int64)
     off = 0
-    for frames_dev, starts in self.segments:
+    device = resolve_device(device)
+    for frames_dev, starts, _ in self.segments:
       if frames_dev.device != device:
         raise RuntimeError('DeviceWindows: episode frames live on %s but the model on %s (each rank must upload to its '
                            'own GPU)' % (frames_dev.device, device))
@@ -276,7 +280,7 @@ class DeviceWindows:
     from . import ops
     fe = int(np.prod(self.frame_shape))
     off = 0
-    for frames_dev, starts in self.segments:
+    for frames_dev, starts, divisor in self.segments:
       n = len(starts)
       if frames_dev is None:
         raise RuntimeError('DeviceWindows: this image stream was not uploaded (device_keys excluded it)')
@@ -284,7 +288,7 @@ class DeviceWindows:
         raise RuntimeError('DeviceWindows: episode frames live on %s but the batch buffer on %s (each rank must '
                            'upload to its own GPU)' % (frames_dev.device, out.device))
       st = torch.as_tensor(starts).to(out.device, non_blocking=True)
-      ops.gather_windows_into(out[off:off + n], frames_dev, st, n, self.K, fe, self.divisor)
+      ops.gather_windows_into(out[off:off + n], frames_dev, st, n, self.K, fe, divisor)
       off += n
 
   def numpy(self):
@@ -311,8 +315,7 @@ class FeedArena:
   ALIGN = 256
 
   def __init__(self, device):
-    import torch
-    self.device = torch.device(device)
+    self.device = resolve_device(device)      # indexed (a bare 'cuda' never compares equal to a tensor's cuda:N)
     self._layout = {}       # key -> (offset, nbytes, np dtype, shape)
     self._size = 0
     self.block = None
@@ -396,7 +399,11 @@ class WindowFeed:
     self.shape = tuple(windows.shape)
     self.table = self.buffer = None
     self._want_table = False
-    self._live = collections.deque(maxlen=2)    # the batches whose frames a queued replay may still read
+    # The batches whose frames a QUEUED replay may still read through the address table: the host runs up to
+    # FeedArena.SLOTS feeds ahead of the device, so that many (+ the one being written) stay referenced here.  The uploads
+    # of the prefetch thread and the replays share the default stream today (the caching allocator then orders any reuse
+    # behind the replays anyway); this bound does not rely on that.
+    self._live = collections.deque(maxlen=FeedArena.SLOTS + 1)
     if self.u8:
       arena.reserve(key, (self.n,), np.int64)
 

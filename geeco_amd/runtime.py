@@ -66,10 +66,19 @@ class TrainStepRunner:
   beside part 2 (default); False = both buckets after part 2 (``bench.py --dp-serial``: the difference between the two
   is what the overlap buys on a given node)."""
 
-  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True, reserved_cus=0):
+  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True, reserved_cus=0, capture_exchange=None):
     """``reserved_cus``: CUs the two persistent kernels of part 2 leave to the collective that runs beside them (0 = none;
-    a launch argument of those kernels, applied around THIS runner's part 2 only)."""
+    a launch argument of those kernels, applied around THIS runner's part 2 only).  ``capture_exchange``: capture the
+    whole data-parallel step -- the three parts AND both all-reduces, the early one as a branch beside part 2 -- into ONE
+    hipGraph (RCCL's launches are stream work like any other; the fork to the communicator's stream and the joins become
+    graph edges): one graph launch per step instead of three and no host-side stream joins (measured at one rank, bench.py
+    ``dp_one_rank``: +28 us over the single-GPU step instead of +87).  ``overlap`` / ``skip_allreduce`` are then fixed at
+    capture time.  None (default) = whenever the backend's launches can be captured (RCCL); if that capture fails the runner
+    says so once and captures the three-graph form.  False = three graphs with the exchange launched between them."""
     self.model = model
+    if capture_exchange is None:
+      capture_exchange = gdist.group_active() and gdist.backend() == 'nccl'
+    self.capture_exchange = bool(capture_exchange)
     self.reserved_cus = int(reserved_cus)
     self.world = gdist.world_size()
     model.world = self.world
@@ -109,7 +118,8 @@ class TrainStepRunner:
       self.early_calls = list(self.early)
 
   def bucket_info(self):
-    return {'early_bytes': 4 * sum(n for _, n in self.early), 'early_ranges': len(self.early),
+    return {'graphs_per_step': (1 if (self.capture_exchange or not self.dp) else 3) if self.use_graph else 0,
+            'early_bytes': 4 * sum(n for _, n in self.early), 'early_ranges': len(self.early),
             'early_allreduce_calls': len(self.early_calls), 'early_bytes_on_the_wire': 4 * sum(n for _, n in self.early_calls),
             'late_bytes': 4 * sum(n for _, n in self.late), 'late_ranges': len(self.late),
             'late_written_in_place': self.redirected, 'mode': 'overlap' if self.overlap else 'serial'}
@@ -165,20 +175,47 @@ class TrainStepRunner:
       return []
     return [gdist.allreduce_async(self.staging)]
 
+  def _dp_step(self, run=None):
+    """The data-parallel step: ``run`` = the three parts as callables (captured graphs' replays or the eager functions)."""
+    run = run or [self._part1, self._part2, self._part3]
+    run[0]()
+    works = self._exchange_early() if self.overlap else []   # on the communicator's stream, behind part 1, beside part 2
+    run[1]()
+    if not self.overlap:
+      works = self._exchange_early()
+    works += self._exchange_late()
+    for w in works:
+      w.wait()                             # the compute stream waits; the host does not (RCCL)
+    run[2]()
+
   def _parts(self):
-    return [self._part1, self._part2, self._part3] if self.dp else [self._whole_step]
+    if not self.dp:
+      return [self._whole_step]
+    return [self._dp_step] if self.capture_exchange else [self._part1, self._part2, self._part3]
 
   def _capture(self):
     # the warm-up steps before this call already ran eagerly
     # single process: the whole step is one graph (no inter-graph launch gap); data parallel: the exchange sits between
-    graphs = []
-    with CAPTURE_LOCK:
-      for fn in self._parts():
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
-          fn()
-        graphs.append(g.replay)
-    self._graphs = graphs
+    def capture(parts):
+      graphs = []
+      with CAPTURE_LOCK:
+        for fn in parts:
+          g = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+            fn()
+          graphs.append(g.replay)
+      return graphs
+    if self.dp and self.capture_exchange:
+      try:
+        self._graphs = capture(self._parts())
+        return
+      except Exception as e:           # a backend whose collectives cannot be captured: the three-graph form always can
+        import warnings
+        warnings.warn('TrainStepRunner: capturing the exchange into the step graph failed (%s: %s); using three graphs '
+                      'with the exchange between them' % (type(e).__name__, str(e)[:200]))
+        self.capture_exchange = False
+        torch.cuda.synchronize()
+    self._graphs = capture(self._parts())
 
   def prepare(self):
     """Untimed set-up for benchmarks: run the eager warm-up steps and capture the graphs now, so that
@@ -193,18 +230,10 @@ class TrainStepRunner:
       self._capture()
     self._calls += 1
     run = self._graphs if self._graphs is not None else self._parts()
-    if not self.dp:
+    if len(run) == 1:
       run[0]()
-      return
-    run[0]()
-    works = self._exchange_early() if self.overlap else []   # on the communicator's stream, behind part 1, beside part 2
-    run[1]()
-    if not self.overlap:
-      works = self._exchange_early()
-    works += self._exchange_late()
-    for w in works:
-      w.wait()                             # the compute stream waits; the host does not (RCCL)
-    run[2]()
+    else:
+      self._dp_step(run)
 
   def null_step(self):
     """A step of a rank that holds no sample (ragged end of an epoch under data parallelism): zero gradients into

@@ -69,7 +69,35 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   d = json.loads(line[0])
   assert d['n_gpus'] == 2 and 'REHEARSAL' in d['data'] and len(d['ranks']['ms_per_step']) == 2 and d['ranks']['distinct_devices'] == 1
   c = d['comm']
-  assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'no_exchange', 'overlap_reserve16'}
+  assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'three_graphs_overlap', 'three_graphs_serial',
+                                                         'no_exchange', 'overlap_reserve16'}
+  # gloo's collectives cannot be captured: every form of this rehearsal is the three-graph one (RCCL: tests/test_dp_gpu.py)
+  assert c['timed_form'] == 'three_graphs_serial' and set(c['graphs_per_step'].values()) == {3} and d['config']['graphs_per_step'] == 3
   assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c
   assert c['buckets']['early_allreduce_calls'] == 1 and c['buckets']['late_written_in_place']
   assert d['roofline']['kernel'] and d['roofline']['frac'] > 0 and len(d['layers']) >= 20      # rank 0's table, at any N
+
+
+def test_bench_one_gpu_line_and_dp_one_rank_leg():
+  """``python bench.py`` at N = 1 on a small batch: stdout is EXACTLY one line (RCCL's banner and everything else goes to
+  stderr), and the line carries the ``dp_one_rank`` object: the data-parallel step over a one-rank RCCL group formed inside
+  the bench process, one graph with the exchange captured next to round 4's three graphs."""
+  import json
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '2', '--batch', '2', '--seq-len', '4',
+                        '--skip-cpu', '--skip-other-configs', '--skip-input-pipeline', '--skip-inference'],
+                       capture_output=True, text=True, timeout=600, env=env)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  lines = out.stdout.splitlines()
+  assert len(lines) == 1, lines[:5]
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 1 and d['config']['graphs_per_step'] == 1 and 'roofline' in d
+  o = d['dp_one_rank']
+  assert o['status'] == 'ok' and o['backend'] == 'nccl', o
+  assert o['graphs_per_step']['overlap'] == 1 and o['graphs_per_step']['three_graphs_overlap'] == 3
+  assert set(o['ms_per_step']) == set(o['delta_vs_single_graph_us']) == {n for n, _, _ in __import__('bench').DP_MODES}
+  assert all(v > 0 for v in o['ms_per_step'].values()) and len(o['allreduce_us_one_rank']) == 2

@@ -280,3 +280,47 @@ def test_ragged_schedule_null_steps_world4():
     for r in range(world):
       np.testing.assert_allclose(res[r][1][s], want, rtol=2e-6, err_msg='step %d rank %d' % (s, r))
       np.testing.assert_array_equal(res[r][1][s], res[0][1][s])
+
+
+# ----------------------------------------------------------------------------------------------------
+# bench.py's exit protocol at N > 1: ranks 1..N-1 wait on the HOST (a counter in the rendezvous store, no collective
+# enqueued) until rank 0 has finished its post-processing; nobody leaves before the last rank has arrived.
+# ----------------------------------------------------------------------------------------------------
+def _rendezvous_worker(rank, world, port, q):
+  import time
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from geeco_amd import dist as gdist
+  assert gdist.init_from_env('gloo') == world
+  if rank == 0:
+    time.sleep(1.5)                      # rank 0's tables
+  t_arrive = time.time()
+  gdist.host_rendezvous('bench_done')
+  t_leave = time.time()
+  gdist.host_rendezvous('second_tag')    # tags are independent counters
+  dist.barrier()
+  dist.destroy_process_group()
+  q.put((rank, t_arrive, t_leave))
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_host_rendezvous_all_ranks_leave_together(world):
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29950 + os.getpid() % 40 + world
+  procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = sorted(q.get(timeout=120) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  last_arrival = max(a for _, a, _ in res)
+  assert all(l >= last_arrival for _, _, l in res)                 # nobody left before the slowest rank arrived
+  assert min(a for _, a, _ in res) < last_arrival - 1.0            # (the others really did wait)
+
+
+def test_host_rendezvous_without_a_group_returns():
+  sys.path.insert(0, ROOT)
+  from geeco_amd import dist as gdist
+  gdist.host_rendezvous('nobody')

@@ -172,13 +172,14 @@ def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
 
 
 # ----------------------------------------------------------------------------------------------------
-# The data-parallel step through the REAL backend string: "nccl" (= RCCL) with ONE rank.  Three captured graphs
+# The data-parallel step through the REAL backend string: "nccl" (= RCCL) with ONE rank.  ONE captured graph that holds the
+# exchange too (the default with RCCL) and three captured graphs with the exchange between them
 # (thread_local capture mode beside RCCL's watchdog thread), the early bucket as ONE all-reduce over the arena span, the
 # late bucket written in place into its staging buffer, both orders of the exchange.  RCCL refuses two ranks on one
 # device, so one rank is all a one-GPU box can give; the sum over one rank is the identity, hence BITWISE equality
 # with the plain one-graph step.
 # ----------------------------------------------------------------------------------------------------
-def _rccl_worker(port, overlap, q):
+def _rccl_worker(port, overlap, one_graph, q):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                     HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -193,7 +194,9 @@ def _rccl_worker(port, overlap, q):
   model.store.initialize(seed=9)
   gdist.broadcast_variables(model.store)
   model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
-  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap)
+  # default (None) = the exchange captured into the step graph whenever the backend is RCCL; False = round 4's three graphs
+  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap, capture_exchange=None if one_graph else False)
+  assert runner.capture_exchange == one_graph
   info = runner.bucket_info()
   losses = []
   for i in range(5):
@@ -213,23 +216,25 @@ def _rccl_worker(port, overlap, q):
     assert model.enc.late is None and model.enc.reserved_cus == 0 and np.isfinite(float(model.loss))
     assert not torch.equal(before, model.store.params)
     model.store.params.copy_(before)      # (the comparison below is about the first runner's five steps)
-  q.put((model.store.params.detach().cpu().numpy(), losses, info, runner._graphs is not None and len(runner._graphs) == 3))
+  q.put((model.store.params.detach().cpu().numpy(), losses, info, runner._graphs is not None and len(runner._graphs) == (1 if one_graph else 3)
+         and runner.capture_exchange == one_graph))
   torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap', [True, False], ids=['overlap', 'serial'])
-def test_three_graph_step_over_rccl_one_rank(dev, overlap):
+@pytest.mark.parametrize('overlap,one_graph', [(True, True), (False, True), (True, False), (False, False)],
+                         ids=['one graph overlap', 'one graph serial', 'three graphs overlap', 'three graphs serial'])
+def test_dp_step_over_rccl_one_rank(dev, overlap, one_graph):
   from geeco_amd import graph
   from geeco_amd.params import create_e2evmc_config
   from geeco_amd.runtime import TrainStepRunner
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  p = ctx.Process(target=_rccl_worker, args=(32800 + os.getpid() % 1000 + (0 if overlap else 1), overlap, q))
+  p = ctx.Process(target=_rccl_worker, args=(32800 + os.getpid() % 1000 + 2 * int(one_graph) + int(overlap), overlap, one_graph, q))
   p.start()
   params, losses, info, three = q.get(timeout=600)
   p.join(timeout=120)
   assert p.exitcode == 0
-  assert three and info['early_allreduce_calls'] == 1 and info['late_written_in_place'] and info['late_ranges'] == 3
+  assert three and info['graphs_per_step'] == (1 if one_graph else 3) and info['early_allreduce_calls'] == 1 and info['late_written_in_place'] and info['late_ranges'] == 3
   assert info['mode'] == ('overlap' if overlap else 'serial')
   feats, labels = _batch(4)
   model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, dev, training=True)
