@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, _dev.env('GEECO_LIB', 'libgeeco_hip.so'))   # GEE
 
 
 GEECO_EINVAL, GEECO_ENOSUP = -1, -2      # include/geeco_hip.h
-ABI_VERSION = 4        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
+ABI_VERSION = 5        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
 
 
 class GeecoNativeError(RuntimeError):
@@ -39,6 +39,7 @@ class SlabReduce(Structure):
 SIGNATURES = {
     'geeco_abi_version': (_I, []),
     'geeco_last_error': (c_char_p, []),
+    'geeco_has_dev_kernels': (_I, []),
     'geeco_debug_kernel_trace_begin': (None, []),
     'geeco_debug_kernel_trace_end': (c_char_p, []),
     'geeco_dynimg_alpha': (None, [_I, _P]),
@@ -77,7 +78,6 @@ SIGNATURES = {
     'geeco_conv3x3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     'geeco_relu_fields_elems': (_L, [_I, _I, _I]),
     'geeco_conv2_fwd_relu_fields': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
-    'geeco_conv1_conv2_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P]),
     'geeco_conv3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_relu_bits_rows': (_L, [_I]),
     'geeco_conv1_fwd_relu_bits': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds the C-ABI shared library for gfx950 in-tree (geeco_amd/libgeeco_hip.so).
+# Builds the C-ABI shared library for gfx950 in-tree (geeco_amd/libgeeco_hip.so): the PRODUCT kernel set only -- no GEECO_*
+# switch is compiled in and no kernel that only a switch could select (those live in scripts/dev/build_dev_lib.sh's library).
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libgeeco_hip.so
@@ -13,12 +14,12 @@ FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -ml
 extra_flags() {
   case $1 in
     conv_gemm) echo "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
-    conv_halo|conv_dgrad_lds|conv_bottom_fwd) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+    conv_halo|conv_dgrad_lds) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
   esac
 }
 rm -rf build && mkdir -p build
 pids=()
-for f in conv_gemm conv_halo conv_bottom_fwd conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
+for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
   $HIPCC $FLAGS $(extra_flags $f) -c $f.hip -o build/$f.o &
   pids+=($!)
 done

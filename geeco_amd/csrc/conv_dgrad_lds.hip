@@ -389,12 +389,20 @@ static int dgrad_lds_impl(const float* dz, const float* w_hwio, const float* yma
     p.n_cib = Cin / 32;
     p.items = (int)(2 * items64);
     const int blocks = p.items < 512 ? p.items : 512;
+#ifdef GEECO_DEV_KERNELS      // variant 2 only gets here with GEECO_DGRAD_NO_SMALL (two-frame tiles of the 8 x 8 layers)
     rc = variant == 1 ? launch_dgrad_lds<1, 16, 1, 2>(p, blocks, stream) : launch_dgrad_lds<2, 8, 2, 2>(p, blocks, stream);
+#else
+    rc = launch_dgrad_lds<1, 16, 1, 2>(p, blocks, stream);
+#endif
   } else {
     p.n_cib = Cin / 64;
     p.items = (int)items64;
     const int blocks = p.items < 256 ? p.items : 256;
+#ifdef GEECO_DEV_KERNELS
     rc = variant == 1 ? launch_dgrad_lds<1, 16, 1, 4>(p, blocks, stream) : launch_dgrad_lds<2, 8, 2, 4>(p, blocks, stream);
+#else
+    rc = launch_dgrad_lds<1, 16, 1, 4>(p, blocks, stream);
+#endif
   }
   if (rc) return rc;
   GEECO_LAUNCH_CHECK();

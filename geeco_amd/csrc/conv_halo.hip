@@ -582,6 +582,7 @@ static int launch_s2_halo_fwd_ws(HaloFwdParams& p, hipStream_t s) {
   return 0;
 }
 
+#ifdef GEECO_DEV_KERNELS      // the pre-warp-specialised conv2 forward (GEECO_HALO_WS=0, GEECO_HALO_RW): development build only
 template <int CIN, int COUT, bool RW>
 static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
   constexpr int CQ = CIN / 4;
@@ -603,15 +604,18 @@ static int launch_s2_halo_fwd_v(HaloFwdParams& p, hipStream_t s) {
   GEECO_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
 template <int CIN, int COUT>
 static int launch_s2_halo_fwd(HaloFwdParams& p, hipStream_t s) {
+#ifdef GEECO_DEV_KERNELS
   static const int rw = geeco_dev_getenv("GEECO_HALO_RW") ? atoi(geeco_dev_getenv("GEECO_HALO_RW")) : 1;   // measured +2.4..3.6 % on the launch
   // loader waves (0 = the kernels above): 4 measured +3.5 % on the launch, 2 are too few (-5 %)
   static const int ws = geeco_dev_getenv("GEECO_HALO_WS") ? atoi(geeco_dev_getenv("GEECO_HALO_WS")) : 4;
-  if (ws == 4) return launch_s2_halo_fwd_ws<CIN, COUT, 4>(p, s);
   if (ws == 2) return launch_s2_halo_fwd_ws<CIN, COUT, 2>(p, s);
-  return rw ? launch_s2_halo_fwd_v<CIN, COUT, true>(p, s) : launch_s2_halo_fwd_v<CIN, COUT, false>(p, s);
+  if (ws != 4) return rw ? launch_s2_halo_fwd_v<CIN, COUT, true>(p, s) : launch_s2_halo_fwd_v<CIN, COUT, false>(p, s);
+#endif
+  return launch_s2_halo_fwd_ws<CIN, COUT, 4>(p, s);      // 8 compute waves + 4 loader waves
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -252,9 +252,11 @@ extern "C" int geeco_conv3x3_wgrad(const float* x, const float* dz, float* dw, f
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)p.S, (unsigned)(p.row_tiles * p.col_tiles), (unsigned)groups);
   switch (BC) {
+#ifdef GEECO_DEV_KERNELS      // GEECO_WGRAD_BIG: 128-row / 128-column tiles (measured ~1.5 % of the step slower)
     case 128128: geeco_note_kernel("conv_wgrad_kernel<128, 128, 16>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 16>), grid, dim3(256), 0, s, p); break;
     case 128064: geeco_note_kernel("conv_wgrad_kernel<128, 64, 16>"); hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 16>), grid, dim3(256), 0, s, p); break;
     case 64128: geeco_note_kernel("conv_wgrad_kernel<64, 128, 16>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 16>), grid, dim3(256), 0, s, p); break;
+#endif
     case 64064: geeco_note_kernel("conv_wgrad_kernel<64, 64, 32>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32>), grid, dim3(256), 0, s, p); break;
     case 64048: geeco_note_kernel("conv_wgrad_kernel<64, 48, 32>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 48, 32>), grid, dim3(256), 0, s, p); break;
     case 64032: geeco_note_kernel("conv_wgrad_kernel<64, 32, 64>"); hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64>), grid, dim3(256), 0, s, p); break;

@@ -421,12 +421,16 @@ int geeco_try_wgrad_lds(const float* x, const float* dz, float* dw, float* db, i
       default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true, 2, 2>(p, blocks, stream); break;
     }
   } else {
+#ifdef GEECO_DEV_KERNELS      // GEECO_WGRAD_BPC=2: single-buffered images, two blocks per CU
     switch (pl.variant) {
       case 1: rc = launch_wgrad_lds<3, 4, 1, 2, 16, 14, false, 1, 6>(p, blocks, stream); break;
       case 4: rc = launch_wgrad_lds<3, 4, 1, 4, 8, 14, false, 1, 6>(p, blocks, stream); break;
       case 2: rc = launch_wgrad_lds<4, 2, 2, 2, 16, 16, true, 1, 4>(p, blocks, stream); break;
       default: rc = launch_wgrad_lds<4, 2, 2, 4, 8, 16, true, 1, 4>(p, blocks, stream); break;
     }
+#else
+    return 0;                 // (unreachable: the product plan never asks for two blocks per CU)
+#endif
   }
   if (rc) return rc;
   GEECO_LAUNCH_CHECK();

@@ -12,12 +12,22 @@ void geeco_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+#ifdef GEECO_DEV_KERNELS
 const char* geeco_dev_getenv(const char* name) {
   static const bool dev = [] {
     const char* v = getenv("GEECO_DEV");
     return v && v[0] && strcmp(v, "0") != 0;
   }();
   return dev ? getenv(name) : nullptr;
+}
+#endif
+// 1: this library was built with the development kernel variants and reads GEECO_* switches under GEECO_DEV=1; 0: product library
+extern "C" int geeco_has_dev_kernels(void) {
+#ifdef GEECO_DEV_KERNELS
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 // CUs the persistent bottom-of-the-backward kernels leave free: an ARGUMENT of the entry points that launch them (round 4; a

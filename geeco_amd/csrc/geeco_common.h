@@ -15,9 +15,16 @@ void geeco_note_kernel(const char* fmt, ...);
 // conv_wgrad.hip: while set (per thread), geeco_launch_wgrad_reduce records the slab sum there instead of launching it
 void geeco_set_pending_reduce(geeco_slab_reduce* p);
 
-// Development switches (kernel-variant A/B, forced tile shapes; DESIGN.md lists them): the environment is consulted ONLY when
-// GEECO_DEV=1 is set; a production process ignores every GEECO_* variable and always runs the measured-best path.
+// Development switches (kernel-variant A/B, forced tile shapes; scripts/dev/SWITCHES.md lists them).  They exist only in the
+// DEVELOPMENT build of the library (scripts/dev/build_dev_lib.sh: -DGEECO_DEV_KERNELS -> libgeeco_hip_dev.so), where the
+// environment is consulted when GEECO_DEV=1 is set.  In the product library (csrc/build.sh) geeco_dev_getenv is the constant
+// nullptr: every fork below folds to the measured-best path at compile time, the kernels only a switch could select are not
+// compiled in (their launch code sits under #ifdef GEECO_DEV_KERNELS), and no GEECO_* variable is ever read.
+#ifdef GEECO_DEV_KERNELS
 const char* geeco_dev_getenv(const char* name);
+#else
+static inline constexpr const char* geeco_dev_getenv(const char*) { return nullptr; }
+#endif
 
 // CUs the persistent bottom-of-the-backward kernels leave free: the `reserved_cus` argument of the entry point being served on this
 // thread (errors.cpp; 0 outside such a call)

@@ -287,8 +287,10 @@ struct FeatureList {
 
 // Spare output buffers of closed episodes.  An inflated episode is ~105 MB: beyond glibc's mmap threshold, so every malloc of one is
 // a fresh mapping whose 26 k pages fault in one by one while the decoder writes (~40 ms per episode, 10 % of reading it); a buffer a
-// closed episode hands back is already mapped.  Bounded: at most kSpareMax buffers / kSpareBytes bytes are kept.
-static const size_t kSpareMax = 32, kSpareBytes = (size_t)6 << 30;
+// closed episode hands back is already mapped.  Bounded: at most g_spare_max buffers (one per reader thread + 1) / kSpareBytes
+// bytes are kept, and the reader frees them all when an epoch's last episode has been read (geeco_host_release_buffers).
+static const size_t kSpareBytes = (size_t)6 << 30;
+static size_t g_spare_max = 8;            // geeco_host_set_buffer_limit: the reader sets it to its thread count + 1
 static pthread_mutex_t g_spare_mu = PTHREAD_MUTEX_INITIALIZER;
 static std::vector<std::pair<uint8_t*, size_t>> g_spare;
 static size_t g_spare_bytes = 0;
@@ -317,13 +319,31 @@ static void take_spare(Buf* b, size_t want) {
 static void give_spare(Buf* b) {
   if (!b->p) return;
   pthread_mutex_lock(&g_spare_mu);
-  if (g_spare.size() < kSpareMax && g_spare_bytes + b->cap <= kSpareBytes) {
+  if (g_spare.size() < g_spare_max && g_spare_bytes + b->cap <= kSpareBytes) {
     g_spare.emplace_back(b->p, b->cap);
     g_spare_bytes += b->cap;
     b->p = nullptr;
     b->cap = b->n = 0;
   }
   pthread_mutex_unlock(&g_spare_mu);
+}
+
+extern "C" void geeco_host_set_buffer_limit(int max_buffers) {
+  pthread_mutex_lock(&g_spare_mu);
+  g_spare_max = (size_t)(max_buffers < 0 ? 0 : max_buffers > 64 ? 64 : max_buffers);
+  while (g_spare.size() > g_spare_max) {
+    g_spare_bytes -= g_spare.back().second;
+    free(g_spare.back().first);
+    g_spare.pop_back();
+  }
+  pthread_mutex_unlock(&g_spare_mu);
+}
+
+extern "C" int geeco_host_spare_buffers(void) {
+  pthread_mutex_lock(&g_spare_mu);
+  int n = (int)g_spare.size();
+  pthread_mutex_unlock(&g_spare_mu);
+  return n;
 }
 
 extern "C" void geeco_host_release_buffers(void) {

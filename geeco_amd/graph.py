@@ -200,16 +200,6 @@ class ConvEncoderStack:
       self.sides = [torch.cuda.Stream(device=dev) for _ in range(nside)] if dev.type == 'cuda' else []
       if self.fused_bottom:
         self.fws_fused = torch.empty(ops.conv2_dgrad_conv1_wgrad_ws_bytes(G) // 4 + 4, **f32)
-    # encoder bottom forward (conv1 -> conv2) in one launch: conv2's MFMAs are fed from an LDS image of y1 that conv1 waves of the
-    # same workgroup produce (csrc/conv_bottom_fwd.hip); bitwise the results of the two separate launches.  Measured (round 4,
-    # DESIGN 5.3b): 534 us alone against 156 + 379 in the step = no gain (step 3.3200 vs 3.3196 ms) -- conv2's forward is bound by
-    # SIMD issue, not by reading y1, so conv1's MFMAs / VALU simply add to it.  Kept as a tested entry point, OFF by default
-    # (GEECO_FUSED_FWD=1 under GEECO_DEV=1 turns it on for A/Bs).
-    L0, L1 = self.layers[0], self.layers[1]
-    self.fused_fwd = (_dev.env('GEECO_FUSED_FWD') is not None and _dev.env('GEECO_NO_HALO') is None and _dev.env('GEECO_HALO_WS') is None
-                      and self.Cpad == 4 and self.Cin in (3, 4) and (L0['Cout'], L0['stride']) == (32, 1)
-                      and (L1['Cout'], L1['stride']) == (48, 2) and L1['H'] % 2 == 0 and L1['W'] % 2 == 0
-                      and L1['H'] * L1['W'] * 4 < 2 ** 31)
     fsb = max(ops.conv3x3_fwd_ws_bytes(G, Nf, L['H'], L['W'], L['Cin'], L['Cout'], L['stride']) for L in self.layers)
     self.fws = torch.empty(fsb // 4 + 4, **f32)
 
@@ -323,20 +313,6 @@ class ConvEncoderStack:
     ops.conv3x3_fwd_into(y, x, w, self._b(l), G, x[0].numel(), gs_w, self.gs_p, y[0].numel(), Nf, L['H'], L['W'],
                          L['Cin'], L['Cout'], L['stride'], relu=True, ws=self.fws)
 
-  def launch_fwd_bottom(self):
-    """conv1 -> conv2 in one launch (``fused_fwd``): y1, y2 and, in training, conv1's sign words / conv2's sign fields."""
-    G, Nf, L0 = self.G, self.Nf, self.layers[0]
-    x, y1, y2 = self.x_in, self.acts[0], self.acts[1]
-    if self.pad1 and self.pad1_copy:
-      w1, gs_w1, w_cin = self.w1p, self.w1p[0].numel(), 4
-    else:
-      w1, gs_w1, w_cin = self._w(0), self.gs_p, self.Cin
-    bits = self.bits1 if (self.training and self.relu_bits) else None
-    fields = self.fields2 if (self.training and self.relu_fields) else None
-    ops.conv1_conv2_fwd_into(y1, bits, y2, fields, x, w1, self._b(0), self._w(1), self._b(1), G, x[0].numel(), gs_w1, self.gs_p,
-                             y1[0].numel(), bits[0].numel() if bits is not None else 0, self.gs_p, self.gs_p, y2[0].numel(),
-                             fields[0].numel() if fields is not None else 0, Nf, L0['H'], L0['W'], w_cin)
-
   def launch_wgrad(self, l, pending=None):
     """Filter + bias gradient of layer l (skipped for conv1 when the encoder bottom is fused: launch_dgrad(1) does it).
     ``pending`` (a list): the kernel's final slab sum is deferred to ``ops.slab_reduce_batch(pending)``."""
@@ -429,12 +405,8 @@ class ConvEncoderStack:
     Returns True if it did (else the caller launches the concat)."""
     if not self.lazy_refresh or self.derived_version != self.store.version:
       self.refresh_derived()
-    first = 0
-    if self.fused_fwd:
-      self.launch_fwd_bottom()
-      first = 2
     top = len(self.layers) - 1
-    for l in range(first, top):
+    for l in range(top):
       self.launch_fwd(l)
     if state is not None and self.concat_in_top and not self.split_top:
       G, Nf, L = self.G, self.Nf, self.layers[top]

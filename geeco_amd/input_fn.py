@@ -664,6 +664,7 @@ class _EpisodeSource:
     self.device, self.image_keys, self.cache = device, tuple(image_keys), cache
     self.num_threads = max(int(num_threads or 1), 1)
     self._pool = ThreadPoolExecutor(max_workers=self.num_threads, thread_name_prefix='geeco-reader')
+    self._reads = 0
 
   def _read(self, path):
     staged = []
@@ -688,6 +689,10 @@ class _EpisodeSource:
         if self.device is not None and self.cache is not None:
           key = self.cache.key(path, self.device, self.fetch_target, self.image_keys)
           entry = self.cache.get(key)
+        if entry is None:
+          if not self._reads:     # the reader keeps one mapped inflate buffer (~105 MB) per thread + 1 between episodes
+            tfrecord._host().geeco_host_set_buffer_limit(self.num_threads + 1)
+          self._reads += 1
         pending.append((path, key, entry if entry is not None else self._pool.submit(self._read, path)))
         return
 
@@ -714,7 +719,12 @@ class _EpisodeSource:
       for _, _, item in pending:
         if not isinstance(item, tuple):
           item.cancel()
-      self._pool.shutdown(wait=False)
+      # reads already running finish (they cannot be interrupted inside the native reader), then the reader's spare inflate
+      # buffers go back to the OS: once every episode sits in the HBM cache no reader runs again, and under data parallelism
+      # every rank would otherwise hold its own pool for the rest of training
+      self._pool.shutdown(wait=True)
+      if self._reads:
+        tfrecord._host().geeco_host_release_buffers()
 
 
 def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size=4, fetch_target=False,

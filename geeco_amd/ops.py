@@ -341,14 +341,6 @@ def conv2_fwd_relu_fields_into(y, fields, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs
                                            H, W, _stream()), 'geeco_conv2_fwd_relu_fields')
 
 
-def conv1_conv2_fwd_into(y1, bits, y2, fields, x, w1, b1, w2, b2, G, gs_x, gs_w1, gs_b1, gs_y1, gs_bits, gs_w2, gs_b2, gs_y2,
-                         gs_fields, N, H, W, w_cin):
-  """Encoder bottom forward in one launch (conv1 -> conv2, y1 halo through LDS); bits / fields may be None."""
-  check(_lib().geeco_conv1_conv2_fwd(_p(x), _p(w1), _p(b1), _p(y1), _p(bits) if bits is not None else None, _p(w2), _p(b2), _p(y2),
-                                     _p(fields) if fields is not None else None, G, gs_x, gs_w1, gs_b1, gs_y1, gs_bits, gs_w2,
-                                     gs_b2, gs_y2, gs_fields, N, H, W, w_cin, _stream()), 'geeco_conv1_conv2_fwd')
-
-
 def conv3_dgrad_relu_fields_into(dx, dz, w, fields, G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W):
   """conv3 input gradient (48 -> 64, stride 2) masked by the sign fields of conv2's output; H, W = dims of dx."""
   check(_lib().geeco_conv3_dgrad_relu_fields(_p(dz), _p(w), _p(fields), _p(dx), G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W,

@@ -27,7 +27,7 @@ import zlib
 import numpy as np
 
 _HOST_LIB = None
-_HOST_ABI_VERSION = 3      # include/geeco_host.h: GEECO_HOST_ABI_VERSION
+_HOST_ABI_VERSION = 4      # include/geeco_host.h: GEECO_HOST_ABI_VERSION
 
 
 def _host():
@@ -71,6 +71,10 @@ def _host():
     lib.geeco_episode_read_u8.argtypes = [c.c_void_p, c.c_char_p, c.c_void_p, c.c_int64, c.c_int64, c.POINTER(c.c_int)]
     lib.geeco_inflate.restype = c.c_int64
     lib.geeco_inflate.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_int]
+    lib.geeco_host_set_buffer_limit.restype = None
+    lib.geeco_host_set_buffer_limit.argtypes = [c.c_int]
+    lib.geeco_host_release_buffers.restype = None
+    lib.geeco_host_release_buffers.argtypes = []
     lib.geeco_inflate_fast.restype = c.c_int64
     lib.geeco_inflate_fast.argtypes = [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]
     lib.geeco_host_set_fast_inflate.restype = None

@@ -24,13 +24,17 @@
 extern "C" {
 #endif
 
-#define GEECO_ABI_VERSION 4   /* = the build round that last changed the entry points or their calling conventions */
+#define GEECO_ABI_VERSION 5   /* = the build round that last changed the entry points or their calling conventions */
 
 #define GEECO_EINVAL  (-1)   /* bad shape / alignment / null pointer */
 #define GEECO_ENOSUP  (-2)   /* shape outside what the kernels were built for */
 
 int geeco_abi_version(void);
 const char* geeco_last_error(void);
+/* 0: the product library (csrc/build.sh): only the kernels the measured-best path launches, no environment variable is ever
+ * read.  1: the development build (scripts/dev/build_dev_lib.sh, -DGEECO_DEV_KERNELS), which also holds every A/B kernel
+ * variant and reads the GEECO_* switches of scripts/dev/SWITCHES.md when GEECO_DEV=1 is set. */
+int geeco_has_dev_kernels(void);
 
 /* Diagnostics (bench.py's per-layer table): between _begin and _end on one host thread every
  * conv entry point records the names of the kernels it dispatched; _end returns them ';'-separated
@@ -250,15 +254,6 @@ int64_t geeco_relu_fields_elems(int N, int H, int W);
 int geeco_conv2_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint16_t* fields, int groups,
                                 int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_fields, int N, int H,
                                 int W, void* stream);
-/* conv1 -> conv2 of the encoder (graph.py:76-85) in ONE launch: geeco_conv1_fwd_relu_bits[_rgb] followed by
- * geeco_conv2_fwd_relu_fields, bitwise the same y1 / bits / y2 / fields, without conv2 reading y1 back from memory (the
- * y1 halo of a conv2 tile is produced in LDS by conv1 waves beside the conv2 waves; y1 is still written: conv2's filter
- * gradient reads it).  x [G][N][H][W][4] (channel-padded), w1 [G][9][w_cin][32] with w_cin = 3 (the RGB variable as stored)
- * or 4, w2 [G][9][32][48]; bits / fields may be NULL (evaluation / prediction).  H, W even. */
-int geeco_conv1_conv2_fwd(const float* x, const float* w1, const float* b1, float* y1, uint32_t* bits, const float* w2,
-                          const float* b2, float* y2, uint16_t* fields, int groups, int64_t gs_x, int64_t gs_w1,
-                          int64_t gs_b1, int64_t gs_y1, int64_t gs_bits, int64_t gs_w2, int64_t gs_b2, int64_t gs_y2,
-                          int64_t gs_fields, int N, int H, int W, int w_cin, void* stream);
 int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_t* y2_fields, float* dx, int groups,
                                   int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H, int W,
                                   void* stream);

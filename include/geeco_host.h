@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GEECO_HOST_ABI_VERSION 3
+#define GEECO_HOST_ABI_VERSION 4
 
 int geeco_host_abi_version(void);
 const char* geeco_host_last_error(void);
@@ -73,7 +73,11 @@ int64_t geeco_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, in
 int64_t geeco_inflate_fast(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
 /* 0: geeco_episode_open inflates with zlib only (A/B measurements, tests); 1 (default): table-driven decoder first. */
 void geeco_host_set_fast_inflate(int on);
-/* geeco_episode_close keeps up to 32 inflate buffers (<= 6 GiB) mapped for the next geeco_episode_open; this frees them. */
+/* geeco_episode_close keeps up to `max_buffers` inflate buffers (default 8, <= 6 GiB in all) mapped for the next
+ * geeco_episode_open (the reader sets its thread count + 1); geeco_host_release_buffers frees the ones kept now (the reader
+ * calls it when an epoch's last episode has been read: once every episode sits in the HBM cache no reader runs again). */
+void geeco_host_set_buffer_limit(int max_buffers);
+int geeco_host_spare_buffers(void);     /* how many are kept right now */
 void geeco_host_release_buffers(void);
 
 #ifdef __cplusplus

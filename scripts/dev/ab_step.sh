@@ -5,7 +5,7 @@ reps=$1; shift
 mkdir -p gpurun_out/ab
 for rep in $(seq $reps); do
 for e in "$@"; do
-  env $e timeout -k 10 200 python bench.py --steps 100 --warmup 20 --skip-cpu --skip-other-configs --skip-layers --skip-input-pipeline --skip-inference > gpurun_out/ab/s.json 2>gpurun_out/ab/s.err || { tail -5 gpurun_out/ab/s.err; continue; }
+  env $e timeout -k 10 200 python bench.py --steps 100 --warmup 20 --skip-cpu --skip-other-configs --skip-layers --skip-input-pipeline --skip-inference --skip-dp-one-rank > gpurun_out/ab/s.json 2>gpurun_out/ab/s.err || { tail -5 gpurun_out/ab/s.err; continue; }
   python - "$e" <<'PY'
 import json, sys
 d = json.loads(open('gpurun_out/ab/s.json').read().strip().splitlines()[-1])

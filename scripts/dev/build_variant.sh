@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds the CURRENT csrc tree as geeco_amd/libgeeco_hip<suffix>.so with extra compiler flags, for same-box A/B runs
-# (GEECO_LIB=libgeeco_hip<suffix>.so python bench.py ...).  usage: build_variant.sh _noskew -DFB_SKEW=0
+# (GEECO_DEV=1 GEECO_LIB=libgeeco_hip<suffix>.so python bench.py ...).  usage: build_variant.sh _noskew -DFB_SKEW=0
+# (the PRODUCT kernel set; with the development variants and switches: build_dev_lib.sh)
 set -euo pipefail
 SUF=$1; shift
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -12,11 +13,11 @@ extra_flags() {      # as geeco_amd/csrc/build.sh; PLAIN=1: none (to A/B the per
   [ -n "${PLAIN:-}" ] && return
   case $1 in
     conv_gemm) echo "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
-    conv_halo|conv_dgrad_lds|conv_bottom_fwd) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+    conv_halo|conv_dgrad_lds) echo "-mllvm -amdgpu-use-amdgpu-trackers=1" ;;
   esac
 }
 pids=()
-for f in conv_gemm conv_halo conv_bottom_fwd conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
+for f in conv_gemm conv_halo conv_wgrad conv_wgrad_halo conv_dgrad_lds dynimg decoder misc; do
   /opt/rocm/bin/hipcc $FLAGS $(extra_flags $f) -c $f.hip -o $B/$f.o &
   pids+=($!)
 done

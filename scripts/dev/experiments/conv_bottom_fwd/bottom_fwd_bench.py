@@ -1,8 +1,10 @@
-"""Encoder bottom forward at the bench shape (3 x 32 frames of 256 x 256): the one-launch kernel (csrc/conv_bottom_fwd.hip)
-against conv1 forward + conv2 forward.  Median of 20 event pairs around 5 launches each.  GEECO_DEV=1 GEECO_LIB=... selects a
-variant build (scripts/dev/build_variant.sh _p1 -DBF_PRIO=1)."""
+"""Encoder bottom forward at the bench shape (3 x 32 frames of 256 x 256): the one-launch kernel (conv_bottom_fwd.hip, this
+directory) against conv1 forward + conv2 forward.  Median of 20 event pairs around 5 launches each.  Needs the development
+library: GEECO_DEV=1 GEECO_LIB=libgeeco_hip_dev.so (scripts/dev/build_dev_lib.sh [suffix] [-DBF_PRIO=1 ...])."""
 import os, sys, statistics, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(HERE, '..', '..', '..', '..'), HERE]
+from binding import launch_fwd_bottom
 from geeco_amd import graph
 from geeco_amd.params import create_e2evmc_config
 cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2, batch_size=32))
@@ -30,8 +32,7 @@ for rep in range(1 if QUICK else 2):
   res.setdefault('conv1 fwd', []).append(timed(lambda: enc.launch_fwd(0)))
   res.setdefault('conv2 fwd', []).append(timed(lambda: enc.launch_fwd(1)))
   res.setdefault('conv1 + conv2 (two launches)', []).append(timed(separate))
-  if enc.fused_fwd:
-    res.setdefault('one launch', []).append(timed(enc.launch_fwd_bottom))
+  res.setdefault('one launch', []).append(timed(lambda: launch_fwd_bottom(enc)))
 flop = 2.0 * 96 * (56623104 + 226492416)
 print('[%s] ' % os.environ.get('GEECO_LIB', 'default') + '; '.join('%s %s us' % (k, '/'.join('%.1f' % v for v in vs)) for k, vs in res.items())
       + '; one launch = %.1f TFLOP/s' % (flop / min(res.get('one launch', [1e9])) / 1e6))

@@ -1,15 +1,15 @@
 #!/bin/bash
-# SQ + FETCH/WRITE counters + effective clock of the encoder bottom forward: the one-launch kernel (csrc/conv_bottom_fwd.hip) and the
+# SQ + FETCH/WRITE counters + effective clock of the encoder bottom forward: the one-launch kernel (conv_bottom_fwd.hip, this directory) and the
 # two kernels it would replace (separate --pmc passes; GEECO_LIB selects a variant build).  out: gpurun_out/bfpmc/report.txt
 R=$GRAFT_REPO_ROOT
-export GEECO_DEV=1 GEECO_FUSED_FWD=1
+export GEECO_DEV=1 GEECO_LIB=${GEECO_LIB:-libgeeco_hip_dev.so}
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/bfpmc${1:-}
 rm -rf $out; mkdir -p $out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE"; do
   i=$((i+1))
-  BF_QUICK=1 timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o p$i -- python3 $R/scripts/dev/bottom_fwd_bench.py > $out/log$i.txt 2>&1 || { echo "rocprof failed"; tail -5 $out/log$i.txt; exit 1; }
+  BF_QUICK=1 timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o p$i -- python3 $R/scripts/dev/experiments/conv_bottom_fwd/bottom_fwd_bench.py > $out/log$i.txt 2>&1 || { echo "rocprof failed"; tail -5 $out/log$i.txt; exit 1; }
 done
 python3 - $out <<'PY' | tee $out/report.txt
 import csv, sys, collections, re

@@ -26,7 +26,8 @@
 //
 // Results are BITWISE those of the two separate kernels (same MFMA sequences per output, same reduction order), which is
 // how tests/test_kernels_gpu.py checks this one.
-#include "geeco_common.h"
+#include "geeco_common.h"        // -I geeco_amd/csrc (scripts/dev/build_dev_lib.sh)
+#include "conv_bottom_fwd.h"
 #include <atomic>
 
 typedef __attribute__((address_space(1))) const void* gptr_t;

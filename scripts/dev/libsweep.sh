@@ -5,7 +5,7 @@ export GEECO_DEV=1   # the product reads GEECO_* switches only under GEECO_DEV=1
 mkdir -p gpurun_out/libsweep
 for rep in 1 2; do
 for v in "$@"; do
-  GEECO_LIB=libgeeco_hip$v.so timeout -k 10 200 python bench.py --steps 30 --warmup 8 --skip-cpu --skip-other-configs --skip-input-pipeline --skip-inference > gpurun_out/libsweep/b.json 2>gpurun_out/libsweep/b.err
+  GEECO_LIB=libgeeco_hip$v.so timeout -k 10 200 python bench.py --steps 30 --warmup 8 --skip-cpu --skip-other-configs --skip-input-pipeline --skip-inference --skip-dp-one-rank > gpurun_out/libsweep/b.json 2>gpurun_out/libsweep/b.err
   python - "$v" <<'PY'
 import json, sys
 d = json.loads(open('gpurun_out/libsweep/b.json').read().strip().splitlines()[-1])

@@ -105,3 +105,18 @@ def test_dev_switches_are_ignored_without_geeco_dev(monkeypatch):
   for path in glob.glob(os.path.join(ROOT, 'geeco_amd', '*.py')):
     if not path.endswith('_dev.py'):
       assert not re.findall(r"os\.environ\.get\('GEECO_", open(path).read()), path
+
+
+def test_product_library_holds_no_switches_and_no_development_kernels():
+  """the shipped library is the path that runs.  It reports itself as the product build, the name of no
+  GEECO_* switch occurs in it (geeco_dev_getenv is the constant nullptr there: nothing reads the environment), and none of
+  the kernels only a switch could select was compiled in (the development build, scripts/dev/build_dev_lib.sh, has them)."""
+  from geeco_amd import _native
+  lib = _native.load()
+  assert lib.geeco_has_dev_kernels() == 0
+  blob = open(os.path.join(ROOT, 'geeco_amd', 'libgeeco_hip.so'), 'rb').read()
+  for name in re.findall(r'`(GEECO_[A-Z0-9_]+)', open(os.path.join(ROOT, 'scripts', 'dev', 'SWITCHES.md')).read()) + ['GEECO_DEV']:
+    assert name.encode() not in blob, name
+  for kernel in (b'conv1_conv2_fwd_kernel', b'conv_s2_halo_fwd_kernel', b'geeco_conv1_conv2_fwd'):
+    assert kernel not in blob, kernel
+  assert b'conv_s2_halo_fwd_ws_kernel' in blob

@@ -225,6 +225,29 @@ def test_table_driven_inflate_equals_zlib(tmp_path):
       np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
 
 
+def test_reader_returns_its_spare_buffers_after_an_epoch(tmp_path):
+  """the native reader keeps mapped inflate buffers between episodes (one per reader thread + 1, not a fixed
+  32 / 6 GiB) and hands them back to the OS when the epoch's last episode has been read."""
+  from geeco_amd import input_fn as I
+  from geeco_amd import tfrecord as T
+  lib = T._host()
+  meta, _ = _make_dataset(str(tmp_path), n_eps=5, T=6, H=16, W=16)
+  lib.geeco_host_release_buffers()
+  assert lib.geeco_host_spare_buffers() == 0
+  lib.geeco_host_set_buffer_limit(8)
+  eps = [I.load_episode(p, meta, True, raw_rgb=True) for p in _paths(str(tmp_path))]        # direct reads: buffers are kept ...
+  assert len(eps) == 5 and 1 <= lib.geeco_host_spare_buffers() <= 8
+  lib.geeco_host_set_buffer_limit(1)                                                         # ... a lower limit trims them
+  assert lib.geeco_host_spare_buffers() <= 1
+  n = sum(1 for _ in I.pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=3, batch_size=2, num_threads=2, seed=0))
+  assert n > 0 and lib.geeco_host_spare_buffers() == 0                                       # the epoch is over: all returned
+  src = I._EpisodeSource(_paths(str(tmp_path)), meta, True, 3, None, ('rgb', 'depth'), None)
+  it = iter(src)
+  next(it)
+  it.close()                                                                                 # abandoned mid-epoch: same
+  assert lib.geeco_host_spare_buffers() == 0
+
+
 def test_inflate_under_address_sanitizer(tmp_path):
   """tests/native/fuzz_inflate.cpp: the decoder built with -fsanitize=address,undefined against 40 valid and ~3 900 damaged
   streams (bit flips, truncations, overwritten stretches, damaged block headers): no access outside the buffers, nothing
