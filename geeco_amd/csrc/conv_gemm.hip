@@ -34,6 +34,8 @@ int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y,
                        int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                        int relu, hipStream_t stream, int* handled);
 
+int geeco_halo_fwd_handles(int H, int W, int Cin, int Cout, int stride);
+int geeco_conv1_fwd_handles(int Cin, int Cout, int stride);
 int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
                         int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                         int relu, hipStream_t stream, int* handled);
@@ -862,7 +864,9 @@ extern "C" int geeco_conv3x3_fwd_state(const float* x, const float* w, const flo
     GEECO_CHECK_ARG(feat_off[g] >= 0 && feat_off[g] + Cout <= Ctot && (feat_off[g] + Cout <= jnt_off || feat_off[g] >= jnt_off + J),
                     "conv3x3_fwd_state: feature columns of encoder %d", g);
   }
-  if (!ws || Cin <= 48) return GEECO_ENOSUP;      // (Cin <= 48: the shapes of the halo kernels, conv1..3 -- never a top layer)
+  // a shape geeco_conv3x3_fwd serves with one of the LDS-halo kernels must not take the gather GEMM here (same layer, same
+  // kernel on every path: the bitwise statements of the tests rest on it) -- ask the dispatchers, as geeco_conv_top_bwd does
+  if (!ws || geeco_halo_fwd_handles(H, W, Cin, Cout, stride) || geeco_conv1_fwd_handles(Cin, Cout, stride)) return GEECO_ENOSUP;
   p.x = x; p.w = w; p.bias = b; p.mask = nullptr; p.out = y;
   p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_out = gs_y;
   p.relu = 1;

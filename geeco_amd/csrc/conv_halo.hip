@@ -842,17 +842,24 @@ static int launch_s2_halo_fwd_chunked(HaloFwdParams& p, hipStream_t s) {
   return 0;
 }
 
+// does the dispatcher below take this shape?  (geeco_conv3x3_fwd_state asks: a layer these kernels serve must not go through
+// the gather GEMM there while every other path runs it through them)
+int geeco_halo_fwd_handles(int H, int W, int Cin, int Cout, int stride) {
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
+  static const int no_chunked = geeco_dev_getenv("GEECO_NO_HALO3") ? 1 : 0;
+  if (disabled || stride != 2 || (H % 2) || (W % 2)) return 0;
+  return (Cin == 32 && Cout == 48) || (Cin == 48 && Cout == 64 && !no_chunked);
+}
+
 // Returns 1 if handled, 0 if the shape is not covered (caller falls back to the gather-GEMM),
 // or an error code < 0 / hipError.
 int geeco_try_halo_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
                        int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                        int relu, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
-  if (disabled || !b) return 0;
-  static const int no_chunked = geeco_dev_getenv("GEECO_NO_HALO3") ? 1 : 0;
-  const bool conv2 = Cin == 32 && Cout == 48, conv3 = Cin == 48 && Cout == 64 && !no_chunked;
-  if (stride == 2 && (conv2 || conv3) && (H % 2 == 0) && (W % 2 == 0)) {
+  if (!b) return 0;
+  const bool conv2 = Cin == 32 && Cout == 48;
+  if (geeco_halo_fwd_handles(H, W, Cin, Cout, stride)) {
     HaloFwdParams p = {};
     p.x = x; p.w = w; p.bias = b; p.y = y;
     p.gs_x = gs_x; p.gs_w = gs_w; p.gs_b = gs_b; p.gs_y = gs_y;
@@ -2517,12 +2524,16 @@ static int launch_conv1_fwd(const float* x, const float* w, const float* b, floa
                             int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_bits, int N, int H, int W,
                             int relu, hipStream_t stream, int w_cin = 4);
 
+int geeco_conv1_fwd_handles(int Cin, int Cout, int stride) {
+  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
+  return !disabled && stride == 1 && Cin == 4 && Cout == 32;
+}
+
 int geeco_try_conv1_fwd(const float* x, const float* w, const float* b, float* y, int groups, int64_t gs_x,
                         int64_t gs_w, int64_t gs_b, int64_t gs_y, int N, int H, int W, int Cin, int Cout, int stride,
                         int relu, hipStream_t stream, int* handled) {
   *handled = 0;
-  static const int disabled = geeco_dev_getenv("GEECO_NO_HALO") ? 1 : 0;
-  if (disabled || !b || !(stride == 1 && Cin == 4 && Cout == 32)) return 0;
+  if (!b || !geeco_conv1_fwd_handles(Cin, Cout, stride)) return 0;
   *handled = 1;
   return launch_conv1_fwd(x, w, b, y, nullptr, groups, gs_x, gs_w, gs_b, gs_y, 0, N, H, W, relu, stream);
 }

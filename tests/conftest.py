@@ -18,3 +18,26 @@ def dev():
   if not torch.cuda.is_available():
     pytest.skip('no GPU')
   return torch.device('cuda:0')
+
+
+def usable_cores():
+  """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows all 256
+  cores of its host to os.cpu_count() while the job owns 16: torch's default thread pool would be 16x oversubscribed)."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      quota, period = f.read().split()
+    if quota != 'max':
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return max(1, min(n, 32))
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _oracle_threads():
+  """The CPU oracle (torch) on exactly the cores this job owns (the full-size oracle evaluations are half of the
+  GPU suite's wall time)."""
+  import torch
+  torch.set_num_threads(usable_cores())
+  yield

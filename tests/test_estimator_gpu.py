@@ -127,6 +127,43 @@ def test_device_windows_match_host_pipeline(dev, tmp_path):
   np.testing.assert_allclose(res[0]['loss'], res[1]['loss'], rtol=1e-6)
 
 
+def test_batch_that_mixes_uint8_and_float_episodes(dev, tmp_path):
+  """a dataset may hold episodes whose RGB values are integral (resident as uint8, divisor 255) next to episodes
+  whose values are not (resident as float32 / 255, divisor 1).  A batch that straddles two such episodes is gathered segment
+  by segment with each segment's own divisor (round 4 raised ValueError at the first such batch): bitwise the host pipeline's
+  batches; the mixed batch is not ``is_u8()``, so the Estimator runs it through the dense-window model, and training works."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_host_logic_cpu import _make_dataset
+  from geeco_amd import estimator as est
+  from geeco_amd import input_fn as I
+  root = str(tmp_path / 'ds')
+  os.makedirs(root)
+  meta, eps = _make_dataset(root, n_eps=2, T=9, H=136, W=136)
+  d = eps[1]                      # rewrite episode 1 with non-integral colour values
+  I.write_episode(os.path.join(root, 'data', 'ep001.tfrecord.zlib'), meta, d['rgb'].astype(np.float32) * np.float32(0.5) + np.float32(0.25),
+                  d['depth'], d['cmd'], d['ctrl'], d['qpos'], d['qvel'], d['mocap'], d['obj'], d['goal'])
+  kw = dict(window_size=3, fetch_target=True, batch_size=4)
+  host = list(I.pickplace_input_fn(root, 'default', 'eval', **kw))
+  devb = list(I.pickplace_input_fn(root, 'default', 'eval', device='cuda', cache=False, **kw))
+  assert len(host) == len(devb) == 3
+  kinds = []
+  for (fh, _), (fd, _) in zip(host, devb):
+    kinds.append((fd['rgb'].is_u8(), sorted({dv for _, _, dv in fd['rgb'].segments})))
+    for k in ('rgb', 'target_rgb', 'depth'):
+      np.testing.assert_array_equal(fd[k].numpy(), fh[k], err_msg=k)
+  assert kinds == [(True, [255.0]), (False, [1.0, 255.0]), (False, [1.0])], kinds     # 6 + 6 windows in batches of 4: the middle one straddles
+  params = {'e2evmc_config': __import__('geeco_amd.params', fromlist=['x']).create_e2evmc_config(
+      dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=4)), 'log_steps': 1, 'debug': False}
+  res = []
+  for device in (None, 'cuda'):
+    e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path / ('m_%s' % device)), est.RunConfig(), params)
+    e.train(input_fn=lambda: I.pickplace_input_fn(root, 'default', 'train', seed=3, device=device, cache=False, **kw))
+    res.append(e.evaluate(input_fn=lambda: I.pickplace_input_fn(root, 'default', 'eval', device=device, cache=False, **kw)))
+  assert res[0]['global_step'] == res[1]['global_step'] == 3
+  np.testing.assert_allclose(res[0]['loss'], res[1]['loss'], rtol=1e-6)
+
+
 def test_u8_window_addresses_equal_dense_windows(dev, tmp_path):
   """geeco-f on HBM-resident episodes: the model's input kernel follows window addresses into the uint8 frames
   (input_fn.WindowFeed.pointers(), no fp32 window tensor, no gather launch); training and evaluation are BITWISE what the
