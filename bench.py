@@ -320,11 +320,11 @@ def hbm_table(model, args, iters):
         lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
   if args.model == 'geeco-f' and getattr(model, 'last_from_dynimg', False) \
       and HW % 4 == 0 and (C == 3 or getattr(model, 'split_rgbd', False)):
-    # what the step really runs: both images + the current frame's padded copy in two launches (one shared
-    # normalisation launch); algorithmic bytes = the two dynimg figures of SURVEY 8(d)
+    # what the step really runs: both images + the current frame's padded copy in ONE launch, one pass over the window (both
+    # images normalised in registers); algorithmic bytes = the two dynimg figures of SURVEY 8(d)
     inp, x_in = model.inputs, model.enc.x_in
     kw = dict(depth=inp['depth'], tgt_depth=inp['target_depth'], dsample_stride=K * HW, dframe_stride=HW) if C == 4 else {}
-    add('goal inputs as in the step: buffer image (K=%d) + diff image (K=2) + current frame, 2 launches' % K,
+    add('goal inputs as in the step: buffer image (K=%d) + diff image (K=2) + current frame, 1 launch' % K,
         4.0 * N * HW * C * (K + 1 + 3),
         lambda: ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], inp['rgb'], inp['target_rgb'], K, N, HW, model.dyn_ws2,
                                       K * HW * 3, HW * 3, **kw))

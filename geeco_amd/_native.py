@@ -45,8 +45,7 @@ SIGNATURES = {
     'geeco_dynimg_alpha': (None, [_I, _P]),
     'geeco_dynimg_ws_bytes': (_L, [_I, _L]),
     'geeco_dynimg_fwd': (_I, [_P, _P, _L, _L, _P, _I, _I, _L, _I, _I, _P, _P, _P]),
-    'geeco_dynimg_fwd_last': (_I, [_P, _L, _L, _P, _I, _I, _L, _P, _P, _P, _P]),
-    'geeco_dynimg_rgbd_fwd_last': (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P, _P]),
+    'geeco_goal_dynimgs_ws_bytes': (_L, [_I, _L]),
     'geeco_goal_dynimgs_fwd': (_I, [_P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
     'geeco_goal_dynimgs_u8_fwd': (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
     'geeco_dynimg_rgbd_fwd': (_I, [_P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P]),

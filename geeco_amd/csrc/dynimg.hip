@@ -59,25 +59,6 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float* ds
   }
 }
 
-__device__ __forceinline__ void block_minmax_store2(float mn, float mx, float* dst, float mn2, float mx2, float* dst2) {
-  __shared__ float s4[4][4];
-  mn = wave_reduce_min(mn);
-  mx = wave_reduce_max(mx);
-  mn2 = wave_reduce_min(mn2);
-  mx2 = wave_reduce_max(mx2);
-  const int wid = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    s4[wid][0] = mn; s4[wid][1] = mx; s4[wid][2] = mn2; s4[wid][3] = mx2;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    dst[0] = fminf(fminf(s4[0][0], s4[1][0]), fminf(s4[2][0], s4[3][0]));
-    dst[1] = fmaxf(fmaxf(s4[0][1], s4[1][1]), fmaxf(s4[2][1], s4[3][1]));
-    dst2[0] = fminf(fminf(s4[0][2], s4[1][2]), fminf(s4[2][2], s4[3][2]));
-    dst2[1] = fmaxf(fmaxf(s4[0][3], s4[1][3]), fmaxf(s4[2][3], s4[3][3]));
-  }
-}
-
 // float(u8) / 255.0f (_parse_v4, geeco_gym.py:312) without the division sequence: one Newton correction of a * (1/255) is the
 // correctly rounded quotient for every a in 0..255 (tests/test_kernels_gpu.py::test_u8_unit_conversion_is_the_division checks all
 // 256 values bitwise against the division of geeco_gather_windows).
@@ -95,8 +76,12 @@ __device__ __forceinline__ f32x4 u8x4_unit(unsigned int b) {
 
 // 4 pixels = 12 bytes = three dwords of a uint8 RGB frame -> the three float4 the fp32 path loads
 __device__ __forceinline__ void load_u8_unit(const unsigned char* frame, long long u, f32x4& v0, f32x4& v1, f32x4& v2) {
-  const unsigned int* s = reinterpret_cast<const unsigned int*>(frame) + u * 3;
-  const unsigned int b0 = s[0], b1 = s[1], b2 = s[2];
+  // (the frame address comes out of a table in memory: say that it is global memory, or the compiler emits flat loads)
+  typedef const __attribute__((address_space(1))) unsigned int* gptr;
+  gptr s = (gptr)(reinterpret_cast<const unsigned int*>(frame) + u * 3);
+  // non-temporal: the window is read once; what should stay in L2 / the memory-side cache are the three images this kernel writes
+  // for conv1 (measured, same box: uint8 input stage 73 -> 58 us, fp32 131-136 -> 111-116 us in the step)
+  const unsigned int b0 = __builtin_nontemporal_load(s), b1 = __builtin_nontemporal_load(s + 1), b2 = __builtin_nontemporal_load(s + 2);
   v0 = u8x4_unit(b0);
   v1 = u8x4_unit(b1);
   v2 = u8x4_unit(b2);
@@ -105,84 +90,29 @@ __device__ __forceinline__ void load_u8_unit(const unsigned char* frame, long lo
 // C == 3, Cpad == 4, HW % 4 == 0: one thread = 4 pixels = 3 float4 in, 4 float4 out.  DEPTH: a 4th channel comes from its
 // own tensor (one more float4 = the depth of the 4 pixels per frame): rgb || depth (estimator.py:169,172) is formed in
 // registers instead of packing all N * K frames to 4 channels first (1.07 GB read + 1.43 GB written per step at K = 32).
-// U8: the RGB source is uint8 frames behind a per-sample address table (the window is never materialised as fp32: a quarter of
-// the bytes, and no gather launch in front); everything downstream of the load is the fp32 path, so the images are bitwise equal.
-template <bool DEPTH, bool DIFF = false, bool U8 = false>
+// (The single-image form: per-timestep pair images of the sequence models, standalone dynimg calls.  The goal model's input
+// stage is dynimg_goal_onepass_kernel below.)
+template <bool DEPTH>
 __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
   const int n = blockIdx.y;
-  [[maybe_unused]] const unsigned char* wbase = U8 ? p.win[n] : nullptr;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;   // 4-pixel unit
   const long long U = p.HW >> 2;
   float mn = INFINITY, mx = -INFINITY;
-  [[maybe_unused]] float mn2 = INFINITY, mx2 = -INFINITY;
   if (u < U) {
     f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-    [[maybe_unused]] f32x4 d0 = a0, d1 = a0, d2 = a0, d3 = a0;
 #pragma unroll 4
     for (int t = 0; t < p.K; ++t) {
       const float w = p.alpha[t];
-      f32x4 v0, v1, v2;
-      if (U8) {
-        load_u8_unit(wbase + (long long)t * p.HW * 3, u, v0, v1, v2);
-      } else {
-        const f32x4* src = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t)) + u * 3;
-        v0 = src[0]; v1 = src[1]; v2 = src[2];
-      }
+      const f32x4* src = reinterpret_cast<const f32x4*>(dyn_frame_ptr(p, n, t)) + u * 3;
+      const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
       a0 += w * v0;
       a1 += w * v1;
       a2 += w * v2;
-      f32x4 v3 = {0.f, 0.f, 0.f, 0.f};
       if (DEPTH) {
         const float* dp = (p.depth2 && t == 1) ? p.depth2 + (long long)n * p.HW
                                                : p.depth + (long long)n * p.dsample_stride + (long long)t * p.dframe_stride;
-        v3 = reinterpret_cast<const f32x4*>(dp)[u];
-        a3 += w * v3;
+        a3 += w * reinterpret_cast<const f32x4*>(dp)[u];
       }
-      if (p.last && t == p.K - 1) {     // the frame is in registers anyway: its channel-padded copy costs no extra read
-        f32x4* lo = reinterpret_cast<f32x4*>(p.last + ((long long)n * p.HW + u * 4) * 4);
-        lo[0] = f32x4{v0.x, v0.y, v0.z, v3.x};
-        lo[1] = f32x4{v0.w, v1.x, v1.y, v3.y};
-        lo[2] = f32x4{v1.z, v1.w, v2.x, v3.z};
-        lo[3] = f32x4{v2.y, v2.z, v2.w, v3.w};
-      }
-      if (DIFF && t == p.K - 1) {       // the pair image, summed in the order of the two-frame pass: 0 + alpha2[0] * current, + alpha2[1] * target
-        f32x4 t0, t1, t2;
-        if (U8) {
-          load_u8_unit(p.tgt_u8[n], u, t0, t1, t2);
-        } else {
-          const f32x4* ts = reinterpret_cast<const f32x4*>(p.tgt + (long long)n * p.HW * 3) + u * 3;
-          t0 = ts[0]; t1 = ts[1]; t2 = ts[2];
-        }
-        const float w0 = p.alpha2[0], w1 = p.alpha2[1];
-        d0 += w0 * v0; d1 += w0 * v1; d2 += w0 * v2;
-        d0 += w1 * t0; d1 += w1 * t1; d2 += w1 * t2;
-        if (DEPTH) {
-          const f32x4 t3 = reinterpret_cast<const f32x4*>(p.tgt_depth + (long long)n * p.HW)[u];
-          d3 += w0 * v3;
-          d3 += w1 * t3;
-        }
-      }
-    }
-    if (DIFF) {
-      float e2[12] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w};
-      float q4[4] = {d3.x, d3.y, d3.z, d3.w};
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        mn2 = fminf(mn2, e2[i]);
-        mx2 = fmaxf(mx2, e2[i]);
-      }
-      if (DEPTH) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          mn2 = fminf(mn2, q4[i]);
-          mx2 = fmaxf(mx2, q4[i]);
-        }
-      }
-      f32x4* dd = reinterpret_cast<f32x4*>(p.diff_out + ((long long)n * p.HW + u * 4) * 4);
-      dd[0] = f32x4{e2[0], e2[1], e2[2], DEPTH ? q4[0] : 0.f};
-      dd[1] = f32x4{e2[3], e2[4], e2[5], DEPTH ? q4[1] : 0.f};
-      dd[2] = f32x4{e2[6], e2[7], e2[8], DEPTH ? q4[2] : 0.f};
-      dd[3] = f32x4{e2[9], e2[10], e2[11], DEPTH ? q4[3] : 0.f};
     }
     float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
     float d4[4] = {a3.x, a3.y, a3.z, a3.w};
@@ -204,11 +134,295 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
     dst[2] = f32x4{e[6], e[7], e[8], DEPTH ? d4[2] : 0.f};
     dst[3] = f32x4{e[9], e[10], e[11], DEPTH ? d4[3] : 0.f};
   }
-  if (DIFF)
-    block_minmax_store2(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2, mn2, mx2,
-                        p.part2 + ((long long)n * p.nblk + blockIdx.x) * 2);
-  else
-    block_minmax_store(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2);
+  block_minmax_store(mn, mx, p.part + ((long long)n * p.nblk + blockIdx.x) * 2);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The goal model's input stage in ONE pass (round 5; rounds 3-4: the K-frame pass + a normalisation launch that re-read and
+// re-wrote both images: 134 MB of the stage's 662 MB).  A thread keeps its pixels of BOTH images in registers across the
+// per-sample min / max, then normalises and stores them once:
+//   * thread = UPT units of 4 pixels (units u, u + THREADS, ...: consecutive lanes read consecutive 48 B), block = THREADS
+//     threads; a sample is covered by bps = ceil(HW / 4 / (THREADS * UPT)) blocks with consecutive block indices;
+//   * block min / max of the two images -> ONE lane publishes them as write-through (sc1) stores into the block's slot of the
+//     sample's partial array, waits for those stores, and counts the block in with an agent-scope atomic add (memory side); the
+//     same wave polls the sample's counter (sc1 loads) until its bps blocks are in, then fetches the bps slots with sc1 loads
+//     and reduces them -- every hand-off byte is written through and read past this XCD's L2 (per-XCD L2s are not coherent), so
+//     no L2 write-back / invalidate is needed; critical path = one store, one atomic, one load latency;
+//   * a block waits only for the OTHER BLOCKS OF ITS SAMPLE (not a grid barrier): they run the same K-frame pass and arrive
+//     together; blocks of a sample have consecutive indices and workgroups start in index order, so every sample ahead of a
+//     partially started one is complete or fully resident: the wait cannot deadlock however many blocks fit on the chip;
+//   * the LAST block of a sample to leave zeroes the sample's two counters again: every call finds and leaves them zero (the
+//     slots need no reset: every block rewrites its own before it counts itself in).
+// The arithmetic per pixel is that of dynimg_wsum3_kernel + dynimg_norm_kernel (same sums in the same order, (D - min) / range
+// with the IEEE division): bitwise the same images.
+// ------------------------------------------------------------------------------------------------------------------
+struct DynCtl {           // per sample: the two counters, on a 64-byte line of their own; zero between calls.  Behind the N
+  unsigned arrive, depart;      // control blocks: N x bps slots of {min, max of the buffer image, min, max of the pair image}
+  unsigned pad[14];
+};
+
+// a wave-uniform address as such (two SGPRs): loads from it + a 32-bit per-lane offset take the scalar-base form and need one VGPR
+// of address instead of a 64-bit pair per load (which the compiler precomputes per frame of the unrolled ring and spills)
+__device__ __forceinline__ const char* dyn_uniform(const void* q) {
+  const unsigned long long v = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <bool DEPTH, bool U8, int THREADS, int UPT>
+__global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynParams p, DynCtl* ctl, int bps) {
+  constexpr int NW = THREADS / 64;
+  const int n = blockIdx.x / bps, b = blockIdx.x - n * bps;
+  const int tid = threadIdx.x;
+  [[maybe_unused]] const unsigned char* wbase = U8 ? p.win[n] : nullptr;
+  const long long U = p.HW >> 2;             // units of 4 pixels per frame
+  const long long ub = (long long)b * (THREADS * UPT);      // first unit of this block
+  // Two register layouts of a thread's 12 RGB floats per unit slot j (the depths, one float4 per unit, always belong to unit
+  // ub + j * THREADS + tid):
+  //   unit layout (U8 source): x[j][c] = c-th float4 of unit ub + j * THREADS + tid (one dwordx3 of bytes per lane and frame);
+  //   flat layout (fp32 source): x[j][c] = float4 number (j * 3 + c) * THREADS + tid of the block's stretch of the frame, so
+  //     every load instruction of a wave reads 1 KiB contiguous (the unit layout reads 16 of every 48 bytes per instruction:
+  //     three times the cache-line requests; measured on the first form of this kernel).  Sums, products and min / max do not
+  //     care which pixel a float belongs to; the three arrays that are stored per pixel (current frame, both images) go through
+  //     an LDS transposition (to_units) once, after the frame loop.
+  f32x4 A[UPT][4], D[UPT][4];      // buffer image / pair image: [slot][three RGB float4, the 4 depths]
+#pragma unroll
+  for (int j = 0; j < UPT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[j][q] = D[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float w0 = p.alpha2[0], w1 = p.alpha2[1];
+  // Threads past the end of a ragged last block read the frame's last unit / float4 again and drop what they computed: the frame
+  // loop has no branch.
+  // (per-lane positions as 32-bit BYTE offsets from wave-uniform frame addresses: one VGPR each, and the loads take the
+  // scalar-base form; a frame is at most HW * 16 bytes, checked by the launcher to stay below 2^31)
+  unsigned uc[UPT], fo[UPT][3];      // unit index (clamped); byte offset of the slot's c-th float4 in the frame (flat layout)
+  bool live[UPT], flive[UPT][3];
+#pragma unroll
+  for (int j = 0; j < UPT; ++j) {
+    const long long u = ub + (long long)j * THREADS + tid;
+    live[j] = u < U;
+    uc[j] = (unsigned)(live[j] ? u : U - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long f = ub * 3 + (long long)(j * 3 + c) * THREADS + tid;
+      flive[j][c] = U8 ? live[j] : f < 3 * U;
+      fo[j][c] = (unsigned)((f < 3 * U ? f : 3 * U - 1) * 16);
+    }
+  }
+  auto ld4 = [](const f32x4* q0) {      // (global address space said explicitly: a pointer rebuilt from integers would load "flat")
+    typedef const __attribute__((address_space(1))) f32x4* gptr;
+    gptr q = (gptr)q0;
+    return __builtin_nontemporal_load(q);
+  };
+  auto load = [&](int t, int j, f32x4& v0, f32x4& v1, f32x4& v2, f32x4& v3) {
+    if (U8) {
+      load_u8_unit(wbase + (long long)t * p.HW * 3, uc[j], v0, v1, v2);
+    } else {
+      const char* src = dyn_uniform(p.frames + (long long)n * p.sample_stride + (long long)t * p.frame_stride);
+      v0 = ld4(reinterpret_cast<const f32x4*>(src + fo[j][0])); v1 = ld4(reinterpret_cast<const f32x4*>(src + fo[j][1]));
+      v2 = ld4(reinterpret_cast<const f32x4*>(src + fo[j][2]));
+    }
+    if (DEPTH) v3 = ld4(reinterpret_cast<const f32x4*>(dyn_uniform(p.depth + (long long)n * p.dsample_stride + (long long)t * p.dframe_stride) + uc[j] * 16u));
+  };
+  // Frames 0 .. K-2, software-pipelined: a ring of UNR frames of staging registers; a frame's registers are refilled with the
+  // frame UNR ahead as soon as its products are taken, so a wave always has ~UNR * UPT * 3 loads in flight.
+  constexpr int UNR = DEPTH ? 2 : 3;      // (the pair image's registers are not live yet in this loop)
+  const int KM = p.K - 1;
+  const int groups = KM / UNR;
+  if (groups > 0) {
+    f32x4 v[UNR][UPT][4];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k)
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) load(k, j, v[k][j][0], v[k][j][1], v[k][j][2], v[k][j][3]);
+    for (int g = 0; g + 1 < groups; ++g) {      // steady state: no condition inside
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const float w = p.alpha[g * UNR + k];
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+          A[j][0] += w * v[k][j][0]; A[j][1] += w * v[k][j][1]; A[j][2] += w * v[k][j][2];
+          if (DEPTH) A[j][3] += w * v[k][j][3];
+        }
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) load((g + 1) * UNR + k, j, v[k][j][0], v[k][j][1], v[k][j][2], v[k][j][3]);
+        __builtin_amdgcn_sched_barrier(0);      // keep this order: (consume frame k, refill its registers), next k -- the scheduler
+      }                                         // otherwise sinks all refills behind the last wait of the round
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const float w = p.alpha[(groups - 1) * UNR + k];
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) {
+        A[j][0] += w * v[k][j][0]; A[j][1] += w * v[k][j][1]; A[j][2] += w * v[k][j][2];
+        if (DEPTH) A[j][3] += w * v[k][j][3];
+      }
+    }
+  }
+  for (int t = groups * UNR; t < KM; ++t) {     // K - 1 not a multiple of UNR: the remaining frames one by one
+    const float w = p.alpha[t];
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      f32x4 v0, v1, v2, v3;
+      load(t, j, v0, v1, v2, v3);
+      A[j][0] += w * v0; A[j][1] += w * v1; A[j][2] += w * v2;
+      if (DEPTH) A[j][3] += w * v3;
+    }
+  }
+  // flat layout -> unit layout of one slot's three float4 through LDS (fp32 source only; every thread of the block takes part)
+  __shared__ f32x4 tbuf[U8 ? 1 : THREADS * 3];
+  auto to_units = [&](f32x4& x0, f32x4& x1, f32x4& x2) {
+    if (U8) return;
+    __syncthreads();
+    tbuf[tid] = x0; tbuf[THREADS + tid] = x1; tbuf[2 * THREADS + tid] = x2;
+    __syncthreads();
+    x0 = tbuf[3 * tid]; x1 = tbuf[3 * tid + 1]; x2 = tbuf[3 * tid + 2];
+  };
+  {   // the window's last frame = the current frame: also the ConvEncoder's input and the first term of the pair image
+    const float w = p.alpha[p.K - 1];
+    f32x4 c[UPT][4], g[UPT][4];
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      c[j][3] = g[j][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+      load(p.K - 1, j, c[j][0], c[j][1], c[j][2], c[j][3]);
+      if (U8) {
+        load_u8_unit(p.tgt_u8[n], uc[j], g[j][0], g[j][1], g[j][2]);
+      } else {
+        const char* ts = dyn_uniform(p.tgt + (long long)n * p.HW * 3);
+        g[j][0] = ld4(reinterpret_cast<const f32x4*>(ts + fo[j][0])); g[j][1] = ld4(reinterpret_cast<const f32x4*>(ts + fo[j][1]));
+        g[j][2] = ld4(reinterpret_cast<const f32x4*>(ts + fo[j][2]));
+      }
+      if (DEPTH) g[j][3] = ld4(reinterpret_cast<const f32x4*>(dyn_uniform(p.tgt_depth + (long long)n * p.HW) + uc[j] * 16u));
+    }
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      A[j][0] += w * c[j][0]; A[j][1] += w * c[j][1]; A[j][2] += w * c[j][2];
+      if (DEPTH) A[j][3] += w * c[j][3];
+      // the pair image, summed in the order of the two-frame pass: 0 + alpha2[0] * current, + alpha2[1] * target
+      D[j][0] += w0 * c[j][0]; D[j][1] += w0 * c[j][1]; D[j][2] += w0 * c[j][2];
+      D[j][0] += w1 * g[j][0]; D[j][1] += w1 * g[j][1]; D[j][2] += w1 * g[j][2];
+      if (DEPTH) {
+        D[j][3] += w0 * c[j][3];
+        D[j][3] += w1 * g[j][3];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+      to_units(c[j][0], c[j][1], c[j][2]);
+      if (live[j]) {
+        const f32x4 v0 = c[j][0], v1 = c[j][1], v2 = c[j][2], v3 = c[j][3];
+        f32x4* lo = reinterpret_cast<f32x4*>(p.last + ((long long)n * p.HW + (long long)uc[j] * 4) * 4);
+        lo[0] = f32x4{v0.x, v0.y, v0.z, v3.x};
+        lo[1] = f32x4{v0.w, v1.x, v1.y, v3.y};
+        lo[2] = f32x4{v1.z, v1.w, v2.x, v3.z};
+        lo[3] = f32x4{v2.y, v2.z, v2.w, v3.w};
+      }
+    }
+  }
+  // ---- per-sample min / max of both images --------------------------------------------------------------------------
+  float mn1 = INFINITY, mx1 = -INFINITY, mn2 = INFINITY, mx2 = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < UPT; ++j) {
+#pragma unroll
+    for (int q = 0; q < (DEPTH ? 4 : 3); ++q) {
+      if (!(q < 3 ? flive[j][q] : live[j])) continue;
+      const f32x4 a = A[j][q], d = D[j][q];
+      mn1 = fminf(fminf(mn1, fminf(a.x, a.y)), fminf(a.z, a.w));
+      mx1 = fmaxf(fmaxf(mx1, fmaxf(a.x, a.y)), fmaxf(a.z, a.w));
+      mn2 = fminf(fminf(mn2, fminf(d.x, d.y)), fminf(d.z, d.w));
+      mx2 = fmaxf(fmaxf(mx2, fmaxf(d.x, d.y)), fmaxf(d.z, d.w));
+    }
+  }
+  __shared__ float red[NW][4];
+  __shared__ float s_norm[4];      // min1, range1, min2, range2
+  mn1 = wave_reduce_min(mn1); mx1 = wave_reduce_max(mx1);
+  mn2 = wave_reduce_min(mn2); mx2 = wave_reduce_max(mx2);
+  const int wid = tid >> 6;
+  if ((tid & 63) == 0) {
+    red[wid][0] = mn1; red[wid][1] = mx1; red[wid][2] = mn2; red[wid][3] = mx2;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    // wave 0: lane 0 folds the waves' partials and publishes the block's four numbers as write-through stores into its slot of
+    // the sample's partial array, waits for those stores, then counts the block in (agent-scope atomic add, memory side).  Then
+    // it polls the sample's counter; once all bps blocks are in, lanes 0..bps-1 fetch the slots (sc1 loads: served past this
+    // XCD's L2) and a wave reduction gives the sample's min / max -- one store, one atomic and one load latency on the critical
+    // path (the first form used four returning atomic max + four read-backs: ~15 us of latency).
+    DynCtl* c = ctl + n;
+    f32x4* slots = reinterpret_cast<f32x4*>(ctl + p.N) + (long long)n * bps;
+    const int lane = tid;
+    if (lane == 0) {
+      for (int i = 1; i < NW; ++i) {
+        mn1 = fminf(mn1, red[i][0]); mx1 = fmaxf(mx1, red[i][1]);
+        mn2 = fminf(mn2, red[i][2]); mx2 = fmaxf(mx2, red[i][3]);
+      }
+      float* sp = reinterpret_cast<float*>(slots + b);
+      __hip_atomic_store(sp + 0, mn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent-scope relaxed = sc1 write-through stores)
+      __hip_atomic_store(sp + 1, mx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sp + 2, mn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sp + 3, mx2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned got = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      // the other blocks of this sample run the same pass over the same number of frames: they are at most a few us behind.
+      // The spin is bounded (~0.5 s): a sample whose blocks never all arrive would be a launch-geometry bug, not something to hang on.
+      for (unsigned spin = 0; got < (unsigned)bps && spin < (1u << 22); ++spin) {
+        __builtin_amdgcn_s_sleep(4);
+        got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // (wave 0 reconverges here: the other lanes waited for lane 0's poll at the end of the divergent region)
+    f32x4 q = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int i = lane; i < bps; i += 64) {
+      const float* sp = reinterpret_cast<const float*>(slots + i);
+      const float q0 = __hip_atomic_load(sp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float q1 = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float q2 = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float q3 = __hip_atomic_load(sp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q.x = fminf(q.x, q0); q.y = fmaxf(q.y, q1); q.z = fminf(q.z, q2); q.w = fmaxf(q.w, q3);
+    }
+    const float a1 = wave_reduce_min(q.x), b1 = wave_reduce_max(q.y), a2 = wave_reduce_min(q.z), b2 = wave_reduce_max(q.w);
+    if (lane == 0) {
+      s_norm[0] = a1; s_norm[1] = b1 - a1 + 1e-6f;      // graph.py:49
+      s_norm[2] = a2; s_norm[3] = b2 - a2 + 1e-6f;
+      // leave: the last block out zeroes the two counters for the next call (every block has read the slots by then)
+      if (__hip_atomic_fetch_add(&c->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)bps - 1u) {
+        __hip_atomic_exchange(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_exchange(&c->depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __syncthreads();
+  const float m1 = s_norm[0], r1 = s_norm[1], m2 = s_norm[2], r2 = s_norm[3];
+  // ---- normalise in registers, store once ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < UPT; ++j) {
+    to_units(A[j][0], A[j][1], A[j][2]);
+    to_units(D[j][0], D[j][1], D[j][2]);
+    if (!live[j]) continue;
+    const long long u = (long long)uc[j];
+    float e[12], f[12], e4[4] = {0.f, 0.f, 0.f, 0.f}, f4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      e[4 * q + 0] = (A[j][q].x - m1) / r1; e[4 * q + 1] = (A[j][q].y - m1) / r1;
+      e[4 * q + 2] = (A[j][q].z - m1) / r1; e[4 * q + 3] = (A[j][q].w - m1) / r1;
+      f[4 * q + 0] = (D[j][q].x - m2) / r2; f[4 * q + 1] = (D[j][q].y - m2) / r2;
+      f[4 * q + 2] = (D[j][q].z - m2) / r2; f[4 * q + 3] = (D[j][q].w - m2) / r2;
+    }
+    if (DEPTH) {
+      e4[0] = (A[j][3].x - m1) / r1; e4[1] = (A[j][3].y - m1) / r1; e4[2] = (A[j][3].z - m1) / r1; e4[3] = (A[j][3].w - m1) / r1;
+      f4[0] = (D[j][3].x - m2) / r2; f4[1] = (D[j][3].y - m2) / r2; f4[2] = (D[j][3].z - m2) / r2; f4[3] = (D[j][3].w - m2) / r2;
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(p.out + ((long long)n * p.HW + u * 4) * 4);
+    dst[0] = f32x4{e[0], e[1], e[2], e4[0]};
+    dst[1] = f32x4{e[3], e[4], e[5], e4[1]};
+    dst[2] = f32x4{e[6], e[7], e[8], e4[2]};
+    dst[3] = f32x4{e[9], e[10], e[11], e4[3]};
+    f32x4* dd = reinterpret_cast<f32x4*>(p.diff_out + ((long long)n * p.HW + u * 4) * 4);
+    dd[0] = f32x4{f[0], f[1], f[2], f4[0]};
+    dd[1] = f32x4{f[3], f[4], f[5], f4[1]};
+    dd[2] = f32x4{f[6], f[7], f[8], f4[2]};
+    dd[3] = f32x4{f[9], f[10], f[11], f4[3]};
+  }
 }
 
 // Generic: one thread = one pixel, C <= Cpad <= 8 channels (C == 4: one float4 per frame).
@@ -251,12 +465,8 @@ __global__ __launch_bounds__(256) void dynimg_wsum_generic_kernel(const DynParam
 
 // Pass 2: fold partials, normalise in place.  One thread = 4 consecutive floats of out.
 __global__ __launch_bounds__(256) void dynimg_norm_kernel(float* out, const float* part, int nblk, long long HW,
-                                                          int C, int Cpad, float* out2, const float* part2) {
+                                                          int C, int Cpad) {
   const int n = blockIdx.y;
-  if (blockIdx.z == 1) {      // second image of a pair (geeco_goal_dynimgs_fwd): same shape, its own partials
-    out = out2;
-    part = part2;
-  }
   __shared__ float s_mn, s_rng;
   {
     float mn = INFINITY, mx = -INFINITY;
@@ -334,15 +544,6 @@ extern "C" int geeco_dynimg_fwd(const float* frames, const float* frames2, int64
                          stream);
 }
 
-extern "C" int geeco_dynimg_fwd_last(const float* frames, int64_t sample_stride, int64_t frame_stride,
-                                     const float* alpha_host, int N, int K, int64_t HW, float* out, float* last, void* ws,
-                                     void* stream) {
-  GEECO_CHECK_ARG(last, "dynimg_fwd_last: null pointer");
-  GEECO_CHECK_ARG((HW & 3) == 0 && sample_stride % 4 == 0 && frame_stride % 4 == 0,
-                  "dynimg_fwd_last: RGB frames, HW %% 4 == 0, 16-byte aligned strides");
-  return dynimg_fwd_impl(frames, nullptr, sample_stride, frame_stride, alpha_host, N, K, HW, 3, 4, out, last, ws, stream);
-}
-
 static int dynimg_fwd_impl(const float* frames, const float* frames2, int64_t sample_stride, int64_t frame_stride,
                            const float* alpha_host, int N, int K, int64_t HW, int C, int Cpad, float* out, float* last,
                            void* ws, void* stream) {
@@ -368,8 +569,7 @@ static int dynimg_fwd_impl(const float* frames, const float* frames2, int64_t sa
   }
   GEECO_LAUNCH_CHECK();
   dim3 g2((unsigned)cdiv64(HW * Cpad, 1024), (unsigned)N);
-  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, C, Cpad, (float*)nullptr,
-                     (const float*)nullptr);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, C, Cpad);
   GEECO_LAUNCH_CHECK();
   return 0;
 }
@@ -384,14 +584,6 @@ extern "C" int geeco_dynimg_rgbd_fwd(const float* rgb, const float* rgb2, int64_
                                      const float* alpha_host, int N, int K, int64_t HW, float* out, void* ws, void* stream) {
   return dynimg_rgbd_impl(rgb, rgb2, sample_stride, frame_stride, depth, depth2, dsample_stride, dframe_stride, alpha_host, N,
                           K, HW, out, nullptr, ws, stream);
-}
-
-extern "C" int geeco_dynimg_rgbd_fwd_last(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* depth,
-                                          int64_t dsample_stride, int64_t dframe_stride, const float* alpha_host, int N,
-                                          int K, int64_t HW, float* out, float* last, void* ws, void* stream) {
-  GEECO_CHECK_ARG(last, "dynimg_rgbd_fwd_last: null pointer");
-  return dynimg_rgbd_impl(rgb, nullptr, sample_stride, frame_stride, depth, nullptr, dsample_stride, dframe_stride, alpha_host,
-                          N, K, HW, out, last, ws, stream);
 }
 
 static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
@@ -414,44 +606,54 @@ static int dynimg_rgbd_impl(const float* rgb, const float* rgb2, int64_t sample_
   hipLaunchKernelGGL(dynimg_wsum3_kernel<true>, dim3((unsigned)p.nblk, (unsigned)N), dim3(256), 0, s, p);
   GEECO_LAUNCH_CHECK();
   dim3 g2((unsigned)cdiv64(HW * 4, 1024), (unsigned)N);
-  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, 4, 4, (float*)nullptr,
-                     (const float*)nullptr);
+  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, out, (const float*)ws, p.nblk, (long long)HW, 4, 4);
   GEECO_LAUNCH_CHECK();
   return 0;
 }
 
-// The goal model's three conv1 inputs (graph.py:386-401) in TWO launches (round 3: three; before: five): one pass over the window
-// writes the buffer image, the current frame's padded copy AND the pair image of (current frame, target); one normalisation
-// launch serves both images.
+// The goal model's three conv1 inputs (graph.py:386-401) in ONE launch (round 5; round 4: two, round 3: three, before: five):
+// one pass over the window computes the buffer image and the pair image of (current frame, target) in registers, writes the
+// current frame's padded copy, and normalises both images before their only store (dynimg_goal_onepass_kernel).
+// ws = geeco_goal_dynimgs_ws_bytes(N, HW) bytes, ZERO-FILLED once by the caller; every call leaves its counters zero.
+extern "C" int64_t geeco_goal_dynimgs_ws_bytes(int N, int64_t HW) {
+  if (N <= 0 || HW <= 0) return 0;
+  return (int64_t)N * ((int64_t)sizeof(DynCtl) + cdiv64(HW >> 2, 256) * 16);      // counters + the most slots a sample can have
+}
+
+template <bool DEPTH, bool U8>
+static void goal_onepass_dispatch(const DynParams& p, DynCtl* ctl, hipStream_t s) {
+  const long long U = p.HW >> 2;
+  // 1024-thread blocks of 2 units per thread (8 pixels: 48 / 64 accumulator registers of both images) when that still gives
+  // the chip about a block per CU; otherwise 256-thread blocks of one unit (small batches: the predictor's N = 1)
+  const long long bps_big = cdiv64(U, 2048);
+  if ((long long)p.N * bps_big >= 192) {
+    geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 1024, 2>", DEPTH ? "true" : "false", U8 ? "true" : "false");
+    hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 1024, 2>), dim3((unsigned)(p.N * bps_big)), dim3(1024), 0, s, p, ctl, (int)bps_big);
+  } else {
+    const long long bps = cdiv64(U, 256);
+    geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 256, 1>", DEPTH ? "true" : "false", U8 ? "true" : "false");
+    hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 256, 1>), dim3((unsigned)(p.N * bps)), dim3(256), 0, s, p, ctl, (int)bps);
+  }
+}
+
 static int goal_dynimgs_launch(DynParams& p, const float* alpha_host, const float* alpha2_host, bool u8, float* cur_out,
                                float* buf_out, float* diff_out, void* ws, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  const int nblk = dyn_nblk(p.HW, 3);
-  float* part1 = (float*)ws;
-  float* part2 = part1 + (long long)p.N * nblk * 2;
-  p.C = 3; p.Cpad = 4; p.out = buf_out; p.last = cur_out; p.part = part1; p.nblk = nblk;
+  GEECO_CHECK_ARG((long long)p.N * cdiv64(p.HW >> 2, 256) < (1ll << 31) && p.HW * 16 < (1ll << 31),
+                  "goal_dynimgs: %d samples of %lld pixels exceed the grid / the 32-bit in-frame offsets", p.N, p.HW);
+  p.C = 3; p.Cpad = 4; p.out = buf_out; p.last = cur_out;
   for (int t = 0; t < p.K; ++t) p.alpha[t] = alpha_host[t];
-  // ONE pass for both images (round 4): the pair image needs the current frame, which this pass holds in registers at t = K - 1
-  p.diff_out = diff_out; p.part2 = part2;
+  p.diff_out = diff_out;
   p.alpha2[0] = alpha2_host[0]; p.alpha2[1] = alpha2_host[1];
-  const dim3 grid((unsigned)nblk, (unsigned)p.N);
+  DynCtl* ctl = (DynCtl*)ws;
   const bool depth = p.depth != nullptr;
   if (u8) {
-    if (depth)
-      hipLaunchKernelGGL((dynimg_wsum3_kernel<true, true, true>), grid, dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL((dynimg_wsum3_kernel<false, true, true>), grid, dim3(256), 0, s, p);
+    if (depth) goal_onepass_dispatch<true, true>(p, ctl, s);
+    else goal_onepass_dispatch<false, true>(p, ctl, s);
   } else {
-    if (depth)
-      hipLaunchKernelGGL((dynimg_wsum3_kernel<true, true>), grid, dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL((dynimg_wsum3_kernel<false, true>), grid, dim3(256), 0, s, p);
+    if (depth) goal_onepass_dispatch<true, false>(p, ctl, s);
+    else goal_onepass_dispatch<false, false>(p, ctl, s);
   }
-  GEECO_LAUNCH_CHECK();
-  const int C = depth ? 4 : 3;
-  dim3 g2((unsigned)cdiv64(p.HW * 4, 1024), (unsigned)p.N, 2);
-  hipLaunchKernelGGL(dynimg_norm_kernel, g2, dim3(256), 0, s, buf_out, (const float*)part1, nblk, p.HW, C, 4, diff_out,
-                     (const float*)part2);
   GEECO_LAUNCH_CHECK();
   return 0;
 }

@@ -764,7 +764,7 @@ class GoalE2EVMC(_ModelBase):
     self.decoder = LSTMDecoder(self.store, root + '/LSTMDecoder', cfg, N, T, D, training)
     self._bind_labels()
     self.dyn_ws = ops.dynimg_ws(N, H * W * 4, self.device)
-    self.dyn_ws2 = torch.empty(2 * self.dyn_ws.numel(), dtype=torch.float32, device=self.device)   # partials of two images
+    self.dyn_ws2 = ops.goal_dynimgs_ws(N, H * W, self.device)      # control block of the one-pass input stage (zero-filled once)
     # geeco-f reads its K-frame window ONCE, in the input kernel: that kernel can take the episodes' resident uint8 frames
     # directly (RGB, or RGB of RGB-D with depth dense), see ops.goal_dynimgs_u8_into
     if (self.mode == 'dynimg' and self.last_from_dynimg and (H * W) % 4 == 0 and (C == 3 or self.split_rgbd) and
@@ -821,8 +821,8 @@ class GoalE2EVMC(_ModelBase):
         ops.goal_dynimgs_u8_into(x_in[0], x_in[1], x_in[2], self.inputs['rgb'].table, self.inputs['target_rgb'].table, K, N,
                                  HW, self.dyn_ws2)
       elif C == 3 and HW % 4 == 0 and self.last_from_dynimg:
-        # two launches: the buffer-image pass has the current frame in registers and writes its channel-padded copy and the pair image
-        # too; one normalisation launch serves both images
+        # ONE launch: the pass over the window has the current frame in registers (its channel-padded copy and the pair image come
+        # from there) and keeps both images in registers across their per-sample min / max
         ops.goal_dynimgs_into(x_in[0], x_in[1], x_in[2], frames, tgt, K, N, HW, self.dyn_ws2, K * HW * C, HW * C)
       else:
         ops.pack_pixels_into(x_in[0], cur, K * HW * C, N, HW, C, 4)

@@ -719,12 +719,35 @@ class _EpisodeSource:
       for _, _, item in pending:
         if not isinstance(item, tuple):
           item.cancel()
-      # reads already running finish (they cannot be interrupted inside the native reader), then the reader's spare inflate
-      # buffers go back to the OS: once every episode sits in the HBM cache no reader runs again, and under data parallelism
-      # every rank would otherwise hold its own pool for the rest of training
+      # reads already running finish (they cannot be interrupted inside the native reader).  An epoch that read NOTHING (every
+      # episode came out of the HBM cache) hands the reader's spare inflate buffers back to the OS: no reader will run again, and
+      # under data parallelism every rank would otherwise hold its own pool (up to num_threads + 1 buffers of ~105 MB) for the
+      # rest of training.  An epoch that did read keeps them for the next one (sixteen threads faulting fresh 105 MB mappings in
+      # at once cost epoch 1 of the bench 0.13 s when the pool was emptied after every epoch).
       self._pool.shutdown(wait=True)
-      if self._reads:
+      if not self._reads:
         tfrecord._host().geeco_host_release_buffers()
+
+
+def usable_host_cores():
+  """Host threads this process may use: the affinity mask capped by the cgroup CPU quota."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      quota, period = f.read().split()
+    if quota != 'max':
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return max(1, n)
+
+
+def default_reader_threads(world=1):
+  """``num_threads=None``: this rank's share of the host, usable cores // ranks on the node, within 4 (the reference's default,
+  train_e2evmc.py:67) ... 32.  Reading an episode is 97 % inflate and scales with threads up to the cores a rank owns
+  (profiles/r05/reader_scaling.json): one rank's GPU consumes ~119 episodes/s, one reader thread delivers ~9, so epoch 1 (before
+  the HBM episode cache serves everything) is reader-bound below ~13 cores per rank."""
+  return max(4, min(32, usable_host_cores() // max(int(world), 1)))
 
 
 def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size=4, fetch_target=False,
@@ -732,7 +755,7 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
                        shard=None, device=None, device_keys=None, cache=True):
   """Same signature as the reference's pickplace_input_fn (geeco_gym.py:234-279).  Returns an iterable of
   (features, labels) numpy batches.  ``num_threads`` episodes are read in parallel, in order (num_parallel_reads /
-  num_parallel_calls of :442-473); ``prefetch_size`` batches are prepared ahead of the consumer (:473).
+  num_parallel_calls of :442-473; None = ``default_reader_threads``: this rank's share of the host cores); ``prefetch_size`` batches are prepared ahead of the consumer (:473).
   Extensions: ``shard = (rank, world)`` makes each data-parallel rank read a disjoint, rank-strided subset of the
   episodes.  ``device`` (e.g. 'cuda'): upload every episode's frames once and hand out image features as DeviceWindows
   (windows are gathered in HBM); ``device_keys``: which image streams the model reads (default both; ('rgb',) for an
@@ -742,6 +765,8 @@ def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size
   if encoding != 'v4':
     # v1-v3 are dead code in the reference (undefined PickAndPlaceEncodingV1/2/3 -> NameError)
     raise KeyError(encoding)
+  if num_threads is None:
+    num_threads = default_reader_threads(shard[1] if shard is not None else 1)
   if dataset_dir.startswith('synthetic:'):
     return synthetic_from_spec(dataset_dir, mode, window_size, fetch_target, batch_size, seed)
   meta = get_meta_v4(dataset_dir)

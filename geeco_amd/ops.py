@@ -87,23 +87,16 @@ def dynimg_rgbd_into(out, rgb, depth, K, N, HW, ws, sample_stride, frame_stride,
                                      _stream()), 'geeco_dynimg_rgbd_fwd')
 
 
-def dynimg_last_into(out, last, frames, K, N, HW, ws, sample_stride, frame_stride):
-  """RGB stack: out [N][HW][4] <- normalised dynamic image; last [N][HW][4] <- the stack's last frame, channel-padded."""
-  check(_lib().geeco_dynimg_fwd_last(_p(frames), sample_stride, frame_stride, ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N,
-                                     K, HW, _p(out), _p(last), _p(ws), _stream()), 'geeco_dynimg_fwd_last')
-
-
-def dynimg_rgbd_last_into(out, last, rgb, depth, K, N, HW, ws, sample_stride, frame_stride, dsample_stride, dframe_stride):
-  """RGB-D stack (rgb / depth in separate tensors): dynamic image + the last frame's (R, G, B, depth)."""
-  check(_lib().geeco_dynimg_rgbd_fwd_last(_p(rgb), sample_stride, frame_stride, _p(depth), dsample_stride, dframe_stride,
-                                          ctypes.cast(_alpha_buf(K), ctypes.c_void_p), N, K, HW, _p(out), _p(last), _p(ws),
-                                          _stream()), 'geeco_dynimg_rgbd_fwd_last')
+def goal_dynimgs_ws(N, HW, device):
+  """The workspace of goal_dynimgs_into / goal_dynimgs_u8_into (per-sample arrival counters + per-block min / max slots):
+  zero-filled here ONCE; every call finds and leaves the counters zero."""
+  return torch.zeros(max(int(_lib().geeco_goal_dynimgs_ws_bytes(N, HW)) // 4, 1), dtype=torch.int32, device=device)
 
 
 def goal_dynimgs_into(cur_out, buf_out, diff_out, rgb, tgt_rgb, K, N, HW, ws, sample_stride, frame_stride, depth=None,
                       tgt_depth=None, dsample_stride=0, dframe_stride=0):
-  """The goal model's three conv1 inputs (current frame padded, buffer image, diff image) in two launches: one pass over the
-  window for all three + one normalisation of both images."""
+  """The goal model's three conv1 inputs (current frame padded, buffer image, diff image) in ONE launch and one pass over the
+  window (both images normalised in registers before their only store).  ``ws`` = goal_dynimgs_ws(N, HW, device)."""
   check(_lib().geeco_goal_dynimgs_fwd(_p(rgb), sample_stride, frame_stride, _p(tgt_rgb), _p(depth), dsample_stride,
                                       dframe_stride, _p(tgt_depth), ctypes.cast(_alpha_buf(K), ctypes.c_void_p),
                                       ctypes.cast(_alpha_buf(2), ctypes.c_void_p), N, K, HW, _p(cur_out), _p(buf_out),

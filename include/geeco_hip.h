@@ -56,12 +56,6 @@ int geeco_dynimg_fwd(const float* frames, const float* frames2, int64_t sample_s
                      int64_t frame_stride, const float* alpha_host, int N, int K, int64_t HW,
                      int C, int Cpad, float* out, void* ws, void* stream);
 
-/* geeco_dynimg_fwd for RGB stacks (C = 3 -> Cpad = 4, HW % 4 == 0, 16-byte aligned strides) that ALSO writes the LAST
- * frame of the stack channel-padded, last [N][HW][4] = (R, G, B, 0): the goal model feeds exactly that frame to its
- * ConvEncoder (graph.py:387), and the kernel has it in registers (one launch and one read of the frame less). */
-int geeco_dynimg_fwd_last(const float* frames, int64_t sample_stride, int64_t frame_stride, const float* alpha_host,
-                          int N, int K, int64_t HW, float* out, float* last, void* ws, void* stream);
-
 /* RGB-D form of geeco_dynimg_fwd without packing: `rgb` [N][K][HW][3] and `depth` [N][K][HW] stay separate tensors
  * (each with its own sample / frame strides, 16-byte aligned, HW % 4 == 0) and tf.concat([rgb, depth], -1)
  * (estimator.py:169,172) happens in registers; out [N][HW][4] normalised over all four channels (graph.py:47-54).
@@ -69,15 +63,15 @@ int geeco_dynimg_fwd_last(const float* frames, int64_t sample_stride, int64_t fr
 int geeco_dynimg_rgbd_fwd(const float* rgb, const float* rgb2, int64_t sample_stride, int64_t frame_stride,
                           const float* depth, const float* depth2, int64_t dsample_stride, int64_t dframe_stride,
                           const float* alpha_host, int N, int K, int64_t HW, float* out, void* ws, void* stream);
-/* ... and the RGB-D form with the last frame's (R, G, B, depth) written to last [N][HW][4]. */
-int geeco_dynimg_rgbd_fwd_last(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* depth,
-                               int64_t dsample_stride, int64_t dframe_stride, const float* alpha_host, int N, int K,
-                               int64_t HW, float* out, float* last, void* ws, void* stream);
-
-/* All three conv1 inputs of the goal model's dynimg branch (graph.py:386-401) in two launches: buf_out = dynimg of the
- * K-frame stack, diff_out = dynimg of (last frame, target) with the 2-frame coefficients alpha2, cur_out = the last
- * frame channel-padded; both images are normalised by ONE launch.  depth / tgt_depth NULL: RGB ((R, G, B, 0) pixels),
- * else RGB-D from separate tensors.  ws: 2 x geeco_dynimg_ws_bytes(N, HW * 4) bytes. */
+/* All three conv1 inputs of the goal model's dynimg branch (graph.py:386-401) in ONE launch and one pass over the window:
+ * buf_out = dynimg of the K-frame stack, diff_out = dynimg of (last frame, target) with the 2-frame coefficients alpha2,
+ * cur_out = the last frame channel-padded.  Both images stay in registers across their per-sample min / max (the blocks of
+ * a sample meet at a per-sample arrival counter in `ws`) and are stored once, normalised; bitwise the images of
+ * geeco_dynimg_fwd / geeco_dynimg_rgbd_fwd.  depth / tgt_depth NULL: RGB ((R, G, B, 0) pixels), else RGB-D from separate
+ * tensors.  HW % 4 == 0, 16-byte aligned strides.
+ * ws: geeco_goal_dynimgs_ws_bytes(N, HW) bytes that the caller ZERO-FILLS ONCE (per-sample arrival counters, which every call
+ * finds and leaves zero, + per-block min / max slots); calls that share a `ws` must be stream-ordered. */
+int64_t geeco_goal_dynimgs_ws_bytes(int N, int64_t HW);
 int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t frame_stride, const float* tgt_rgb,
                            const float* depth, int64_t dsample_stride, int64_t dframe_stride, const float* tgt_depth,
                            const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW, float* cur_out,

@@ -13,8 +13,8 @@ win = torch.tensor([e.data_ptr() + int(r.integers(0, 84)) * fe for e in eps], dt
 tpt = torch.tensor([t.data_ptr() for t in tg], dtype=torch.int64, device=dev)
 rgb = torch.rand(N, K, H, W, 3, device=dev)
 tgt = torch.rand(N, H, W, 3, device=dev)
-ws = ops.dynimg_ws(N, HW * 4, dev)
-ws2 = torch.empty(2 * ws.numel(), dtype=torch.float32, device=dev)
+
+ws2 = ops.goal_dynimgs_ws(N, HW, dev)
 out = [torch.empty(N, H, W, 4, device=dev) for _ in range(3)]
 big = torch.empty(256 << 20, dtype=torch.uint8, device=dev)      # flushes the caches between samples
 def timeit(fn, reps=30):
@@ -30,5 +30,5 @@ u8 = lambda: ops.goal_dynimgs_u8_into(out[0], out[1], out[2], win, tpt, K, N, HW
 f32 = lambda: ops.goal_dynimgs_into(out[0], out[1], out[2], rgb, tgt, K, N, HW, ws2, K * fe, fe)
 for _ in range(3):
   u8(); f32()
-print('%s: uint8 by address %.1f us (p10 %.1f p90 %.1f) | fp32 windows %.1f us (both incl. the normalisation launch)' %
+print('%s: uint8 by address %.1f us (p10 %.1f p90 %.1f) | fp32 windows %.1f us (one launch each)' %
       ((os.environ.get('GEECO_LIB', 'default'),) + timeit(u8) + timeit(f32)[:1]))

@@ -162,6 +162,10 @@ def main(args):
   if world > 1 and not synthetic and args.batch_size % world:
     raise ValueError('--batch_size %d (the GLOBAL batch) must be divisible by the %d ranks' % (args.batch_size, world))
 
+  # --num_threads as given; when the flag is absent, this rank's share of the host cores instead of the reference's fixed 4
+  # (input_fn.default_reader_threads: epoch 1 of real-data training is reader-bound below ~13 cores per rank)
+  reader_threads = args.num_threads if any(a == '--num_threads' or a.startswith('--num_threads=') for a in sys.argv[1:]) else None
+
   def input_fn(estimator_mode):
     import torch
     dev = torch.device('cuda', local_rank)
@@ -176,7 +180,7 @@ def main(args):
     return pickplace_input_fn(
         dataset_dir=args.dataset_dir, split_name=args.split_name, mode=estimator_mode, encoding=args.data_encoding,
         window_size=e2evmc_config.window_size, fetch_target=(args.goal_condition == 'target'),
-        shuffle_buffer=args.shuffle_buffer, num_epochs=1, num_threads=args.num_threads,
+        shuffle_buffer=args.shuffle_buffer, num_epochs=1, num_threads=reader_threads,
         prefetch_size=args.prefetch_size,
         # episodes are uploaded once (to THIS rank's GPU), stay there across epochs (input_fn.EPISODE_CACHE) and windows are
         # gathered in HBM unless GEECO_HOST_WINDOWS is set; an RGB model never reads the depth stream

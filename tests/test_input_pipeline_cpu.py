@@ -225,9 +225,10 @@ def test_table_driven_inflate_equals_zlib(tmp_path):
       np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
 
 
-def test_reader_returns_its_spare_buffers_after_an_epoch(tmp_path):
-  """the native reader keeps mapped inflate buffers between episodes (one per reader thread + 1, not a fixed
-  32 / 6 GiB) and hands them back to the OS when the epoch's last episode has been read."""
+def test_reader_returns_its_spare_buffers_after_a_cached_epoch(tmp_path):
+  """the native reader keeps mapped inflate buffers between episodes -- one per reader thread + 1, not a fixed
+  32 / 6 GiB -- and an epoch that read nothing (every episode served by the HBM cache: no reader will run again) hands them
+  back to the OS; an epoch that did read keeps them for the next."""
   from geeco_amd import input_fn as I
   from geeco_amd import tfrecord as T
   lib = T._host()
@@ -240,12 +241,17 @@ def test_reader_returns_its_spare_buffers_after_an_epoch(tmp_path):
   lib.geeco_host_set_buffer_limit(1)                                                         # ... a lower limit trims them
   assert lib.geeco_host_spare_buffers() <= 1
   n = sum(1 for _ in I.pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=3, batch_size=2, num_threads=2, seed=0))
-  assert n > 0 and lib.geeco_host_spare_buffers() == 0                                       # the epoch is over: all returned
-  src = I._EpisodeSource(_paths(str(tmp_path)), meta, True, 3, None, ('rgb', 'depth'), None)
-  it = iter(src)
-  next(it)
-  it.close()                                                                                 # abandoned mid-epoch: same
-  assert lib.geeco_host_spare_buffers() == 0
+  assert n > 0 and 1 <= lib.geeco_host_spare_buffers() <= 3                                  # an epoch that read: kept, at most threads + 1
+
+  class AllCached:                       # stands in for input_fn.EPISODE_CACHE with every episode resident
+    def key(self, path, *a):
+      return path
+    def get(self, key):
+      return ({'step': np.zeros(5, np.int64)}, {})
+  import torch
+  src = I._EpisodeSource(_paths(str(tmp_path)), meta, True, 3, torch.device('cpu'), ('rgb', 'depth'), AllCached())
+  assert sum(1 for _ in src) == 5 and src._reads == 0
+  assert lib.geeco_host_spare_buffers() == 0                                                 # nothing was read: all returned
 
 
 def test_inflate_under_address_sanitizer(tmp_path):

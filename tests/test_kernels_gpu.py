@@ -472,52 +472,32 @@ def test_conv2_relu_fields_and_conv3_dgrad_fields(dev, G, N, H, W):
   assert not torch.isnan(dx).any() and torch.equal(dx, dx_ref)
 
 
-@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4)])
-def test_dynimg_with_last_frame(dev, N, K, H, W, C):
-  """The buffer-image kernel that also writes the stack's last frame channel-padded: image bitwise as without the extra
-  output, last frame = the packed copy pack_pixels makes (rgb: (R, G, B, 0); rgbd: rgb || depth from separate tensors)."""
-  from geeco_amd import ops
-  r = np.random.default_rng(53)
-  HW = H * W
-  rgb = torch.tensor(r.random([N, K, H, W, 3]).astype(np.float32), device=dev)
-  ws = ops.dynimg_ws(N, HW * 4, dev)
-  out_ref = torch.empty(N, H, W, 4, device=dev)
-  out = torch.full((N, H, W, 4), float('nan'), device=dev)
-  last = torch.full((N, H, W, 4), float('nan'), device=dev)
-  last_ref = torch.empty(N, H, W, 4, device=dev)
-  if C == 3:
-    ops.dynimg_into(out_ref, rgb, K, N, HW, 3, 4, ws, K * HW * 3, HW * 3)
-    ops.pack_pixels_into(last_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4)
-    ops.dynimg_last_into(out, last, rgb, K, N, HW, ws, K * HW * 3, HW * 3)
-  else:
-    dep = torch.tensor((0.5 + 2.5 * r.random([N, K, H, W, 1])).astype(np.float32), device=dev)
-    ops.dynimg_rgbd_into(out_ref, rgb, dep, K, N, HW, ws, K * HW * 3, HW * 3, K * HW, HW)
-    ops.pack_pixels_into(last_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4, dep[:, K - 1], K * HW, 1)
-    ops.dynimg_rgbd_last_into(out, last, rgb, dep, K, N, HW, ws, K * HW * 3, HW * 3, K * HW, HW)
-  torch.cuda.synchronize()
-  assert torch.equal(out, out_ref) and torch.equal(last, last_ref)
-
-
-@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (2, 2, 40, 36, 4)])
+@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (2, 2, 40, 36, 4),
+                                       (24, 3, 256, 256, 3), (26, 2, 128, 256, 4), (5, 2, 100, 164, 3)])
 def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
-  """The goal model's input stage (graph.py:386-401) as the step runs it: ONE pass over the window writes the buffer image, the
-  current frame's padded copy and the pair image of (current frame, target), one normalisation launch serves both images.
+  """The goal model's input stage (graph.py:386-401) as the step runs it: ONE launch, one pass over the window: the buffer image
+  and the pair image of (current frame, target) stay in registers across their per-sample min / max (the blocks of a sample meet
+  at an arrival counter) and are stored once, normalised; the current frame's padded copy comes from the same pass.
   Bitwise equal to the separate launches (buffer image; two-frame image with the target as second frame), and both images
-  against the fp64 oracle; K = 1 (alpha = [0]: the buffer image is identically 0), rgb and rgb + depth."""
+  against the fp64 oracle; K = 1 (alpha = [0]: the buffer image is identically 0), rgb and rgb + depth; both block shapes
+  (1024 threads x 8 pixels from 192 blocks on: the 24- and 26-sample cases, 8 resp. 4 blocks per sample; 256 x 4 below), a
+  ragged last block (100 x 164); run three times on one control block (every call must leave it zero-filled)."""
   from geeco_amd import ops
   r = np.random.default_rng(57)
   HW = H * W
   rgb = torch.tensor(r.random([N, K, H, W, 3]).astype(np.float32), device=dev)
   tgt = torch.tensor(r.random([N, H, W, 3]).astype(np.float32), device=dev)
   ws = ops.dynimg_ws(N, HW * 4, dev)
-  ws2 = torch.empty(2 * ws.numel(), dtype=torch.float32, device=dev)
+  ws2 = ops.goal_dynimgs_ws(N, HW, dev)
   cur, buf, dif = (torch.full((N, H, W, 4), float('nan'), device=dev) for _ in range(3))
   buf_ref, dif_ref, cur_ref = (torch.empty(N, H, W, 4, device=dev) for _ in range(3))
   if C == 3:
     ops.dynimg_into(buf_ref, rgb, K, N, HW, 3, 4, ws, K * HW * 3, HW * 3)
     ops.dynimg_into(dif_ref, rgb[:, K - 1], 2, N, HW, 3, 4, ws, K * HW * 3, 0, frames2=tgt)
     ops.pack_pixels_into(cur_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4)
-    ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3)
+    names = ops.kernel_trace(lambda: ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3))
+    for _ in range(2):
+      ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3)
     frames64 = rgb.cpu().double()
     tgt64 = tgt.cpu().double()
   else:
@@ -526,19 +506,27 @@ def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
     ops.dynimg_rgbd_into(buf_ref, rgb, dep, K, N, HW, ws, K * HW * 3, HW * 3, K * HW, HW)
     ops.dynimg_rgbd_into(dif_ref, rgb[:, K - 1], dep[:, K - 1], 2, N, HW, ws, K * HW * 3, 0, K * HW, 0, rgb2=tgt, depth2=tdep)
     ops.pack_pixels_into(cur_ref, rgb[:, K - 1], K * HW * 3, N, HW, 3, 4, dep[:, K - 1], K * HW, 1)
-    ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3, depth=dep, tgt_depth=tdep,
-                          dsample_stride=K * HW, dframe_stride=HW)
+    run = lambda: ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws2, K * HW * 3, HW * 3, depth=dep, tgt_depth=tdep,
+                                        dsample_stride=K * HW, dframe_stride=HW)
+    names = ops.kernel_trace(run)
+    for _ in range(2):
+      run()
     frames64 = torch.cat([rgb, dep], -1).cpu().double()
     tgt64 = torch.cat([tgt, tdep], -1).cpu().double()
   torch.cuda.synchronize()
+  big = N * -(-(HW // 4) // 2048) >= 192
+  assert names == ['dynimg_goal_onepass_kernel<%s, false, %s>' % ('true' if C == 4 else 'false', '1024, 2' if big else '256, 1')], names
+  assert not ws2[:16 * N].view(N, 16)[:, :2].any()      # the arrival / departure counters are zero again
   assert torch.equal(cur, cur_ref)
   assert torch.equal(buf, buf_ref)
   assert torch.equal(dif, dif_ref)
-  _close(buf[..., :C], O.dynimg(frames64), 0, 5e-6, 'buffer image vs fp64')
-  _close(dif[..., :C], O.dynimg(torch.stack([frames64[:, K - 1], tgt64], 1)), 0, 5e-6, 'pair image vs fp64')
+  sub = slice(0, N if HW <= 136 * 136 else 2)          # (the oracle in fp64 on the big cases: two samples)
+  _close(buf[sub][..., :C], O.dynimg(frames64[sub]), 0, 5e-6, 'buffer image vs fp64')
+  _close(dif[sub][..., :C], O.dynimg(torch.stack([frames64[sub, K - 1], tgt64[sub]], 1)), 0, 5e-6, 'pair image vs fp64')
 
 
-@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (4, 2, 40, 36, 4)])
+@pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (4, 2, 40, 36, 4),
+                                       (25, 2, 256, 256, 3), (24, 2, 256, 256, 4)])
 def test_goal_dynimgs_from_resident_u8_frames(dev, N, K, H, W, C):
   """The input stage fed from the episodes' resident uint8 frames through per-sample window addresses
   (geeco_goal_dynimgs_u8_fwd): bitwise the three images of geeco_gather_windows (/ 255, geeco_gym.py:312) followed by
@@ -564,8 +552,7 @@ def test_goal_dynimgs_from_resident_u8_frames(dev, N, K, H, W, C):
     ops.gather_windows_into(tgt[n:n + 1].view(1, 1, H, W, 3), tgts[e], torch.zeros(1, dtype=torch.int32, device=dev), 1, 1, fe, 255.0)
   win = torch.tensor([eps[e].data_ptr() + st * fe for e, st in pick], dtype=torch.int64, device=dev)
   tpt = torch.tensor([tgts[e].data_ptr() for e, _ in pick], dtype=torch.int64, device=dev)
-  ws = ops.dynimg_ws(N, HW * 4, dev)
-  ws2 = torch.empty(2 * ws.numel(), dtype=torch.float32, device=dev)
+  ws2 = ops.goal_dynimgs_ws(N, HW, dev)
   ref = [torch.empty(N, H, W, 4, device=dev) for _ in range(3)]
   got = [torch.full((N, H, W, 4), float('nan'), device=dev) for _ in range(3)]
   kw = {}
