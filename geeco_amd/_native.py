@@ -29,6 +29,11 @@ _PP = POINTER(c_void_p)
 _I, _L, _F = c_int, c_int64, c_float
 
 
+class HeadsFinish(Structure):
+  """geeco_heads_finish (include/geeco_hip.h): the pending batch sums of the heads' backward, opaque to the caller."""
+  _fields_ = [('opaque', ctypes.c_ubyte * 1024)]
+
+
 class SlabReduce(Structure):
   """geeco_slab_reduce (include/geeco_hip.h): one pending slab sum of a filter-gradient kernel."""
   _fields_ = [('part', c_void_p), ('dw', c_void_p), ('db', c_void_p), ('gs_dw', c_int64), ('gs_db', c_int64),
@@ -95,11 +100,14 @@ SIGNATURES = {
     'geeco_lstm_input_step_fwd': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'geeco_lstm_gates_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'geeco_lstm_step_bwd_ws_bytes': (_L, [_I, _I, _I]),
-    'geeco_lstm_step_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _P, _P]),
+    'geeco_lstm_step_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _PP, _PP, POINTER(_I), _I, _I, _I, _I, _P, _P, _P]),
     'geeco_colsum': (_I, [_P, _L, _I, _I, _P, _I, _P]),
     'geeco_heads_ws_bytes': (_L, [_I, _I, _I]),
     'geeco_heads_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _PP, _PP, POINTER(_I), POINTER(_I), POINTER(_F), _PP,
                                       POINTER(_L), _F, _I, _I, _I, _P, _P, _I, _P, _P, _P, _PP, _PP, _P, _P]),
+    'geeco_lstm_step_heads_fwd_bwd': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _PP, _PP, POINTER(_I),
+                                           POINTER(_I), POINTER(_F), _PP, POINTER(_L), _F, _I, _P, _P, _I, _P, _P, _P, _PP, _PP,
+                                           _P, _P, _P]),
     'geeco_adam_prepare': (_I, [_P, _F, _F, _F, _P, _P]),
     'geeco_adam_tf': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     'geeco_sumsq': (_I, [_P, _L, _P, _P]),

@@ -343,10 +343,8 @@ struct ConcatScatter {
   }
 };
 
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const LstmBwdBatch q) {
-  __shared__ float sA[2][GEMM_BK * GEMM_LD];
-  __shared__ float sB[2][GEMM_BK * GEMM_LD];
-  const int blk = blockIdx.x;
+__device__ __forceinline__ void lstm_step_bwd_body(const LstmBwdBatch& q, int blk, float (*sA)[GEMM_BK * GEMM_LD],
+                                                   float (*sB)[GEMM_BK * GEMM_LD]) {
   if (blk < q.nA) {
     gemm_block(q.a, blk % q.ax, blk / q.ax, 0, sA, sB, NoStore());
   } else if (blk < q.nA + q.nB) {
@@ -364,9 +362,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const LstmBwdBatch q
   }
 }
 
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const LstmBwdBatch q) {
+  __shared__ float sA[2][GEMM_BK * GEMM_LD];
+  __shared__ float sB[2][GEMM_BK * GEMM_LD];
+  lstm_step_bwd_body(q, (int)blockIdx.x, sA, sB);
+}
+
 // slab sum of dX (fixed slab order, as gemm_reduce_kernel) + the state-concat scatter of the sums
-__global__ __launch_bounds__(256) void lstm_step_bwd_finish_kernel(const LstmBwdBatch q) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void lstm_step_bwd_finish_body(const LstmBwdBatch& q, int block) {
+  const long long i = (long long)block * 256 + threadIdx.x;
   const long long MN = (long long)q.b.M * q.b.N;
   if (i >= MN) return;
   float s = 0.f;
@@ -385,48 +389,11 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_finish_kernel(const LstmBwd
   if (q.cc.nfeat > 0) ConcatScatter{q.cc}(m, n, s);
 }
 
-extern "C" int64_t geeco_lstm_step_bwd_ws_bytes(int N, int D, int H4) { return geeco_gemm_ws_bytes(N, D, H4); }
-
-extern "C" int geeco_lstm_step_bwd(const float* x, int64_t ldx, const float* dz, int64_t ldz, const float* wx, int64_t ldw,
-                                   float* dwx, int64_t lddw, float* db, float* dx, int64_t lddx, int N, int D, int H4,
-                                   const float* const* feats_fwd, float* const* dfeats, const int* feat_ch, int nfeat,
-                                   int jnt_pos, int J, int cells, void* ws, void* stream) {
-  GEECO_CHECK_ARG(x && dz && wx && dwx && db && dx, "lstm_step_bwd: null pointer");
-  GEECO_CHECK_ARG(N >= 1 && D >= 1 && H4 >= 1, "lstm_step_bwd: bad dims");
-  GEECO_CHECK_ARG(nfeat >= 0 && nfeat <= 3 && (nfeat == 0 || (feats_fwd && dfeats && feat_ch && jnt_pos >= 0 && jnt_pos <= nfeat)),
-                  "lstm_step_bwd: concat description");
-  LstmBwdBatch q = {};
-  // dWx [D][4H] = X^T dz: A = X [N][D] transposed, B = dz [N][4H]
-  q.a.A = x; q.a.lda = ldx; q.a.ta = 1; q.a.B = dz; q.a.ldb = ldz; q.a.tb = 0; q.a.C = dwx; q.a.ldc = lddw;
-  q.a.M = D; q.a.N = H4; q.a.K = N; q.a.S = 1; q.a.k_per_split = cdiv(N, 16) * 16;
-  // dX [N][D] = dz Wx^T: A = dz [N][4H], B = Wx [D][4H] transposed
-  q.b.A = dz; q.b.lda = ldz; q.b.ta = 0; q.b.B = wx; q.b.ldb = ldw; q.b.tb = 1; q.b.C = dx; q.b.ldc = lddx;
-  q.b.M = N; q.b.N = D; q.b.K = H4; q.b.part = (float*)ws;
-  gemm_plan(N, D, H4, &q.b.S, &q.b.k_per_split);
-  GEECO_CHECK_ARG(q.b.S == 1 || ws, "lstm_step_bwd: workspace required (geeco_lstm_step_bwd_ws_bytes)");
-  q.ax = cdiv(H4, 64); q.nA = q.ax * cdiv(D, 64);
-  q.bx = cdiv(D, 64); q.by = cdiv(N, 64); q.nB = q.bx * q.by * q.b.S;
-  q.dz = dz; q.ldz = ldz; q.Mz = N; q.Nz = H4; q.db = db;
-  if (nfeat > 0) {
-    const int ctot = fill_concat(&q.cc, feat_ch, nfeat, jnt_pos, J);
-    GEECO_CHECK_ARG((int64_t)cells * ctot <= D, "lstm_step_bwd: %d cells x %d channels exceed the state width %d", cells, ctot, D);
-    q.cc.N = N; q.cc.cells = cells; q.cc.scale = 1.f;
-    for (int i = 0; i < nfeat; ++i) {
-      GEECO_CHECK_ARG(!dfeats[i] || feats_fwd[i], "lstm_step_bwd: feats_fwd[%d] is null", i);
-      q.cc.feats[i] = feats_fwd[i];
-      q.cc.dfeats[i] = dfeats[i];
-    }
-  }
-  const int blocks = q.nA + q.nB + cdiv(H4, 256);
-  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, q);
-  GEECO_LAUNCH_CHECK();
-  if (q.b.S > 1) {
-    hipLaunchKernelGGL(lstm_step_bwd_finish_kernel, dim3((unsigned)cdiv64((long long)N * D, 256)), dim3(256), 0,
-                       (hipStream_t)stream, q);
-    GEECO_LAUNCH_CHECK();
-  }
-  return 0;
+__global__ __launch_bounds__(256) void lstm_step_bwd_finish_kernel(const LstmBwdBatch q) {
+  lstm_step_bwd_finish_body(q, (int)blockIdx.x);
 }
+
+extern "C" int64_t geeco_lstm_step_bwd_ws_bytes(int N, int D, int H4) { return geeco_gemm_ws_bytes(N, D, H4); }
 
 // =====================================================================================================
 // LSTM gate math (tf.nn.rnn_cell.LSTMCell, gate order i, j, f, o; forget_bias = 1)
@@ -580,7 +547,8 @@ struct HeadsParams {
   float* dhb[GEECO_MAX_HEADS];
   float* a1;    // ws: [N][Hfc]
   float* da1;   // ws: [N][Hfc]
-  float* dpred; // ws: [N][OT]
+  float* dpred; // ws: [N][OT]  (the single-workgroup kernel keeps its packed head matrix behind it: [N * OT ...)
+  float* lterm; // ws: [N][8] per-sample loss terms of every head (per-sample kernel -> finish role)
 };
 
 template <class T>
@@ -729,301 +697,384 @@ __global__ __launch_bounds__(1024) void heads_loss_kernel(const HeadsParams p) {
   block_mfma_gemm(N, H, F, p.da1, F, 1, p.fc1_w, 1, F, [&](int n, int k, float v) { p.dh[n * H + k] = v; });
 }
 
-// Same computation with every operand resident in LDS (N <= 32, H == Hfc == 128: the shapes of all
-// BASELINE.json configs with batch <= 32; other sizes take heads_loss_kernel).  The phases of heads_loss_kernel hand their results
-// over through global memory (~1-2 us of store->load latency per phase, and an L2 round trip per
-// MFMA operand); here h, fc1/kernel, the packed head matrix and every intermediate live in LDS, so a
-// phase costs LDS latency only.  Gradients and predictions are written straight to their outputs.
-// Row pitches of the LDS arrays.  Every array is an MFMA operand in two roles: "row-strided" (lane (r, q) reads element
-// [r][k0 + q]: bank r * P + q) and "k-strided" ([k0 + q][r]: bank q * P + r); ds_read_b32 serves 32 lanes (r = 0..15, q = 0..1)
-// per cycle over 32 banks.  P = 146 = 18 (mod 32): r * 18 takes 16 distinct even banks (row-strided: conflict free) and
-// q * 18 + r overlaps in 2 of 32 lanes only (k-strided: 1.06 cycles instead of 1).  Round 2's pitches (129 for the
-// activations: 2-way in both roles; 144 for fc1/kernel: conflict free k-strided but 8-way row-strided in the d(h) product)
-// made this one-workgroup kernel LDS-bandwidth bound: PMC 53 % conflict cycles, 2 b32 reads per MFMA.
-constexpr int HL_NMAX = 32, HL_DMAX = 128, HL_OMAX = 24;
-constexpr int HL_WP = 146;              // fc1/kernel [h][f]
-constexpr int HL_RP = 146;              // [n][..] activations and the packed head matrix [o][f]
-constexpr int HL_OP = 33;               // predictions / targets [n][o] (element-wise use only)
-constexpr int HL_OPD = 50;              // d(loss)/d(pred) [n][o]: MFMA operand in both roles (18 mod 32)
-constexpr int HL_LDS_FLOATS = HL_DMAX * HL_WP + 3 * HL_NMAX * HL_RP + HL_OMAX * HL_RP + 2 * HL_NMAX * HL_OP + HL_NMAX * HL_OPD;
+// =====================================================================================================
+// fc1 + heads + losses per SAMPLE (round 5).  Everything from the LSTM output to d(loss)/d(h) is independent per sample
+// (graph.py:229-259, 430-500): only the loss means and the weight / bias gradients sum over the batch.  Round 2-4 ran the
+// whole tail in ONE workgroup (six dependent MFMA tile loops with a barrier between: 34 us of pure latency at N = 32, three
+// MFLOP of work).  Here:
+//   * heads_sample_kernel: one 1024-thread workgroup per sample, N workgroups side by side: fc1/kernel staged in LDS once
+//     (read twice: forward and d(h)), every product a few hundred FMAs per thread on the vector ALU (a 1 x 128 row times a
+//     128 x 128 matrix is no MFMA shape), partial sums folded through LDS / half-wave shuffles in a fixed order.  Writes the
+//     predictions, the per-sample loss terms, a1, d(a1), d(pred) and d(h).
+//     FUSE (one-step decoders, zero initial state: the goal model's dynimg branch): the same workgroup first sums the split-K
+//     slabs of its sample's gate pre-activations and runs the gate math (lstm_gates_fwd_slabs_kernel's work, same slab
+//     order), and at the end turns d(h) into the gate gradients dz (lstm_gates_bwd_kernel's work): two dependent launches
+//     less around the heads.
+//   * heads_finish_role: what sums over the batch -- d(fc1/kernel) = h^T d(a1) (row tiles), the head kernels' gradients,
+//     the bias gradients and the loss means, each a sum over n in ascending order.  A handful of independent blocks that ride
+//     at the end of another launch's grid (lstm_step_bwd_finish_kernel) or run as heads_finish_kernel.
+// Shapes: H <= 128, Hfc in {64, 128} (the reference's defaults are 128 / 128, params.py:21-22); anything else takes the
+// single-workgroup heads_loss_kernel above.
+// =====================================================================================================
+constexpr int HS_THREADS = 1024, HS_HMAX = 128, HS_FMAX = 128;
+constexpr int HS_WP = HS_FMAX + 4;      // LDS row pitch of fc1/kernel: rows of two half-waves fall on different bank groups
+constexpr size_t HS_LDS_BYTES = (size_t)(HS_HMAX * HS_WP + HS_THREADS * 4) * 4;
 
-__global__ __launch_bounds__(1024) void heads_loss_lds_kernel(const HeadsParams p) {
-  const int tid = threadIdx.x, NT = 1024;
-  constexpr int H = HL_DMAX, F = HL_DMAX;      // the launcher takes this path only for H == Hfc == 128 (the defaults)
-  const int N = p.N, OT = p.OT;
-  extern __shared__ __attribute__((aligned(16))) float hl_smem[];
-  float* sW1 = hl_smem;                          // [H][HL_WP]   fc1/kernel [h][f]
-  float* sH = sW1 + HL_DMAX * HL_WP;             // [N][HL_RP]   LSTM output
-  float* sA1 = sH + HL_NMAX * HL_RP;             // [N][HL_RP]   relu(fc1)
-  float* sDA = sA1 + HL_NMAX * HL_RP;            // [N][HL_RP]   d(loss)/d(fc1 pre-activation)
-  float* sWh = sDA + HL_NMAX * HL_RP;            // [OT][HL_RP]  head kernels side by side, transposed
-  float* sPr = sWh + HL_OMAX * HL_RP;            // [N][OP] predictions
-  float* sDp = sPr + HL_NMAX * HL_OP;            // [N][OPD] d(loss)/d(pred)
-  constexpr int OP = HL_OP, OPD = HL_OPD;
-  __shared__ float s_red[16][GEECO_MAX_HEADS];
-  __shared__ float s_hb[32], s_b1[HL_DMAX];
-  __shared__ int s_hd[32], s_hc[32];
-#ifdef GEECO_STAMPS
-#define HSTAMP(i) do { if (tid == 0) reinterpret_cast<unsigned long long*>(p.dpred)[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define HSTAMP(i)
-#endif
-  float* sTg = sDp + HL_NMAX * HL_OPD;           // [N][OP] targets (kind 1: the label in the head's first column)
-  HSTAMP(0);
-  // P0: every global input is fetched up front (independent loads, issued together), then one barrier
-  auto head_of = [&](int o) {
-    int hd = 0;
+struct StepFuse {
+  const float* part;        // split-K slabs of z = x Wx: [S][N][4H]
+  int S;
+  const float* bias;        // lstm_cell/bias [4H]
+  float* z;                 // [N][4H] slab sums (kept: geeco_lstm_input_step_fwd writes them too)
+  float* c; float* hout;    // [N][H]
+  float* gates;             // [N][4H] activated gates i, j, f, o
+  float* dz;                // backward: gate gradients [N][4H]
+};
+
+__device__ __forceinline__ int heads_head_of(const HeadsParams& p, int o) {
+  int hd = 0;
 #pragma unroll
-    for (int k = 1; k < GEECO_MAX_HEADS; ++k)
-      if (k < p.nheads && o >= p.off[k]) hd = k;
-    return hd;
-  };
-  if (tid < OT) {
-    const int hd = head_of(tid);
-    s_hd[tid] = hd;
-    s_hc[tid] = tid - sel5(p.off, hd);
-    s_hb[tid] = sel5(p.hb, hd)[tid - sel5(p.off, hd)];
+  for (int k = 1; k < GEECO_MAX_HEADS; ++k)
+    if (k < p.nheads && o >= p.off[k]) hd = k;
+  return hd;
+}
+
+template <bool FUSE, int G>              // G = Hfc / 4: float4 column groups of fc1/kernel, 16 or 32
+__global__ __launch_bounds__(HS_THREADS) void heads_sample_kernel(const HeadsParams p, const StepFuse sf) {
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int H = p.H, OT = p.OT, N = p.N;
+  constexpr int F = 4 * G;
+  constexpr int P = HS_THREADS / G;      // row parts (fc1 forward) / rows per pass (d(h))
+  extern __shared__ __attribute__((aligned(16))) float hs_dyn[];           // HS_LDS_BYTES (more than the 64 KiB a static array may take)
+  float* sW1 = hs_dyn;                                                        // [H][HS_WP] fc1/kernel
+  float* sPart = hs_dyn + HS_HMAX * HS_WP;                                    // [P][F] partial sums of the fc1 forward
+  __shared__ __attribute__((aligned(16))) float sH[HS_HMAX], sA1[HS_FMAX], sDA[HS_FMAX], sDH[HS_HMAX], sB1[HS_FMAX];
+  __shared__ float sZ[FUSE ? 4 * HS_HMAX : 1];
+  __shared__ float sPr[32], sDp[32], sHb[32], sTg[32];
+  __shared__ int sHd[32], sHc[32];
+  __shared__ float sWh[32 * HS_FMAX];     // the head kernels side by side, transposed: [o][f] (both uses walk f across lanes)
+  // ---- P0: fc1/kernel -> LDS (issued first: independent of everything), small tables, the sample's LSTM output -----------
+  f32x4 wv[4];
+  const int W4 = H * G;                  // float4 of fc1/kernel (<= 4096 = 4 per thread)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e4 = tid + HS_THREADS * i;
+    wv[i] = e4 < W4 ? reinterpret_cast<const f32x4*>(p.fc1_w)[e4] : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int e = tid; e < F; e += NT) s_b1[e] = p.fc1_b[e];
-  if ((F & 3) == 0 && (H & 3) == 0) {
-    constexpr int WV = HL_DMAX * HL_DMAX / 4 / 1024;      // float4 of fc1/kernel per thread (4)
-    f32x4 wv[WV], hv;
-    const int F4 = F >> 2;
+  // every global input of the sample is fetched here, up front: after this phase only LDS is read
+  if (tid < OT) {
+    const int hd = heads_head_of(p, tid), cc = tid - sel5(p.off, hd);
+    sHd[tid] = hd;
+    sHc[tid] = cc;
+    sHb[tid] = sel5(p.hb, hd)[cc];
+    if (sel5(p.kind, hd) == 0 || cc == 0) sTg[tid] = sel5(p.tgt, hd)[(long long)n * sel5(p.tstride, hd) + cc];
+  }
+  if (tid < F) sB1[tid] = p.fc1_b[tid];
+  for (int e = tid; e < OT * F; e += HS_THREADS) {      // consecutive threads: consecutive o of one f (the variables are [f][size])
+    const int f = e / OT, o = e - f * OT;
+    const int hd = heads_head_of(p, o);
+    sWh[o * HS_FMAX + f] = sel5(p.hw, hd)[(long long)f * sel5(p.size, hd) + (o - sel5(p.off, hd))];
+  }
+  [[maybe_unused]] float g_si = 0.f, g_tj = 0.f, g_sf = 0.f, g_so = 0.f, g_tc = 0.f;
+  if (FUSE) {
+    // gate pre-activations of this sample: column tid of [4H], slabs summed in slab order (as gemm_reduce_kernel)
+    if (tid < 4 * H) {
+      const long long MN = (long long)N * 4 * H;
+      const float* src = sf.part + (long long)n * 4 * H + tid;
+      float s = 0.f;
+      int k = 0;
+      for (; k + 16 <= sf.S; k += 16) {
+        float v[16];
 #pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int e4 = tid + NT * i;
-      wv[i] = e4 < H * F4 ? reinterpret_cast<const f32x4*>(p.fc1_w)[e4] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    hv = tid < (N * H >> 2) ? reinterpret_cast<const f32x4*>(p.h)[tid] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 16; ++q) v[q] = src[(long long)(k + q) * MN];
 #pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int e4 = tid + NT * i;
-      if (e4 < H * F4) {      // the row pitch is even, not a multiple of 4 floats: two 8-byte stores
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2* d = reinterpret_cast<f32x2*>(sW1 + (e4 / F4) * HL_WP + (e4 % F4) * 4);
-        d[0] = f32x2{wv[i].x, wv[i].y};
-        d[1] = f32x2{wv[i].z, wv[i].w};
+        for (int q = 0; q < 16; ++q) s += v[q];
       }
-    }
-    if (tid < (N * H >> 2)) {
-      const int e = tid * 4;
-      float* d = sH + (e / H) * HL_RP + (e % H);
-      d[0] = hv.x; d[1] = hv.y; d[2] = hv.z; d[3] = hv.w;
+      if (k < sf.S) {      // the remaining slabs (< 16) in ONE round of predicated loads; a skipped slab adds nothing
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = k + q < sf.S ? src[(long long)(k + q) * MN] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (k + q < sf.S) s += v[q];
+      }
+      sf.z[(long long)n * 4 * H + tid] = s;
+      sZ[tid] = s + sf.bias[tid];
     }
   } else {
-    for (int e = tid; e < H * F; e += NT) sW1[(e / F) * HL_WP + (e % F)] = p.fc1_w[e];
-    for (int e = tid; e < N * H; e += NT) sH[(e / H) * HL_RP + (e % H)] = p.h[e];
+    if (tid < H) sH[tid] = p.h[(long long)n * H + tid];
   }
-  for (int e = tid; e < OT * F; e += NT) {
-    const int o = e / F, f = e - o * F;
-    const int hd = head_of(o);
-    sWh[o * HL_RP + f] = sel5(p.hw, hd)[f * sel5(p.size, hd) + (o - sel5(p.off, hd))];
-  }
-  for (int e = tid; e < N * OT; e += NT) {
-    const int n = e / OT, o = e - n * OT;
-    const int hd = head_of(o), c = o - sel5(p.off, hd);
-    if (sel5(p.kind, hd) == 0 || c == 0) sTg[n * OP + o] = sel5(p.tgt, hd)[(long long)n * sel5(p.tstride, hd) + c];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e4 = tid + HS_THREADS * i;
+    if (e4 < W4) *reinterpret_cast<f32x4*>(sW1 + (e4 / G) * HS_WP + (e4 % G) * 4) = wv[i];
   }
   __syncthreads();
-  HSTAMP(1);
-  HSTAMP(2);
-  // The six small GEMMs run through ONE copy of the MFMA tile loop (operands and results in LDS, or a
-  // global result): the kernel executes once per step from a cold instruction cache, so its run time
-  // follows its code size - six inlined, unrolled GEMMs (47 KB of code) took 3x longer than this loop.
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int nph = p.backward ? 6 : 2;
-#pragma unroll 1
-  for (int ph = 0; ph < nph; ++ph) {
-    // C(i, j) = sum_k A(i, k) B(k, j);  A(i, k) = smem[a + i a_rs + k a_ks], B(k, j) = smem[b + k b_ks + j b_cs],
-    // C -> smem[c + i c_rs + j c_cs] or, if gc, gc[i c_rs + j c_cs]
-    int M, Nn, K, a, a_rs, a_ks, b, b_ks, b_cs, c = 0, c_rs, c_cs;
-    float* gc = nullptr;
-    const int oH = (int)(sH - hl_smem), oW1 = 0, oA1 = (int)(sA1 - hl_smem), oDA = (int)(sDA - hl_smem);
-    const int oWh = (int)(sWh - hl_smem), oPr = (int)(sPr - hl_smem), oDp = (int)(sDp - hl_smem);
-    switch (ph) {
-      case 0:   // P1: fc1 pre-activation = h W1                                  graph.py:229-230
-        M = N; Nn = F; K = H; a = oH; a_rs = HL_RP; a_ks = 1; b = oW1; b_ks = HL_WP; b_cs = 1; c = oA1; c_rs = HL_RP; c_cs = 1;
-        break;
-      case 1:   // P2: preds = a1 Wh                                              graph.py:233-259
-        M = N; Nn = OT; K = F; a = oA1; a_rs = HL_RP; a_ks = 1; b = oWh; b_ks = 1; b_cs = HL_RP; c = oPr; c_rs = OP; c_cs = 1;
-        break;
-      case 2:   // d(a1) = dpred Wh^T (ReluGrad applied after the loop body)
-        M = N; Nn = F; K = OT; a = oDp; a_rs = OPD; a_ks = 1; b = oWh; b_ks = HL_RP; b_cs = 1; c = oDA; c_rs = HL_RP; c_cs = 1;
-        break;
-      case 3:   // head kernel gradients [f][o] = a1^T dpred, into the (now free) packed head matrix as [o][f]
-        M = F; Nn = OT; K = N; a = oA1; a_rs = 1; a_ks = HL_RP; b = oDp; b_ks = OPD; b_cs = 1; c = oWh; c_rs = 1; c_cs = HL_RP;
-        break;
-      case 4:   // d(h) = d(a1) W1^T
-        M = N; Nn = H; K = F; a = oDA; a_rs = HL_RP; a_ks = 1; b = oW1; b_ks = 1; b_cs = HL_WP; gc = p.dh; c_rs = H; c_cs = 1;
-        break;
-      default:  // d(fc1/kernel) = h^T d(a1)
-        M = H; Nn = F; K = N; a = oH; a_rs = 1; a_ks = HL_RP; b = oDA; b_ks = HL_RP; b_cs = 1; gc = p.d_fc1_w; c_rs = F; c_cs = 1;
-        break;
-    }
-    const int tn = (Nn + 15) >> 4, nt = ((M + 15) >> 4) * tn;
-#pragma unroll 1
-    for (int t = wave; t < nt; t += 16) {
-      const int ti = t / tn, tj = t - ti * tn;
-      const int i = ti * 16 + r, j = tj * 16 + r;
-      const bool iv = i < M, jv = j < Nn;
-      // rows / columns beyond the matrix read row / column 0 (valid data); their results are never stored,
-      // so only the K tail needs masking.  The K loop is pointer bumps: integer multiplies for the operand
-      // addresses (quarter rate) made the VALU, not the MFMA pipe, the limit of these tiny GEMMs.
-      const float* ap = hl_smem + a + (iv ? i : 0) * a_rs + q * a_ks;
-      const float* bp = hl_smem + b + (jv ? j : 0) * b_cs + q * b_ks;
-      const int a4 = 4 * a_ks, b4 = 4 * b_ks;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      int k0 = 0;
-#pragma unroll 1
-      for (; k0 + 16 <= K; k0 += 16) {      // 4 k-steps per pass, two accumulator chains
-        const float a0 = ap[0], a1 = ap[a4], a2 = ap[2 * a4], a3 = ap[3 * a4];
-        const float b0 = bp[0], b1 = bp[b4], b2 = bp[2 * b4], b3 = bp[3 * b4];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
-        ap += 4 * a4;
-        bp += 4 * b4;
-      }
-      for (; k0 < K; k0 += 4) {             // tail: clamped address, value zeroed by a 0/1 factor
-        const int k = k0 + q;
-        const float mk = k < K ? 1.f : 0.f;
-        const int back = k < K ? 0 : k - (K - 1);     // steps past the last valid k
-        const float av = ap[-back * a_ks] * mk, bv = bp[-back * b_ks] * mk;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
-        ap += a4;
-        bp += b4;
-      }
-      const f32x4 acc = acc0 + acc1;
-      const float e[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int io = ti * 16 + 4 * q + k;
-        if (io < M && jv) {
-          if (gc)
-            gc[io * c_rs + j * c_cs] = e[k];
-          else
-            hl_smem[c + io * c_rs + j * c_cs] = e[k];
-        }
-      }
+  if (FUSE) {
+    if (tid < H) {      // tf.nn.rnn_cell.LSTMCell from a zero state (graph.py:217-225): gate order i, j, f, o; forget_bias 1
+      const int u = tid;
+      g_si = sigmoidf_(sZ[u]); g_tj = tanhf(sZ[H + u]); g_sf = sigmoidf_(sZ[2 * H + u] + 1.0f); g_so = sigmoidf_(sZ[3 * H + u]);
+      const float cn = g_sf * 0.f + g_si * g_tj;
+      g_tc = tanhf(cn);
+      const float hv = g_so * g_tc;
+      const long long i = (long long)n * H + u;
+      sf.c[i] = cn;
+      sf.hout[i] = hv;
+      float* gr = sf.gates + (long long)n * 4 * H;
+      gr[u] = g_si; gr[H + u] = g_tj; gr[2 * H + u] = g_sf; gr[3 * H + u] = g_so;
+      sH[u] = hv;
     }
     __syncthreads();
-    HSTAMP(3 + ph);
-    if (ph == 0) {            // a1 = relu(. + b1)
-      for (int e = tid; e < N * F; e += NT) {
-        const int n = e / F, f = e - n * F;
-        sA1[n * HL_RP + f] = fmaxf(sA1[n * HL_RP + f] + s_b1[f], 0.f);
-      }
-      __syncthreads();
-    } else if (ph == 1) {     // + head biases; predictions out; losses and d(loss)/d(pred)
-      for (int e = tid; e < N * OT; e += NT) {
-        const int n = e / OT, o = e - n * OT;
-        const float v = sPr[n * OP + o] + s_hb[o];
-        sPr[n * OP + o] = v;
-        p.preds[e] = v;
-      }
-      __syncthreads();
-      // P3           graph.py:430-500, estimator.py:206-239 (as heads_loss_kernel)
-      float lsum[GEECO_MAX_HEADS];
+  }
+  // ---- P1: a1 = relu(h W1 + b1)                                                              graph.py:229-230 ----------
+  {
+    const int pp = tid / G, g = tid - pp * G;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int hh = pp; hh < H; hh += P) acc += sH[hh] * *reinterpret_cast<const f32x4*>(sW1 + hh * HS_WP + 4 * g);
+    *reinterpret_cast<f32x4*>(sPart + pp * F + 4 * g) = acc;
+  }
+  __syncthreads();
+  if (tid < F) {
+    float v = sB1[tid];
+#pragma unroll 16
+    for (int pp = 0; pp < P; ++pp) v += sPart[pp * F + tid];
+    v = fmaxf(v, 0.f);
+    sA1[tid] = v;
+    if (p.backward) p.a1[(long long)n * F + tid] = v;
+  }
+  __syncthreads();
+  // ---- P2: predictions = a1 Wh + bh (all heads side by side)                                   graph.py:233-259 ----------
+  if (tid < OT * 32) {
+    const int o = tid >> 5, l = tid & 31;
+    float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < GEECO_MAX_HEADS; ++k) lsum[k] = 0.f;
-      const float invn = 1.f / N;
-      for (int n = tid; n < N; n += NT) {
-        const float* pr = sPr + n * OP;
-        float* dp = sDp + n * OPD;
-#pragma unroll 1
-        for (int hd = 0; hd < p.nheads; ++hd) {
-          const int sz = sel5(p.size, hd), of = sel5(p.off, hd);
-          const float* tg = sTg + n * OP + of;
-          const float wsc = sel5(p.weight, hd) * p.loss_scale;
-          float l = 0.f;
-          if (sel5(p.kind, hd) == 0) {
-            const float c2 = 2.f / (float)(N * sz) * wsc;
-            for (int cc = 0; cc < sz; ++cc) {
-              const float d = pr[of + cc] - tg[cc];
-              l += d * d;
-              dp[of + cc] = d * c2;
-            }
-          } else {
-            const int label = (int)rintf(tg[0]) + 1;             // estimator.py:213-215
-            float mx = pr[of];
-            for (int cc = 1; cc < sz; ++cc) mx = fmaxf(mx, pr[of + cc]);
-            float se = 0.f;
-            for (int cc = 0; cc < sz; ++cc) se += expf(pr[of + cc] - mx);
-            const bool lv = label >= 0 && label < sz;             // one_hot of an out-of-range label is all-zero
-            if (lv) l = mx + logf(se) - pr[of + label];
-            for (int cc = 0; cc < sz; ++cc)
-              dp[of + cc] = lv ? (expf(pr[of + cc] - mx) / se - (cc == label ? 1.f : 0.f)) * invn * wsc : 0.f;
-          }
+    for (int f = l; f < F; f += 32) s += sA1[f] * sWh[o * HS_FMAX + f];
 #pragma unroll
-          for (int k = 0; k < GEECO_MAX_HEADS; ++k)
-            if (k == hd) lsum[k] += l;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < GEECO_MAX_HEADS; ++k) {
-        lsum[k] = wave_reduce_sum(lsum[k]);
-        if ((tid & 63) == 0) s_red[tid >> 6][k] = lsum[k];
-      }
-      __syncthreads();
-      if (tid == 0) {
-        float total = 0.f;
-        for (int hd = 0; hd < p.nheads; ++hd) {
-          float acc_l = 0.f;
-          for (int w = 0; w < 16; ++w) acc_l += s_red[w][hd];
-          acc_l *= sel5(p.kind, hd) == 0 ? 1.f / (float)(N * sel5(p.size, hd)) : invn;
-          p.losses[1 + hd] = acc_l;
-          total += sel5(p.weight, hd) * acc_l;
-        }
-        p.losses[0] = total;
-      }
-    } else if (ph == 2) {     // ReluGrad of fc1; head bias gradients
-      for (int e = tid; e < N * F; e += NT) {
-        const int n = e / F, f = e - n * F;
-        if (!(sA1[n * HL_RP + f] > 0.f)) sDA[n * HL_RP + f] = 0.f;
-      }
-      for (int o = tid; o < OT; o += NT) {
-        float sum = 0.f;
-        for (int n = 0; n < N; ++n) sum += sDp[n * OPD + o];
-        sel5(p.dhb, s_hd[o])[s_hc[o]] = sum;
-      }
-      __syncthreads();
-    } else if (ph == 3) {     // scatter the head kernel gradients to their variables
-      for (int e = tid; e < OT * F; e += NT) {
-        const int o = e / F, f = e - o * F;
-        const int hd = s_hd[o];
-        sel5(p.dhw, hd)[f * sel5(p.size, hd) + s_hc[o]] = sWh[o * HL_RP + f];
-      }
-    } else if (ph == 4) {     // d(fc1/bias)
-      for (int jj = tid; jj < F; jj += NT) {
-        float sum = 0.f;
-        for (int n = 0; n < N; ++n) sum += sDA[n * HL_RP + jj];
-        p.d_fc1_b[jj] = sum;
-      }
+    for (int m = 16; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (l == 0) {
+      const float v = s + sHb[o];
+      sPr[o] = v;
+      p.preds[(long long)n * OT + o] = v;
     }
   }
-  HSTAMP(10);
+  __syncthreads();
+  // ---- P3: this sample's loss terms and d(loss)/d(pred)                 graph.py:430-500, estimator.py:206-239 ----------
+  if (tid < p.nheads) {
+    const int hd = tid;
+    const int sz = sel5(p.size, hd), of = sel5(p.off, hd);
+    const float* tg = sTg + of;
+    const float wsc = sel5(p.weight, hd) * p.loss_scale;
+    const float invn = 1.f / N;
+    float l = 0.f;
+    if (sel5(p.kind, hd) == 0) {
+      const float c2 = 2.f / (float)(N * sz) * wsc;
+      for (int cc = 0; cc < sz; ++cc) {
+        const float d = sPr[of + cc] - tg[cc];
+        l += d * d;
+        sDp[of + cc] = d * c2;
+      }
+    } else {
+      const int label = (int)rintf(tg[0]) + 1;             // estimator.py:213-215
+      float mx = sPr[of];
+      for (int cc = 1; cc < sz; ++cc) mx = fmaxf(mx, sPr[of + cc]);
+      float se = 0.f;
+      for (int cc = 0; cc < sz; ++cc) se += expf(sPr[of + cc] - mx);
+      const bool lv = label >= 0 && label < sz;             // one_hot of an out-of-range label is all-zero
+      if (lv) l = mx + logf(se) - sPr[of + label];
+      for (int cc = 0; cc < sz; ++cc)
+        sDp[of + cc] = lv ? (expf(sPr[of + cc] - mx) / se - (cc == label ? 1.f : 0.f)) * invn * wsc : 0.f;
+    }
+    p.lterm[(long long)n * 8 + hd] = l;
+  }
+  if (!p.backward) return;
+  __syncthreads();
+  // ---- P4: d(a1) = ReluGrad(dpred Wh^T) ----------------------------------------------------------------------------------
+  if (tid < OT) p.dpred[(long long)n * OT + tid] = sDp[tid];
+  if (tid < F) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int o = 0; o < OT; ++o) s += sDp[o] * sWh[o * HS_FMAX + tid];
+    s = sA1[tid] > 0.f ? s : 0.f;
+    sDA[tid] = s;
+    p.da1[(long long)n * F + tid] = s;
+  }
+  __syncthreads();
+  // ---- P5: d(h) = d(a1) W1^T: G lanes share a row of fc1/kernel, half-wave shuffle sum ----------------------------------------
+  {
+    const int r = tid / G, g = tid - r * G;
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDA + 4 * g);
+    for (int hh = r; hh < H; hh += P) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(sW1 + hh * HS_WP + 4 * g);
+      float s = d4.x * w4.x + d4.y * w4.y + d4.z * w4.z + d4.w * w4.w;
+#pragma unroll
+      for (int m = G >> 1; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+      if (g == 0) sDH[hh] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < H) {
+    const float dhv = sDH[tid];
+    if (p.dh) p.dh[(long long)n * H + tid] = dhv;
+    if (FUSE) {      // lstm_gates_bwd_kernel for the zero-state single step: dc = 0, c_prev = 0
+      const int u = tid;
+      const float dct = 0.f + dhv * g_so * (1.f - g_tc * g_tc);
+      float* dr = sf.dz + (long long)n * 4 * H;
+      dr[u] = dct * g_tj * g_si * (1.f - g_si);
+      dr[H + u] = dct * g_si * (1.f - g_tj * g_tj);
+      dr[2 * H + u] = dct * 0.f * g_sf * (1.f - g_sf);
+      dr[3 * H + u] = dhv * g_tc * g_so * (1.f - g_so);
+    }
+  }
+}
+
+// ---- what sums over the batch: role blocks of 256 threads ---------------------------------------------------------------
+// blocks [0, nW): rows of d(fc1/kernel) = h^T d(a1), 256 / G rows each; blocks [nW, nW + nWh): the head kernels' gradients, 256
+// elements each; the last block: the bias gradients and the loss means.  Forward only: just the loss means (one block).
+__host__ __device__ __forceinline__ int heads_finish_blocks(int H, int F, int OT, int backward) {
+  return backward ? (H + 256 / (F >> 2) - 1) / (256 / (F >> 2)) + (F * OT + 255) / 256 + 1 : 1;
+}
+
+constexpr int HF_NC = 32;      // samples staged per chunk
+
+// `lds`: HF_LDS_FLOATS floats of shared memory lent by the calling kernel (the GEMM tile buffers of lstm_step_bwd_heads_kernel: a
+// block of that grid must not need more LDS than a tile block, or fewer of them fit on a CU)
+constexpr int HF_LDS_FLOATS = HF_NC * HS_FMAX + HF_NC * 32;
+
+__device__ __forceinline__ void heads_finish_role(const HeadsParams& p, const float* h, int role, float* lds) {
+  const int tid = threadIdx.x;
+  const int N = p.N, H = p.H, F = p.Hfc, OT = p.OT;
+  const int G = F >> 2, R = 256 / G;
+  const int nW = (H + R - 1) / R;
+  // Operands come through LDS in chunks of HF_NC samples, fetched with independent coalesced loads (all in flight at once): a
+  // thread that walks n with dependent global loads pays a memory latency per sample (the first form of these roles: 36 us).
+  float* sA = lds;                             // a chunk of d(a1) or a1: [n][F]
+  float* sB = lds + HF_NC * HS_FMAX;           // a chunk of h rows [n][R] or of dpred [n][OT]
+  // (rows past the chunk's end are zero-filled and every loop below runs all HF_NC rows: constant trip counts, so the LDS reads of
+  // consecutive samples are issued together instead of one latency per sample)
+  auto stage = [&](const float* src, int n0, int nc) {                    // [nc][F] floats (F % 4 == 0, rows contiguous)
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + (long long)n0 * F);
+    for (int e = tid; e < HF_NC * G; e += 256) reinterpret_cast<f32x4*>(sA)[e] = e < nc * G ? s4[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  if (p.backward && role < nW) {            // d(fc1/kernel)[hh][4g..] = sum_n h[n][hh] d(a1)[n][4g..]
+    const int r = tid / G, g = tid - r * G, hh = role * R + r;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int n0 = 0; n0 < N; n0 += HF_NC) {
+      const int nc = N - n0 < HF_NC ? N - n0 : HF_NC;
+      if (n0) __syncthreads();
+      stage(p.da1, n0, nc);
+      for (int e = tid; e < HF_NC * R; e += 256) {
+        const int nn = e / R, rr = e - nn * R;
+        sB[e] = (nn < nc && role * R + rr < H) ? h[(long long)(n0 + nn) * H + role * R + rr] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int nn = 0; nn < HF_NC; ++nn) acc += sB[nn * R + r] * reinterpret_cast<const f32x4*>(sA + nn * F)[g];
+    }
+    if (hh < H) reinterpret_cast<f32x4*>(p.d_fc1_w + (long long)hh * F)[g] = acc;
+    return;
+  }
+  const int nWh = (F * OT + 255) / 256;
+  if (p.backward && role < nW + nWh) {      // head kernel gradients [f][c] = sum_n a1[n][f] dpred[n][o], one element per thread
+    const int e = (role - nW) * 256 + tid;
+    const bool live = e < F * OT;
+    const int f = live ? e / OT : 0, o = live ? e - f * OT : 0;
+    float acc = 0.f;
+    for (int n0 = 0; n0 < N; n0 += HF_NC) {
+      const int nc = N - n0 < HF_NC ? N - n0 : HF_NC;
+      if (n0) __syncthreads();
+      stage(p.a1, n0, nc);
+      for (int i = tid; i < HF_NC * OT; i += 256) sB[i] = i < nc * OT ? p.dpred[(long long)n0 * OT + i] : 0.f;
+      __syncthreads();
+#pragma unroll 8
+      for (int nn = 0; nn < HF_NC; ++nn) acc += sA[nn * F + f] * sB[nn * OT + o];
+    }
+    if (live) {
+      const int hd = heads_head_of(p, o);
+      sel5(p.dhw, hd)[(long long)f * sel5(p.size, hd) + (o - sel5(p.off, hd))] = acc;
+    }
+    return;
+  }
+  // bias gradients and loss means
+  float accb = 0.f, acco = 0.f, accl = 0.f;      // thread f < F: d(fc1/bias)[f]; thread o < OT: d(head bias)[o]; thread hd: loss sum
+  for (int n0 = 0; n0 < N; n0 += HF_NC) {
+    const int nc = N - n0 < HF_NC ? N - n0 : HF_NC;
+    if (n0) __syncthreads();
+    if (p.backward) {
+      stage(p.da1, n0, nc);
+      for (int e = tid; e < HF_NC * OT; e += 256) sB[e] = e < nc * OT ? p.dpred[(long long)n0 * OT + e] : 0.f;
+    }
+    __shared__ float sL[HF_NC * 8];
+    for (int e = tid; e < HF_NC * 8; e += 256) sL[e] = (e < nc * 8 && (e & 7) < p.nheads) ? p.lterm[(long long)n0 * 8 + e] : 0.f;
+    __syncthreads();
+    if (p.backward) {
+      if (tid < F) {
+#pragma unroll 8
+        for (int nn = 0; nn < HF_NC; ++nn) accb += sA[nn * F + tid];
+      }
+      if (tid < OT) {
+#pragma unroll 8
+        for (int nn = 0; nn < HF_NC; ++nn) acco += sB[nn * OT + tid];
+      }
+    }
+    if (tid < p.nheads) {
+#pragma unroll 8
+      for (int nn = 0; nn < HF_NC; ++nn) accl += sL[nn * 8 + tid];
+    }
+  }
+  if (p.backward) {
+    if (tid < F) p.d_fc1_b[tid] = accb;
+    if (tid < OT) {
+      const int hd = heads_head_of(p, tid);
+      sel5(p.dhb, hd)[tid - sel5(p.off, hd)] = acco;
+    }
+  }
+  __shared__ float s_l[GEECO_MAX_HEADS];
+  if (tid < p.nheads) {
+    const float sum = accl * (sel5(p.kind, tid) == 0 ? 1.f / (float)(N * sel5(p.size, tid)) : 1.f / N);
+    p.losses[1 + tid] = sum;
+    s_l[tid] = sum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.f;
+    for (int hd = 0; hd < p.nheads; ++hd) total += sel5(p.weight, hd) * s_l[hd];
+    p.losses[0] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void heads_finish_kernel(const HeadsParams p, const float* h) {
+  __shared__ __attribute__((aligned(16))) float lds[HF_LDS_FLOATS];
+  heads_finish_role(p, h, (int)blockIdx.x, lds);      // (forward only: one block, which falls through to the loss means)
 }
 
 extern "C" int64_t geeco_heads_ws_bytes(int N, int H, int Hfc) {
   (void)H;
-  return ((int64_t)2 * N * Hfc + (int64_t)N * 32 + (int64_t)32 * Hfc) * 4;
+  return ((int64_t)2 * N * Hfc + (int64_t)N * 32 + (int64_t)32 * Hfc + (int64_t)N * 8) * 4;
 }
 
-extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b, int nheads,
-                                        const float* const* heads_w, const float* const* heads_b,
-                                        const int* head_size, const int* head_kind, const float* head_weight,
-                                        const float* const* targets, const int64_t* target_stride, float loss_scale,
-                                        int N, int H, int Hfc, float* preds, float* losses, int backward, float* dh,
-                                        float* d_fc1_w, float* d_fc1_b, float* const* d_heads_w,
-                                        float* const* d_heads_b, float* ws, void* stream) {
-  GEECO_CHECK_ARG(h && fc1_w && fc1_b && heads_w && heads_b && head_size && head_kind && head_weight && targets &&
+struct HeadsPending {       // what geeco_heads_finish (include/geeco_hip.h) holds
+  HeadsParams p;
+  const float* h;
+  int valid;
+};
+static_assert(sizeof(HeadsPending) <= sizeof(geeco_heads_finish), "geeco_heads_finish is too small for HeadsPending");
+
+// the per-sample kernel serves these shapes; the rest takes the single-workgroup kernel
+static bool heads_sample_shapes(int H, int Hfc, int OT) {
+  return H >= 1 && H <= HS_HMAX && (Hfc == 64 || Hfc == 128) && OT <= 32;
+}
+
+static int heads_fill(HeadsParams* pp, const float* h, const float* fc1_w, const float* fc1_b, int nheads,
+                      const float* const* heads_w, const float* const* heads_b, const int* head_size, const int* head_kind,
+                      const float* head_weight, const float* const* targets, const int64_t* target_stride, float loss_scale,
+                      int N, int H, int Hfc, float* preds, float* losses, int backward, float* dh, float* d_fc1_w,
+                      float* d_fc1_b, float* const* d_heads_w, float* const* d_heads_b, float* ws) {
+  GEECO_CHECK_ARG(fc1_w && fc1_b && heads_w && heads_b && head_size && head_kind && head_weight && targets &&
                       target_stride && preds && losses && ws, "heads_loss: null pointer");
   GEECO_CHECK_ARG(nheads >= 1 && nheads <= GEECO_MAX_HEADS, "heads_loss: nheads=%d outside 1..%d", nheads, GEECO_MAX_HEADS);
   GEECO_CHECK_ARG(N >= 1 && N <= 4096 && H >= 1 && Hfc >= 1, "heads_loss: bad dims");
-  GEECO_CHECK_ARG(!backward || (dh && d_fc1_w && d_fc1_b && d_heads_w && d_heads_b), "heads_loss: null gradient pointer");
-  HeadsParams p = {};
+  GEECO_CHECK_ARG(!backward || (d_fc1_w && d_fc1_b && d_heads_w && d_heads_b), "heads_loss: null gradient pointer");
+  HeadsParams& p = *pp;
+  p = HeadsParams{};
   p.h = h; p.fc1_w = fc1_w; p.fc1_b = fc1_b; p.nheads = nheads; p.loss_scale = loss_scale;
   p.N = N; p.H = H; p.Hfc = Hfc; p.backward = backward; p.preds = preds; p.losses = losses;
   p.dh = dh; p.d_fc1_w = d_fc1_w; p.d_fc1_b = d_fc1_b;
@@ -1043,23 +1094,161 @@ extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, cons
   GEECO_CHECK_ARG(off <= 32, "heads_loss: %d outputs > 32", off);
   p.OT = off;
   p.a1 = ws; p.da1 = ws + (long long)N * Hfc; p.dpred = ws + 2ll * N * Hfc;
-  static const int no_lds = geeco_dev_getenv("GEECO_HEADS_NO_LDS") ? 1 : 0;
-  if (!no_lds && N <= HL_NMAX && H == HL_DMAX && Hfc == HL_DMAX && off <= HL_OMAX) {
-    const size_t lds = (size_t)HL_LDS_FLOATS * 4;
-    static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&heads_loss_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) {
-        geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
-        return (int)e;
-      }
-      attr_set = true;
+  p.lterm = ws + 2ll * N * Hfc + (long long)N * 32 + 32ll * Hfc;
+  return 0;
+}
+
+template <bool FUSE, int G>
+static int launch_heads_sample_g(const HeadsParams& p, const StepFuse& sf, hipStream_t stream) {
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: racing threads at worst repeat it
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&heads_sample_kernel<FUSE, G>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS_BYTES);
+    if (e != hipSuccess) {
+      geeco_set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", HS_LDS_BYTES, hipGetErrorString(e));
+      return (int)e;
     }
-    hipLaunchKernelGGL(heads_loss_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, p);
+    attr_set = true;
+  }
+  geeco_note_kernel("heads_sample_kernel<%s>", FUSE ? "true" : "false");
+  hipLaunchKernelGGL((heads_sample_kernel<FUSE, G>), dim3((unsigned)p.N), dim3(HS_THREADS), HS_LDS_BYTES, stream, p, sf);
+  GEECO_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool FUSE>
+static int launch_heads_sample(const HeadsParams& p, const StepFuse& sf, hipStream_t stream) {
+  return p.Hfc == 128 ? launch_heads_sample_g<FUSE, 32>(p, sf, stream) : launch_heads_sample_g<FUSE, 16>(p, sf, stream);
+}
+
+extern "C" int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b, int nheads,
+                                        const float* const* heads_w, const float* const* heads_b,
+                                        const int* head_size, const int* head_kind, const float* head_weight,
+                                        const float* const* targets, const int64_t* target_stride, float loss_scale,
+                                        int N, int H, int Hfc, float* preds, float* losses, int backward, float* dh,
+                                        float* d_fc1_w, float* d_fc1_b, float* const* d_heads_w,
+                                        float* const* d_heads_b, float* ws, void* stream) {
+  GEECO_CHECK_ARG(h && (!backward || dh), "heads_loss: null pointer");
+  HeadsParams p;
+  if (int rc = heads_fill(&p, h, fc1_w, fc1_b, nheads, heads_w, heads_b, head_size, head_kind, head_weight, targets, target_stride,
+                          loss_scale, N, H, Hfc, preds, losses, backward, dh, d_fc1_w, d_fc1_b, d_heads_w, d_heads_b, ws))
+    return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (heads_sample_shapes(H, Hfc, p.OT)) {
+    if (int rc = launch_heads_sample<false>(p, StepFuse{}, s)) return rc;
+    geeco_note_kernel("heads_finish_kernel");
+    hipLaunchKernelGGL(heads_finish_kernel, dim3((unsigned)heads_finish_blocks(H, Hfc, p.OT, backward)), dim3(256), 0, s, p, h);
   } else {
-    hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+    geeco_note_kernel("heads_loss_kernel");
+    hipLaunchKernelGGL(heads_loss_kernel, dim3(1), dim3(1024), 0, s, p);
   }
   GEECO_LAUNCH_CHECK();
   return 0;
 }
+
+// One-step decoder (zero initial state): gate GEMM, then ONE per-sample launch for the gate math, fc1, the heads, the losses and --
+// with `backward` -- everything back to the gate gradients dz.  `pending` non-null: the batch sums of the heads' backward (and
+// the loss means) are left for geeco_lstm_step_bwd to run at the end of its second grid; null: heads_finish_kernel runs here.
+extern "C" int geeco_lstm_step_heads_fwd_bwd(const float* x, int64_t ldx, const float* wx, int64_t ldw, const float* bias,
+                                             float* z, float* c, float* h, float* gates, int N, int H, int D, void* gemm_ws,
+                                             const float* fc1_w, const float* fc1_b, int nheads, const float* const* heads_w,
+                                             const float* const* heads_b, const int* head_size, const int* head_kind,
+                                             const float* head_weight, const float* const* targets,
+                                             const int64_t* target_stride, float loss_scale, int Hfc, float* preds,
+                                             float* losses, int backward, float* dz, float* d_fc1_w, float* d_fc1_b,
+                                             float* const* d_heads_w, float* const* d_heads_b, float* heads_ws,
+                                             geeco_heads_finish* pending, void* stream) {
+  GEECO_CHECK_ARG(x && wx && bias && z && c && h && gates && (!backward || dz), "lstm_step_heads: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && H >= 1 && D >= 1 && ldx >= D && ldw >= 4 * (int64_t)H, "lstm_step_heads: bad dims");
+  if (pending) reinterpret_cast<HeadsPending*>(pending)->valid = 0;
+  HeadsPending hp;
+  if (int rc = heads_fill(&hp.p, h, fc1_w, fc1_b, nheads, heads_w, heads_b, head_size, head_kind, head_weight, targets,
+                          target_stride, loss_scale, N, H, Hfc, preds, losses, backward, nullptr, d_fc1_w, d_fc1_b, d_heads_w,
+                          d_heads_b, heads_ws))
+    return rc;
+  if (!heads_sample_shapes(H, Hfc, hp.p.OT)) return GEECO_ENOSUP;      // nothing launched: the caller runs the separate entry points
+  GemmParams g = {};
+  g.A = x; g.B = wx; g.C = z; g.part = (float*)gemm_ws; g.lda = ldx; g.ldb = ldw; g.ldc = 4 * H;
+  g.M = N; g.N = 4 * H; g.K = D;
+  gemm_plan(g.M, g.N, g.K, &g.S, &g.k_per_split);
+  GEECO_CHECK_ARG(g.S == 1 || gemm_ws, "lstm_step_heads: workspace required for split-K (geeco_gemm_ws_bytes(N, 4H, D))");
+  hipStream_t s = (hipStream_t)stream;
+  geeco_note_kernel("gemm_f32_kernel");
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)cdiv(g.N, 64), (unsigned)cdiv(g.M, 64), (unsigned)g.S), dim3(256), 0, s, g);
+  GEECO_LAUNCH_CHECK();
+  StepFuse sf = {};
+  sf.part = g.S > 1 ? (const float*)g.part : (const float*)z;      // unsplit: the GEMM wrote z itself (one "slab")
+  sf.S = g.S; sf.bias = bias; sf.z = z; sf.c = c; sf.hout = h; sf.gates = gates; sf.dz = dz;
+  if (int rc = launch_heads_sample<true>(hp.p, sf, s)) return rc;
+  if (pending) {
+    hp.h = h;
+    hp.valid = 1;
+    *reinterpret_cast<HeadsPending*>(pending) = hp;
+  } else {
+    geeco_note_kernel("heads_finish_kernel");
+    hipLaunchKernelGGL(heads_finish_kernel, dim3((unsigned)heads_finish_blocks(H, Hfc, hp.p.OT, backward)), dim3(256), 0, s, hp.p, (const float*)h);
+    GEECO_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// Grid 1 of geeco_lstm_step_bwd with the heads' pending batch sums as its FIRST blocks: a handful of independent ~5 us blocks
+// beside the tiles of dWx / dX (13 us), in a launch that exists anyway (at the end of the SECOND grid, whose blocks take ~1 us,
+// they set that launch's length: measured 15.7 instead of 5.0 us).
+__global__ __launch_bounds__(256) void lstm_step_bwd_heads_kernel(const LstmBwdBatch q, const HeadsParams hp, const float* h, int hb) {
+  static_assert(4 * GEMM_BK * GEMM_LD >= HF_LDS_FLOATS, "the finish roles borrow the tile buffers");
+  __shared__ __attribute__((aligned(16))) float tiles[4][GEMM_BK * GEMM_LD];      // sA[2], sB[2]
+  if ((int)blockIdx.x < hb)
+    heads_finish_role(hp, h, (int)blockIdx.x, &tiles[0][0]);
+  else
+    lstm_step_bwd_body(q, (int)blockIdx.x - hb, &tiles[0], &tiles[2]);
+}
+
+extern "C" int geeco_lstm_step_bwd(const float* x, int64_t ldx, const float* dz, int64_t ldz, const float* wx, int64_t ldw,
+                                   float* dwx, int64_t lddw, float* db, float* dx, int64_t lddx, int N, int D, int H4,
+                                   const float* const* feats_fwd, float* const* dfeats, const int* feat_ch, int nfeat,
+                                   int jnt_pos, int J, int cells, void* ws, const geeco_heads_finish* pending, void* stream) {
+  GEECO_CHECK_ARG(x && dz && wx && dwx && db && dx, "lstm_step_bwd: null pointer");
+  GEECO_CHECK_ARG(N >= 1 && D >= 1 && H4 >= 1, "lstm_step_bwd: bad dims");
+  GEECO_CHECK_ARG(nfeat >= 0 && nfeat <= 3 && (nfeat == 0 || (feats_fwd && dfeats && feat_ch && jnt_pos >= 0 && jnt_pos <= nfeat)),
+                  "lstm_step_bwd: concat description");
+  LstmBwdBatch q = {};
+  // dWx [D][4H] = X^T dz: A = X [N][D] transposed, B = dz [N][4H]
+  q.a.A = x; q.a.lda = ldx; q.a.ta = 1; q.a.B = dz; q.a.ldb = ldz; q.a.tb = 0; q.a.C = dwx; q.a.ldc = lddw;
+  q.a.M = D; q.a.N = H4; q.a.K = N; q.a.S = 1; q.a.k_per_split = cdiv(N, 16) * 16;
+  // dX [N][D] = dz Wx^T: A = dz [N][4H], B = Wx [D][4H] transposed
+  q.b.A = dz; q.b.lda = ldz; q.b.ta = 0; q.b.B = wx; q.b.ldb = ldw; q.b.tb = 1; q.b.C = dx; q.b.ldc = lddx;
+  q.b.M = N; q.b.N = D; q.b.K = H4; q.b.part = (float*)ws;
+  gemm_plan(N, D, H4, &q.b.S, &q.b.k_per_split);
+  GEECO_CHECK_ARG(q.b.S == 1 || ws, "lstm_step_bwd: workspace required (geeco_lstm_step_bwd_ws_bytes)");
+  q.ax = cdiv(H4, 64); q.nA = q.ax * cdiv(D, 64);
+  q.bx = cdiv(D, 64); q.by = cdiv(N, 64); q.nB = q.bx * q.by * q.b.S;
+  q.dz = dz; q.ldz = ldz; q.Mz = N; q.Nz = H4; q.db = db;
+  if (nfeat > 0) {
+    const int ctot = fill_concat(&q.cc, feat_ch, nfeat, jnt_pos, J);
+    GEECO_CHECK_ARG((int64_t)cells * ctot <= D, "lstm_step_bwd: %d cells x %d channels exceed the state width %d", cells, ctot, D);
+    q.cc.N = N; q.cc.cells = cells; q.cc.scale = 1.f;
+    for (int i = 0; i < nfeat; ++i) {
+      GEECO_CHECK_ARG(!dfeats[i] || feats_fwd[i], "lstm_step_bwd: feats_fwd[%d] is null", i);
+      q.cc.feats[i] = feats_fwd[i];
+      q.cc.dfeats[i] = dfeats[i];
+    }
+  }
+  const int blocks = q.nA + q.nB + cdiv(H4, 256);
+  const HeadsPending* hp = reinterpret_cast<const HeadsPending*>(pending);
+  if (hp && hp->valid) {
+    const int hb = heads_finish_blocks(hp->p.H, hp->p.Hfc, hp->p.OT, hp->p.backward);
+    geeco_note_kernel("lstm_step_bwd_heads_kernel");
+    hipLaunchKernelGGL(lstm_step_bwd_heads_kernel, dim3((unsigned)(hb + blocks)), dim3(256), 0, (hipStream_t)stream, q, hp->p, hp->h, hb);
+  } else {
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, q);
+  }
+  GEECO_LAUNCH_CHECK();
+  if (q.b.S > 1) {
+    hipLaunchKernelGGL(lstm_step_bwd_finish_kernel, dim3((unsigned)cdiv64((long long)N * D, 256)), dim3(256), 0,
+                       (hipStream_t)stream, q);
+    GEECO_LAUNCH_CHECK();
+  }
+  return 0;
+}
+

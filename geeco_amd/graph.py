@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from . import _dev, ops
+from . import _dev, _native, ops
 from .variables import ENC_FILTERS, ENC_STRIDES, VariableStore, decoder_shapes, encoder_shapes
 
 _CELLS = 4   # the reference hard-codes the 2x2 tiling of the joint state (graph.py:139,163,188)
@@ -518,6 +518,9 @@ class LSTMDecoder:
     # dependent ones (GEECO_DEV=1 GEECO_NO_LSTM_BATCH: the separate launches)
     self.one_launch_bwd = _dev.env('GEECO_NO_LSTM_BATCH') is None
     self.one_launch_fwd = _dev.env('GEECO_NO_LSTM_FWD_FUSE') is None   # ... and the forward's slab sum inside the gate kernel
+    # round 5: gate math + fc1 + heads + losses (+ their backward down to the gate gradients) per sample in ONE launch
+    self.fused_step = _dev.env('GEECO_NO_STEP_HEADS') is None
+    self.heads_pending, self.dz_from_heads = None, False
 
   def _v(self, n):
     return self.store.var('%s/%s' % (self.scope, n))
@@ -530,6 +533,27 @@ class LSTMDecoder:
     W = self._v('lstm_cell/kernel')            # [D + H][4H]: rows 0..D-1 multiply x, D.. multiply h
     Wx, Wh = W[:D], W[D:]
     bias = self._v('lstm_cell/bias')
+    names = [h[0] for h in self.heads]
+    hkw = {}
+    if backward_too:
+      hkw = dict(d_fc1_w=self._g('fc1/kernel'), d_fc1_b=self._g('fc1/bias'),
+                 d_heads_w=[self._g(n + '/kernel') for n in names], d_heads_b=[self._g(n + '/bias') for n in names])
+    self.heads_pending = None
+    if T == 1 and self.one_launch_fwd and self.one_launch_bwd and self.fused_step:
+      # one step from a zero state: gate GEMM + ONE per-sample launch for the slab sum, the gate math, fc1, the heads, the loss
+      # terms and (training) everything back to the gate gradients dz; the batch sums (weight / bias gradients, loss means)
+      # ride in the first grid of backward()'s launch pair -- losses / those gradients are final after backward()
+      pend = _native.HeadsFinish() if backward_too else None
+      if ops.lstm_step_heads_into(self.z[0], self.c[0], self.h[0], self.gates[0], self.states[0], Wx, bias, N, H, D, D, 4 * H,
+                                  self.gemm_ws, self.preds, self.losses, self._v('fc1/kernel'), self._v('fc1/bias'),
+                                  [self._v(n + '/kernel') for n in names], [self._v(n + '/bias') for n in names],
+                                  [h[2] for h in self.heads], [h[3] for h in self.heads], [h[4] for h in self.heads],
+                                  self.targets, self.target_strides, float(self.loss_scale), F, self.heads_ws,
+                                  dz=self.dz[0] if backward_too else None, pending=pend, **hkw):
+        self.heads_pending = pend if backward_too else None
+        self.dz_from_heads = backward_too
+        return
+    self.dz_from_heads = False
     if T == 1 and self.one_launch_fwd:
       # one step from a zero state: the slab sum of the gate GEMM rides in the gate kernel (bitwise the same)
       ops.lstm_input_step_fwd_into(self.z[0], self.c[0], self.h[0], self.gates[0], self.states[0], Wx, bias, N, H, D, D, 4 * H,
@@ -543,11 +567,7 @@ class LSTMDecoder:
         ops.gemm_into(self.z[t], self.h[t - 1], Wh, N, 4 * H, H, H, 4 * H, 4 * H, accumulate=True, ws=self.gemm_ws)
       ops.lstm_gates_fwd_into(self.c[t], self.h[t], self.gates[t], self.z[t], bias,
                               self.c[t - 1] if t > 0 else None, N, H)
-    names = [h[0] for h in self.heads]
-    kw = {}
-    if backward_too:
-      kw = dict(dh=self.dh, d_fc1_w=self._g('fc1/kernel'), d_fc1_b=self._g('fc1/bias'),
-                d_heads_w=[self._g(n + '/kernel') for n in names], d_heads_b=[self._g(n + '/bias') for n in names])
+    kw = dict(dh=self.dh, **hkw) if backward_too else {}
     ops.heads_loss_into(self.preds, self.losses, self.h[self.T - 1], self._v('fc1/kernel'), self._v('fc1/bias'),
                         [self._v(n + '/kernel') for n in names], [self._v(n + '/bias') for n in names],
                         [h[2] for h in self.heads], [h[3] for h in self.heads], [h[4] for h in self.heads],
@@ -564,11 +584,13 @@ class LSTMDecoder:
     dW = self._g('lstm_cell/kernel')
     if T == 1 and self.one_launch_bwd:
       # one step from a zero state: dWh = h_prev^T dz = 0 (the arena's rows stay zero); everything else in ONE launch
-      ops.lstm_gates_bwd_into(self.dz[0], None, self.gates[0], None, self.c[0], self.dh, None, N, H)
+      if not self.dz_from_heads:       # (the fused forward left dz itself)
+        ops.lstm_gates_bwd_into(self.dz[0], None, self.gates[0], None, self.c[0], self.dh, None, N, H)
       kw = dict(feats_fwd=concat['feats'], dfeats=concat['dfeats'], feat_ch=concat['feat_ch'], jnt_pos=concat['jnt_pos'],
                 J=concat['J'], cells=concat['cells']) if concat else {}
       ops.lstm_step_bwd_into(dW[:D], self._g('lstm_cell/bias'), self.dstates[0], self.states[0], self.dz[0], Wx, N, D, 4 * H,
-                             4 * H, self.gemm_ws, **kw)
+                             4 * H, self.gemm_ws, pending=self.heads_pending, **kw)
+      self.heads_pending = None
       return concat is not None
     for t in range(T - 1, -1, -1):
       last = t == T - 1

@@ -463,13 +463,15 @@ def lstm_step_bwd_ws_bytes(N, D, H4):
 
 
 def lstm_step_bwd_into(dwx, db, dx, x, dz, wx, N, D, H4, ldw, ws, feats_fwd=None, dfeats=None, feat_ch=None, jnt_pos=0, J=0,
-                       cells=0):
+                       cells=0, pending=None):
   """Two launches: dwx = x^T dz, db = colsum(dz), split-K partials of dx = dz wx^T side by side; then dx's slab sum with
-  the state-concat backward (``dfeats``) in its epilogue."""
+  the state-concat backward (``dfeats``) in its epilogue -- and, if ``pending`` (what lstm_step_heads_into left behind), the
+  heads' batch sums as extra blocks of the first grid."""
   nf = len(feats_fwd) if feats_fwd else 0
   check(_lib().geeco_lstm_step_bwd(_p(x), D, _p(dz), H4, _p(wx), ldw, _p(dwx), ldw, _p(db), _p(dx), D, N, D, H4,
                                    _parr(feats_fwd) if nf else None, _parr(dfeats) if nf else None,
-                                   _iarr(feat_ch) if nf else None, nf, jnt_pos, J, cells, _p(ws), _stream()),
+                                   _iarr(feat_ch) if nf else None, nf, jnt_pos, J, cells, _p(ws),
+                                   ctypes.byref(pending) if pending is not None else None, _stream()),
         'geeco_lstm_step_bwd')
 
 
@@ -494,6 +496,28 @@ def heads_loss_into(preds, losses, h, fc1_w, fc1_b, heads_w, heads_b, head_size,
       _parr(targets), larr, loss_scale, N, H, Hfc, _p(preds), _p(losses), 1 if backward else 0, _p(dh),
       _p(d_fc1_w), _p(d_fc1_b), _parr(d_heads_w) if backward else None, _parr(d_heads_b) if backward else None,
       _p(ws), _stream()), 'geeco_heads_loss_fwd_bwd')
+
+
+def lstm_step_heads_into(z, c, h, gates, x, wx, bias, N, H, D, ldx, ldw, gemm_ws, preds, losses, fc1_w, fc1_b, heads_w, heads_b,
+                         head_size, head_kind, head_weight, targets, target_stride, loss_scale, Hfc, heads_ws, dz=None,
+                         d_fc1_w=None, d_fc1_b=None, d_heads_w=None, d_heads_b=None, pending=None):
+  """One-step decoder from a zero state: the gate GEMM + ONE per-sample launch (slab sum, gate math, fc1, heads, loss terms and,
+  when ``dz`` is given, everything back to the gate gradients).  ``pending`` (an _native.HeadsFinish): the batch sums are left for
+  lstm_step_bwd_into(pending=...); None: they run here.  Returns False (nothing launched) for shapes the per-sample kernel does
+  not serve: the caller then runs lstm_input_step_fwd_into + heads_loss_into (+ lstm_gates_bwd_into)."""
+  backward = dz is not None
+  nh = len(heads_w)
+  farr = (ctypes.c_float * nh)(*[float(v) for v in head_weight])
+  larr = (ctypes.c_int64 * nh)(*[int(v) for v in target_stride])
+  rc = _lib().geeco_lstm_step_heads_fwd_bwd(
+      _p(x), ldx, _p(wx), ldw, _p(bias), _p(z), _p(c), _p(h), _p(gates), N, H, D, _p(gemm_ws), _p(fc1_w), _p(fc1_b), nh,
+      _parr(heads_w), _parr(heads_b), _iarr(head_size), _iarr(head_kind), farr, _parr(targets), larr, loss_scale, Hfc, _p(preds),
+      _p(losses), 1 if backward else 0, _p(dz), _p(d_fc1_w), _p(d_fc1_b), _parr(d_heads_w) if backward else None,
+      _parr(d_heads_b) if backward else None, _p(heads_ws), ctypes.byref(pending) if pending is not None else None, _stream())
+  if rc == _native.GEECO_ENOSUP:
+    return False
+  check(rc, 'geeco_lstm_step_heads_fwd_bwd')
+  return True
 
 
 # --------------------------------------------------------------------------------------------

@@ -335,16 +335,19 @@ int geeco_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c
  * geeco_state_concat_bwd.  dx: same K / slab order as geeco_gemm_f32, bitwise the same for every N.  dwx: ONE K loop over
  * the N rows (no split), bitwise equal to geeco_gemm_f32 where that does not split K either, i.e. N < 128 (the batch sizes
  * of the reference: params.py:26); for N >= 128 geeco_gemm_f32 splits the batch dimension and the two differ in rounding
- * (tests/test_kernels_gpu.py: tolerance there, bitwise below).  ws: geeco_lstm_step_bwd_ws_bytes bytes. */
+ * (tests/test_kernels_gpu.py: tolerance there, bitwise below).  ws: geeco_lstm_step_bwd_ws_bytes bytes.
+ * `pending` (may be NULL): the batch sums geeco_lstm_step_heads_fwd_bwd left behind (weight / bias gradients of fc1 and the
+ * heads, loss means); they run as the first blocks of grid 1, beside the tiles of dwx / dx. */
+typedef struct geeco_heads_finish { unsigned char opaque[1024]; } geeco_heads_finish;    /* filled and read by the library only */
 int64_t geeco_lstm_step_bwd_ws_bytes(int N, int D, int H4);
 int geeco_lstm_step_bwd(const float* x, int64_t ldx, const float* dz, int64_t ldz, const float* wx, int64_t ldw, float* dwx,
                         int64_t lddw, float* db, float* dx, int64_t lddx, int N, int D, int H4,
                         const float* const* feats_fwd, float* const* dfeats, const int* feat_ch, int nfeat, int jnt_pos,
-                        int J, int cells, void* ws, void* stream);
+                        int J, int cells, void* ws, const geeco_heads_finish* pending, void* stream);
 /* column sums: out[j] = sum_i a[i][j] (bias gradients). */
 int geeco_colsum(const float* a, int64_t lda, int M, int N, float* out, int accumulate, void* stream);
 
-/* ---- fc1 + heads + losses, forward and backward in one launch ----------------------------------
+/* ---- fc1 + heads + losses, forward and backward ------------------------------------------------
  * graph.py:229-259 (fc1 ReLU, linear heads), :430-500 (losses), estimator.py:206-239 (targets,
  * loss composition).  `nheads` <= 5 linear heads [Hfc][size_i] are described by parallel arrays:
  *   head_kind 0: tf.losses.mean_squared_error against target rows (size_i floats at
@@ -357,7 +360,9 @@ int geeco_colsum(const float* a, int64_t lda, int M, int N, float* out, int accu
  * pred_aux_ee, pred_aux_obj (MSE vs features[...][:, -1, :3]).
  * Outputs: preds [N][sum size_i], losses[1 + nheads] = {total, L_0, ...} (unscaled local means); when
  * `backward` != 0 also dh [N][H] and d_fc1_w, d_fc1_b, d_heads_w[i], d_heads_b[i] (overwritten).
- * Single workgroup (in-block MFMA tiles); N <= 4096, sum size_i <= 32. */
+ * Two launches (round 5): one workgroup PER SAMPLE for everything that is independent per sample (fc1, heads, loss terms, and
+ * back to dh), then a few blocks for what sums over the batch (weight / bias gradients, loss means; sums over n ascending).
+ * H <= 128 and Hfc in {64, 128}; other sizes run a single-workgroup kernel.  N <= 4096, sum size_i <= 32. */
 int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc1_b, int nheads,
                              const float* const* heads_w, const float* const* heads_b,
                              const int* head_size, const int* head_kind, const float* head_weight,
@@ -366,6 +371,22 @@ int geeco_heads_loss_fwd_bwd(const float* h, const float* fc1_w, const float* fc
                              int backward, float* dh, float* d_fc1_w, float* d_fc1_b,
                              float* const* d_heads_w, float* const* d_heads_b, float* ws, void* stream);
 int64_t geeco_heads_ws_bytes(int N, int H, int Hfc);
+/* The decoder of the models that run ONE LSTM step from the zero state (goal model, dynimg branch: graph.py:405-407, 217-260):
+ * geeco_lstm_input_step_fwd + geeco_heads_loss_fwd_bwd + (backward) geeco_lstm_gates_bwd as TWO launches: the gate GEMM
+ * (x [N][D] wx [D][4H], split-K slabs in gemm_ws), then one workgroup per sample that sums its slabs, runs the gate math
+ * (z, c, h, gates written as geeco_lstm_input_step_fwd does), fc1, the heads and the loss terms and -- `backward` != 0 -- returns
+ * through d(h) to the gate gradients dz [N][4H] (no dh output: nothing else reads it).  Arguments as the three entry points.
+ * `pending` NULL: the batch sums (loss means; weight / bias gradients) run here as a third small launch; non-NULL: they are
+ * described in *pending and geeco_lstm_step_bwd runs them inside its own first grid -- losses and the heads' / fc1's
+ * gradients are valid only after that call.  GEECO_ENOSUP (nothing launched) outside H <= 128, Hfc in {64, 128}. */
+int geeco_lstm_step_heads_fwd_bwd(const float* x, int64_t ldx, const float* wx, int64_t ldw, const float* bias, float* z,
+                                  float* c, float* h, float* gates, int N, int H, int D, void* gemm_ws, const float* fc1_w,
+                                  const float* fc1_b, int nheads, const float* const* heads_w, const float* const* heads_b,
+                                  const int* head_size, const int* head_kind, const float* head_weight,
+                                  const float* const* targets, const int64_t* target_stride, float loss_scale, int Hfc,
+                                  float* preds, float* losses, int backward, float* dz, float* d_fc1_w, float* d_fc1_b,
+                                  float* const* d_heads_w, float* const* d_heads_b, float* heads_ws,
+                                  geeco_heads_finish* pending, void* stream);
 
 /* ---- optimiser: tf.train.AdamOptimizer(lr).minimize, estimator.py:105,243-244 ------------------
  * TF semantics (epsilon outside the bias correction):

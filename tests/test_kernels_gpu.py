@@ -198,13 +198,15 @@ def test_gemm(dev, M, N, K, ta, tb):
   _close(C, ref, 1e-5, 2e-5 * np.sqrt(K), 'gemm')
 
 
-# fc1 + heads + losses (+ gradients): N <= 32 runs the LDS-resident kernel, larger batches the
-# global-memory one; both against the oracle's decoder tail differentiated by autograd in fp64.
-@pytest.mark.parametrize('N,mode', [(1, 'cartesian'), (7, 'cartesian'), (32, 'cartesian'), (33, 'cartesian'),
-                                    (64, 'cartesian'), (32, 'velocity'), (40, 'velocity')])
-def test_heads_loss(dev, N, mode):
+# fc1 + heads + losses (+ gradients): one workgroup per sample + a few blocks for the sums over the batch (H <= 128, Hfc 64 / 128);
+# other widths run the single-workgroup kernel; both against the oracle's decoder tail differentiated by autograd in fp64.
+@pytest.mark.parametrize('N,mode,H,F', [(1, 'cartesian', 128, 128), (7, 'cartesian', 128, 128), (32, 'cartesian', 128, 128),
+                                        (33, 'cartesian', 128, 128), (64, 'cartesian', 128, 128), (32, 'velocity', 128, 128),
+                                        (40, 'velocity', 128, 128), (9, 'cartesian', 100, 64), (6, 'cartesian', 64, 96),
+                                        (5, 'velocity', 160, 128)])
+def test_heads_loss(dev, N, mode, H, F):
   from geeco_amd import ops
-  H = F = 128
+  names_expected = ['heads_sample_kernel<false>', 'heads_finish_kernel'] if (H <= 128 and F in (64, 128)) else ['heads_loss_kernel']
   g = torch.Generator().manual_seed(100 + N)
   if mode == 'cartesian':   # (size, kind, weight): graph.py:233-239; lambda_aux = 0.5
     heads = [(3, 0, 1.0), (3, 1, 1.0), (3, 0, 0.5), (3, 0, 0.5)]
@@ -240,9 +242,11 @@ def test_heads_loss(dev, N, mode):
   dhw = [torch.empty(F, sz, device=dev) for sz, _, _ in heads]
   dhb = [torch.empty(sz, device=dev) for sz, _, _ in heads]
   tgd = [d(t) for t in tg]
-  ops.heads_loss_into(preds, losses, d(h), d(w1), d(b1), [d(t) for t in hw], [d(t) for t in hb], [sz for sz, _, _ in heads],
-                      [k for _, k, _ in heads], [w for _, _, w in heads], tgd, [t.shape[1] for t in tg], 1.0, N, H, F, ws,
-                      dh=dh, d_fc1_w=dw1, d_fc1_b=db1, d_heads_w=dhw, d_heads_b=dhb)
+  dev_in = (d(h), d(w1), d(b1), [d(t) for t in hw], [d(t) for t in hb])
+  names = ops.kernel_trace(lambda: ops.heads_loss_into(
+      preds, losses, *dev_in, [sz for sz, _, _ in heads], [k for _, k, _ in heads], [w for _, _, w in heads], tgd,
+      [t.shape[1] for t in tg], 1.0, N, H, F, ws, dh=dh, d_fc1_w=dw1, d_fc1_b=db1, d_heads_w=dhw, d_heads_b=dhb))
+  assert names == names_expected, names
   torch.cuda.synchronize()
   _close(preds, torch.cat(preds_ref, 1), 1e-5, 1e-5, 'preds')
   _close(losses[0], total, 1e-5, 1e-6, 'loss')
@@ -865,6 +869,79 @@ def test_lstm_input_step_fwd_two_launches(dev, N, H, D):
   for name, a, b in zip(('z', 'c', 'h', 'gates'), got, ref):
     assert not torch.isnan(a).any() and torch.equal(a, b), name
   _close(got[0], x.double().cpu() @ w[:D].double().cpu(), 1e-5, 2e-5, 'z vs fp64')
+
+
+@pytest.mark.parametrize('N,D,mode,deferred', [(32, 3100, 'cartesian', True), (5, 3100, 'cartesian', False), (33, 1052, 'velocity', True),
+                                               (64, 40, 'cartesian', True), (1, 3100, 'cartesian', True)])
+def test_lstm_step_heads_one_launch_per_sample(dev, N, D, mode, deferred):
+  """geeco_lstm_step_heads_fwd_bwd (one-step decoder from the zero state: gate GEMM, then ONE workgroup per sample for the slab
+  sum, the gate math, fc1, the heads, the loss terms and the way back to the gate gradients dz) against the entry points it
+  stands for: geeco_lstm_input_step_fwd + geeco_heads_loss_fwd_bwd + geeco_lstm_gates_bwd.  z, c, h, gates, the predictions,
+  every loss and every gradient BITWISE (same per-sample code, same slab / summation orders); with ``deferred`` the batch sums
+  ride in geeco_lstm_step_bwd's first grid (pending), whose own outputs stay bitwise those of the call without them; split
+  (39 slabs) and unsplit (D = 40) gate products; forward only (evaluation): predictions and losses."""
+  from geeco_amd import _native, ops
+  r = np.random.default_rng(131 + N)
+  H = F = 128
+  heads = [(3, 0, 1.0), (3, 1, 1.0), (3, 0, 0.5), (3, 0, 0.5)] if mode == 'cartesian' else \
+          [(7, 0, 1.0), (3, 0, 1.0), (2, 0, 1.0), (3, 0, 1.0), (3, 0, 1.0)]
+  t = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)
+  x = t(r.standard_normal([N, D]))
+  w = t(r.standard_normal([D + H, 4 * H]) / np.sqrt(D))
+  bias = t(r.standard_normal([4 * H]))
+  w1, b1 = t(0.1 * r.standard_normal([H, F])), t(0.1 * r.standard_normal([F]))
+  hw = [t(0.1 * r.standard_normal([F, sz])) for sz, _, _ in heads]
+  hb = [t(0.1 * r.standard_normal([sz])) for sz, _, _ in heads]
+  tg = [t(r.standard_normal([N, sz])) if kind == 0 else t(r.integers(-1, 2, [N, 1])) for sz, kind, _ in heads]
+  meta = ([sz for sz, _, _ in heads], [k for _, k, _ in heads], [wt for _, _, wt in heads], tg, [a.shape[1] for a in tg])
+  OT = sum(meta[0])
+  gws = torch.empty(max(ops.gemm_ws_bytes(N, 4 * H, D), ops.lstm_step_bwd_ws_bytes(N, D, 4 * H)) // 4 + 4, device=dev)
+  hws = torch.empty(ops.heads_ws_bytes(N, H, F) // 4 + 4, device=dev)
+
+  def outputs():
+    o = dict(z=torch.full((N, 4 * H), float('nan'), device=dev), c=torch.full((N, H), float('nan'), device=dev),
+             h=torch.full((N, H), float('nan'), device=dev), gates=torch.full((N, 4 * H), float('nan'), device=dev),
+             preds=torch.full((N, OT), float('nan'), device=dev), losses=torch.zeros(8, device=dev),
+             dz=torch.full((N, 4 * H), float('nan'), device=dev), dw1=torch.full((H, F), float('nan'), device=dev),
+             db1=torch.full((F,), float('nan'), device=dev), dhw=[torch.full_like(a, float('nan')) for a in hw],
+             dhb=[torch.full_like(a, float('nan')) for a in hb], dwx=torch.zeros(D, 4 * H, device=dev),
+             dbx=torch.full((4 * H,), float('nan'), device=dev), dx=torch.full((N, D), float('nan'), device=dev))
+    return o
+  # ---- the separate entry points ----
+  a = outputs()
+  dh = torch.empty(N, H, device=dev)
+  ops.lstm_input_step_fwd_into(a['z'], a['c'], a['h'], a['gates'], x, w[:D], bias, N, H, D, D, 4 * H, gws)
+  ops.heads_loss_into(a['preds'], a['losses'], a['h'], w1, b1, hw, hb, *meta, 1.0, N, H, F, hws, dh=dh, d_fc1_w=a['dw1'],
+                      d_fc1_b=a['db1'], d_heads_w=a['dhw'], d_heads_b=a['dhb'])
+  ops.lstm_gates_bwd_into(a['dz'], None, a['gates'], None, a['c'], dh, None, N, H)
+  ops.lstm_step_bwd_into(a['dwx'], a['dbx'], a['dx'], x, a['dz'], w[:D], N, D, 4 * H, 4 * H, gws)
+  torch.cuda.synchronize()
+  # ---- the fused form ----
+  b = outputs()
+  hws2 = torch.empty_like(hws)
+  pend = _native.HeadsFinish() if deferred else None
+  names = ops.kernel_trace(lambda: ops.lstm_step_heads_into(
+      b['z'], b['c'], b['h'], b['gates'], x, w[:D], bias, N, H, D, D, 4 * H, gws, b['preds'], b['losses'], w1, b1, hw, hb, *meta, 1.0, F,
+      hws2, dz=b['dz'], d_fc1_w=b['dw1'], d_fc1_b=b['db1'], d_heads_w=b['dhw'], d_heads_b=b['dhb'], pending=pend))
+  assert names == ['gemm_f32_kernel', 'heads_sample_kernel<true>'] + ([] if deferred else ['heads_finish_kernel']), names
+  names = ops.kernel_trace(lambda: ops.lstm_step_bwd_into(b['dwx'], b['dbx'], b['dx'], x, b['dz'], w[:D], N, D, 4 * H, 4 * H, gws,
+                                                         pending=pend))
+  assert ('lstm_step_bwd_heads_kernel' in names) == deferred, names
+  torch.cuda.synchronize()
+  for k in a:
+    for u, v in zip(a[k] if isinstance(a[k], list) else [a[k]], b[k] if isinstance(b[k], list) else [b[k]]):
+      assert not torch.isnan(v).any() and torch.equal(u, v), k
+  # ---- forward only ----
+  c = outputs()
+  assert ops.lstm_step_heads_into(c['z'], c['c'], c['h'], c['gates'], x, w[:D], bias, N, H, D, D, 4 * H, gws, c['preds'], c['losses'],
+                                  w1, b1, hw, hb, *meta, 1.0, F, hws2)
+  torch.cuda.synchronize()
+  for k in ('z', 'c', 'h', 'gates', 'preds', 'losses'):
+    assert torch.equal(a[k], c[k]), k
+  # a shape the per-sample kernel does not serve is declined, nothing launched
+  assert ops.lstm_step_heads_into(c['z'], c['c'], c['h'], c['gates'], x, w[:D], bias, N, H, D, D, 4 * H, gws, c['preds'], c['losses'],
+                                  torch.zeros(H, 96, device=dev), torch.zeros(96, device=dev), [torch.zeros(96, sz, device=dev) for sz in meta[0]],
+                                  hb, *meta, 1.0, 96, torch.empty(ops.heads_ws_bytes(N, H, 96) // 4 + 4, device=dev)) is False
 
 
 @pytest.mark.parametrize('G,N,C,J', [(3, 32, 256, 7), (3, 5, 256, 7), (1, 2, 64, 3), (2, 33, 128, 7)])
