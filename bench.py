@@ -52,6 +52,8 @@ def parse_args():
   ap.add_argument('--dp-serial', action='store_true',
                   help='N > 1: run the gradient exchange AFTER the backward instead of beside its bottom part (the timed '
                        'region then measures the serial step; comm.step_ms always reports both)')
+  ap.add_argument('--dp-fixed', action='store_true',
+                  help='N > 1: time the overlapped exchange without the short trial that picks the fastest form on this node')
   ap.add_argument('--dp-three-graphs', action='store_true',
                   help='N > 1: launch the exchange between three captured graphs (round 4) instead of capturing it into ONE step graph')
   ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
@@ -437,16 +439,22 @@ def build_model(model_name, channels, seq_len, batch, dev):
   return cfg, graph.E2EVMC(cfg, batch, dev, training=True)
 
 
-def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=True, capture_exchange=None):
+def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=True, capture_exchange=None, autotune=False):
   """First optimiser step eager (its loss is the one checked against the oracle), second eager step + hipGraph capture,
-  `warmup` untimed replays, then EXACTLY `steps` steps between barrier + synchronize on both sides."""
+  `warmup` untimed replays, then EXACTLY `steps` steps between barrier + synchronize on both sides.  ``autotune`` (N > 1): the
+  form of the gradient exchange (overlapped / overlapped with 16 CUs left to RCCL / serial) is the one that measured fastest on
+  this node in a short untimed trial before the warm-up (runtime.pick_dp_runner)."""
   import torch
   from geeco_amd import dist as gdist
-  from geeco_amd.runtime import TrainStepRunner
+  from geeco_amd.runtime import TrainStepRunner, pick_dp_runner
   runner = TrainStepRunner(model, use_graph=use_graph, warmup=2, overlap=overlap, capture_exchange=capture_exchange)
   runner.step()
   torch.cuda.synchronize()
   first_loss = float(model.loss)
+  trial = {}
+  if autotune and world > 1:
+    del runner
+    runner, trial = pick_dp_runner(model, use_graph=use_graph, capture_exchange=capture_exchange, log=log if verbose else None)
   runner.prepare()     # second eager step + hipGraph capture, outside warm-up and timed region
   torch.cuda.synchronize()
   if verbose:
@@ -471,7 +479,7 @@ def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=Tr
     torch.distributed.barrier()
   torch.cuda.synchronize()
   dt_local = time.perf_counter() - t0
-  return {'runner': runner, 'first_loss': first_loss, 'final_loss': float(model.loss), 'dt_local': dt_local,
+  return {'runner': runner, 'first_loss': first_loss, 'final_loss': float(model.loss), 'dt_local': dt_local, 'dp_trial_ms': trial,
           'dt': gdist.max_over_ranks(dt_local, dev), 'total_steps': runner._calls,
           'per_step': sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))}
 
@@ -750,6 +758,8 @@ def comm_report(args, model, runner, dev, world, step_ms):
   wire = 4 * sum(n for _, n in runner.early_calls) + (runner.staging.numel() * 4 if runner.staging is not None else 0)
   timed = ('overlap' if runner.overlap else 'serial') if runner.capture_exchange else \
           ('three_graphs_overlap' if runner.overlap else 'three_graphs_serial')
+  if runner.reserved_cus:
+    timed += '_reserve%d' % runner.reserved_cus
   rk = 'overlap_reserve%d' % DP_RESERVE_PROBE
   return {'mode': 'overlap' if runner.overlap else 'serial', 'timed_form': timed, 'graphs_per_step': forms,
           'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(model.store.grads.numel() * 4),
@@ -873,7 +883,7 @@ def main():
   log('model built: %d parameters, batch %d/GPU, world %d' % (model.store.count_parameters(), args.batch, world))
 
   r = timed_steps(model, args.steps, args.warmup, not args.no_graph, not args.dp_serial, world, dev,
-                  capture_exchange=False if args.dp_three_graphs else None)
+                  capture_exchange=False if args.dp_three_graphs else None, autotune=not (args.dp_serial or args.dp_fixed))
   runner, dt, per_step = r['runner'], r['dt'], r['per_step']
   first_loss, loss, total_steps = r['first_loss'], r['final_loss'], r['total_steps']
   log('timed region: %d steps in %.3f s' % (args.steps, dt))
@@ -904,6 +914,9 @@ def main():
     if not ok:
       rc = 4
     if comm:
+      comm['picked_before_the_warmup'] = {'ms_per_step': {k: round(v, 4) for k, v in r['dp_trial_ms'].items()},
+                                          'note': 'short untimed trial of each form (max over ranks); the timed region runs the fastest'} \
+          if r['dp_trial_ms'] else None
       out['comm'] = comm
     if not args.skip_layers:      # rank 0's GPU alone, after the timed region (any N: the per-GPU work is the same)
       samples = max(30, min(args.steps, 50))

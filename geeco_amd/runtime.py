@@ -247,6 +247,48 @@ class TrainStepRunner:
     self._part3()
 
 
+DP_CANDIDATES = (      # name, TrainStepRunner arguments
+    ('overlap', dict(overlap=True)),                               # early bucket beside part 2, every CU to the compute kernels
+    ('overlap_reserve16', dict(overlap=True, reserved_cus=16)),    # ... part 2's two persistent kernels leave 16 CUs to RCCL
+    ('serial', dict(overlap=False)),                               # both buckets behind part 2
+)
+
+
+def pick_dp_runner(model, use_graph=True, steps=8, candidates=DP_CANDIDATES, capture_exchange=None, log=None):
+  """N > 1: which form of the exchange is fastest ON THIS NODE is not knowable in advance -- the early bucket runs beside two
+  persistent one-block-per-CU kernels (0.83 ms), and whether RCCL's workgroups slow those blocks down by more than the
+  collective hides depends on the link topology and RCCL's channel count.  So measure: every candidate captures its graph(s)
+  and runs ``steps`` real optimiser steps between barriers; the time is the MAX over ranks (identical on every rank, so all
+  ranks pick the same candidate without another exchange).  Returns (runner of the fastest form, {name: ms per step}).  With one
+  rank (or one candidate) nothing is measured."""
+  import time
+  world = gdist.world_size()
+  if world == 1 or len(candidates) == 1:
+    name, kw = candidates[0]
+    return TrainStepRunner(model, use_graph=use_graph, warmup=2, capture_exchange=capture_exchange, **kw), {}
+  dev = model.store.params.device
+  timings, runners = {}, {}
+  for name, kw in candidates:
+    r = TrainStepRunner(model, use_graph=use_graph, warmup=2, capture_exchange=capture_exchange, **kw)
+    r.prepare()
+    for _ in range(3):
+      r.step()
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      r.step()
+    torch.cuda.synchronize()
+    timings[name] = gdist.max_over_ranks((time.perf_counter() - t0) / steps * 1e3, dev)
+    runners[name] = r
+    if log:
+      log('dp form %-18s %.4f ms/step (max over %d ranks, %d steps, %d graph(s) per step)' %
+          (name, timings[name], world, steps, r.bucket_info()['graphs_per_step']))
+  best = min(timings, key=lambda k: (timings[k], list(timings).index(k)))
+  return runners[best], timings
+
+
 class EvalStepRunner:
   """Forward-only replay (Estimator.evaluate / predict)."""
 

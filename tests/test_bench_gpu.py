@@ -61,7 +61,7 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
           '--batch', '2', '--seq-len', '4', '--skip-cpu']
   out = subprocess.run(base + ['--master-port', str(33100 + os.getpid() % 500)] + tail, capture_output=True, text=True, timeout=600, env=env)
   assert out.returncode != 0 and 'distinct GPU' in out.stderr, out.stderr[-2000:]
-  out = subprocess.run(base + ['--master-port', str(33700 + os.getpid() % 500)] + tail + ['--allow-shared-gpu', '--dp-serial'],
+  out = subprocess.run(base + ['--master-port', str(33700 + os.getpid() % 500)] + tail + ['--allow-shared-gpu'],
                        capture_output=True, text=True, timeout=600, env=env)
   assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
   line = [l for l in out.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
@@ -69,10 +69,15 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   d = json.loads(line[0])
   assert d['n_gpus'] == 2 and 'REHEARSAL' in d['data'] and len(d['ranks']['ms_per_step']) == 2 and d['ranks']['distinct_devices'] == 1
   c = d['comm']
-  assert c['mode'] == 'serial' and set(c['step_ms']) == {'overlap', 'serial', 'three_graphs_overlap', 'three_graphs_serial',
-                                                         'no_exchange', 'overlap_reserve16'}
+  assert c['mode'] in ('overlap', 'serial') and set(c['step_ms']) == {'overlap', 'serial', 'three_graphs_overlap', 'three_graphs_serial',
+                                                                      'no_exchange', 'overlap_reserve16'}
+  # the form of the exchange the timed region ran was picked in a short trial before the warm-up (runtime.pick_dp_runner)
+  trial = c['picked_before_the_warmup']['ms_per_step']
+  assert set(trial) == {'overlap', 'overlap_reserve16', 'serial'} and all(v > 0 for v in trial.values())
+  best = min(trial, key=trial.get)
   # gloo's collectives cannot be captured: every form of this rehearsal is the three-graph one (RCCL: tests/test_dp_gpu.py)
-  assert c['timed_form'] == 'three_graphs_serial' and set(c['graphs_per_step'].values()) == {3} and d['config']['graphs_per_step'] == 3
+  assert c['timed_form'] == 'three_graphs_' + best.replace('_reserve16', '') + ('_reserve16' if 'reserve' in best else ''), (c['timed_form'], trial)
+  assert set(c['graphs_per_step'].values()) == {3} and d['config']['graphs_per_step'] == 3
   assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c
   assert c['buckets']['early_allreduce_calls'] == 1 and c['buckets']['late_written_in_place']
   assert d['roofline']['kernel'] and d['roofline']['frac'] > 0 and len(d['layers']) >= 20      # rank 0's table, at any N
