@@ -338,3 +338,122 @@ def test_synthetic_dataset_writer_round_trip(tmp_path):
   np.testing.assert_array_equal(ex['target_depth'], depth[-1])
   batches = list(I.pickplace_input_fn(str(tmp_path), 'default', 'train', window_size=2, batch_size=4, seed=0, num_threads=2))
   assert sum(len(f['step']) for f, _ in batches) == 3 * 4
+
+
+# ----------------------------------------------------------------------------------------------------
+# Interoperability with an INDEPENDENT encoder / decoder of the wire format: the protobuf runtime (google.protobuf 7.x, the
+# same wire format TensorFlow's tf.train.SequenceExample uses; the message types of tensorflow/core/example/{example,
+# feature}.proto are declared here field by field).  Until round 5 the reader had only ever parsed files its sibling writer
+# (input_fn.write_episode) or a test had assembled.  TensorFlow itself is not installable here; this is the closest third
+# party that speaks the format.
+# ----------------------------------------------------------------------------------------------------
+def _tf_example_classes():
+  from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+  T = descriptor_pb2.FieldDescriptorProto
+  fd = descriptor_pb2.FileDescriptorProto(name='tf_example_subset.proto', package='tensorflow', syntax='proto3')
+
+  def msg(name, parent=None):
+    m = (parent.nested_type if parent is not None else fd.message_type).add()
+    m.name = name
+    return m
+
+  def field(m, name, num, typ, label=1, type_name=None, packed=None, oneof=None):
+    f = m.field.add(name=name, number=num, type=typ, label=label)
+    if type_name:
+      f.type_name = type_name
+    if packed is not None:
+      f.options.packed = packed
+    if oneof is not None:
+      f.oneof_index = oneof
+  field(msg('BytesList'), 'value', 1, T.TYPE_BYTES, 3)
+  field(msg('FloatList'), 'value', 1, T.TYPE_FLOAT, 3, packed=True)
+  field(msg('Int64List'), 'value', 1, T.TYPE_INT64, 3, packed=True)
+  m = msg('Feature')
+  m.oneof_decl.add(name='kind')
+  for n, num in (('bytes_list', 1), ('float_list', 2), ('int64_list', 3)):
+    field(m, n, num, T.TYPE_MESSAGE, 1, '.tensorflow.' + n.title().replace('_', ''), oneof=0)
+  for outer, entry, key, val in (('Features', 'FeatureEntry', 'feature', 'Feature'),
+                                 ('FeatureLists', 'FeatureListEntry', 'feature_list', 'FeatureList')):
+    if outer == 'FeatureLists':
+      field(msg('FeatureList'), 'feature', 1, T.TYPE_MESSAGE, 3, '.tensorflow.Feature')
+    m = msg(outer)
+    e = msg(entry, m)
+    e.options.map_entry = True
+    field(e, 'key', 1, T.TYPE_STRING)
+    field(e, 'value', 2, T.TYPE_MESSAGE, 1, '.tensorflow.' + val)
+    field(m, key, 1, T.TYPE_MESSAGE, 3, '.tensorflow.%s.%s' % (outer, entry))
+  m = msg('SequenceExample')
+  field(m, 'context', 1, T.TYPE_MESSAGE, 1, '.tensorflow.Features')
+  field(m, 'feature_lists', 2, T.TYPE_MESSAGE, 1, '.tensorflow.FeatureLists')
+  pool = descriptor_pool.DescriptorPool()
+  pool.Add(fd)
+  return message_factory.GetMessageClass(pool.FindMessageTypeByName('tensorflow.SequenceExample'))
+
+
+def test_reader_and_writer_interoperate_with_the_protobuf_runtime(tmp_path):
+  """(a) An episode ENCODED BY THE PROTOBUF RUNTIME (map entries in the runtime's own order, its varint / packed encodings),
+  framed as a TFRecord with this file's bit-wise CRC-32C and compressed by Python's zlib, is read by the native reader and by the
+  pure-Python reader: every array equals its source.  (b) An episode written by input_fn.write_episode is un-framed here by hand
+  and DECODED BY THE PROTOBUF RUNTIME: every feature list equals what was written."""
+  import struct
+  pytest.importorskip('google.protobuf')
+  from test_host_logic_cpu import _masked
+  from geeco_amd import input_fn as I
+  SE = _tf_example_classes()
+  meta, eps = _make_dataset(str(tmp_path / 'ours'), n_eps=1, T=6, H=10, W=12)
+  d = eps[0]
+  T_, joints = 6, list(meta.monitored_joints)
+  # ---- (a) protobuf-encoded episode -> our readers ----
+  se = SE()
+  ctx = se.context.feature
+  for k, v in (('episode_length', meta.episode_length), ('img_height', meta.img_height), ('img_width', meta.img_width),
+               ('dim_cmd', meta.dim_cmd), ('dim_ctrl', meta.dim_ctrl)):
+    ctx[k].int64_list.value.append(int(v))
+  for k, names in (('monitored_joints', joints), ('actuated_joints', list(meta.actuated_joints)),
+                   ('monitored_mocaps', list(meta.monitored_mocaps)), ('monitored_objects', list(meta.monitored_objects))):
+    ctx[k].bytes_list.value.extend(n.encode() for n in names)
+  ctx['task_goal'].bytes_list.value.append(b'goal')
+  ctx['task_object'].bytes_list.value.append(b'object')
+  fl = se.feature_lists.feature_list
+  for t in range(T_):
+    fl['step'].feature.add().int64_list.value.append(t)
+    fl['ts'].feature.add().float_list.value.append(0.04 * t)
+    fl['rgb'].feature.add().float_list.value.extend(d['rgb'][t].reshape(-1).astype(np.float32).tolist())
+    fl['depth'].feature.add().float_list.value.extend(d['depth'][t].reshape(-1).tolist())
+    for key, arr in (('cmd', d['cmd']), ('ctrl', d['ctrl']), ('goal_qpos', d['goal']), ('obj_qpos', d['obj'])):
+      fl[key].feature.add().float_list.value.extend(arr[t].tolist())
+    for j, name in enumerate(joints):
+      fl['joint_qpos-%s' % name].feature.add().float_list.value.append(float(d['qpos'][t, j]))
+      fl['joint_qvel-%s' % name].feature.add().float_list.value.append(float(d['qvel'][t, j]))
+    for name in meta.monitored_mocaps:
+      fl['mocap_qpos-%s' % name].feature.add().float_list.value.extend(d['mocap'][t].tolist())
+    for name in meta.monitored_objects:
+      fl['object_qpos-%s' % name].feature.add().float_list.value.extend(d['obj'][t].tolist())
+  payload = se.SerializeToString()
+  ln = struct.pack('<Q', len(payload))
+  record = ln + struct.pack('<I', _masked(ln)) + payload + struct.pack('<I', _masked(payload))
+  path = str(tmp_path / 'pb.tfrecord.zlib')
+  open(path, 'wb').write(zlib.compress(record, 6))
+  ours = _paths(str(tmp_path / 'ours'))[0]
+  for reader in (I.load_episode, I.load_episode_py):
+    a, b = reader(path, meta, True, raw_rgb=True), reader(ours, meta, True, raw_rgb=True)
+    assert set(a) == set(b)
+    for k in a:
+      np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg='%s %s' % (reader.__name__, k))
+    np.testing.assert_array_equal(np.asarray(a['rgb']).astype(np.float32), d['rgb'][:-1].astype(np.float32))
+    np.testing.assert_array_equal(a['jnt_state'], d['qpos'][:-1, :7])
+  # ---- (b) our writer -> protobuf runtime ----
+  raw = zlib.decompress(open(ours, 'rb').read())
+  n, = struct.unpack('<Q', raw[:8])
+  assert struct.unpack('<I', raw[8:12])[0] == _masked(raw[:8]) and struct.unpack('<I', raw[12 + n:16 + n])[0] == _masked(raw[12:12 + n])
+  got = SE()
+  got.ParseFromString(raw[12:12 + n])
+  assert got.context.feature['episode_length'].int64_list.value[0] == meta.episode_length
+  assert [v.decode() for v in got.context.feature['monitored_joints'].bytes_list.value] == joints
+  gl = got.feature_lists.feature_list
+  assert len(gl['rgb'].feature) == T_ and [f.int64_list.value[0] for f in gl['step'].feature] == list(range(T_))
+  for t in range(T_):
+    np.testing.assert_array_equal(np.asarray(gl['rgb'].feature[t].float_list.value, np.float32), d['rgb'][t].reshape(-1).astype(np.float32))
+    np.testing.assert_array_equal(np.asarray(gl['depth'].feature[t].float_list.value, np.float32), d['depth'][t].reshape(-1))
+    np.testing.assert_array_equal(np.asarray(gl['cmd'].feature[t].float_list.value, np.float32), d['cmd'][t])
+    np.testing.assert_array_equal(np.float32(gl['joint_qpos-%s' % joints[3]].feature[t].float_list.value[0]), d['qpos'][t, 3])
