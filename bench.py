@@ -278,7 +278,7 @@ def recorded_traffic(kname):
   this is the RECORDED measurement of the same kernel and shapes from the committed rocprofv3 PMC passes
   (profiles/rNN/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on gfx950,
   + WRITE_SIZE; separate --pmc passes), newest round first, or (None, None) when there is none."""
-  for rnd in ('r04', 'r03', 'r02', 'r01'):
+  for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
     rel = os.path.join('profiles', rnd, 'pmc_roofline_kernel.json')
     try:
       with open(os.path.join(ROOT, rel)) as f:

@@ -61,8 +61,8 @@ def main(bench_path, pmc_path, tag):
     print('| %s %s | `%s` | %.2f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f |'
           % (key[0], key[1], r['kernel'], r['flop'] / 1e9, r['us'], r['tflops'], 100 * r['frac'], p['us'], p['mfma'],
              p['ldsbc'], p['rd'], p['wr']))
-  print('\nSum of the conv launches alone: %.0f us of a %.0f us step (%.1f k frames/s); the rest: input stage (dynimg x2, '
-        'normalisation x2), decoder chain, slab reduces / split-K epilogues, Adam (`%s_step_trace.txt`).'
+  print('\nSum of the conv launches alone: %.0f us of a %.0f us step (%.1f k frames/s); the rest: input stage, decoder '
+        'chain, slab reduces / split-K epilogues, Adam (`%s_step_trace.txt`).'
         % (total, 1e3 * d['ms_per_step'], d['value'] / 1e3, tag))
 
 
