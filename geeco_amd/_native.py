@@ -72,6 +72,7 @@ SIGNATURES = {
     'geeco_conv2_dgrad_conv1_wgrad_partial': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I,
                                                    _P, _P, POINTER(SlabReduce), _I]),
     'geeco_slab_reduce_batch': (_I, [POINTER(SlabReduce), _I, _P]),
+    'geeco_slab_reduce_batch_prepare': (_I, [POINTER(SlabReduce), _I, _P, _F, _F, _F, _P, _P]),
     'geeco_conv_top_bwd': (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P,
                                 _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P,
                                 _P, _P, _P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, POINTER(SlabReduce)]),

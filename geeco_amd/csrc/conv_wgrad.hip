@@ -98,11 +98,26 @@ struct SlabReduceBatch {
   int bpg[GEECO_SLAB_REDUCE_MAX];     // blocks per group
   int split[GEECO_SLAB_REDUCE_MAX];
   int n;
+  // optional rider (geeco_slab_reduce_batch_prepare): the optimiser's per-step scalars, geeco_adam_prepare's work, as block
+  // `prep_block` of this grid -- it depends on nothing here and only has to precede the Adam launch: one dependent launch less
+  int prep_block;                     // -1: none
+  long long* step;
+  float* scal;
+  float lr, b1, b2;
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const SlabReduceBatch b) {
   __shared__ f32x4 sred[4][64];
   const int bid = blockIdx.x;
+  if (bid == b.prep_block) {          // tf.train.AdamOptimizer's lr_t (misc.hip: adam_prepare_kernel)
+    if (threadIdx.x == 0) {
+      const long long t = *b.step + 1;
+      *b.step = t;
+      const double b1t = pow((double)b.b1, (double)t), b2t = pow((double)b.b2, (double)t);
+      b.scal[0] = (float)((double)b.lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+    }
+    return;
+  }
   // static indices only (a dynamically indexed by-value argument would be copied to scratch)
   geeco_slab_reduce it = b.it[0];
   int first = 0, bpg = b.bpg[0], split = b.split[0];
@@ -143,10 +158,25 @@ void geeco_launch_wgrad_reduce(const float* part, float* dw, float* db, long lon
   }
 }
 
+static int slab_reduce_batch_impl(const geeco_slab_reduce* items, int n, int64_t* step, float lr, float b1, float b2, float* scal,
+                                  void* stream);
+
 extern "C" int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream) {
+  return slab_reduce_batch_impl(items, n, nullptr, 0.f, 0.f, 0.f, nullptr, stream);
+}
+
+extern "C" int geeco_slab_reduce_batch_prepare(const geeco_slab_reduce* items, int n, int64_t* global_step_dev, float lr, float beta1,
+                                               float beta2, float* scal_dev, void* stream) {
+  GEECO_CHECK_ARG(global_step_dev && scal_dev, "slab_reduce_batch_prepare: null pointer");
+  return slab_reduce_batch_impl(items, n, global_step_dev, lr, beta1, beta2, scal_dev, stream);
+}
+
+static int slab_reduce_batch_impl(const geeco_slab_reduce* items, int n, int64_t* step, float lr, float b1, float b2, float* scal,
+                                  void* stream) {
   GEECO_CHECK_ARG(n >= 0 && n <= GEECO_SLAB_REDUCE_MAX && (items || n == 0), "slab_reduce_batch: n = %d (0..%d)", n,
                   GEECO_SLAB_REDUCE_MAX);
   SlabReduceBatch b = {};
+  b.prep_block = -1;
   long long blocks = 0;
   for (int i = 0; i < n; ++i) {
     const geeco_slab_reduce& r = items[i];
@@ -160,7 +190,11 @@ extern "C" int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, vo
     b.first[k] = (int)blocks;
     blocks += (long long)b.bpg[k] * r.groups;
   }
-  if (b.n == 0) return 0;
+  if (step) {                           // the rider takes the block behind the last reduce block (a launch of its own if nothing is pending)
+    b.prep_block = (int)blocks++;
+    b.step = (long long*)step; b.scal = scal; b.lr = lr; b.b1 = b1; b.b2 = b2;
+  }
+  if (blocks == 0) return 0;
   geeco_note_kernel("wgrad_reduce_batch_kernel");
   hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
   GEECO_LAUNCH_CHECK();

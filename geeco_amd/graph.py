@@ -417,9 +417,10 @@ class ConvEncoderStack:
     self.launch_fwd(top)
     return False
 
-  def backward(self, hi=7, lo=0):
+  def backward(self, hi=7, lo=0, prepare=None):
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied).  Runs layers
-    hi..lo (the data-parallel runner splits the chain at conv3 / conv2 to start the gradient exchange early)."""
+    hi..lo (the data-parallel runner splits the chain at conv3 / conv2 to start the gradient exchange early).
+    ``prepare`` = (global_step, lr, scal): the optimiser's per-step scalars ride in this part's slab-sum launch."""
     main = torch.cuda.current_stream()
     sides = self.sides if self.two_streams else []
     pending = [] if self.batch_reduce else None   # slab sums of all layers of this part: one launch at the end
@@ -461,8 +462,10 @@ class ConvEncoderStack:
         break
     for side in sides:
       main.wait_stream(side)
-    if pending:
-      ops.slab_reduce_batch(pending)
+    if pending or (prepare is not None and pending is not None):
+      ops.slab_reduce_batch(pending, prepare)
+    elif prepare is not None:
+      ops.adam_prepare(*prepare)
 
   SPLIT = 2   # backward(part='upper') = layers 7..SPLIT, 'bottom' = SPLIT-1..0
 
@@ -707,9 +710,20 @@ class _ModelBase:
     return self.enc.redirect_late_gradients(staging, late_ranges)
 
   # -- optimiser step (estimator.py:243-244) -------------------------------------------------
+  def _prepare_args(self, adam_prepare):
+    """backward(adam_prepare=True): the step counter / lr_t update rides in the backward's last slab-sum launch (one dependent
+    launch less); apply_gradients() then skips its own adam_prepare.  Only callers that DO apply the gradients next pass it
+    (train_step, runtime.TrainStepRunner): the counter must advance exactly once per optimiser step."""
+    if not adam_prepare:
+      return None
+    self._prepared = True
+    return (self.store.global_step, float(self.cfg.lr), self.scal)
+
   def apply_gradients(self):
     s, cfg = self.store, self.cfg
-    ops.adam_prepare(s.global_step, float(cfg.lr), self.scal)
+    if not getattr(self, '_prepared', False):
+      ops.adam_prepare(s.global_step, float(cfg.lr), self.scal)
+    self._prepared = False
     ops.adam_tf(s.params, s.grads, s.adam_m, s.adam_v, s.size, self.scal, grad_scale=1.0 / self.world,
                 l2=float(cfg.l2_regularizer))
     # weights changed: re-derive the padded / transposed copies now (the version stamp is unchanged, so
@@ -752,7 +766,7 @@ class _ModelBase:
 
   def train_step(self):
     self.forward(backward_too=True)
-    self.backward()
+    self.backward(adam_prepare=True)
     self.apply_gradients()
 
 
@@ -878,11 +892,12 @@ class GoalE2EVMC(_ModelBase):
     d.forward(backward_too)
     self._finish_forward()
 
-  def backward(self, part=None):
+  def backward(self, part=None, adam_prepare=False):
     """part None = whole backward; 'upper' / 'bottom' = the two halves the data-parallel runner captures
-    separately (runtime.py): everything down to conv3, then the encoder bottom (conv2 / conv1)."""
+    separately (runtime.py): everything down to conv3, then the encoder bottom (conv2 / conv1).  ``adam_prepare``: see
+    _prepare_args (ignored for part 'upper': the optimiser's scalars ride in the LAST slab-sum launch of the step)."""
     if part == 'bottom':
-      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0)
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare))
       return
     N, K, jn = self.N, self.K, self.cfg.dim_jnt_state
     d = self.decoder
@@ -912,7 +927,8 @@ class GoalE2EVMC(_ModelBase):
       df = [self.enc.dfeatures[g].view(K, N, _CELLS, self.feat_ch[g]) for g in range(2)]
       for t in range(K):
         ops.state_concat_bwd_into([df[0][t], df[1][t]], d.dstates[t], d.D, [f[0][t], f[1][t]], self.feat_ch, 1, jn, N, _CELLS)
-    self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0)
+    self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
+                      prepare=self._prepare_args(adam_prepare and part is None))
 
   def endpoints(self):
     """dynbuff / dyndiff debug endpoints (graph.py:377,393,401): the LAST computed images."""
@@ -955,9 +971,9 @@ class E2EVMC(_ModelBase):
     d.forward(backward_too)
     self._finish_forward()
 
-  def backward(self, part=None):
+  def backward(self, part=None, adam_prepare=False):
     if part == 'bottom':
-      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0)
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare))
       return
     N, K = self.N, self.K
     d = self.decoder
@@ -966,7 +982,8 @@ class E2EVMC(_ModelBase):
     dfe = self.enc.dfeatures[0].view(K, N, _CELLS, 256)
     for t in range(K):
       ops.state_concat_bwd_into([dfe[t]], d.dstates[t], d.D, [feats[t]], [256], 1, self.cfg.dim_jnt_state, N, _CELLS)
-    self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0)
+    self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
+                      prepare=self._prepare_args(adam_prepare and part is None))
 
   def endpoints(self):
     return {'conv8': self.enc.features}

@@ -258,13 +258,19 @@ def conv_top_bwd_into(d, a, b, G, stride, pending=None):
   return True
 
 
-def slab_reduce_batch(pending):
-  """Finishes the deferred slab sums of ``pending`` (<= 8 per launch) and empties the list."""
+def slab_reduce_batch(pending, prepare=None, beta1=0.9, beta2=0.999):
+  """Finishes the deferred slab sums of ``pending`` (<= 8 per launch) and empties the list.  ``prepare`` = (global_step, lr,
+  scal): the last launch also does adam_prepare's work (one block more instead of a dependent launch)."""
   MAX = 8
-  for i in range(0, len(pending), MAX):
-    chunk = pending[i:i + MAX]
-    arr = (_native.SlabReduce * len(chunk))(*chunk)
-    check(_lib().geeco_slab_reduce_batch(arr, len(chunk), _stream()), 'geeco_slab_reduce_batch')
+  chunks = [pending[i:i + MAX] for i in range(0, len(pending), MAX)] or ([[]] if prepare is not None else [])
+  for j, chunk in enumerate(chunks):
+    arr = (_native.SlabReduce * max(len(chunk), 1))(*chunk)
+    if prepare is not None and j == len(chunks) - 1:
+      step, lr, scal = prepare
+      check(_lib().geeco_slab_reduce_batch_prepare(arr, len(chunk), _p(step), float(lr), beta1, beta2, _p(scal), _stream()),
+            'geeco_slab_reduce_batch_prepare')
+    else:
+      check(_lib().geeco_slab_reduce_batch(arr, len(chunk), _stream()), 'geeco_slab_reduce_batch')
   del pending[:]
 
 

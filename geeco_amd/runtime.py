@@ -130,7 +130,7 @@ class TrainStepRunner:
     if self.dp:
       self.model.backward(part='upper')
     else:
-      self.model.backward()
+      self.model.backward(adam_prepare=True)      # (the optimiser's scalars ride in the backward's last slab-sum launch)
 
   def _part2(self):
     enc = getattr(self.model, 'enc', None)
@@ -139,7 +139,7 @@ class TrainStepRunner:
     if enc is not None and self.reserved_cus:
       enc.reserved_cus = self.reserved_cus
     try:
-      self.model.backward(part='bottom')
+      self.model.backward(part='bottom', adam_prepare=True)
     finally:
       if enc is not None:
         enc.reserved_cus = 0

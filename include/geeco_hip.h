@@ -196,6 +196,11 @@ int geeco_conv2_dgrad_conv1_wgrad_partial(const float* dz2, const float* w2, con
                                           int64_t gs_db1, int N, int H, int W, int real_channels, void* ws,
                                           void* stream, geeco_slab_reduce* pending, int reserved_cus);
 int geeco_slab_reduce_batch(const geeco_slab_reduce* items, int n, void* stream);
+/* ... and, as one more block of the same launch, geeco_adam_prepare (below): the step counter and lr_t depend on nothing the
+ * slab sums touch and only have to be in place before geeco_adam_tf -- the training step's last slab-sum launch carries them
+ * instead of a dependent launch of their own.  n may be 0. */
+int geeco_slab_reduce_batch_prepare(const geeco_slab_reduce* items, int n, int64_t* global_step_dev, float lr, float beta1,
+                                    float beta2, float* scal_dev, void* stream);
 /* TWO independent filter gradients of the 64 x 64-tile generic kernel as ONE grid (the model: conv7's + conv8's, both ready
  * once conv8's input gradient exists; problem 0 = the longer one).  Arguments per problem as geeco_conv3x3_wgrad; common
  * groups / stride; pending2: NULL or TWO items (deferred slab sums as geeco_conv3x3_wgrad_partial; S = 0 where the kernel wrote

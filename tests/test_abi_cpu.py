@@ -48,13 +48,13 @@ def test_host_side_argument_checks_need_no_gpu():
   rc = lib.geeco_dynimg_fwd(one, None, 0, 0, one, 1, 65, 16, 3, 4, one, one, None)
   assert rc == -1 and b'K=65' in lib.geeco_last_error()
   # the batched LSTM-step backward: null operands, a concat description without its arrays, a state narrower than its cells
-  rc = lib.geeco_lstm_step_bwd(None, 8, one, 8, one, 8, one, 8, one, one, 8, 2, 8, 8, None, None, None, 0, 0, 0, 0, one, None)
+  rc = lib.geeco_lstm_step_bwd(None, 8, one, 8, one, 8, one, 8, one, one, 8, 2, 8, 8, None, None, None, 0, 0, 0, 0, one, None, None)
   assert rc == -1 and b'null pointer' in lib.geeco_last_error()
-  rc = lib.geeco_lstm_step_bwd(one, 8, one, 8, one, 8, one, 8, one, one, 8, 2, 8, 8, None, None, None, 2, 0, 0, 4, one, None)
+  rc = lib.geeco_lstm_step_bwd(one, 8, one, 8, one, 8, one, 8, one, one, 8, 2, 8, 8, None, None, None, 2, 0, 0, 4, one, None, None)
   assert rc == -1 and b'concat description' in lib.geeco_last_error()
   arr = (ctypes.c_void_p * 1)(16)
   chs = (ctypes.c_int * 1)(256)
-  rc = lib.geeco_lstm_step_bwd(one, 8, one, 8, one, 8, one, 8, one, one, 8, 2, 8, 8, arr, arr, chs, 1, 1, 7, 4, one, None)
+  rc = lib.geeco_lstm_step_bwd(one, 8, one, 8, one, 8, one, 8, one, one, 8, 2, 8, 8, arr, arr, chs, 1, 1, 7, 4, one, None, None)
   assert rc == -1 and b'exceed the state width' in lib.geeco_last_error()
   assert lib.geeco_lstm_step_bwd_ws_bytes(32, 3100, 512) == lib.geeco_gemm_ws_bytes(32, 3100, 512) > 0
 

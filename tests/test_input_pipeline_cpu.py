@@ -251,6 +251,10 @@ def test_reader_returns_its_spare_buffers_after_a_cached_epoch(tmp_path):
   import torch
   src = I._EpisodeSource(_paths(str(tmp_path)), meta, True, 3, torch.device('cpu'), ('rgb', 'depth'), AllCached())
   assert sum(1 for _ in src) == 5 and src._reads == 0
+  for _ in range(200):                                                                       # (released by a background thread)
+    if lib.geeco_host_spare_buffers() == 0:
+      break
+    time.sleep(0.01)
   assert lib.geeco_host_spare_buffers() == 0                                                 # nothing was read: all returned
 
 

@@ -160,3 +160,28 @@ def test_loss_trajectory_graph_replay(dev):
   assert runner._graphs is not None                      # the last steps were graph replays
   assert int(model.store.global_step.item()) == 10
   print('loss trajectory (hip, oracle):', ['%.5f/%.5f' % p for p in losses])
+
+
+@pytest.mark.parametrize('goal', [True, False], ids=['geeco-f', 'e2e_vmc'])
+def test_optimiser_scalars_ride_in_the_last_slab_sum(dev, goal):
+  """train_step() / the step runner let the Adam step counter and lr_t ride in the backward's last slab-sum launch
+  (geeco_slab_reduce_batch_prepare) instead of a dependent launch of their own.  Same trajectory, bitwise, as forward / backward /
+  apply_gradients called one by one (where apply_gradients launches geeco_adam_prepare itself), the counter advances exactly
+  once per optimiser step in both, and a backward that is NOT followed by an update leaves the counter alone."""
+  cfg_kw = dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, lr=1e-3) if goal else dict(window_size=3, lr=1e-3)
+  ocfg, P, feats, labels = _mk(cfg_kw, goal, 2, 136)
+  a = _build(ocfg, goal, P, feats, labels, dev)
+  b = _build(ocfg, goal, P, feats, labels, dev)
+  for _ in range(3):
+    a.train_step()
+    b.forward(backward_too=True)
+    b.backward()
+    b.apply_gradients()
+  torch.cuda.synchronize()
+  assert int(a.store.global_step.item()) == int(b.store.global_step.item()) == 3
+  assert torch.equal(a.store.params, b.store.params) and torch.equal(a.store.adam_v, b.store.adam_v)
+  assert float(a.scal[0]) == float(b.scal[0])
+  b.forward(backward_too=True)
+  b.backward()                        # no update follows: nothing may have advanced
+  torch.cuda.synchronize()
+  assert int(b.store.global_step.item()) == 3
