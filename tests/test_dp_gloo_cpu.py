@@ -124,7 +124,7 @@ class _FakeModel:
   def forward(self, backward_too=False):
     self.store.grads.fill_(float('nan'))            # every element must be rewritten by the two backward parts
 
-  def backward(self, part=None):
+  def backward(self, part=None, adam_prepare=False):
     g = self.store.grads
     idx = torch.arange(g.numel(), dtype=torch.float32)
     val = (self.rank + 1) * (1.0 + 0.001 * (idx % 97))
