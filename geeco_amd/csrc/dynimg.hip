@@ -425,6 +425,230 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynP
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same stage with TWO samples per block, one after the other (round 5, second form): with one sample per block every
+// block of the chip reads for ~85 us and then stores for ~20 us, all in step -- the 100 MB of stores never overlap the 430 MB
+// of loads.  Here a group of bps consecutive blocks owns samples pi and pi + half; a block runs the frame loop of its chunk of
+// sample pi, publishes its min / max, and normalises + stores that sample's images from INSIDE the frame loop of sample
+// pi + half (half-way through: every block of the group has long finished the first sample), so the first half of the stores
+// rides beside the second half of the loads.  One unit (4 pixels) per thread and sample; everything else as above.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DEPTH, bool U8, int THREADS>
+__global__ __launch_bounds__(THREADS) void dynimg_goal_onepass2_kernel(const DynParams p, DynCtl* ctl, int bps, int half) {
+  constexpr int NW = THREADS / 64;
+  const int pi = blockIdx.x / bps, b = blockIdx.x - pi * bps;
+  const int tid = threadIdx.x, wid = tid >> 6;
+  const long long U = p.HW >> 2;
+  const long long ub = (long long)b * THREADS;
+  unsigned uc, fo[3];
+  bool live, flive[3];
+  {
+    const long long u = ub + tid;
+    live = u < U;
+    uc = (unsigned)(live ? u : U - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const long long f = ub * 3 + (long long)c * THREADS + tid;
+      flive[c] = U8 ? live : f < 3 * U;
+      fo[c] = (unsigned)((f < 3 * U ? f : 3 * U - 1) * 16);
+    }
+  }
+  const float w0 = p.alpha2[0], w1 = p.alpha2[1];
+  __shared__ f32x4 tbuf[U8 ? 1 : THREADS * 3];
+  __shared__ float red[NW][4];
+  __shared__ float s_norm[4];
+  auto ld4 = [](const f32x4* q0) {
+    typedef const __attribute__((address_space(1))) f32x4* gptr;
+    return __builtin_nontemporal_load((gptr)q0);
+  };
+  auto to_units = [&](f32x4& x0, f32x4& x1, f32x4& x2) {
+    if (U8) return;
+    __syncthreads();
+    tbuf[tid] = x0; tbuf[THREADS + tid] = x1; tbuf[2 * THREADS + tid] = x2;
+    __syncthreads();
+    x0 = tbuf[3 * tid]; x1 = tbuf[3 * tid + 1]; x2 = tbuf[3 * tid + 2];
+  };
+  // ---- frame loop + last frame of sample n: A = buffer image, D = pair image (flat layout for fp32 sources); `mid()` is called
+  // once, about half-way through the frames
+  auto accumulate = [&](int n, f32x4 (&A)[4], f32x4 (&D)[4], auto&& mid) {
+    [[maybe_unused]] const unsigned char* wbase = U8 ? p.win[n] : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[q] = D[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int t, f32x4& v0, f32x4& v1, f32x4& v2, f32x4& v3) {
+      if (U8) {
+        load_u8_unit(wbase + (long long)t * p.HW * 3, uc, v0, v1, v2);
+      } else {
+        const char* src = dyn_uniform(p.frames + (long long)n * p.sample_stride + (long long)t * p.frame_stride);
+        v0 = ld4(reinterpret_cast<const f32x4*>(src + fo[0])); v1 = ld4(reinterpret_cast<const f32x4*>(src + fo[1]));
+        v2 = ld4(reinterpret_cast<const f32x4*>(src + fo[2]));
+      }
+      if (DEPTH) v3 = ld4(reinterpret_cast<const f32x4*>(dyn_uniform(p.depth + (long long)n * p.dsample_stride + (long long)t * p.dframe_stride) + uc * 16u));
+    };
+    constexpr int UNR = DEPTH ? 3 : 4;      // frames in flight: 12 loads of 16 B per lane (the first sample's images stay live meanwhile)
+    const int KM = p.K - 1;
+    const int groups = KM / UNR;
+    const int gmid = groups >> 1;
+    bool called = false;
+    if (groups > 0) {
+      f32x4 v[UNR][4];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) load(k, v[k][0], v[k][1], v[k][2], v[k][3]);
+      for (int g = 0; g + 1 < groups; ++g) {
+        if (g == gmid) {
+          mid();
+          called = true;
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+          const float w = p.alpha[g * UNR + k];
+          A[0] += w * v[k][0]; A[1] += w * v[k][1]; A[2] += w * v[k][2];
+          if (DEPTH) A[3] += w * v[k][3];
+          load((g + 1) * UNR + k, v[k][0], v[k][1], v[k][2], v[k][3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const float w = p.alpha[(groups - 1) * UNR + k];
+        A[0] += w * v[k][0]; A[1] += w * v[k][1]; A[2] += w * v[k][2];
+        if (DEPTH) A[3] += w * v[k][3];
+      }
+    }
+    if (!called) mid();
+    for (int t = groups * UNR; t < KM; ++t) {
+      const float w = p.alpha[t];
+      f32x4 v0, v1, v2, v3;
+      load(t, v0, v1, v2, v3);
+      A[0] += w * v0; A[1] += w * v1; A[2] += w * v2;
+      if (DEPTH) A[3] += w * v3;
+    }
+    const float w = p.alpha[p.K - 1];
+    f32x4 c[4], g[4];
+    c[3] = g[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load(p.K - 1, c[0], c[1], c[2], c[3]);
+    if (U8) {
+      load_u8_unit(p.tgt_u8[n], uc, g[0], g[1], g[2]);
+    } else {
+      const char* ts = dyn_uniform(p.tgt + (long long)n * p.HW * 3);
+      g[0] = ld4(reinterpret_cast<const f32x4*>(ts + fo[0])); g[1] = ld4(reinterpret_cast<const f32x4*>(ts + fo[1]));
+      g[2] = ld4(reinterpret_cast<const f32x4*>(ts + fo[2]));
+    }
+    if (DEPTH) g[3] = ld4(reinterpret_cast<const f32x4*>(dyn_uniform(p.tgt_depth + (long long)n * p.HW) + uc * 16u));
+    A[0] += w * c[0]; A[1] += w * c[1]; A[2] += w * c[2];
+    if (DEPTH) A[3] += w * c[3];
+    D[0] += w0 * c[0]; D[1] += w0 * c[1]; D[2] += w0 * c[2];
+    D[0] += w1 * g[0]; D[1] += w1 * g[1]; D[2] += w1 * g[2];
+    if (DEPTH) {
+      D[3] += w0 * c[3];
+      D[3] += w1 * g[3];
+    }
+    to_units(c[0], c[1], c[2]);
+    if (live) {
+      f32x4* lo = reinterpret_cast<f32x4*>(p.last + ((long long)n * p.HW + (long long)uc * 4) * 4);
+      lo[0] = f32x4{c[0].x, c[0].y, c[0].z, c[3].x};
+      lo[1] = f32x4{c[0].w, c[1].x, c[1].y, c[3].y};
+      lo[2] = f32x4{c[1].z, c[1].w, c[2].x, c[3].z};
+      lo[3] = f32x4{c[2].y, c[2].z, c[2].w, c[3].w};
+    }
+  };
+  // ---- block min / max of sample n -> its slot; count the block in
+  auto publish = [&](int n, const f32x4 (&A)[4], const f32x4 (&D)[4]) {
+    float mn1 = INFINITY, mx1 = -INFINITY, mn2 = INFINITY, mx2 = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < (DEPTH ? 4 : 3); ++q) {
+      if (!(q < 3 ? flive[q] : live)) continue;
+      const f32x4 a = A[q], d = D[q];
+      mn1 = fminf(fminf(mn1, fminf(a.x, a.y)), fminf(a.z, a.w));
+      mx1 = fmaxf(fmaxf(mx1, fmaxf(a.x, a.y)), fmaxf(a.z, a.w));
+      mn2 = fminf(fminf(mn2, fminf(d.x, d.y)), fminf(d.z, d.w));
+      mx2 = fmaxf(fmaxf(mx2, fmaxf(d.x, d.y)), fmaxf(d.z, d.w));
+    }
+    mn1 = wave_reduce_min(mn1); mx1 = wave_reduce_max(mx1);
+    mn2 = wave_reduce_min(mn2); mx2 = wave_reduce_max(mx2);
+    __syncthreads();                     // (red may still be read by the previous sample's publish)
+    if ((tid & 63) == 0) {
+      red[wid][0] = mn1; red[wid][1] = mx1; red[wid][2] = mn2; red[wid][3] = mx2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < NW; ++i) {
+        mn1 = fminf(mn1, red[i][0]); mx1 = fmaxf(mx1, red[i][1]);
+        mn2 = fminf(mn2, red[i][2]); mx2 = fmaxf(mx2, red[i][3]);
+      }
+      float* sp = reinterpret_cast<float*>(reinterpret_cast<f32x4*>(ctl + p.N) + (long long)n * bps + b);
+      __hip_atomic_store(sp + 0, mn1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sp + 1, mx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sp + 2, mn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sp + 3, mx2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&ctl[n].arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  // ---- wait for sample n's blocks, fold their slots, normalise this block's part in registers and store it
+  auto finish = [&](int n, f32x4 (&A)[4], f32x4 (&D)[4]) {
+    __syncthreads();                     // (s_norm may still be read by the previous sample's finish)
+    if (wid == 0) {
+      DynCtl* c = ctl + n;
+      const f32x4* slots = reinterpret_cast<const f32x4*>(ctl + p.N) + (long long)n * bps;
+      if (tid == 0) {
+        unsigned got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned spin = 0; got < (unsigned)bps && spin < (1u << 22); ++spin) {      // bounded (~0.5 s), see above
+          __builtin_amdgcn_s_sleep(4);
+          got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      f32x4 q = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+      for (int i = tid; i < bps; i += 64) {
+        const float* sp = reinterpret_cast<const float*>(slots + i);
+        const float q0 = __hip_atomic_load(sp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float q1 = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float q2 = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float q3 = __hip_atomic_load(sp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q.x = fminf(q.x, q0); q.y = fmaxf(q.y, q1); q.z = fminf(q.z, q2); q.w = fmaxf(q.w, q3);
+      }
+      const float a1 = wave_reduce_min(q.x), b1 = wave_reduce_max(q.y), a2 = wave_reduce_min(q.z), b2 = wave_reduce_max(q.w);
+      if (tid == 0) {
+        s_norm[0] = a1; s_norm[1] = b1 - a1 + 1e-6f;      // graph.py:49
+        s_norm[2] = a2; s_norm[3] = b2 - a2 + 1e-6f;
+        if (__hip_atomic_fetch_add(&c->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)bps - 1u) {
+          __hip_atomic_exchange(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_exchange(&c->depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    __syncthreads();
+    // one image at a time (normalise in place, transpose, store): half the live registers of doing both together
+    auto emit = [&](f32x4 (&X)[4], float m, float r, float* out) {
+#pragma unroll
+      for (int q = 0; q < (DEPTH ? 4 : 3); ++q) {
+        X[q].x = (X[q].x - m) / r; X[q].y = (X[q].y - m) / r; X[q].z = (X[q].z - m) / r; X[q].w = (X[q].w - m) / r;
+      }
+      to_units(X[0], X[1], X[2]);
+      if (!live) return;
+      const f32x4 z = DEPTH ? X[3] : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4* dst = reinterpret_cast<f32x4*>(out + ((long long)n * p.HW + (long long)uc * 4) * 4);
+      dst[0] = f32x4{X[0].x, X[0].y, X[0].z, z.x};
+      dst[1] = f32x4{X[0].w, X[1].x, X[1].y, z.y};
+      dst[2] = f32x4{X[1].z, X[1].w, X[2].x, z.z};
+      dst[3] = f32x4{X[2].y, X[2].z, X[2].w, z.w};
+    };
+    emit(A, s_norm[0], s_norm[1], p.out);
+    emit(D, s_norm[2], s_norm[3], p.diff_out);
+  };
+  const int nA = pi, nB = pi + half;
+  f32x4 AA[4], DA[4];
+  accumulate(nA, AA, DA, [] {});
+  publish(nA, AA, DA);
+  if (nB < p.N) {
+    f32x4 AB[4], DB[4];
+    accumulate(nB, AB, DB, [&] { finish(nA, AA, DA); });
+    publish(nB, AB, DB);
+    finish(nB, AB, DB);
+  } else {
+    finish(nA, AA, DA);
+  }
+}
+
 // Generic: one thread = one pixel, C <= Cpad <= 8 channels (C == 4: one float4 per frame).
 __global__ __launch_bounds__(256) void dynimg_wsum_generic_kernel(const DynParams p) {
   const int n = blockIdx.y;
@@ -627,8 +851,18 @@ static void goal_onepass_dispatch(const DynParams& p, DynCtl* ctl, hipStream_t s
   // the chip about a block per CU; otherwise 256-thread blocks of one unit (small batches: the predictor's N = 1)
   const long long bps_big = cdiv64(U, 2048);
   if ((long long)p.N * bps_big >= 192) {
-    geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 1024, 2>", DEPTH ? "true" : "false", U8 ? "true" : "false");
-    hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 1024, 2>), dim3((unsigned)(p.N * bps_big)), dim3(1024), 0, s, p, ctl, (int)bps_big);
+    if constexpr (!U8) {
+      // fp32 windows: two samples per block, the first one's stores inside the second one's frame loop (same box, in the step:
+      // 105.7-108.0 us against 110.9-114.7 for one sample per block)
+      const int half = (p.N + 1) / 2, bps2 = (int)cdiv64(U, 1024);
+      geeco_note_kernel("dynimg_goal_onepass2_kernel<%s, %s, 1024>", DEPTH ? "true" : "false", U8 ? "true" : "false");
+      hipLaunchKernelGGL((dynimg_goal_onepass2_kernel<DEPTH, U8, 1024>), dim3((unsigned)(half * bps2)), dim3(1024), 0, s, p, ctl, bps2, half);
+    } else {
+      // uint8 frames: a quarter of the bytes and twelve conversions per pixel: the load phase is short and the one-sample form
+      // with two units per thread keeps more of it in flight (58.6 us alone against 63.8)
+      geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 1024, 2>", DEPTH ? "true" : "false", U8 ? "true" : "false");
+      hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 1024, 2>), dim3((unsigned)(p.N * bps_big)), dim3(1024), 0, s, p, ctl, (int)bps_big);
+    }
   } else {
     const long long bps = cdiv64(U, 256);
     geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 256, 1>", DEPTH ? "true" : "false", U8 ? "true" : "false");

@@ -477,14 +477,15 @@ def test_conv2_relu_fields_and_conv3_dgrad_fields(dev, G, N, H, W):
 
 
 @pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (2, 2, 40, 36, 4),
-                                       (24, 3, 256, 256, 3), (26, 2, 128, 256, 4), (5, 2, 100, 164, 3)])
+                                       (25, 3, 256, 256, 3), (26, 2, 128, 256, 4), (5, 2, 100, 164, 3)])
 def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
   """The goal model's input stage (graph.py:386-401) as the step runs it: ONE launch, one pass over the window: the buffer image
   and the pair image of (current frame, target) stay in registers across their per-sample min / max (the blocks of a sample meet
   at an arrival counter) and are stored once, normalised; the current frame's padded copy comes from the same pass.
   Bitwise equal to the separate launches (buffer image; two-frame image with the target as second frame), and both images
   against the fp64 oracle; K = 1 (alpha = [0]: the buffer image is identically 0), rgb and rgb + depth; both block shapes
-  (1024 threads x 8 pixels from 192 blocks on: the 24- and 26-sample cases, 8 resp. 4 blocks per sample; 256 x 4 below), a
+  (from 192 blocks on, 1024 threads carry TWO samples each, the first one's stores inside the second one's frame loop: the 25-
+  sample case has an odd count (the last block pair holds one sample), the 26-sample one is even; 256 x 4 pixels below), a
   ragged last block (100 x 164); run three times on one control block (every call must leave it zero-filled)."""
   from geeco_amd import ops
   r = np.random.default_rng(57)
@@ -519,7 +520,7 @@ def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
     tgt64 = torch.cat([tgt, tdep], -1).cpu().double()
   torch.cuda.synchronize()
   big = N * -(-(HW // 4) // 2048) >= 192
-  assert names == ['dynimg_goal_onepass_kernel<%s, false, %s>' % ('true' if C == 4 else 'false', '1024, 2' if big else '256, 1')], names
+  assert names == [('dynimg_goal_onepass2_kernel<%s, false, 1024>' if big else 'dynimg_goal_onepass_kernel<%s, false, 256, 1>') % ('true' if C == 4 else 'false')], names
   assert not ws2[:16 * N].view(N, 16)[:, :2].any()      # the arrival / departure counters are zero again
   assert torch.equal(cur, cur_ref)
   assert torch.equal(buf, buf_ref)
