@@ -1551,6 +1551,15 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
   const int hx_lane = 16 * half + r + 1;                                  // - dx
   const int b_lane = r * WP + q;                                          // + (tap*CIN + 16 t)*WP + 4 chunk
   static_assert(NCH % 2 == 0, "the chunk loop is unrolled with the LDS buffer index = chunk & 1: a tile must take an even number of chunks");
+  // Deferred output stores: the (masked) results of tile t are kept in registers and leave one float4 at a time from inside the
+  // tap loops of tile t + 1 (class c in chunk c * NCH / 4, after taps 1, 4, 7, ...).  In a block all eight waves reach the
+  // end of a tile together, so an epilogue of 4 x TCI stores per lane is time in which no MFMA issues: measured with the
+  // stores removed, 204-212 -> 179-180 us at the bench shape.
+  f32x4 pend[4][TCI];
+  float* pend_o[4];
+  bool pend_ok[4] = {false, false, false, false};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pend_o[c] = p.dx;
   for (;;) {
     const bool more = tile + 1 < tend;
     int g2 = g, n2 = n, ty2 = ty, tx2 = tx;
@@ -1622,6 +1631,19 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
               acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[t][s], a_cur[s], acc[c][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        {
+          // pending results of the previous tile: class pc's float4 number pt leaves behind tap min(3 pt + 1, 8) of its chunk
+#pragma unroll
+          for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+            for (int pt = 0; pt < TCI; ++pt)
+              if (pc * NCH / 4 == chunk) {
+                // (both waves of a SIMD store behind the same taps: staggering them by a tap measured 198-201 us against 193-197;
+                // all of a class's stores behind tap 0, or behind taps 0, 1, 2: 201 / 196-203)
+                if ((3 * pt + 1 < 8 ? 3 * pt + 1 : 8) == tap && pend_ok[pc]) stream_store<3>(pend_o[pc] + 16 * pt, pend[pc][pt]);
+              }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         a_cur = a_nxt;
 #pragma unroll
         for (int t = 0; t < TCI; ++t) b_cur[t] = b_nxt[t];
@@ -1646,8 +1668,19 @@ __global__ __launch_bounds__(512) void conv_s2_halo_dgrad_chunked_kernel(const H
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
           v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
-        stream_store<3>(o + 16 * t, v);
+        pend[c][t] = v;
       }
+      pend_o[c] = o;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pend_ok[c] = okc[c];
+    if (!more) {        // the block's last tile: nothing left to hide behind
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (pend_ok[c]) {
+#pragma unroll
+          for (int t = 0; t < TCI; ++t) stream_store<3>(pend_o[c] + 16 * t, pend[c][t]);
+        }
     }
     if (!more) break;
     if (g2 != g_w) {          // (the barrier above already separated everyone from the old kernel)
