@@ -695,12 +695,63 @@ def inference_report(args, dev, estimator, dataset_root, input_kw, workdir):
   return out
 
 
+def rccl_debug_on():
+  """RCCL's INIT / GRAPH lines into a private file (channel count, rings, transports: what decides whether the early bucket
+  really runs beside part 2).  A caller who directs RCCL's log to a file of its own, or asked for more than INFO, is left
+  alone; a plain NCCL_DEBUG=WARN / VERSION from the environment is raised to INFO (rccl_info repeats the warnings on stderr)."""
+  if 'NCCL_DEBUG_FILE' in os.environ or os.environ.get('NCCL_DEBUG', '').upper() in ('TRACE', 'ABORT'):
+    return None
+  import tempfile
+  path = os.path.join(tempfile.gettempdir(), 'geeco_rccl_%d.log' % os.getpid())
+  os.environ['NCCL_DEBUG'] = 'INFO'
+  os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH')
+  os.environ['NCCL_DEBUG_FILE'] = path
+  return path
+
+
+def rccl_info(path):
+  """What RCCL said when the communicator was created: version, collective channels, ring / tree lines (first few), transports."""
+  import re
+  if not path:
+    return {'status': 'the caller directs RCCL\'s log itself: not captured'}
+  try:
+    with open(path, errors='replace') as f:
+      lines = f.read().splitlines()
+  except OSError as e:
+    return {'status': 'no log: %s' % e}
+  finally:
+    try:
+      os.unlink(path)
+    except OSError:
+      pass
+  out = {'status': 'ok', 'log_lines': len(lines)}
+  for l in [l for l in lines if ' WARN ' in l][:10]:
+    log('RCCL: ' + l[:300])
+  text = '\n'.join(lines)
+  m = re.search(r'(\d+) coll channels', text)
+  if m:
+    out['coll_channels'] = int(m.group(1))
+  m = re.search(r'(?:RCCL|NCCL) version[^\n]*', text)
+  if m:
+    out['version'] = m.group(0)[:120]
+  chans = sorted({int(c) for c in re.findall(r'Channel (\d+)(?:/\d+)? *:', text)})
+  if chans:
+    out['ring_channels_seen'] = len(chans)
+  via = sorted(set(re.findall(r'via ([A-Za-z0-9/_-]+)', text)))
+  if via:
+    out['transports'] = via[:8]
+  keep = [l.split('] ', 1)[-1][:160] for l in lines if re.search(r'coll channels|Trees|Ring 0|nChannels|Pattern|minCompCap|Setting affinity', l)]
+  out['lines'] = keep[:8]
+  return out
+
+
 DP_MODES = (   # name, TrainStepRunner arguments, skip the exchange
     ('overlap', dict(overlap=True), False),                                   # the default form: ONE graph, exchange captured
     ('serial', dict(overlap=False), False),
     ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # exchange launched between three graphs
     ('three_graphs_serial', dict(overlap=False, capture_exchange=False), False),
     ('overlap_reserve%d' % DP_RESERVE_PROBE, dict(overlap=True, reserved_cus=DP_RESERVE_PROBE), False),
+    ('overlap_reserve%d' % (2 * DP_RESERVE_PROBE), dict(overlap=True, reserved_cus=2 * DP_RESERVE_PROBE), False),
     ('no_exchange', dict(overlap=True, capture_exchange=False), True),        # three graphs, no all-reduce: the graph gaps alone
 )
 
@@ -743,6 +794,16 @@ def comm_report(args, model, runner, dev, world, step_ms):
   exchange()
   torch.distributed.barrier()
   ar_ms = gdist.max_over_ranks(time_region(exchange, iters), dev)
+
+  def early_only():
+    for w in runner._exchange_early():
+      w.wait()
+
+  def late_only():
+    for w in runner._exchange_late():
+      w.wait()
+  ar_each = {'early': round(gdist.max_over_ranks(time_region(early_only, iters), dev), 4),
+             'late': round(gdist.max_over_ranks(time_region(late_only, iters), dev), 4)}
   modes, forms, _ = dp_step_modes(args, model, lambda fn: (gdist.max_over_ranks(time_region(fn, iters), dev), None, None))
   modes = {k: round(v[0], 4) for k, v in modes.items()}
   # the no_exchange probe applied Adam to UN-reduced per-rank gradients (the batches differ per rank): the replicas have diverged.
@@ -762,7 +823,7 @@ def comm_report(args, model, runner, dev, world, step_ms):
     timed += '_reserve%d' % runner.reserved_cus
   rk = 'overlap_reserve%d' % DP_RESERVE_PROBE
   return {'mode': 'overlap' if runner.overlap else 'serial', 'timed_form': timed, 'graphs_per_step': forms,
-          'allreduce_ms': round(ar_ms, 4), 'allreduce_bytes': int(model.store.grads.numel() * 4),
+          'allreduce_ms': round(ar_ms, 4), 'allreduce_ms_each_bucket_alone': ar_each, 'allreduce_bytes': int(model.store.grads.numel() * 4),
           'allreduce_bytes_on_the_wire': int(wire),
           'bus_GB/s': round(2.0 * (world - 1) / world * wire / (ar_ms * 1e-3) / 1e9, 1),
           'step_ms': modes, 'step_ms_without_allreduce': modes['no_exchange'],
@@ -796,6 +857,7 @@ def dp_one_rank_report(args, model, runner, dev):
     for _ in range(3):
       runner.step()
     single = time_launches(runner.step, samples)
+    rccl_log = rccl_debug_on()
     assert gdist.init_from_env('nccl', device_index=dev.index or 0, single_rank_group=True) == 1 and gdist.group_active()
     out['backend'] = torch.distributed.get_backend()
     modes, forms, info = dp_step_modes(args, model, lambda fn: time_launches(fn, samples))
@@ -823,6 +885,7 @@ def dp_one_rank_report(args, model, runner, dev):
         'allreduce_us_one_rank': {'early_%d_bytes' % (4 * sum(n for _, n in r_dp.early_calls)): us(ar_early),
                                   'late_%d_bytes' % (4 * r_dp.staging.numel() if r_dp.staging is not None else 0): us(ar_late)},
         'efficiency_bound_wire_hidden': round(one / modes['overlap'][0], 4),
+        'rccl': rccl_info(rccl_log),
         'note': 'one rank: RCCL launches both all-reduces for real (launch floor) but moves no bytes over xGMI; at N > 1 add the '
                 'exposed wire time of the late bucket (and of the early one if it outlasts part 2, ~0.85 ms of kernels)'})
     del r_dp
@@ -857,6 +920,7 @@ def main():
   json_fd = os.dup(1)
   os.dup2(2, 1)
 
+  rccl_log = rccl_debug_on() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None
   world = gdist.init_from_env('nccl')      # a launcher that formed the group already (tests/_dp_launch.py) is respected
   rank = gdist.rank()
   if world != args.gpus:
@@ -917,6 +981,7 @@ def main():
       comm['picked_before_the_warmup'] = {'ms_per_step': {k: round(v, 4) for k, v in r['dp_trial_ms'].items()},
                                           'note': 'short untimed trial of each form (max over ranks); the timed region runs the fastest'} \
           if r['dp_trial_ms'] else None
+      comm['rccl'] = rccl_info(rccl_log)
       out['comm'] = comm
     if not args.skip_layers:      # rank 0's GPU alone, after the timed region (any N: the per-GPU work is the same)
       samples = max(30, min(args.steps, 50))
@@ -960,6 +1025,11 @@ def main():
   # N > 1: ranks 1..N-1 have nothing to do after the timed region and the comm report; they wait here ON THE HOST (no
   # collective pending, GPUs idle) until rank 0 has finished its tables and printed the line, then all ranks leave together
   gdist.host_rendezvous('bench_done')
+  if rccl_log and rank != 0:
+    try:
+      os.unlink(rccl_log)
+    except OSError:
+      pass
   if torch.distributed.is_available() and torch.distributed.is_initialized():
     torch.cuda.synchronize()
     torch.distributed.barrier()

@@ -250,6 +250,7 @@ class TrainStepRunner:
 DP_CANDIDATES = (      # name, TrainStepRunner arguments
     ('overlap', dict(overlap=True)),                               # early bucket beside part 2, every CU to the compute kernels
     ('overlap_reserve16', dict(overlap=True, reserved_cus=16)),    # ... part 2's two persistent kernels leave 16 CUs to RCCL
+    ('overlap_reserve32', dict(overlap=True, reserved_cus=32)),    # ... or 32 (RCCL's channel count decides; bench.py reports it)
     ('serial', dict(overlap=False)),                               # both buckets behind part 2
 )
 

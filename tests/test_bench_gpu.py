@@ -70,13 +70,15 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   assert d['n_gpus'] == 2 and 'REHEARSAL' in d['data'] and len(d['ranks']['ms_per_step']) == 2 and d['ranks']['distinct_devices'] == 1
   c = d['comm']
   assert c['mode'] in ('overlap', 'serial') and set(c['step_ms']) == {'overlap', 'serial', 'three_graphs_overlap', 'three_graphs_serial',
-                                                                      'no_exchange', 'overlap_reserve16'}
+                                                                      'no_exchange', 'overlap_reserve16', 'overlap_reserve32'}
   # the form of the exchange the timed region ran was picked in a short trial before the warm-up (runtime.pick_dp_runner)
   trial = c['picked_before_the_warmup']['ms_per_step']
-  assert set(trial) == {'overlap', 'overlap_reserve16', 'serial'} and all(v > 0 for v in trial.values())
+  assert set(trial) == {'overlap', 'overlap_reserve16', 'overlap_reserve32', 'serial'} and all(v > 0 for v in trial.values())
   best = min(trial, key=trial.get)
   # gloo's collectives cannot be captured: every form of this rehearsal is the three-graph one (RCCL: tests/test_dp_gpu.py)
-  assert c['timed_form'] == 'three_graphs_' + best.replace('_reserve16', '') + ('_reserve16' if 'reserve' in best else ''), (c['timed_form'], trial)
+  base_form, _, res = best.partition('_reserve')
+  assert c['timed_form'] == 'three_graphs_' + base_form + ('_reserve' + res if res else ''), (c['timed_form'], trial)
+  assert 'rccl' in c            # (gloo rehearsal: whatever RCCL logged, or the reason there is no log)
   assert set(c['graphs_per_step'].values()) == {3} and d['config']['graphs_per_step'] == 3
   assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c
   assert c['buckets']['early_allreduce_calls'] == 1 and c['buckets']['late_written_in_place']
@@ -106,3 +108,6 @@ def test_bench_one_gpu_line_and_dp_one_rank_leg():
   assert o['graphs_per_step']['overlap'] == 1 and o['graphs_per_step']['three_graphs_overlap'] == 3
   assert set(o['ms_per_step']) == set(o['delta_vs_single_graph_us']) == {n for n, _, _ in __import__('bench').DP_MODES}
   assert all(v > 0 for v in o['ms_per_step'].values()) and len(o['allreduce_us_one_rank']) == 2
+  # what RCCL said when the communicator was created (INIT lines into a private file): the channel count is what decides how
+  # many CUs the early bucket needs beside part 2
+  assert o['rccl']['status'] == 'ok' and o['rccl']['log_lines'] > 0, o['rccl']
