@@ -2,6 +2,7 @@
 reader's windowing against a literal restatement of the reference's pipeline, checkpoints."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -412,6 +413,42 @@ def test_bench_refuses_missing_gpus():
   assert out.returncode == 2, (out.returncode, out.stderr[-500:])
   assert '"metric"' not in out.stdout
   assert 'only' in out.stderr and 'GPU' in out.stderr
+
+
+def test_bench_reads_what_rccl_logged(tmp_path, monkeypatch):
+  """bench.py sends RCCL's INIT / GRAPH lines to a private file and reports version, collective channels, rings and transports
+  in ``comm.rccl`` (the channel count decides how many CUs the early bucket wants beside part 2).  The parser on lines of the
+  shape RCCL 2.26 writes; a caller who directs the log itself is left alone; a plain NCCL_DEBUG=VERSION is raised to INFO."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  try:
+    import bench
+  finally:
+    sys.path.remove(root)
+  log = tmp_path / 'rccl.log'
+  log.write_text('\n'.join([
+      'host:123:123 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6',
+      'host:123:140 [0] NCCL INFO Pattern 4, crossNic 0, nChannels 28, bw 48.000000/48.000000, type XGMI/PIX, sameChannels 1',
+      'host:123:140 [0] NCCL INFO Channel 00/28 : 0 1 2 3 4 5 6 7',
+      'host:123:140 [0] NCCL INFO Channel 01/28 : 0 2 4 6 1 3 5 7',
+      'host:123:141 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC',
+      'host:123:141 [0] NCCL WARN something worth repeating',
+      'host:123:140 [0] NCCL INFO 28 coll channels, 28 collnet channels, 0 nvls channels, 32 p2p channels, 4 p2p channels per peer',
+  ]))
+  info = bench.rccl_info(str(log))
+  assert info['status'] == 'ok' and info['coll_channels'] == 28 and info['version'].startswith('RCCL version : 2.26.6')
+  assert info['ring_channels_seen'] == 2 and info['transports'] == ['P2P/IPC'] and not log.exists()
+  assert any('coll channels' in l for l in info['lines'])
+  assert bench.rccl_info(None)['status'].startswith('the caller directs')
+  assert bench.rccl_info(str(tmp_path / 'missing.log'))['status'].startswith('no log')
+  for k in ('NCCL_DEBUG', 'NCCL_DEBUG_FILE', 'NCCL_DEBUG_SUBSYS'):
+    monkeypatch.delenv(k, raising=False)
+  monkeypatch.setenv('NCCL_DEBUG_FILE', '/somewhere/else')
+  assert bench.rccl_debug_on() is None and 'NCCL_DEBUG' not in os.environ
+  monkeypatch.delenv('NCCL_DEBUG_FILE')
+  monkeypatch.setenv('NCCL_DEBUG', 'VERSION')
+  path = bench.rccl_debug_on()
+  assert path and os.environ['NCCL_DEBUG'] == 'INFO' and os.environ['NCCL_DEBUG_FILE'] == path and os.environ['NCCL_DEBUG_SUBSYS'] == 'INIT,GRAPH'
 
 
 def test_tfrecord_sequence_example_hand_assembled_golden(tmp_path):
