@@ -40,6 +40,13 @@ class SlabReduce(Structure):
               ('KC', c_int64), ('S', c_int32), ('Cout', c_int32), ('groups', c_int32), ('reserved', c_int32)]
 
 
+class AdamSegment(Structure):
+  """geeco_adam_segment (include/geeco_hip.h): one piece of the arena with its own gradient source."""
+  _fields_ = [('g', c_void_p), ('p_off', c_int64), ('count', c_int64)]
+
+
+ADAM_SEGMENTS_MAX = 8
+
 # symbol -> (restype, argtypes); mirrors include/geeco_hip.h one to one
 SIGNATURES = {
     'geeco_abi_version': (_I, []),
@@ -111,6 +118,7 @@ SIGNATURES = {
                                            _P, _P, _P]),
     'geeco_adam_prepare': (_I, [_P, _F, _F, _F, _P, _P]),
     'geeco_adam_tf': (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
+    'geeco_adam_tf_segments': (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _F, _F, _F, _F, _P]),
     'geeco_sumsq': (_I, [_P, _L, _P, _P]),
 }
 

@@ -719,6 +719,21 @@ class _ModelBase:
     self._prepared = True
     return (self.store.global_step, float(self.cfg.lr), self.scal)
 
+  def apply_gradients_of(self, segments, g_out=None, last=True):
+    """The optimiser step of SOME pieces of the arena (``ops.adam_tf_segments``; data parallel: everything that came with the early
+    bucket first, the late bucket's variables when it has arrived).  ``last``: the pieces complete the step (weight copies are
+    re-derived behind it)."""
+    s, cfg = self.store, self.cfg
+    if not getattr(self, '_prepared', False):
+      ops.adam_prepare(s.global_step, float(cfg.lr), self.scal)
+      self._prepared = not last
+    if last:
+      self._prepared = False
+    ops.adam_tf_segments(s.params, s.adam_m, s.adam_v, segments, self.scal, g_out=g_out, grad_scale=1.0 / self.world,
+                         l2=float(cfg.l2_regularizer))
+    if last:
+      self._refresh_after_update()
+
   def apply_gradients(self):
     s, cfg = self.store, self.cfg
     if not getattr(self, '_prepared', False):
@@ -726,6 +741,10 @@ class _ModelBase:
     self._prepared = False
     ops.adam_tf(s.params, s.grads, s.adam_m, s.adam_v, s.size, self.scal, grad_scale=1.0 / self.world,
                 l2=float(cfg.l2_regularizer))
+    self._refresh_after_update()
+
+  def _refresh_after_update(self):
+    s = self.store
     # weights changed: re-derive the padded / transposed copies now (the version stamp is unchanged, so
     # the next forward, eager or replayed, launches no pad / transpose kernels).  A model that shares the store
     # with the primary training stack (the one built for a ragged final batch) must refresh THAT stack's copies

@@ -538,6 +538,21 @@ def adam_tf(p, g, m, v, n, scal, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
         'geeco_adam_tf')
 
 
+def adam_tf_segments(p, m, v, segments, scal, g_out=None, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
+  """``geeco_adam_tf_segments``: the Adam update of up to 8 pieces of the arena, ``segments`` = [(gradient tensor of the piece, offset
+  in the arena, count)], offsets / counts in floats and multiples of 4; ``g_out``: the gradient arena that also receives the pieces'
+  gradients (a piece whose source IS its place in that arena needs none)."""
+  if not 1 <= len(segments) <= _native.ADAM_SEGMENTS_MAX:
+    raise ValueError('adam_tf_segments: 1..%d pieces, got %d' % (_native.ADAM_SEGMENTS_MAX, len(segments)))
+  arr = (_native.AdamSegment * len(segments))()
+  for a, (g, off, n) in zip(arr, segments):
+    if g.numel() < n:
+      raise ValueError('adam_tf_segments: a piece of %d floats with %d gradients' % (n, g.numel()))
+    a.g, a.p_off, a.count = _p(g), int(off), int(n)
+  check(_lib().geeco_adam_tf_segments(_p(p), _p(g_out), _p(m), _p(v), arr, len(segments), _p(scal), beta1, beta2, eps, grad_scale, l2,
+                                      _stream()), 'geeco_adam_tf_segments')
+
+
 def sumsq_into(out, p, n):
   check(_lib().geeco_sumsq(_p(p), n, _p(out), _stream()), 'geeco_sumsq')
 

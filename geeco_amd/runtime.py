@@ -23,6 +23,7 @@ import threading
 
 import torch
 
+from . import _dev
 from . import dist as gdist
 
 # hipGraph capture in the default ("global") mode is invalidated by a hipMalloc / synchronous copy issued by ANOTHER
@@ -110,6 +111,11 @@ class TrainStepRunner:
       self.redirected = bool(redirect and redirect(self.staging, self.late))
       if self.redirected:
         redirect(None, None)
+    # The optimiser step in two pieces (whole data-parallel step in one pass over the stream: eager, or captured as ONE graph):
+    # everything that came with the early bucket is updated while the late bucket is on the wire, the late bucket's variables
+    # follow with their gradients read straight from the staging buffer (no unpack copies).  Three replayed graphs keep part 3 whole.
+    self.split_adam = (self.dp and self.staging is not None and hasattr(model, 'apply_gradients_of')
+                       and 1 <= len(self.early) <= 8 and 1 <= len(self.late) <= 8 and _dev.env('GEECO_NO_SPLIT_ADAM') is None)
     if self.redirected and self.early:
       lo = min(off for off, _ in self.early)
       hi = max(off + n for off, n in self.early)
@@ -152,6 +158,17 @@ class TrainStepRunner:
       self.staging[pos:pos + n].copy_(g[off:off + n])
       pos += n
 
+  def _part3_early(self):
+    g = self.model.store.grads
+    self.model.apply_gradients_of([(g[off:off + n], off, n) for off, n in self.early], last=False)
+
+  def _part3_late(self):
+    segs, pos = [], 0
+    for off, n in self.late:
+      segs.append((self.staging[pos:pos + n], off, n))
+      pos += n
+    self.model.apply_gradients_of(segs, g_out=self.model.store.grads, last=True)     # (the gradient arena gets them too)
+
   def _part3(self):
     if self.dp and self.staging is not None:
       g, pos = self.model.store.grads, 0
@@ -177,15 +194,24 @@ class TrainStepRunner:
 
   def _dp_step(self, run=None):
     """The data-parallel step: ``run`` = the three parts as callables (captured graphs' replays or the eager functions)."""
+    whole = run is None                    # not three replayed graphs: the parts run right here (eagerly, or under ONE capture)
     run = run or [self._part1, self._part2, self._part3]
     run[0]()
     works = self._exchange_early() if self.overlap else []   # on the communicator's stream, behind part 1, beside part 2
     run[1]()
     if not self.overlap:
       works = self._exchange_early()
-    works += self._exchange_late()
-    for w in works:
-      w.wait()                             # the compute stream waits; the host does not (RCCL)
+    late = self._exchange_late()
+    if whole and self.split_adam:
+      for w in works:
+        w.wait()                           # the compute stream waits; the host does not (RCCL)
+      self._part3_early()                  # 99 % of the update, beside the late bucket's all-reduce
+      for w in late:
+        w.wait()
+      self._part3_late()
+      return
+    for w in works + late:
+      w.wait()
     run[2]()
 
   def _parts(self):

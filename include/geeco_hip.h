@@ -406,6 +406,20 @@ int geeco_adam_prepare(int64_t* global_step_dev, float lr, float beta1, float be
                        void* stream);
 int geeco_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_t_dev,
                   float beta1, float beta2, float eps, float grad_scale, float l2, void* stream);
+/* The same update over up to GEECO_ADAM_SEGMENTS_MAX pieces of the arena (offsets and counts in floats, multiples of 4), each piece
+ * with its own gradient source; g_out != NULL: every piece's (unscaled) gradients are also stored at its place in that arena.
+ * Any partition of the arena gives bitwise geeco_adam_tf's result.  Data parallel (round 5): the variables whose gradients came
+ * with the early bucket are updated while the late bucket is still on the wire; the encoders' conv1 / conv2 follow, their
+ * gradients read straight from the late bucket's staging buffer (no unpack copies).  The reference has one optimiser op per
+ * variable and no distributed code (estimator.py:243-244). */
+#define GEECO_ADAM_SEGMENTS_MAX 8
+typedef struct geeco_adam_segment {
+  const float* g;       /* gradients of the piece (16-byte aligned) */
+  int64_t p_off, count; /* its place in the parameter / moment arenas */
+} geeco_adam_segment;
+int geeco_adam_tf_segments(float* p, float* g_out, float* m, float* v, const geeco_adam_segment* segs, int nseg,
+                           const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, float l2,
+                           void* stream);
 /* sum of squares of an arena (for the L2 regularisation loss term); out[0] overwritten. */
 int geeco_sumsq(const float* p, int64_t n, float* out, void* stream);
 

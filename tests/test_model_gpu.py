@@ -162,6 +162,42 @@ def test_loss_trajectory_graph_replay(dev):
   print('loss trajectory (hip, oracle):', ['%.5f/%.5f' % p for p in losses])
 
 
+@pytest.mark.parametrize('l2', [0.0, 1e-3])
+def test_optimiser_step_in_pieces_is_the_one_pass_step(dev, l2):
+  """geeco_adam_tf_segments (data parallel: the variables of the early bucket are updated while the late bucket is on the wire,
+  conv1 / conv2 of the encoders follow with their gradients read from the staging buffer): any partition of the arena, with the
+  gradients of some pieces living elsewhere, gives bitwise geeco_adam_tf's parameters and moments; ``g_out`` receives the foreign
+  pieces' gradients; pieces that are not multiples of four floats are refused."""
+  from geeco_amd import ops
+  r = np.random.default_rng(171)
+  n = 4 * 25013
+  p0 = torch.tensor(r.standard_normal(n).astype(np.float32), device=dev)
+  g = torch.tensor(r.standard_normal(n).astype(np.float32), device=dev)
+  m0 = torch.tensor((0.1 * r.standard_normal(n)).astype(np.float32), device=dev)
+  v0 = torch.tensor((0.01 * r.random(n)).astype(np.float32), device=dev)
+  scal = torch.tensor([3.1e-4, 0.0], device=dev)
+  pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+  ops.adam_tf(pa, g, ma, va, n, scal, grad_scale=0.125, l2=l2)
+  cuts = [0, 4 * 216, 4 * 3908, 4 * 3908 + 4, 4 * 20000, n]            # five pieces, one of a single float4
+  pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+  staged = torch.cat([g[cuts[1]:cuts[2]], g[cuts[3]:cuts[4]]]).contiguous()   # two pieces' gradients live in a buffer of their own
+  g_arena = g.clone()
+  g_arena[cuts[1]:cuts[2]] = float('nan')
+  g_arena[cuts[3]:cuts[4]] = float('nan')
+  ops.adam_tf_segments(pb, mb, vb, [(g_arena[cuts[0]:cuts[1]], cuts[0], cuts[1] - cuts[0]), (g_arena[cuts[2]:cuts[3]], cuts[2], 4),
+                                    (g_arena[cuts[4]:], cuts[4], n - cuts[4])], scal, grad_scale=0.125, l2=l2)
+  k = cuts[2] - cuts[1]
+  ops.adam_tf_segments(pb, mb, vb, [(staged[:k], cuts[1], k), (staged[k:], cuts[3], cuts[4] - cuts[3])], scal, g_out=g_arena,
+                       grad_scale=0.125, l2=l2)
+  torch.cuda.synchronize()
+  assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+  assert torch.equal(g_arena, g)
+  with pytest.raises(Exception):
+    ops.adam_tf_segments(pb, mb, vb, [(g, 0, 6)], scal)
+  with pytest.raises(ValueError):
+    ops.adam_tf_segments(pb, mb, vb, [(g, 0, 4)] * 9, scal)
+
+
 @pytest.mark.parametrize('goal', [True, False], ids=['geeco-f', 'e2e_vmc'])
 def test_optimiser_scalars_ride_in_the_last_slab_sum(dev, goal):
   """train_step() / the step runner let the Adam step counter and lr_t ride in the backward's last slab-sum launch
