@@ -417,16 +417,20 @@ class ConvEncoderStack:
     self.launch_fwd(top)
     return False
 
-  def backward(self, hi=7, lo=0, prepare=None):
+  def backward(self, hi=7, lo=0, prepare=None, defer_dgrad=False, lead_dgrad=None):
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied).  Runs layers
     hi..lo (the data-parallel runner splits the chain at conv3 / conv2 to start the gradient exchange early).
-    ``prepare`` = (global_step, lr, scal): the optimiser's per-step scalars ride in this part's slab-sum launch."""
+    ``prepare`` = (global_step, lr, scal): the optimiser's per-step scalars ride in this part's slab-sum launch.
+    ``defer_dgrad``: layer lo's INPUT gradient is left to the next part, which opens with it (``lead_dgrad=lo``): every
+    gradient of the early bucket exists once layer lo's filter gradient does, so the bucket leaves a launch earlier."""
     main = torch.cuda.current_stream()
     sides = self.sides if self.two_streams else []
     pending = [] if self.batch_reduce else None   # slab sums of all layers of this part: one launch at the end
     # conv8's filter gradient waits for conv7's: one launch for both (independent work batched into one grid)
     pair_top = (hi == 7 and lo <= 6 and not self.split_top and not sides and self.pair_top
                 and self.layers[6]['stride'] == self.layers[7]['stride'] == 2)
+    if lead_dgrad is not None:
+      self.launch_dgrad(lead_dgrad, pending)
     for l in range(hi, lo - 1, -1):
       if pair_top and l == 7:
         self.w8_done = self.hetero_top == 2 and self.launch_top_bwd(7, (7,), pending)
@@ -455,8 +459,8 @@ class ConvEncoderStack:
         side.wait_stream(main)          # dz[l] is ready
       with torch.cuda.stream(side if side is not None else main):
         self.launch_wgrad(l, pending)
-      if l == 0:
-        break   # conv1's input is data: no dgrad
+      if l == 0 or (l == lo and defer_dgrad):
+        break   # conv1's input is data: no dgrad / the next part opens with this layer's
       self.launch_dgrad(l, pending)
       if l == 1 and self.fused_bottom:
         break
@@ -468,6 +472,8 @@ class ConvEncoderStack:
       ops.adam_prepare(*prepare)
 
   SPLIT = 2   # backward(part='upper') = layers 7..SPLIT, 'bottom' = SPLIT-1..0
+  # ... except layer SPLIT's INPUT gradient, which opens the bottom part (GEECO_DP_DGRAD_IN_UPPER: round 4's cut)
+  DEFER_SPLIT_DGRAD = _dev.env('GEECO_DP_DGRAD_IN_UPPER') is None
 
 
 # ================================================================================================
@@ -916,7 +922,7 @@ class GoalE2EVMC(_ModelBase):
     separately (runtime.py): everything down to conv3, then the encoder bottom (conv2 / conv1).  ``adam_prepare``: see
     _prepare_args (ignored for part 'upper': the optimiser's scalars ride in the LAST slab-sum launch of the step)."""
     if part == 'bottom':
-      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare))
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None)
       return
     N, K, jn = self.N, self.K, self.cfg.dim_jnt_state
     d = self.decoder
@@ -947,7 +953,7 @@ class GoalE2EVMC(_ModelBase):
       for t in range(K):
         ops.state_concat_bwd_into([df[0][t], df[1][t]], d.dstates[t], d.D, [f[0][t], f[1][t]], self.feat_ch, 1, jn, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
-                      prepare=self._prepare_args(adam_prepare and part is None))
+                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD)
 
   def endpoints(self):
     """dynbuff / dyndiff debug endpoints (graph.py:377,393,401): the LAST computed images."""
@@ -992,7 +998,7 @@ class E2EVMC(_ModelBase):
 
   def backward(self, part=None, adam_prepare=False):
     if part == 'bottom':
-      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare))
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None)
       return
     N, K = self.N, self.K
     d = self.decoder
@@ -1002,7 +1008,7 @@ class E2EVMC(_ModelBase):
     for t in range(K):
       ops.state_concat_bwd_into([dfe[t]], d.dstates[t], d.D, [feats[t]], [256], 1, self.cfg.dim_jnt_state, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
-                      prepare=self._prepare_args(adam_prepare and part is None))
+                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD)
 
   def endpoints(self):
     return {'conv8': self.enc.features}
