@@ -90,7 +90,7 @@ SIGNATURES = {
     'geeco_conv3x3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     'geeco_relu_fields_elems': (_L, [_I, _I, _I]),
     'geeco_conv2_fwd_relu_fields': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
-    'geeco_conv3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _P]),
+    'geeco_conv3_dgrad_relu_fields': (_I, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _I, _I, _I, _P, _I]),
     'geeco_relu_bits_rows': (_L, [_I]),
     'geeco_conv1_fwd_relu_bits': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),
     'geeco_conv1_fwd_relu_bits_rgb': (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P]),

@@ -1707,7 +1707,8 @@ static int launch_dgrad_chunked(HaloDgradParams& p, hipStream_t stream) {
     }
     attr_set = true;
   }
-  long long blocks = p.ntiles < 256 ? p.ntiles : 256;
+  const long long cus = 256 - geeco_call_reserved_cus();     // data parallel: CUs left to the collective that runs beside part 2
+  long long blocks = p.ntiles < cus ? p.ntiles : cus;
   geeco_note_kernel("conv_s2_halo_dgrad_chunked_kernel<%d, %d, %s>", CIN, COUT, FIELDS ? "true" : "false");
   hipLaunchKernelGGL((conv_s2_halo_dgrad_chunked_kernel<CIN, COUT, FIELDS>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
   return 0;
@@ -2596,7 +2597,7 @@ extern "C" int geeco_conv2_fwd_relu_fields(const float* x, const float* w, const
 
 extern "C" int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_t* y2_fields, float* dx,
                                              int groups, int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx,
-                                             int N, int H, int W, void* stream) {
+                                             int N, int H, int W, void* stream, int reserved_cus) {
   GEECO_CHECK_ARG(dz && w && y2_fields && dx, "conv3_dgrad_relu_fields: null pointer");
   GEECO_CHECK_ARG(groups >= 1 && N >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
                   "conv3_dgrad_relu_fields: H = %d, W = %d must be even", H, W);
@@ -2608,7 +2609,9 @@ extern "C" int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, co
   p.tiles_x = cdiv(W, 64); p.tiles_y = cdiv(H, 8);
   p.tiles_per_group = N * p.tiles_x * p.tiles_y;
   p.ntiles = (long long)groups * p.tiles_per_group;
+  if (int e = geeco_enter_reserved_cus(reserved_cus)) return e;
   int rc = launch_dgrad_chunked<48, 64, true>(p, (hipStream_t)stream);
+  geeco_leave_reserved_cus();
   if (rc) return rc;
   GEECO_LAUNCH_CHECK();
   return 0;

@@ -394,7 +394,7 @@ class ConvEncoderStack:
       return
     if l == 2 and self.relu_fields:
       ops.conv3_dgrad_relu_fields_into(dx, dz, self._w(2), self.fields2, G, dz[0].numel(), self.gs_p, self.fields2[0].numel(),
-                                       dx[0].numel(), Nf, L['H'], L['W'])
+                                       dx[0].numel(), Nf, L['H'], L['W'], reserved_cus=self.reserved_cus)
       return
     ops.conv3x3_dgrad_into(dx, dz, wt, x, G, dz[0].numel(), wt[0].numel() if wt is not None else 0, dx[0].numel(), Nf, L['H'],
                            L['W'], L['Cin'], L['Cout'], L['stride'], ws=self.dws, w=self._w(l), gs_w=self.gs_p)

@@ -340,10 +340,11 @@ def conv2_fwd_relu_fields_into(y, fields, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs
                                            H, W, _stream()), 'geeco_conv2_fwd_relu_fields')
 
 
-def conv3_dgrad_relu_fields_into(dx, dz, w, fields, G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W):
-  """conv3 input gradient (48 -> 64, stride 2) masked by the sign fields of conv2's output; H, W = dims of dx."""
+def conv3_dgrad_relu_fields_into(dx, dz, w, fields, G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W, reserved_cus=0):
+  """conv3 input gradient (48 -> 64, stride 2) masked by the sign fields of conv2's output; H, W = dims of dx.
+  ``reserved_cus`` (data parallel): CUs this persistent kernel leaves to a collective running beside it."""
   check(_lib().geeco_conv3_dgrad_relu_fields(_p(dz), _p(w), _p(fields), _p(dx), G, gs_dz, gs_w, gs_fields, gs_dx, N, H, W,
-                                             _stream()), 'geeco_conv3_dgrad_relu_fields')
+                                             _stream(), int(reserved_cus)), 'geeco_conv3_dgrad_relu_fields')
 
 
 def conv3_fwd_relu_fields_into(y, fields, x, w, b, G, gs_x, gs_w, gs_b, gs_y, gs_fields, N, H, W):

@@ -248,14 +248,16 @@ int geeco_conv1_fwd_relu_bits_rgb(const float* x, const float* w3, const float* 
  * sign fields of its output y2, and conv3's input gradient (48 -> 64, stride 2; dz [G][N][H/2][W/2][64], dx = d(y2)
  * [G][N][H][W][48]) masked by those fields instead of by y2 itself (302 MB at the bench shape).
  *   fields[g][n][y][x][q], q = 0..3: uint16, bit 4 i + j set iff y2[g][n][y][x][16 i + 4 q + j] > 0; rows / columns
- *   padded to whole 8 x 64 tiles (geeco_relu_fields_elems uint16 per encoder), group stride gs_fields elements. */
+ *   padded to whole 8 x 64 tiles (geeco_relu_fields_elems uint16 per encoder), group stride gs_fields elements.
+ * reserved_cus (round 5): as for the two launches behind it in the data-parallel step (geeco_conv3x3_wgrad_partial): this persistent
+ *   one-block-per-CU kernel is the first of part 2 and leaves that many CUs to the collective running beside it; 0 otherwise. */
 int64_t geeco_relu_fields_elems(int N, int H, int W);
 int geeco_conv2_fwd_relu_fields(const float* x, const float* w, const float* b, float* y, uint16_t* fields, int groups,
                                 int64_t gs_x, int64_t gs_w, int64_t gs_b, int64_t gs_y, int64_t gs_fields, int N, int H,
                                 int W, void* stream);
 int geeco_conv3_dgrad_relu_fields(const float* dz, const float* w, const uint16_t* y2_fields, float* dx, int groups,
                                   int64_t gs_dz, int64_t gs_w, int64_t gs_fields, int64_t gs_dx, int N, int H, int W,
-                                  void* stream);
+                                  void* stream, int reserved_cus);
 /* ... and one more layer up: conv3's forward (48 -> 64, stride 2) writing byte sign fields of its output y3, and the
  * LDS-staged input-gradient kernel of the next layer (the shapes geeco_conv3x3_dgrad_relu_fields_supported reports,
  * e.g. conv4: 64 -> 128) masked by them instead of by y3 (100 MB at the bench shape):

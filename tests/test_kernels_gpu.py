@@ -474,6 +474,13 @@ def test_conv2_relu_fields_and_conv3_dgrad_fields(dev, G, N, H, W):
   torch.cuda.synchronize()
   assert names == ['conv_s2_halo_dgrad_chunked_kernel<48, 64, true>'], names
   assert not torch.isnan(dx).any() and torch.equal(dx, dx_ref)
+  # data parallel: the persistent kernel leaves CUs to the collective beside it (fewer blocks, longer tile ranges): same bits
+  for k in (16, 100):
+    dx2 = torch.full_like(dx_ref, float('nan'))
+    ops.conv3_dgrad_relu_fields_into(dx2, dz3, w3, fields, G, dz3[0].numel(), w3[0].numel(), ne, dx2[0].numel(), N, H2, W2, reserved_cus=k)
+    assert torch.equal(dx2, dx_ref), k
+  with pytest.raises(Exception):
+    ops.conv3_dgrad_relu_fields_into(dx, dz3, w3, fields, G, dz3[0].numel(), w3[0].numel(), ne, dx[0].numel(), N, H2, W2, reserved_cus=200)
 
 
 @pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (2, 2, 40, 36, 4),
