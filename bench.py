@@ -291,35 +291,37 @@ def recorded_traffic(kname):
 
 
 def hbm_table(model, args, iters):
-  """HBM-bound pieces against the 8.0 TB/s peak, algorithmic bytes per SURVEY.md 8(d)."""
+  """HBM-bound pieces against the 8.0 TB/s peak, algorithmic bytes per SURVEY.md 8(d).  ``in_step`` False: the single-image entry
+  point (geeco_dynimg_fwd: a sum launch + a normalisation launch), timed for reference -- the goal model's step runs both images
+  through the one-launch row below."""
   from geeco_amd import ops
   rows = []
   N, K, C = model.N, model.K, model.C
   HW = model.H * model.W
 
-  def add(name, nbytes, fn):
+  def add(name, nbytes, fn, in_step=True):
     fn()
     ms, p10, p90 = time_launches(fn, iters)
     tbs = nbytes / (ms * 1e-3) / 1e12
     rows.append({'piece': name, 'bytes': int(nbytes), 'us': round(ms * 1e3, 1), 'us_p10': round(p10 * 1e3, 1),
-                 'us_p90': round(p90 * 1e3, 1), 'TB/s': round(tbs, 3), 'frac': round(tbs / PEAK_HBM_TBS, 4)})
+                 'us_p90': round(p90 * 1e3, 1), 'TB/s': round(tbs, 3), 'frac': round(tbs / PEAK_HBM_TBS, 4), 'in_step': in_step})
   if args.model == 'geeco-f' and getattr(model, 'split_rgbd', False):
     # RGB-D: the dynimg kernels read rgb and depth from their own tensors (no packed copy of the frames)
     inp, x_in = model.inputs, model.enc.x_in
     rgb, dep = inp['rgb'], inp['depth']
     add('dynimg buffer image (K=%d), rgb + depth unpacked' % K, 4.0 * N * HW * C * (K + 1),
-        lambda: ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, model.dyn_ws, K * HW * 3, HW * 3, K * HW, HW))
+        lambda: ops.dynimg_rgbd_into(x_in[1], rgb, dep, K, N, HW, model.dyn_ws, K * HW * 3, HW * 3, K * HW, HW), in_step=False)
     add('dynimg diff image (K=2), rgb + depth unpacked', 4.0 * N * HW * C * 3,
         lambda: ops.dynimg_rgbd_into(x_in[2], rgb[:, K - 1], dep[:, K - 1], 2, N, HW, model.dyn_ws, K * HW * 3, 0, K * HW, 0,
-                                     rgb2=inp['target_rgb'], depth2=inp['target_depth']))
+                                     rgb2=inp['target_rgb'], depth2=inp['target_depth']), in_step=False)
   elif args.model == 'geeco-f':
     frames, tgt = model._frames()
     x_in = model.enc.x_in
     cur = frames[:, K - 1]
     add('dynimg buffer image (K=%d)' % K, 4.0 * N * HW * C * (K + 1),
-        lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C))
+        lambda: ops.dynimg_into(x_in[1], frames, K, N, HW, C, 4, model.dyn_ws, K * HW * C, HW * C), in_step=False)
     add('dynimg diff image (K=2)', 4.0 * N * HW * C * 3,
-        lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt))
+        lambda: ops.dynimg_into(x_in[2], cur, 2, N, HW, C, 4, model.dyn_ws, K * HW * C, 0, frames2=tgt), in_step=False)
   if args.model == 'geeco-f' and getattr(model, 'last_from_dynimg', False) \
       and HW % 4 == 0 and (C == 3 or getattr(model, 'split_rgbd', False)):
     # what the step really runs: both images + the current frame's padded copy in ONE launch, one pass over the window (both
