@@ -255,11 +255,15 @@ class TrainStepRunner:
       # NB capture itself does not execute the step; fall through to replay
       self._capture()
     self._calls += 1
-    run = self._graphs if self._graphs is not None else self._parts()
-    if len(run) == 1:
-      run[0]()
+    if self._graphs is None:               # eager (warm-up steps, use_graph=False)
+      if self.dp:
+        self._dp_step()
+      else:
+        self._whole_step()
+    elif len(self._graphs) == 1:
+      self._graphs[0]()
     else:
-      self._dp_step(run)
+      self._dp_step(self._graphs)
 
   def null_step(self):
     """A step of a rank that holds no sample (ragged end of an epoch under data parallelism): zero gradients into

@@ -105,13 +105,26 @@ class _FakeModel:
   """Stands in for a graph.* model on the CPU: 'backward' writes rank-dependent gradients, the upper part into
   the early ranges only, the bottom part into the late (conv1 / conv2) ranges only."""
 
-  def __init__(self, store, rank, early, late, can_redirect=False):
+  def __init__(self, store, rank, early, late, can_redirect=False, split=False):
     self.store, self.rank, self.early, self.late = store, rank, early, late
     self.world = 1
     self.applied = None
     self.staging = None
+    self.pieces = []
     if can_redirect:      # like graph.ConvEncoderStack.redirect_late_gradients: the bottom part writes the staging buffer
       self.redirect_late_gradients = self._redirect
+    if split:             # like graph._ModelBase.apply_gradients_of: the optimiser step in pieces (runtime: two, around the late bucket)
+      self.apply_gradients_of = self._apply_of
+
+  def _apply_of(self, segments, g_out=None, last=True):
+    if self.applied is None or not self.pieces:
+      self.applied = torch.full_like(self.store.grads, float('nan'))
+    for g, off, n in segments:
+      assert g.numel() >= n
+      self.applied[off:off + n] = g[:n] / self.world
+      if g_out is not None:
+        g_out[off:off + n] = g[:n]
+    self.pieces.append((len(segments), g_out is not None, last))
 
   def _redirect(self, staging, late_ranges):
     if staging is None:            # the runner ends its redirection right behind its own part 2
@@ -144,7 +157,7 @@ class _FakeModel:
     self.applied = self.store.grads.clone() / self.world
 
 
-def _bucket_worker(rank, world, port, q, can_redirect=False, overlap=True):
+def _bucket_worker(rank, world, port, q, can_redirect=False, overlap=True, split=False):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   torch.set_num_threads(1)
@@ -157,24 +170,28 @@ def _bucket_worker(rank, world, port, q, can_redirect=False, overlap=True):
   cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=2))
   store = VariableStore(model_variable_shapes(cfg, True), 'cpu')
   early, late = gradient_buckets(store)
-  model = _FakeModel(store, rank, early, late, can_redirect)
+  model = _FakeModel(store, rank, early, late, can_redirect, split)
   runner = TrainStepRunner(model, use_graph=False, overlap=overlap)
-  assert runner.world == world and model.world == world
+  assert runner.world == world and model.world == world and runner.split_adam == split
   runner.step()
+  if split:      # two pieces: the early bucket's variables from the arena, then the late ones from the staging buffer (the arena gets them too)
+    assert model.pieces == [(len(early), False, False), (len(late), True, True)], model.pieces
+    assert torch.equal(model.applied, store.grads / world)
   q.put((rank, model.applied.numpy(), early, late, runner.bucket_info()))
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,can_redirect,overlap', [(2, False, True), (2, True, True), (2, True, False), (4, True, True),
-                                                        (4, False, True), (8, True, True)],
+@pytest.mark.parametrize('world,can_redirect,overlap,split', [(2, False, True, False), (2, True, True, False), (2, True, False, False),
+                                                              (4, True, True, False), (4, False, True, False), (8, True, True, False),
+                                                              (2, True, True, True), (2, False, False, True), (4, True, False, True)],
                          ids=['packed-late', 'late-in-place', 'late-in-place-serial', 'world4-late-in-place', 'world4-packed-late',
-                              'world8-late-in-place'])
-def test_bucketed_exchange_covers_the_arena(world, can_redirect, overlap):
+                              'world8-late-in-place', 'adam-in-two-pieces', 'adam-in-two-pieces-packed-serial', 'world4-adam-in-two-pieces-serial'])
+def test_bucketed_exchange_covers_the_arena(world, can_redirect, overlap, split):
   sys.path.insert(0, ROOT)
-  port = 31500 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap) + 10 * world
+  port = 31500 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap) + 10 * world + 100 * int(split)
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, can_redirect, overlap)) for r in range(world)]
+  procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, can_redirect, overlap, split)) for r in range(world)]
   for p in procs:
     p.start()
   res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
