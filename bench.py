@@ -50,12 +50,15 @@ def parse_args():
   ap.add_argument('--cpu-steps', type=int, default=60, help='upper bound; the leg stops after ~12 s of CPU work')
   ap.add_argument('--cpu-batch', type=int, default=4)
   ap.add_argument('--dp-serial', action='store_true',
-                  help='N > 1: run the gradient exchange AFTER the backward instead of beside its bottom part (the timed '
-                       'region then measures the serial step; comm.step_ms always reports both)')
-  ap.add_argument('--dp-fixed', action='store_true',
-                  help='N > 1: time the overlapped exchange without the short trial that picks the fastest form on this node')
-  ap.add_argument('--dp-three-graphs', action='store_true',
-                  help='N > 1: launch the exchange between three captured graphs (round 4) instead of capturing it into ONE step graph')
+                  help='N > 1: the safe form runs the gradient exchange AFTER the backward instead of beside its bottom part, and '
+                       'no other form is timed in full (comm.step_ms still reports every form)')
+  ap.add_argument('--dp-fixed', '--dp-three-graphs', dest='dp_fixed', action='store_true',
+                  help='N > 1: report the safe form (exchange launched between three captured graphs); the ONE-graph forms '
+                       '(RCCL captured into the step graph) are neither tried nor timed in full')
+  ap.add_argument('--dp-watchdog-s', type=float, default=240.0,
+                  help='N > 1: seconds the captured forms (trial, second timed region, comm report) may take after the safe form '
+                       'has been measured; beyond that rank 0 prints the safe form\'s line and every rank exits (0 = no watchdog)')
+  ap.add_argument('--skip-comm-report', action='store_true', help='N > 1: skip the comm report (every form of the step, exchange alone)')
   ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
   ap.add_argument('--skip-input-pipeline', action='store_true', help='skip the input_pipeline leg (on-disk dataset -> Estimator.train)')
   ap.add_argument('--skip-inference', action='store_true', help='skip the inference leg (predictor latency, Estimator.evaluate)')
@@ -441,26 +444,14 @@ def build_model(model_name, channels, seq_len, batch, dev):
   return cfg, graph.E2EVMC(cfg, batch, dev, training=True)
 
 
-def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=True, capture_exchange=None, autotune=False):
-  """First optimiser step eager (its loss is the one checked against the oracle), second eager step + hipGraph capture,
-  `warmup` untimed replays, then EXACTLY `steps` steps between barrier + synchronize on both sides.  ``autotune`` (N > 1): the
-  form of the gradient exchange (overlapped / overlapped with 16 CUs left to RCCL / serial) is the one that measured fastest on
-  this node in a short untimed trial before the warm-up (runtime.pick_dp_runner)."""
+def timed_region(model, runner, steps, warmup, world, dev, verbose=True):
+  """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides (max over ranks)."""
   import torch
   from geeco_amd import dist as gdist
-  from geeco_amd.runtime import TrainStepRunner, pick_dp_runner
-  runner = TrainStepRunner(model, use_graph=use_graph, warmup=2, overlap=overlap, capture_exchange=capture_exchange)
-  runner.step()
-  torch.cuda.synchronize()
-  first_loss = float(model.loss)
-  trial = {}
-  if autotune and world > 1:
-    del runner
-    runner, trial = pick_dp_runner(model, use_graph=use_graph, capture_exchange=capture_exchange, log=log if verbose else None)
-  runner.prepare()     # second eager step + hipGraph capture, outside warm-up and timed region
+  runner.prepare()     # (second eager step +) hipGraph capture, outside warm-up and timed region
   torch.cuda.synchronize()
   if verbose:
-    log('graphs captured' if use_graph else 'eager mode')
+    log('graphs captured (%d per step)' % runner.bucket_info()['graphs_per_step'] if runner.use_graph else 'eager mode')
   for i in range(warmup):
     runner.step()
     if i < 3 and verbose:
@@ -481,9 +472,66 @@ def timed_steps(model, steps, warmup, use_graph, overlap, world, dev, verbose=Tr
     torch.distributed.barrier()
   torch.cuda.synchronize()
   dt_local = time.perf_counter() - t0
-  return {'runner': runner, 'first_loss': first_loss, 'final_loss': float(model.loss), 'dt_local': dt_local, 'dp_trial_ms': trial,
+  return {'runner': runner, 'final_loss': float(model.loss), 'dt_local': dt_local,
           'dt': gdist.max_over_ranks(dt_local, dev), 'total_steps': runner._calls,
+          'rank_ms': gdist.gather_floats(dt_local / steps * 1e3, dev),
           'per_step': sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))}
+
+
+def timed_steps(model, steps, warmup, use_graph, world, dev, verbose=True, form=None):
+  """First optimiser step eager (its loss is the one checked against the oracle), second eager step + hipGraph capture,
+  `warmup` untimed replays, then the timed region.  ``form`` (N > 1): a name of runtime.DP_FORMS (None = the safe default,
+  three graphs with the exchange launched between them)."""
+  import torch
+  from geeco_amd.runtime import TrainStepRunner, dp_form_kwargs
+  runner = TrainStepRunner(model, use_graph=use_graph, warmup=2, **(dp_form_kwargs(form) if world > 1 else {}))
+  runner.step()
+  torch.cuda.synchronize()
+  first_loss = float(model.loss)
+  r = timed_region(model, runner, steps, warmup, world, dev, verbose)
+  model.check_device_errors()      # an input-stage block that gave up waiting wrote NaN images: never report a number over that
+  r['first_loss'] = first_loss
+  return r
+
+
+class Watchdog:
+  """N > 1: the forms of the data-parallel step that capture RCCL's launches into a hipGraph have never run with more than one
+  rank on hardware (no multi-GPU box was available to any round of this build).  A collective that HANGS inside a replayed
+  graph cannot be recovered in-process, and a process that touched the GPU is never restarted.  So: the always-safe form is
+  measured FIRST, in full (warm-up + the K timed steps), its line is kept as `provisional`, and this timer is armed around
+  everything that follows.  If that does not finish in time, rank 0 writes the provisional line -- a complete, valid
+  measurement of the safe form, marked as such -- and every rank leaves with os._exit (no atexit handlers, no destructors
+  that would wait for the stuck stream).  The run cannot end without a number."""
+
+  def __init__(self, seconds, emit):
+    import threading
+    self.seconds, self.emit = float(seconds), emit
+    self._stop = threading.Event()
+    self._t = threading.Thread(target=self._run, name='bench-watchdog', daemon=True)
+    self.provisional = None
+    self.phase = 'start'
+
+  def arm(self):
+    self._t.start()
+
+  def disarm(self):
+    self._stop.set()
+
+  def _run(self):
+    if self._stop.wait(self.seconds):
+      return
+    import faulthandler
+    log('WATCHDOG: the captured forms of the data-parallel step did not finish within %.0f s (phase: %s); leaving with the '
+        'measurement of the safe form' % (self.seconds, self.phase))
+    try:
+      faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+    except Exception:
+      pass
+    try:
+      self.emit(self.provisional, self.phase)
+    finally:
+      sys.stderr.flush()
+      os._exit(0)
 
 
 def step_flop(channels, frames):
@@ -506,7 +554,7 @@ def other_configs(args, dev):
     model.store.initialize(seed=0)
     synthetic_batch(model, 1234)
     steps = max(5, min(args.steps, 10))
-    r = timed_steps(model, steps, 3, not args.no_graph, True, 1, dev, verbose=False)
+    r = timed_steps(model, steps, 3, not args.no_graph, 1, dev, verbose=False)
     ms = r['dt'] / steps * 1e3
     a2 = argparse.Namespace(model=mname, channels=ch, batch=b, seq_len=k)
     chk, ok = check_losses(a2, r['first_loss'], r['final_loss'], r['total_steps'])
@@ -747,13 +795,14 @@ def rccl_info(path):
   return out
 
 
-DP_MODES = (   # name, TrainStepRunner arguments, skip the exchange
-    ('overlap', dict(overlap=True), False),                                   # the default form: ONE graph, exchange captured
-    ('serial', dict(overlap=False), False),
-    ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # exchange launched between three graphs
+DP_MODES = (   # name, TrainStepRunner arguments, skip the exchange.  The three-graph forms FIRST (nothing captures RCCL), then the
+    # one-graph forms, then the probe that leaves the replicas diverged (comm_report puts them back in step behind it)
+    ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # = runtime.DP_FORMS['three_graphs'], the default
     ('three_graphs_serial', dict(overlap=False, capture_exchange=False), False),
-    ('overlap_reserve%d' % DP_RESERVE_PROBE, dict(overlap=True, reserved_cus=DP_RESERVE_PROBE), False),
-    ('overlap_reserve%d' % (2 * DP_RESERVE_PROBE), dict(overlap=True, reserved_cus=2 * DP_RESERVE_PROBE), False),
+    ('overlap', dict(overlap=True, capture_exchange=True), False),                 # ONE graph, exchange captured
+    ('serial', dict(overlap=False, capture_exchange=True), False),
+    ('overlap_reserve%d' % DP_RESERVE_PROBE, dict(overlap=True, capture_exchange=True, reserved_cus=DP_RESERVE_PROBE), False),
+    ('overlap_reserve%d' % (2 * DP_RESERVE_PROBE), dict(overlap=True, capture_exchange=True, reserved_cus=2 * DP_RESERVE_PROBE), False),
     ('no_exchange', dict(overlap=True, capture_exchange=False), True),        # three graphs, no all-reduce: the graph gaps alone
 )
 
@@ -778,6 +827,7 @@ def dp_step_modes(args, model, timer):
     forms[name] = r.bucket_info()['graphs_per_step']
     if name == 'overlap':
       info = r.bucket_info()
+    log('dp form %-22s %.4f ms/step (%d graph(s) per step)' % (name, modes[name][0], forms[name]))
     del r
   return modes, forms, info
 
@@ -948,41 +998,98 @@ def main():
   synthetic_batch(model, 1234 + rank)
   log('model built: %d parameters, batch %d/GPU, world %d' % (model.store.count_parameters(), args.batch, world))
 
-  r = timed_steps(model, args.steps, args.warmup, not args.no_graph, not args.dp_serial, world, dev,
-                  capture_exchange=False if args.dp_three_graphs else None, autotune=not (args.dp_serial or args.dp_fixed))
-  runner, dt, per_step = r['runner'], r['dt'], r['per_step']
-  first_loss, loss, total_steps = r['first_loss'], r['final_loss'], r['total_steps']
-  log('timed region: %d steps in %.3f s' % (args.steps, dt))
-  rank_ms = gdist.gather_floats(r['dt_local'] / args.steps * 1e3, dev)
-
-  comm = comm_report(args, model, runner, dev, world, dt / args.steps * 1e3) if world > 1 else None
-
-  rc = 0
-  if rank == 0:
-    ms_step = dt / args.steps * 1e3
+  def headline(r, form):
+    """The JSON line of one full measurement (every value in it is already on this rank: nothing here talks to another rank)."""
+    ms_step = r['dt'] / args.steps * 1e3
     frames = world * args.batch * args.seq_len
+    info = r['runner'].bucket_info()
     out = {
         'metric': 'train-step frames/sec (256x256 %s, seq_len=%d)' % ('RGB' if args.channels == 3 else 'RGB-D', args.seq_len),
-        'value': round(frames * args.steps / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+        'value': round(frames * args.steps / r['dt'], 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if not shared else 'synthetic (REHEARSAL: ranks share one GPU)',
         'config': {'workload': '%s %s %dx%d seq_len=%d batch=%d/GPU (global %d), fwd+bwd+allreduce+Adam' %
                                (args.model, 'rgb' if args.channels == 3 else 'rgbd', cfg.img_height, cfg.img_width,
                                 args.seq_len, args.batch, world * args.batch),
-                   'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, 'graphs_per_step': runner.bucket_info()['graphs_per_step'], 'params': model.store.count_parameters()},
-        'step_ms': {'median': round(percentile(per_step, 0.5), 4), 'p10': round(percentile(per_step, 0.1), 4),
-                    'p90': round(percentile(per_step, 0.9), 4), 'timer': 'HIP events per step, rank 0'},
-        'final_loss': round(loss, 6),
+                   'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, 'graphs_per_step': info['graphs_per_step'],
+                   'params': model.store.count_parameters()},
+        'step_ms': {'median': round(percentile(r['per_step'], 0.5), 4), 'p10': round(percentile(r['per_step'], 0.1), 4),
+                    'p90': round(percentile(r['per_step'], 0.9), 4), 'timer': 'HIP events per step, rank 0'},
+        'final_loss': round(r['final_loss'], 6),
     }
     if world > 1:
-      out['ranks'] = {'ms_per_step': [round(v, 4) for v in rank_ms], 'devices': details, 'distinct_devices': len(set(idents))}
-    out['loss_check'], ok = check_losses(args, first_loss, loss, total_steps)
+      out['config']['dp_form'] = form
+      out['ranks'] = {'ms_per_step': [round(v, 4) for v in r['rank_ms']], 'devices': details, 'distinct_devices': len(set(idents))}
+    chk, ok = check_losses(args, first_loss, r['final_loss'], r['total_steps'])
+    out['loss_check'] = chk
+    return out, ok
+
+  def emit(out):
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+  # ---- the timed region -----------------------------------------------------------------------------------------------------
+  # N > 1: the ALWAYS-SAFE form first, in full -- three replayed graphs with both all-reduces as ordinary RCCL launches between
+  # them -- and its figure on stderr at once; only then anything that captures RCCL into a graph (see Watchdog).
+  safe_form = 'three_graphs_serial' if args.dp_serial else 'three_graphs'
+  r = timed_steps(model, args.steps, args.warmup, not args.no_graph, world, dev, form=safe_form)
+  first_loss = r['first_loss']
+  form, full, trial, dog, comm = safe_form, {}, {}, None, None
+  log('timed region: %d steps in %.3f s' % (args.steps, r['dt']))
+  if world > 1:
+    from geeco_amd.runtime import pick_dp_runner
+    ms = r['dt'] / args.steps * 1e3
+    full[safe_form] = round(ms, 4)
+    log('N = %d, safe form (%s: exchange launched between three graphs): %.4f ms/step = %.1f frames/s (max over ranks, %d timed steps)'
+        % (world, safe_form, ms, world * args.batch * args.seq_len * args.steps / r['dt'], args.steps))
+
+    def on_watchdog(provisional, phase):
+      if rank == 0 and provisional is not None:
+        provisional['comm'] = {'status': 'WATCHDOG: the forms behind the safe one did not finish (phase: %s); this line is the full '
+                                         'measurement of config.dp_form' % phase, 'forms_timed_in_full_ms': full, 'trial_ms': trial}
+        emit(provisional)
+    dog = Watchdog(args.dp_watchdog_s, on_watchdog)
+    dog.provisional = headline(r, form)[0] if rank == 0 else None
+    if args.dp_watchdog_s > 0:
+      dog.arm()
+    if not (args.dp_fixed or args.dp_serial or args.no_graph):
+      dog.phase = 'trial of the one-graph forms'
+      cand, trial = pick_dp_runner(model, use_graph=True, log=log)
+      best = min(trial, key=trial.get)
+      log('one-graph forms, short trial: %s; fastest %s' % (json.dumps({k: round(v, 4) for k, v in trial.items()}), best))
+      if trial[best] < ms:
+        dog.phase = 'timed region of %s' % best
+        r2 = timed_region(model, cand, args.steps, args.warmup, world, dev)
+        r2['first_loss'] = first_loss
+        # (a form whose capture fell back -- gloo rehearsal -- is the three-graph form under another name: bucket_info says so)
+        full[best] = round(r2['dt'] / args.steps * 1e3, 4)
+        log('N = %d, form %s: %.4f ms/step in full' % (world, best, full[best]))
+        if r2['dt'] < r['dt']:
+          r, form = r2, best
+          if rank == 0:
+            dog.provisional = headline(r, form)[0]
+      del cand
+  runner, dt, per_step = r['runner'], r['dt'], r['per_step']
+  loss, total_steps = r['final_loss'], r['total_steps']
+  if world > 1 and not args.skip_comm_report:
+    dog.phase = 'comm report'
+    comm = comm_report(args, model, runner, dev, world, dt / args.steps * 1e3)
+  if dog is not None:
+    dog.disarm()
+
+  rc = 0
+  if rank == 0:
+    ms_step = dt / args.steps * 1e3
+    out, ok = headline(r, form)
     if not ok:
       rc = 4
-    if comm:
-      comm['picked_before_the_warmup'] = {'ms_per_step': {k: round(v, 4) for k, v in r['dp_trial_ms'].items()},
-                                          'note': 'short untimed trial of each form (max over ranks); the timed region runs the fastest'} \
-          if r['dp_trial_ms'] else None
+    if world > 1:
+      comm = comm or {'status': 'skipped'}
+      comm['timed_form'] = form
+      comm['forms_timed_in_full_ms'] = full
+      comm['trial_ms'] = {k: round(v, 4) for k, v in trial.items()} or None
+      comm['order'] = ('safe form (%s) in full -> short trial of the one-graph forms -> the fastest of them in full if the trial '
+                       'beats the safe form -> value = the faster full measurement -> comm report' % safe_form)
       comm['rccl'] = rccl_info(rccl_log)
       out['comm'] = comm
     if not args.skip_layers:      # rank 0's GPU alone, after the timed region (any N: the per-GPU work is the same)
@@ -1022,8 +1129,7 @@ def main():
         shutil.rmtree(workdir, ignore_errors=True)
     if world == 1 and not args.skip_cpu:
       out['cpu_baseline'] = cpu_baseline(args)
-    sys.stdout.flush()
-    os.write(json_fd, (json.dumps(out) + '\n').encode())
+    emit(out)
   # N > 1: ranks 1..N-1 have nothing to do after the timed region and the comm report; they wait here ON THE HOST (no
   # collective pending, GPUs idle) until rank 0 has finished its tables and printed the line, then all ranks leave together
   gdist.host_rendezvous('bench_done')

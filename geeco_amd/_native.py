@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, _dev.env('GEECO_LIB', 'libgeeco_hip.so'))   # GEE
 
 
 GEECO_EINVAL, GEECO_ENOSUP = -1, -2      # include/geeco_hip.h
-ABI_VERSION = 5        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
+ABI_VERSION = 6        # GEECO_ABI_VERSION of include/geeco_hip.h this binding was written against
 
 
 class GeecoNativeError(RuntimeError):
@@ -60,6 +60,8 @@ SIGNATURES = {
     'geeco_goal_dynimgs_ws_bytes': (_L, [_I, _L]),
     'geeco_goal_dynimgs_fwd': (_I, [_P, _L, _L, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
     'geeco_goal_dynimgs_u8_fwd': (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P]),
+    'geeco_goal_dynimgs_timeouts': (_I, [_P, _I, _P, _P]),
+    'geeco_goal_dynimgs_set_wait_polls': (ctypes.c_uint, [ctypes.c_uint]),
     'geeco_dynimg_rgbd_fwd': (_I, [_P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _L, _P, _P, _P]),
     'geeco_pack_pixels': (_I, [_P, _L, _P, _L, _I, _L, _I, _I, _I, _P, _P]),
     'geeco_gather_windows': (_I, [_P, _I, _P, _I, _I, _L, _F, _P, _P]),

@@ -7,6 +7,7 @@
 // Algorithmic bytes: N*K*HW*C*4 read + N*HW*Cpad*4 written (+ one extra read/write of D).
 #include "geeco_common.h"
 #include <stdlib.h>
+#include <vector>
 
 #define DYN_MAXK 64
 
@@ -150,7 +151,22 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
 //     no L2 write-back / invalidate is needed; critical path = one store, one atomic, one load latency;
 //   * a block waits only for the OTHER BLOCKS OF ITS SAMPLE (not a grid barrier): they run the same K-frame pass and arrive
 //     together; blocks of a sample have consecutive indices and workgroups start in index order, so every sample ahead of a
-//     partially started one is complete or fully resident: the wait cannot deadlock however many blocks fit on the chip;
+//     partially started one is complete or fully resident: the wait cannot deadlock however many blocks fit on the chip.
+//     In-order start of workgroups is how the dispatcher of every CDNA part behaves, NOT a documented guarantee (CU masking, a
+//     partitioned device or a co-resident persistent kernel could starve a sample's last blocks).  So the wait is BOUNDED
+//     (g_wait_polls polls, seconds) and an expired wait is LOUD: the block counts itself into the sample's sticky `timeouts`
+//     word and normalises with NaN -- the images of that sample, the loss and every gradient behind them are NaN, and
+//     geeco_goal_dynimgs_timeouts() (which the host calls wherever it synchronises anyway) reports the count.  Nothing ever
+//     continues on stale min / max.  A workspace that has seen a timeout stays poisoned (its counters are no longer zero
+//     between calls) until the caller zero-fills it again;
+//   * ordering of the hand-off, at the hardware level (the C++ model has no word for "write-through store"): the slot stores
+//     and the counter add are agent-scope atomics = sc1 accesses that complete at the memory side, past the non-coherent
+//     per-XCD L2s; the producer drains its slot stores (s_waitcnt vmcnt(0)) BEFORE it issues the add, the consumer issues its
+//     slot loads AFTER the poll that saw the full count has returned (a workgroup-scope acquire fence: no cache maintenance,
+//     but neither the compiler nor the wave may move the slot loads above it), and every lane of the polling wave takes the
+//     count from lane 0 through readfirstlane, so "behind the poll" holds for all 64 lanes by data dependence, not by
+//     reconvergence.  Agent-scope release / acquire instead (buffer_wbl2 / buffer_inv sc1 per block) would write back and
+//     invalidate an XCD's whole L2 for four floats that never live in it;
 //   * the LAST block of a sample to leave zeroes the sample's two counters again: every call finds and leaves them zero (the
 //     slots need no reset: every block rewrites its own before it counts itself in).
 // The arithmetic per pixel is that of dynimg_wsum3_kernel + dynimg_norm_kernel (same sums in the same order, (D - min) / range
@@ -158,8 +174,28 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 struct DynCtl {           // per sample: the two counters, on a 64-byte line of their own; zero between calls.  Behind the N
   unsigned arrive, depart;      // control blocks: N x bps slots of {min, max of the buffer image, min, max of the pair image}
-  unsigned pad[14];
+  unsigned timeouts;            // sticky: blocks of this sample whose wait expired (never reset by the kernels)
+  unsigned pad[13];
 };
+
+// polls of the sample counter before a block gives up (s_sleep 4 + one sc1 load each: 2^22 polls are seconds; the blocks of a
+// sample arrive within microseconds of each other).  geeco_goal_dynimgs_set_wait_polls: tests set 0, so that every block that is
+// not the last of its sample to arrive reports a timeout.
+static unsigned g_wait_polls = 1u << 22;
+
+// the wait itself: lane 0 polls, every lane of the wave gets the final count
+__device__ __forceinline__ unsigned dyn_wait_for_sample(DynCtl* c, unsigned got, unsigned bps, unsigned polls, bool lane0) {
+  if (lane0) {
+    for (unsigned spin = 0; got < bps && spin < polls; ++spin) {
+      __builtin_amdgcn_s_sleep(4);
+      got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (got < bps) __hip_atomic_fetch_add(&c->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  got = __builtin_amdgcn_readfirstlane(got);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return got;
+}
 
 // a wave-uniform address as such (two SGPRs): loads from it + a 32-bit per-lane offset take the scalar-base form and need one VGPR
 // of address instead of a 64-bit pair per load (which the compiler precomputes per frame of the unrolled ring and spills)
@@ -170,7 +206,7 @@ __device__ __forceinline__ const char* dyn_uniform(const void* q) {
 }
 
 template <bool DEPTH, bool U8, int THREADS, int UPT>
-__global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynParams p, DynCtl* ctl, int bps) {
+__global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynParams p, DynCtl* ctl, int bps, unsigned polls) {
   constexpr int NW = THREADS / 64;
   const int n = blockIdx.x / bps, b = blockIdx.x - n * bps;
   const int tid = threadIdx.x;
@@ -351,6 +387,7 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynP
     DynCtl* c = ctl + n;
     f32x4* slots = reinterpret_cast<f32x4*>(ctl + p.N) + (long long)n * bps;
     const int lane = tid;
+    unsigned got = 0;
     if (lane == 0) {
       for (int i = 1; i < NW; ++i) {
         mn1 = fminf(mn1, red[i][0]); mx1 = fmaxf(mx1, red[i][1]);
@@ -362,15 +399,10 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynP
       __hip_atomic_store(sp + 2, mn2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sp + 3, mx2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned got = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      // the other blocks of this sample run the same pass over the same number of frames: they are at most a few us behind.
-      // The spin is bounded (~0.5 s): a sample whose blocks never all arrive would be a launch-geometry bug, not something to hang on.
-      for (unsigned spin = 0; got < (unsigned)bps && spin < (1u << 22); ++spin) {
-        __builtin_amdgcn_s_sleep(4);
-        got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      got = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     }
-    // (wave 0 reconverges here: the other lanes waited for lane 0's poll at the end of the divergent region)
+    // the other blocks of this sample run the same pass over the same number of frames: they are at most a few us behind
+    const bool expired = dyn_wait_for_sample(c, got, (unsigned)bps, polls, lane == 0) < (unsigned)bps;
     f32x4 q = {INFINITY, -INFINITY, INFINITY, -INFINITY};
     for (int i = lane; i < bps; i += 64) {
       const float* sp = reinterpret_cast<const float*>(slots + i);
@@ -382,8 +414,8 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynP
     }
     const float a1 = wave_reduce_min(q.x), b1 = wave_reduce_max(q.y), a2 = wave_reduce_min(q.z), b2 = wave_reduce_max(q.w);
     if (lane == 0) {
-      s_norm[0] = a1; s_norm[1] = b1 - a1 + 1e-6f;      // graph.py:49
-      s_norm[2] = a2; s_norm[3] = b2 - a2 + 1e-6f;
+      s_norm[0] = a1; s_norm[1] = expired ? NAN : b1 - a1 + 1e-6f;      // graph.py:49 (expired wait: NaN images, never stale ones)
+      s_norm[2] = a2; s_norm[3] = expired ? NAN : b2 - a2 + 1e-6f;
       // leave: the last block out zeroes the two counters for the next call (every block has read the slots by then)
       if (__hip_atomic_fetch_add(&c->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)bps - 1u) {
         __hip_atomic_exchange(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -434,7 +466,7 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynP
 // rides beside the second half of the loads.  One unit (4 pixels) per thread and sample; everything else as above.
 // ------------------------------------------------------------------------------------------------------------------
 template <bool DEPTH, bool U8, int THREADS>
-__global__ __launch_bounds__(THREADS) void dynimg_goal_onepass2_kernel(const DynParams p, DynCtl* ctl, int bps, int half) {
+__global__ __launch_bounds__(THREADS) void dynimg_goal_onepass2_kernel(const DynParams p, DynCtl* ctl, int bps, int half, unsigned polls) {
   constexpr int NW = THREADS / 64;
   const int pi = blockIdx.x / bps, b = blockIdx.x - pi * bps;
   const int tid = threadIdx.x, wid = tid >> 6;
@@ -590,13 +622,9 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass2_kernel(const Dyn
     if (wid == 0) {
       DynCtl* c = ctl + n;
       const f32x4* slots = reinterpret_cast<const f32x4*>(ctl + p.N) + (long long)n * bps;
-      if (tid == 0) {
-        unsigned got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (unsigned spin = 0; got < (unsigned)bps && spin < (1u << 22); ++spin) {      // bounded (~0.5 s), see above
-          __builtin_amdgcn_s_sleep(4);
-          got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      unsigned got = 0;
+      if (tid == 0) got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool expired = dyn_wait_for_sample(c, got, (unsigned)bps, polls, tid == 0) < (unsigned)bps;
       f32x4 q = {INFINITY, -INFINITY, INFINITY, -INFINITY};
       for (int i = tid; i < bps; i += 64) {
         const float* sp = reinterpret_cast<const float*>(slots + i);
@@ -608,8 +636,8 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass2_kernel(const Dyn
       }
       const float a1 = wave_reduce_min(q.x), b1 = wave_reduce_max(q.y), a2 = wave_reduce_min(q.z), b2 = wave_reduce_max(q.w);
       if (tid == 0) {
-        s_norm[0] = a1; s_norm[1] = b1 - a1 + 1e-6f;      // graph.py:49
-        s_norm[2] = a2; s_norm[3] = b2 - a2 + 1e-6f;
+        s_norm[0] = a1; s_norm[1] = expired ? NAN : b1 - a1 + 1e-6f;      // graph.py:49 (expired wait: NaN images, never stale ones)
+        s_norm[2] = a2; s_norm[3] = expired ? NAN : b2 - a2 + 1e-6f;
         if (__hip_atomic_fetch_add(&c->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)bps - 1u) {
           __hip_atomic_exchange(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_exchange(&c->depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -844,6 +872,35 @@ extern "C" int64_t geeco_goal_dynimgs_ws_bytes(int N, int64_t HW) {
   return (int64_t)N * ((int64_t)sizeof(DynCtl) + cdiv64(HW >> 2, 256) * 16);      // counters + the most slots a sample can have
 }
 
+// Blocks whose wait for the other blocks of their sample has EVER expired on this workspace, summed over the N samples (sticky
+// until the caller zero-fills ws again; such samples' images are NaN, see above).  0 = every image that came out of this
+// workspace was normalised with its sample's true min / max.  Copies N x 64 bytes to the host and SYNCHRONISES the stream: for
+// the places where the host waits for the device anyway (loss read-out, end of an epoch), not for the step.
+extern "C" int geeco_goal_dynimgs_timeouts(const void* ws, int N, void* stream, int64_t* count_host) {
+  GEECO_CHECK_ARG(ws && count_host && N >= 1, "goal_dynimgs_timeouts: null pointer / N=%d", N);
+  std::vector<DynCtl> host((size_t)N);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(host.data(), ws, (size_t)N * sizeof(DynCtl), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    geeco_set_error("goal_dynimgs_timeouts: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  int64_t n = 0;
+  for (const DynCtl& c : host) n += c.timeouts;
+  *count_host = n;
+  return 0;
+}
+
+// Polls a block spends waiting for its sample's blocks before it reports a timeout (process-wide; default 2^22, i.e. seconds).
+// Returns the previous value.  0 makes every block that is not the last of its sample to arrive report at once: how the tests
+// provoke the error path deterministically.
+extern "C" unsigned geeco_goal_dynimgs_set_wait_polls(unsigned polls) {
+  const unsigned old = g_wait_polls;
+  g_wait_polls = polls;
+  return old;
+}
+
 template <bool DEPTH, bool U8>
 static void goal_onepass_dispatch(const DynParams& p, DynCtl* ctl, hipStream_t s) {
   const long long U = p.HW >> 2;
@@ -856,17 +913,17 @@ static void goal_onepass_dispatch(const DynParams& p, DynCtl* ctl, hipStream_t s
       // 105.7-108.0 us against 110.9-114.7 for one sample per block)
       const int half = (p.N + 1) / 2, bps2 = (int)cdiv64(U, 1024);
       geeco_note_kernel("dynimg_goal_onepass2_kernel<%s, %s, 1024>", DEPTH ? "true" : "false", U8 ? "true" : "false");
-      hipLaunchKernelGGL((dynimg_goal_onepass2_kernel<DEPTH, U8, 1024>), dim3((unsigned)(half * bps2)), dim3(1024), 0, s, p, ctl, bps2, half);
+      hipLaunchKernelGGL((dynimg_goal_onepass2_kernel<DEPTH, U8, 1024>), dim3((unsigned)(half * bps2)), dim3(1024), 0, s, p, ctl, bps2, half, g_wait_polls);
     } else {
       // uint8 frames: a quarter of the bytes and twelve conversions per pixel: the load phase is short and the one-sample form
       // with two units per thread keeps more of it in flight (58.6 us alone against 63.8)
       geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 1024, 2>", DEPTH ? "true" : "false", U8 ? "true" : "false");
-      hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 1024, 2>), dim3((unsigned)(p.N * bps_big)), dim3(1024), 0, s, p, ctl, (int)bps_big);
+      hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 1024, 2>), dim3((unsigned)(p.N * bps_big)), dim3(1024), 0, s, p, ctl, (int)bps_big, g_wait_polls);
     }
   } else {
     const long long bps = cdiv64(U, 256);
     geeco_note_kernel("dynimg_goal_onepass_kernel<%s, %s, 256, 1>", DEPTH ? "true" : "false", U8 ? "true" : "false");
-    hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 256, 1>), dim3((unsigned)(p.N * bps)), dim3(256), 0, s, p, ctl, (int)bps);
+    hipLaunchKernelGGL((dynimg_goal_onepass_kernel<DEPTH, U8, 256, 1>), dim3((unsigned)(p.N * bps)), dim3(256), 0, s, p, ctl, (int)bps, g_wait_polls);
   }
 }
 

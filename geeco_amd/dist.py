@@ -13,6 +13,11 @@ import os
 # The host driver of this pool only supports dmabuf IPC: without this RCCL / cross-process device memory fails with
 # `hipIpcGetMemHandle: invalid argument`.  Already exported on the GPU boxes; kept here for any other launcher.
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# Collectives captured into a hipGraph (runtime.DP_FORMS 'overlap' / 'serial' / 'overlap_reserve*'): no user-buffer registration at
+# capture time.  With registration on, a rank that REPLAYS its captured all-reduce and a rank that issues the same all-reduce
+# eagerly (ragged end of an epoch: a new-batch-size runner in its warm-up steps, null_step) would hand the communicator
+# differently registered buffers for one collective.  Read by RCCL when the communicator is created; the caller's own value wins.
+os.environ.setdefault('NCCL_GRAPH_REGISTER', '0')
 
 import torch
 import torch.distributed as dist

@@ -26,7 +26,7 @@ import torch
 
 from . import dist as gdist
 from . import graph
-from .runtime import EvalStepRunner, TrainStepRunner
+from .runtime import EvalStepRunner, TrainStepRunner, dp_form_kwargs
 
 
 class ModeKeys:
@@ -53,7 +53,7 @@ class RunConfig:
   """tf.estimator.RunConfig(session_config, save_checkpoints_steps, keep_checkpoint_max) (train_e2evmc.py:221-224)."""
 
   def __init__(self, session_config=None, save_checkpoints_steps=None, keep_checkpoint_max=5, device=None,
-               use_hipgraph=True, init_seed=0, save_tf_bundle=False):
+               use_hipgraph=True, init_seed=0, save_tf_bundle=False, dp_form=None):
     self.session_config = session_config or ConfigProto()
     self.save_checkpoints_steps = save_checkpoints_steps
     self.keep_checkpoint_max = keep_checkpoint_max
@@ -64,6 +64,11 @@ class RunConfig:
     # reference's variable names, Adam slots and global_step): what tf.train.Saver consumers such as the reference's
     # predictor (predictor.py:85-95) and _export_snapshot (train_e2evmc.py:160-181) expect to find
     self.save_tf_bundle = save_tf_bundle
+    # data parallel only: the form of the step (runtime.DP_FORMS).  None = 'three_graphs' -- every
+    # collective an ordinary RCCL launch between three replayed graphs, safe with ragged epochs by construction.  'overlap'
+    # (the whole step incl. both all-reduces as ONE hipGraph), 'overlap_reserve16/32', 'serial', 'three_graphs_serial' are
+    # opt-in: take the one bench.py reports as fastest on the node at hand (comm.step_ms / comm.timed_form of an N > 1 run)
+    self.dp_form = dp_form
 
 
 EstimatorSpec = collections.namedtuple(
@@ -151,6 +156,7 @@ class _SummarySaverHook:
   def after_run(self, step, model_dir):
     if step % self.every or gdist.rank() != 0:
       return
+    self.model.check_device_errors()        # (the loss read-out below waits for the device anyway)
     parts = {k: float(v) for k, v in self.model.loss_parts().items()}
     parts['global_step'] = step
     parts['wall_time'] = time.time()
@@ -207,7 +213,7 @@ def _model_fn(features, labels, mode, params, goal):
     raise ValueError("features['step'] must be int64")
   print('>>> Graph Summary (%d trainable parameters):' % (model.store.count_parameters(),))
   if mode == ModeKeys.TRAIN:
-    runner = TrainStepRunner(model, use_graph=params.get('use_hipgraph', True))
+    runner = TrainStepRunner(model, use_graph=params.get('use_hipgraph', True), **dp_form_kwargs(params.get('dp_form')))
     hooks = [_SummarySaverHook(model, params.get('log_steps', 1000))]
     return EstimatorSpec(mode=mode, loss=model.loss, train_op=runner.step, training_hooks=hooks, model=model)
   runner = EvalStepRunner(model, use_graph=params.get('use_hipgraph', True))
@@ -358,6 +364,7 @@ class Estimator:
     params = dict(self.params)
     params['_variable_store'] = self._store
     params.setdefault('use_hipgraph', self.config.use_hipgraph)
+    params.setdefault('dp_form', getattr(self.config, 'dp_form', None))
     spec = self._model_fn(fbuf, lbuf, mode, params)
     spec.model.decoder.loss_scale = float(loss_scale)
     if self._store is None:
@@ -461,6 +468,8 @@ class Estimator:
       source.close()      # an epoch left early must not leave reader threads filling a queue nobody drains
     if nsteps and torch.cuda.is_available():
       torch.cuda.synchronize()
+      for sp, _, _ in self._specs.values():      # a device-side error of any model that ran this epoch (input-stage timeout)
+        sp.model.check_device_errors()
     # wall time of the input + step loop alone (the checkpoint written below is not part of the data path)
     self.last_train_stats = {'steps': nsteps, 'loop_seconds': time.time() - t0}
     if nsteps and rank == 0 and self.model_dir:
@@ -507,6 +516,8 @@ class Estimator:
     if world > 1:
       torch.distributed.all_reduce(vec)
     vec = vec.double().cpu()
+    for sp, _, _ in self._specs.values():
+      sp.model.check_device_errors()
     if float(vec[1]) == 0.0:
       raise RuntimeError('evaluate(): input_fn produced no batches on any rank')
     out = {'loss': float(vec[0] / vec[1])}

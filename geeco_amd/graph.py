@@ -716,6 +716,13 @@ class _ModelBase:
     return self.enc.redirect_late_gradients(staging, late_ranges)
 
   # -- optimiser step (estimator.py:243-244) -------------------------------------------------
+  def _begin_step(self, backward_too):
+    """A training forward opens a new optimiser step: a ``_prepared`` left over from a step whose apply_gradients never came
+    (an exception between the parts, a one-graph capture that failed after recording part 2, a caller that ran the backward
+    alone to look at gradients) must not make THIS step's apply_gradients skip its adam_prepare."""
+    if backward_too:
+      self._prepared = False
+
   def _prepare_args(self, adam_prepare):
     """backward(adam_prepare=True): the step counter / lr_t update rides in the backward's last slab-sum launch (one dependent
     launch less); apply_gradients() then skips its own adam_prepare.  Only callers that DO apply the gradients next pass it
@@ -767,6 +774,14 @@ class _ModelBase:
       out[key] = p[:, off:off + size]
       off += size
     return out
+
+  def check_device_errors(self):
+    """Raises if a kernel of this model reported an error on the device (today: a block of the one-pass input stage that gave up
+    waiting, csrc/dynimg.hip).  SYNCHRONISES the stream: called where the host reads results anyway (Estimator's loss
+    read-outs and epoch ends, bench.py's loss check, ``endpoints``), never inside the step."""
+    ws = getattr(self, 'dyn_ws2', None)
+    if ws is not None and getattr(self, 'mode', None) == 'dynimg':
+      ops.check_input_stage(ws, self.N)
 
   def _finish_forward(self):
     if self.cfg.l2_regularizer > 0.0:    # loss_reg = l2 * sum(v^2)/2 over every variable (graph.py:13-15, estimator.py:66,202)
@@ -846,6 +861,7 @@ class GoalE2EVMC(_ModelBase):
       ops.state_concat_fwd_into(d.states[0], [feats[0], feats[1], feats[2]], ch, 2, jnt, K * jn, jn, N, _CELLS, d.D)
 
   def forward(self, backward_too=False):
+    self._begin_step(backward_too)
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
     HW = H * W
     x_in = self.enc.x_in
@@ -958,6 +974,7 @@ class GoalE2EVMC(_ModelBase):
   def endpoints(self):
     """dynbuff / dyndiff debug endpoints (graph.py:377,393,401): the LAST computed images."""
     C, K, N = self.C, self.K, self.N
+    self.check_device_errors()
     ep = {'conv8': self.enc.features}
     if self.mode == 'dynimg':
       ep['dynbuff'] = self.enc.x_in[1][..., :C]
@@ -980,6 +997,7 @@ class E2EVMC(_ModelBase):
     self._bind_labels()
 
   def forward(self, backward_too=False):
+    self._begin_step(backward_too)
     N, K, H, W, C = self.N, self.K, self.H, self.W, self.C
     HW = H * W
     x_in = self.enc.x_in[0].view(K, N, H, W, 4)

@@ -691,7 +691,7 @@ class _EpisodeSource:
           entry = self.cache.get(key)
         if entry is None:
           if not self._reads:     # the reader keeps one mapped inflate buffer (~105 MB) per thread + 1 between episodes
-            tfrecord._host().geeco_host_set_buffer_limit(self.num_threads + 1)
+            _buffer_limit(self, self.num_threads + 1)
           self._reads += 1
         pending.append((path, key, entry if entry is not None else self._pool.submit(self._read, path)))
         return
@@ -717,18 +717,44 @@ class _EpisodeSource:
         yield states, dev
     finally:
       for _, _, item in pending:
-        if not isinstance(item, tuple):
-          item.cancel()
+        if not isinstance(item, tuple) and not item.cancel():
+          item.add_done_callback(_return_staging)      # a read already running: nobody will take its result
       # reads already running finish (they cannot be interrupted inside the native reader).  An epoch that read NOTHING (every
       # episode came out of the HBM cache) hands the reader's spare inflate buffers back to the OS: no reader will run again, and
       # under data parallelism every rank would otherwise hold its own pool (up to num_threads + 1 buffers of ~105 MB) for the
       # rest of training.  An epoch that did read keeps them for the next one (sixteen threads faulting fresh 105 MB mappings in
       # at once cost epoch 1 of the bench 0.13 s when the pool was emptied after every epoch).
-      self._pool.shutdown(wait=True)
+      # (not waited for: an epoch left early -- Estimator.train(steps=...), an exception in the step -- returns at once)
+      self._pool.shutdown(wait=False)
+      _buffer_limit(self, None)
       if not self._reads:
         # off this thread: unmapping up to num_threads + 1 touched 105 MB buffers takes ~0.15 s (measured: the first fully cached
         # epoch of the bench ran 0.68 s instead of 0.53 s with the release inline); nothing waits for it
         threading.Thread(target=tfrecord._host().geeco_host_release_buffers, name='geeco-release', daemon=True).start()
+
+
+def _return_staging(fut):
+  """Done-callback of a read whose result nobody takes (the epoch was left early): its pinned staging blocks go back."""
+  if fut.cancelled() or fut.exception() is not None:
+    return
+  for t in fut.result()[1]:
+    _PINNED.give(t)
+
+
+_LIMITS, _LIMITS_LOCK = {}, threading.Lock()
+
+
+def _buffer_limit(source, n):
+  """The native reader's spare-buffer limit is ONE number per process (geeco_host_set_buffer_limit): with several sources alive
+  (a train and an eval pipeline with different thread counts) it is the MAX of what they asked for; ``n`` None = the source is done
+  (the limit stays where it is while no source reads, so the next epoch finds the buffers of this one)."""
+  with _LIMITS_LOCK:
+    if n is None:
+      _LIMITS.pop(id(source), None)
+    else:
+      _LIMITS[id(source)] = int(n)
+    if _LIMITS:
+      tfrecord._host().geeco_host_set_buffer_limit(max(_LIMITS.values()))
 
 
 def usable_host_cores():
@@ -745,11 +771,16 @@ def usable_host_cores():
 
 
 def default_reader_threads(world=1):
-  """``num_threads=None``: this rank's share of the host, usable cores // ranks on the node, within 4 (the reference's default,
+  """``num_threads=None``: this rank's share of the host, usable cores // ranks ON THIS NODE (LOCAL_WORLD_SIZE as torchrun exports
+  it; ``world`` -- the global size -- only where that is absent, i.e. one node), within 4 (the reference's default,
   train_e2evmc.py:67) ... 32.  Reading an episode is 97 % inflate and scales with threads up to the cores a rank owns
   (profiles/r05/reader_scaling.json): one rank's GPU consumes ~119 episodes/s, one reader thread delivers ~9, so epoch 1 (before
   the HBM episode cache serves everything) is reader-bound below ~13 cores per rank."""
-  return max(4, min(32, usable_host_cores() // max(int(world), 1)))
+  try:
+    local = int(os.environ.get('LOCAL_WORLD_SIZE', '') or world)
+  except ValueError:
+    local = world
+  return max(4, min(32, usable_host_cores() // max(min(int(local), max(int(world), 1)), 1)))
 
 
 def pickplace_input_fn(dataset_dir, split_name, mode, encoding='v4', window_size=4, fetch_target=False,

@@ -117,6 +117,24 @@ def goal_dynimgs_u8_into(cur_out, buf_out, diff_out, win_ptrs, tgt_ptrs, K, N, H
                                          _p(diff_out), _p(ws), _stream()), 'geeco_goal_dynimgs_u8_fwd')
 
 
+def goal_dynimgs_timeouts(ws, N) -> int:
+  """Blocks of the one-pass input stage whose wait for their sample's blocks EVER expired on this workspace (their images are
+  NaN).  Synchronises the current stream: for the places where the host reads the loss anyway."""
+  n = ctypes.c_int64(-1)
+  check(_lib().geeco_goal_dynimgs_timeouts(_p(ws), N, _stream(), ctypes.cast(ctypes.byref(n), ctypes.c_void_p)), 'geeco_goal_dynimgs_timeouts')
+  return int(n.value)
+
+
+def check_input_stage(ws, N):
+  """Raises when the one-pass input stage reported a timeout on ``ws`` (include/geeco_hip.h: geeco_goal_dynimgs_timeouts)."""
+  n = goal_dynimgs_timeouts(ws, N)
+  if n:
+    raise RuntimeError('geeco_amd: %d block(s) of the one-pass input stage gave up waiting for the other blocks of their sample '
+                       '(the device did not start the blocks of a launch in index order: CU masking, a partitioned device, a '
+                       'co-resident persistent kernel?).  The images of those samples were written as NaN, and so were the loss '
+                       'and the gradients of those steps; zero-fill the workspace (ops.goal_dynimgs_ws) before using it again.' % n)
+
+
 def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:
   """frames [N,K,H,W,C] contiguous -> [N,H,W,Cpad]."""
   N, K, H, W, C = frames.shape

@@ -73,12 +73,14 @@ class TrainStepRunner:
     whole data-parallel step -- the three parts AND both all-reduces, the early one as a branch beside part 2 -- into ONE
     hipGraph (RCCL's launches are stream work like any other; the fork to the communicator's stream and the joins become
     graph edges): one graph launch per step instead of three and no host-side stream joins (measured at one rank, bench.py
-    ``dp_one_rank``: +28 us over the single-GPU step instead of +87).  ``overlap`` / ``skip_allreduce`` are then fixed at
-    capture time.  None (default) = whenever the backend's launches can be captured (RCCL); if that capture fails the runner
-    says so once and captures the three-graph form.  False = three graphs with the exchange launched between them."""
+    ``dp_one_rank``: +18 us over the single-GPU step instead of +71).  ``overlap`` / ``skip_allreduce`` are then fixed at
+    capture time; if that capture fails on ANY rank every rank says so once and captures the three-graph form (``_capture``).
+    None / False (default) = three graphs with the exchange launched eagerly between them: the form that is safe by
+    construction (every collective is an ordinary RCCL launch, so a rank that replays and a rank that runs eagerly -- ragged
+    end of an epoch, ``null_step`` -- issue the same kind of call on the communicator).  The one-graph form has only ever run
+    with ONE rank on hardware (no multi-GPU box was available to any round), so it is opt-in: ``dp_form`` of RunConfig /
+    ``--dp_form`` of scripts/train_e2evmc.py, and bench.py, which times the safe form first and the captured forms behind it."""
     self.model = model
-    if capture_exchange is None:
-      capture_exchange = gdist.group_active() and gdist.backend() == 'nccl'
     self.capture_exchange = bool(capture_exchange)
     self.reserved_cus = int(reserved_cus)
     self.world = gdist.world_size()
@@ -232,15 +234,33 @@ class TrainStepRunner:
           graphs.append(g.replay)
       return graphs
     if self.dp and self.capture_exchange:
+      # A capture records and executes nothing, so a failed one has moved no byte and advanced no counter; what it can leave
+      # behind is (a) the stream still in capture mode, (b) python-side flags set while recording (model._prepared: reset by
+      # the next forward(backward_too=True)), (c) on ONE rank only, a different form than its peers.  Hence: only the errors a
+      # capture-unsupported collective raises (RuntimeError: torch's HIP / c10d errors) are handled, the stream must be out of
+      # capture mode and idle afterwards, and the ranks AGREE on the form (MAX of "mine failed": itself a collective, which
+      # doubles as the check that the communicator still works) before anyone captures three graphs.  Anything else propagates
+      # and the process exits non-zero; a process that touched the GPU is never restarted.
+      err, graphs = None, None
       try:
-        self._graphs = capture(self._parts())
+        graphs = capture(self._parts())
+      except RuntimeError as e:
+        err = e
+      if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('TrainStepRunner: the stream is still capturing after a failed one-graph capture') from err
+      torch.cuda.synchronize()
+      failed = gdist.max_over_ranks(0.0 if err is None else 1.0, self.model.store.params.device) > 0.0
+      if not failed:
+        self._graphs = graphs
         return
-      except Exception as e:           # a backend whose collectives cannot be captured: the three-graph form always can
-        import warnings
-        warnings.warn('TrainStepRunner: capturing the exchange into the step graph failed (%s: %s); using three graphs '
-                      'with the exchange between them' % (type(e).__name__, str(e)[:200]))
-        self.capture_exchange = False
-        torch.cuda.synchronize()
+      import warnings
+      warnings.warn('TrainStepRunner: capturing the exchange into the step graph failed on %s (%s); every rank uses three '
+                    'graphs with the exchange between them' %
+                    ('this rank' if err is not None else 'another rank',
+                     'no error here' if err is None else '%s: %s' % (type(err).__name__, str(err)[:200])))
+      del graphs
+      self.capture_exchange = False
+      self.model._prepared = False
     self._graphs = capture(self._parts())
 
   def prepare(self):
@@ -277,16 +297,30 @@ class TrainStepRunner:
     self._part3()
 
 
-DP_CANDIDATES = (      # name, TrainStepRunner arguments
-    ('overlap', dict(overlap=True)),                               # early bucket beside part 2, every CU to the compute kernels
-    ('overlap_reserve16', dict(overlap=True, reserved_cus=16)),    # ... part 2's two persistent kernels leave 16 CUs to RCCL
-    ('overlap_reserve32', dict(overlap=True, reserved_cus=32)),    # ... or 32 (RCCL's channel count decides; bench.py reports it)
-    ('serial', dict(overlap=False)),                               # both buckets behind part 2
-)
+# Every form of the data-parallel step by name (RunConfig.dp_form, --dp_form, bench.py's comm.step_ms keys).
+DP_FORMS = {
+    'three_graphs': dict(overlap=True, capture_exchange=False),          # DEFAULT: exchange launched eagerly between three graphs
+    'three_graphs_serial': dict(overlap=False, capture_exchange=False),  # ... both buckets behind part 2
+    'overlap': dict(overlap=True, capture_exchange=True),                # ONE graph, early bucket beside part 2, every CU to compute
+    'overlap_reserve16': dict(overlap=True, capture_exchange=True, reserved_cus=16),   # ... part 2's persistent kernels leave 16 CUs to RCCL
+    'overlap_reserve32': dict(overlap=True, capture_exchange=True, reserved_cus=32),   # ... or 32 (RCCL's channel count decides)
+    'serial': dict(overlap=False, capture_exchange=True),                # ONE graph, both buckets behind part 2
+}
+DP_FORM_DEFAULT = 'three_graphs'
+DP_CANDIDATES = tuple((k, DP_FORMS[k]) for k in ('overlap', 'overlap_reserve16', 'overlap_reserve32', 'serial'))   # bench.py's trial
 
 
-def pick_dp_runner(model, use_graph=True, steps=8, candidates=DP_CANDIDATES, capture_exchange=None, log=None):
-  """N > 1: which form of the exchange is fastest ON THIS NODE is not knowable in advance -- the early bucket runs beside two
+def dp_form_kwargs(name=None):
+  """TrainStepRunner arguments of a named form.  None = the safe default (the product reads no switch from the environment)."""
+  name = name or DP_FORM_DEFAULT
+  if name not in DP_FORMS:
+    raise ValueError("unknown dp_form '%s' (one of %s)" % (name, ', '.join(DP_FORMS)))
+  return dict(DP_FORMS[name])
+
+
+def pick_dp_runner(model, use_graph=True, steps=8, candidates=DP_CANDIDATES, log=None):
+  """NB every candidate runs ~13 REAL optimiser steps on the model's live parameters (fine for bench.py's repeated batch;
+  anything that cares about its trajectory passes ``dp_form`` instead).  N > 1: which form of the exchange is fastest ON THIS NODE is not knowable in advance -- the early bucket runs beside two
   persistent one-block-per-CU kernels (0.83 ms), and whether RCCL's workgroups slow those blocks down by more than the
   collective hides depends on the link topology and RCCL's channel count.  So measure: every candidate captures its graph(s)
   and runs ``steps`` real optimiser steps between barriers; the time is the MAX over ranks (identical on every rank, so all
@@ -296,11 +330,11 @@ def pick_dp_runner(model, use_graph=True, steps=8, candidates=DP_CANDIDATES, cap
   world = gdist.world_size()
   if world == 1 or len(candidates) == 1:
     name, kw = candidates[0]
-    return TrainStepRunner(model, use_graph=use_graph, warmup=2, capture_exchange=capture_exchange, **kw), {}
+    return TrainStepRunner(model, use_graph=use_graph, warmup=2, **kw), {}
   dev = model.store.params.device
   timings, runners = {}, {}
   for name, kw in candidates:
-    r = TrainStepRunner(model, use_graph=use_graph, warmup=2, capture_exchange=capture_exchange, **kw)
+    r = TrainStepRunner(model, use_graph=use_graph, warmup=2, **kw)
     r.prepare()
     for _ in range(3):
       r.step()

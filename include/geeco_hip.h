@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GEECO_ABI_VERSION 5   /* = the build round that last changed the entry points or their calling conventions */
+#define GEECO_ABI_VERSION 6   /* = the build round that last changed the entry points or their calling conventions */
 
 #define GEECO_EINVAL  (-1)   /* bad shape / alignment / null pointer */
 #define GEECO_ENOSUP  (-2)   /* shape outside what the kernels were built for */
@@ -76,6 +76,17 @@ int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t fram
                            const float* depth, int64_t dsample_stride, int64_t dframe_stride, const float* tgt_depth,
                            const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW, float* cur_out,
                            float* buf_out, float* diff_out, void* ws, void* stream);
+/* The blocks of a sample wait for each other (bounded: seconds).  A wait that expires -- only if the device did not start the
+ * blocks of a launch in index order, see csrc/dynimg.hip -- is never silent: that sample's two images are written as NaN (so is
+ * everything computed from them) and the block counts itself into a sticky per-sample word in `ws`.  This entry sums those words
+ * over the N samples into *count_host (0 = every image ever produced through this ws was normalised with its sample's true
+ * min / max).  It copies N x 64 bytes to the host and SYNCHRONISES `stream`: call it where the host waits for the device
+ * anyway (loss read-out, end of an epoch; the reference reads its loss in the same places, estimator.py:263-269).  A workspace
+ * that has seen a timeout must be zero-filled again before its next use. */
+int geeco_goal_dynimgs_timeouts(const void* ws, int N, void* stream, int64_t* count_host);
+/* Process-wide number of polls a block waits before it reports (default 2^22); returns the previous value.  0 makes every block
+ * that is not the last of its sample to arrive report at once -- the tests provoke the error path with it. */
+unsigned geeco_goal_dynimgs_set_wait_polls(unsigned polls);
 /* The same stage read straight from the episodes' resident uint8 frames: replaces the host-side window + division of the
  * reference's input pipeline (_window_v3, src/data/geeco_gym.py:615-631; rgb / 255.0, _parse_v4 :312) AND the fp32 window
  * tensor they produce.  win_ptrs_dev / tgt_ptrs_dev: DEVICE arrays of N addresses; window n = K consecutive [HW][3] uint8

@@ -64,7 +64,8 @@ _ARGS = [
     # memory / input threads
     ('--batch_size', int, 32, 'The number of data points (windows) per batch.'),
     ('--memcap', float, 0.8, 'Maximum fraction of memory to allocate per GPU.'),
-    ('--num_threads', int, 4, 'How many parallel threads to run for data fetching.'),
+    ('--num_threads', int, None, 'How many parallel threads to run for data fetching (reference default: 4; here, when the '
+                                 'flag is absent: this rank\'s share of the host cores, input_fn.default_reader_threads).'),
     ('--prefetch_size', int, 4, 'How many batches to prefetch.'),
     ('--shuffle_buffer', int, 64, 'Number of shuffled examples to draw minibatch from.'),
     # logging
@@ -75,6 +76,11 @@ for _flag, _type, _default, _help in _ARGS:
 ARGPARSER.add_argument('--debug', default=False, action='store_true', help='Enables debugging mode.')
 ARGPARSER.add_argument('--initial_eval', default=False, action='store_true',
                        help='Runs an evaluation before the first training iteration.')
+# the one flag the reference does not have (it has no data parallelism, train_e2evmc.py:221-224, 260-264)
+ARGPARSER.add_argument('--dp_form', type=str, default=None,
+                       help='Data parallel only: form of the step, one of three_graphs (default: exchange launched between three '
+                            'replayed hipGraphs) | three_graphs_serial | overlap (whole step incl. both all-reduces as ONE hipGraph) '
+                            '| overlap_reserve16 | overlap_reserve32 | serial.  bench.py --gpus N reports which is fastest on a node.')
 
 _OBSERVATION_FORMAT_TO_CHANNELS = {'rgb': 3, 'rgbd': 4}                      # train_e2evmc.py:129-132
 _GOAL_CONDITION_TO_MODEL = {'none': (e2evmc_model_fn, 'VMC'),               # train_e2evmc.py:134-137
@@ -133,7 +139,7 @@ def main(args):
                              save_checkpoints_steps=args.ckpt_steps, keep_checkpoint_max=args.num_last_ckpt,
                              # checkpoints are also written as TF-1.15 tensor bundles (model.ckpt-<step>.index / .data-*),
                              # the files the reference's predictor and snapshot tooling read
-                             save_tf_bundle=_dev.env('GEECO_NO_TF_BUNDLE') is None)
+                             save_tf_bundle=_dev.env('GEECO_NO_TF_BUNDLE') is None, dp_form=args.dp_form)
   config_name = 'e2evmc_config'
   config_path = os.path.join(args.model_dir, '%s.json' % config_name)
   if os.path.exists(config_path):    # a previous run's config wins over the CLI (train_e2evmc.py:229-232)
@@ -164,7 +170,7 @@ def main(args):
 
   # --num_threads as given; when the flag is absent, this rank's share of the host cores instead of the reference's fixed 4
   # (input_fn.default_reader_threads: epoch 1 of real-data training is reader-bound below ~13 cores per rank)
-  reader_threads = args.num_threads if any(a == '--num_threads' or a.startswith('--num_threads=') for a in sys.argv[1:]) else None
+  reader_threads = args.num_threads
 
   def input_fn(estimator_mode):
     import torch

@@ -81,6 +81,70 @@ def test_two_ranks_equal_single_process(dev):
 
 
 # ----------------------------------------------------------------------------------------------------
+# The fallback the one N > 1 run on real hardware relies on: a one-graph capture that FAILS must leave the process able to
+# capture the three-graph form and carry on.  gloo's all-reduce of a device tensor cannot be captured (it synchronises the
+# stream / copies through the host), so forcing capture_exchange=True over gloo provokes exactly that failure, in the same
+# process that then re-captures: the steps that follow must equal, bitwise, those of a runner that never tried.
+# ----------------------------------------------------------------------------------------------------
+def _fallback_worker(rank, world, port, q):
+  import warnings
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from geeco_amd import dist as gdist
+  from geeco_amd import graph
+  from geeco_amd.params import create_e2evmc_config
+  from geeco_amd.runtime import TrainStepRunner
+  torch.cuda.set_device(0)
+  gdist.init_from_env('gloo')
+  feats, labels = _batch(4)
+  lo, hi = gdist.shard_bounds(4)
+  out = {}
+  for name, kw in (('forced', dict(capture_exchange=True)), ('plain', {})):
+    model = graph.GoalE2EVMC(create_e2evmc_config(KW), hi - lo, 'cuda:0', training=True)
+    model.store.initialize(seed=9)
+    gdist.broadcast_variables(model.store)
+    model.load_batch({k: torch.from_numpy(v[lo:hi]) for k, v in feats.items()}, {k: torch.from_numpy(v[lo:hi]) for k, v in labels.items()})
+    runner = TrainStepRunner(model, use_graph=True, warmup=1, **kw)
+    assert runner.capture_exchange == (name == 'forced') and runner.split_adam
+    losses, caught = [], []
+    for i in range(4):
+      with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        runner.step()                     # step 1 eager; step 2 captures (forced: fails, agrees with the peer, re-captures) and replays
+      caught += [str(x.message) for x in w if 'capturing the exchange' in str(x.message)]
+      torch.cuda.synchronize()
+      losses.append(float(model.loss))
+      assert not torch.cuda.is_current_stream_capturing()
+    out[name] = dict(params=model.store.params.detach().cpu().numpy(), m=model.store.adam_m.detach().cpu().numpy(), losses=losses,
+                     step=int(model.store.global_step.item()), graphs=len(runner._graphs), capture_exchange=runner.capture_exchange,
+                     warned=len(caught), prepared=bool(getattr(model, '_prepared', False)))
+  q.put((rank, out))
+  torch.distributed.destroy_process_group()
+
+
+def test_failed_one_graph_capture_falls_back_in_process(dev):
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 34300 + os.getpid() % 1000
+  procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  for rank, out in res:
+    f, pl = out['forced'], out['plain']
+    assert f['warned'] == 1 and pl['warned'] == 0, (rank, f['warned'], pl['warned'])       # said so once
+    assert f['graphs'] == 3 and not f['capture_exchange'] and pl['graphs'] == 3
+    assert f['step'] == pl['step'] == 4 and not f['prepared']                              # the failed capture advanced nothing
+    assert f['losses'] == pl['losses'], (rank, f['losses'], pl['losses'])
+    np.testing.assert_array_equal(f['params'], pl['params'])
+    np.testing.assert_array_equal(f['m'], pl['m'])
+  np.testing.assert_array_equal(res[0][1]['forced']['params'], res[1][1]['forced']['params'])   # replicas identical
+
+
+# ----------------------------------------------------------------------------------------------------
 # Estimator under data parallelism with ragged global batches: 4 -> 2+2, 3 -> 2+1 (loss scales 4/3 and 2/3),
 # 1 -> 1+0 (rank 1 takes a null step: zeros into the exchange, same Adam update)
 # ----------------------------------------------------------------------------------------------------
@@ -194,8 +258,8 @@ def _rccl_worker(port, overlap, one_graph, q):
   model.store.initialize(seed=9)
   gdist.broadcast_variables(model.store)
   model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
-  # default (None) = the exchange captured into the step graph whenever the backend is RCCL; False = round 4's three graphs
-  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap, capture_exchange=None if one_graph else False)
+  # True = the exchange captured into the step graph (opt-in: dp_form 'overlap' / 'serial'); default = three graphs
+  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap, **({'capture_exchange': True} if one_graph else {}))
   assert runner.capture_exchange == one_graph
   info = runner.bucket_info()
   losses = []

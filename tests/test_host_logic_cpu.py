@@ -451,6 +451,40 @@ def test_bench_reads_what_rccl_logged(tmp_path, monkeypatch):
   assert path and os.environ['NCCL_DEBUG'] == 'INFO' and os.environ['NCCL_DEBUG_FILE'] == path and os.environ['NCCL_DEBUG_SUBSYS'] == 'INIT,GRAPH'
 
 
+def test_bench_watchdog_leaves_with_the_provisional_line(tmp_path):
+  """bench.Watchdog (N > 1): when what follows the safe form's measurement does not finish in time, the provisional line is
+  written and the process exits 0 although its main thread is stuck; a disarmed watchdog does nothing.  And the names of
+  runtime.DP_FORMS resolve (default = the three-graph form, nothing captured)."""
+  import subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  prog = (
+      "import sys, json, time, threading\n"
+      "sys.path.insert(0, %r)\n"
+      "import bench\n"
+      "def emit(p, phase):\n"
+      "  p['comm'] = {'status': 'WATCHDOG ' + phase}\n"
+      "  print(json.dumps(p), flush=True)\n"
+      "quiet = bench.Watchdog(0.2, emit); quiet.provisional = {'value': 0}; quiet.arm(); quiet.disarm()\n"
+      "time.sleep(0.5)\n"
+      "dog = bench.Watchdog(0.5, emit); dog.provisional = {'metric': 'm', 'value': 1.5}; dog.phase = 'trial'; dog.arm()\n"
+      "threading.Event().wait(60)\n"             # the main thread 'hangs'
+      "print('not reached')\n") % root
+  t0 = __import__('time').time()
+  out = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, timeout=50)
+  assert out.returncode == 0 and __import__('time').time() - t0 < 30, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1 and 'not reached' not in out.stdout
+  d = json.loads(lines[0])
+  assert d['value'] == 1.5 and d['comm']['status'] == 'WATCHDOG trial'
+  assert 'WATCHDOG' in out.stderr and 'phase: trial' in out.stderr
+  from geeco_amd.runtime import DP_FORMS, DP_FORM_DEFAULT, dp_form_kwargs
+  assert DP_FORM_DEFAULT == 'three_graphs' and dp_form_kwargs() == dict(overlap=True, capture_exchange=False)
+  assert dp_form_kwargs('overlap_reserve16') == dict(overlap=True, capture_exchange=True, reserved_cus=16)
+  assert all(set(kw) <= {'overlap', 'capture_exchange', 'reserved_cus'} for kw in DP_FORMS.values())
+  with pytest.raises(ValueError):
+    dp_form_kwargs('fastest')
+
+
 def test_tfrecord_sequence_example_hand_assembled_golden(tmp_path):
   """A zlib TFRecord file with one tf.train.SequenceExample assembled BY HAND in this test from the published layouts
   (TFRecord framing: u64 length, masked CRC-32C of the length, payload, masked CRC-32C of the payload; example.proto /

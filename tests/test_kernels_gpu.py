@@ -198,6 +198,30 @@ def test_gemm(dev, M, N, K, ta, tb):
   _close(C, ref, 1e-5, 2e-5 * np.sqrt(K), 'gemm')
 
 
+def test_lstm_cell_tf_published_vector(dev):
+  """The vector TF 1.15's own rnn_cell_test.py::testBasicLSTMCell publishes (tests/test_oracle_kat.py has the literals and what
+  they do and do not pin), through the HIP entry points of the cell: geeco_gemm_f32 ([x | h] W) + geeco_lstm_gates_fwd with a
+  NON-zero incoming state, twice (two stacked cells of 2 units)."""
+  from geeco_amd import ops
+  from test_oracle_kat import TF_BASIC_LSTM_OUTPUT, TF_BASIC_LSTM_STATE, TF_BASIC_LSTM_TOL, tf_basic_lstm_case
+  x, state, kernel, bias = (t.to(dev) for t in tf_basic_lstm_case(torch.float32))
+  H = 2
+
+  def cell(inp, c_prev, h_prev):
+    z = ops.gemm(torch.cat([inp, h_prev], 1).contiguous(), kernel)
+    c, h, gates = (torch.full((1, H), float('nan'), device=dev), torch.full((1, H), float('nan'), device=dev),
+                   torch.full((1, 4 * H), float('nan'), device=dev))
+    ops.lstm_gates_fwd_into(c, h, gates, z, bias, c_prev.contiguous(), 1, H)
+    return c, h
+  c1, h1 = cell(x, state[:, 0:2], state[:, 2:4])
+  c2, h2 = cell(h1, state[:, 4:6], state[:, 6:8])
+  torch.cuda.synchronize()
+  new_state = torch.cat([c1, h1, c2, h2], 1).cpu().numpy()
+  np.testing.assert_allclose(h2.cpu().numpy(), TF_BASIC_LSTM_OUTPUT, atol=TF_BASIC_LSTM_TOL, rtol=0)
+  np.testing.assert_allclose(new_state, TF_BASIC_LSTM_STATE, atol=TF_BASIC_LSTM_TOL, rtol=0)
+  np.testing.assert_allclose(new_state, TF_BASIC_LSTM_STATE, atol=2e-6, rtol=0)       # fp32 against the eight-digit literals
+
+
 # fc1 + heads + losses (+ gradients): one workgroup per sample + a few blocks for the sums over the batch (H <= 128, Hfc 64 / 128);
 # other widths run the single-workgroup kernel; both against the oracle's decoder tail differentiated by autograd in fp64.
 @pytest.mark.parametrize('N,mode,H,F', [(1, 'cartesian', 128, 128), (7, 'cartesian', 128, 128), (32, 'cartesian', 128, 128),
@@ -535,6 +559,87 @@ def test_goal_dynimgs_one_pass(dev, N, K, H, W, C):
   sub = slice(0, N if HW <= 136 * 136 else 2)          # (the oracle in fp64 on the big cases: two samples)
   _close(buf[sub][..., :C], O.dynimg(frames64[sub]), 0, 5e-6, 'buffer image vs fp64')
   _close(dif[sub][..., :C], O.dynimg(torch.stack([frames64[sub, K - 1], tgt64[sub]], 1)), 0, 5e-6, 'pair image vs fp64')
+
+
+@pytest.mark.parametrize('N,H,W,u8', [(25, 256, 256, False), (3, 136, 136, False), (26, 256, 256, True)],
+                         ids=['two samples per block', 'small blocks', 'uint8 frames'])
+def test_goal_dynimgs_expired_wait_is_loud(dev, N, H, W, u8):
+  """The one-pass input stage never continues on stale min / max (csrc/dynimg.hip): when a block's wait for the other blocks
+  of its sample expires, that sample's images are NaN, the block counts itself into the workspace's sticky error word, and
+  geeco_goal_dynimgs_timeouts / model.check_device_errors report it.  The wait cannot be made to expire through the data
+  (blocks of a launch start in index order on this hardware, which is exactly why the bound is never reached), so the test
+  sets the bound to ZERO polls: every block that is not the last of its sample to arrive reports at once.  With the default
+  bound the same calls report nothing and produce finite images; a healthy workspace stays at zero across calls."""
+  from geeco_amd import ops
+  from geeco_amd._native import load as lib
+  r = np.random.default_rng(5)
+  K, HW = 3, H * W
+  tgt = torch.tensor(r.random([N, H, W, 3]).astype(np.float32), device=dev)
+  rgb = torch.tensor(r.random([N, K, H, W, 3]).astype(np.float32), device=dev)
+  cur, buf, dif = (torch.zeros(N, H, W, 4, device=dev) for _ in range(3))
+  if u8:
+    rgb8 = (rgb * 255).to(torch.uint8).contiguous()
+    tgt8 = (tgt * 255).to(torch.uint8).contiguous()
+    wp = torch.tensor([rgb8.data_ptr() + n * K * HW * 3 for n in range(N)], dtype=torch.int64, device=dev)
+    tp = torch.tensor([tgt8.data_ptr() + n * HW * 3 for n in range(N)], dtype=torch.int64, device=dev)
+    run = lambda ws: ops.goal_dynimgs_u8_into(cur, buf, dif, wp, tp, K, N, HW, ws)
+  else:
+    run = lambda ws: ops.goal_dynimgs_into(cur, buf, dif, rgb, tgt, K, N, HW, ws, K * HW * 3, HW * 3)
+  good = ops.goal_dynimgs_ws(N, HW, dev)
+  for _ in range(3):
+    run(good)
+  assert ops.goal_dynimgs_timeouts(good, N) == 0
+  ops.check_input_stage(good, N)
+  assert torch.isfinite(buf).all() and torch.isfinite(dif).all()
+  bad = ops.goal_dynimgs_ws(N, HW, dev)
+  old = lib().geeco_goal_dynimgs_set_wait_polls(0)
+  try:
+    assert old == 1 << 22
+    run(bad)
+    n_bad = ops.goal_dynimgs_timeouts(bad, N)
+  finally:
+    assert lib().geeco_goal_dynimgs_set_wait_polls(old) == 0
+  # at least one block of some sample arrived before that sample's last block (several blocks per sample in every case here)
+  assert n_bad >= 1, n_bad
+  per_sample = bad[:16 * N].view(N, 16)[:, 2].cpu().numpy()
+  assert per_sample.sum() == n_bad
+  for n in range(N):      # a sample with a reporting block has NaN pixels in BOTH images; a sample without one is finite throughout
+    has_nan = bool(torch.isnan(buf[n]).any()) and bool(torch.isnan(dif[n]).any())
+    assert has_nan == bool(per_sample[n] > 0), (n, per_sample[n])
+  assert torch.isfinite(cur).all()      # (the current frame's copy does not depend on the hand-off)
+  with pytest.raises(RuntimeError, match='gave up waiting'):
+    ops.check_input_stage(bad, N)
+  run(bad)                              # sticky: a later call with the default bound does not clear the word
+  assert ops.goal_dynimgs_timeouts(bad, N) >= n_bad
+  assert ops.goal_dynimgs_timeouts(good, N) == 0
+
+
+def test_model_reports_an_expired_input_stage_wait(dev):
+  """GoalE2EVMC.check_device_errors (what Estimator.train / evaluate, bench.py and endpoints() call where they synchronise):
+  silent on a healthy model, raises once the input stage of THIS model's workspace reported; the loss of that step is NaN."""
+  from geeco_amd import graph, ops
+  from geeco_amd._native import load as lib
+  from geeco_amd.params import create_e2evmc_config
+  cfg = create_e2evmc_config(dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136, batch_size=3))
+  model = graph.GoalE2EVMC(cfg, 3, dev, training=True)
+  model.store.initialize(seed=1)
+  feats, labels = O.synthetic_batch(O.make_config(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_height=136, img_width=136,
+                                                  batch_size=3), True, 3, seed=8, H=136, W=136)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  model.train_step()
+  model.check_device_errors()
+  assert np.isfinite(float(model.loss)) and 'dynbuff' in model.endpoints()
+  old = lib().geeco_goal_dynimgs_set_wait_polls(0)
+  try:
+    model.forward(backward_too=False)
+    torch.cuda.synchronize()
+  finally:
+    lib().geeco_goal_dynimgs_set_wait_polls(old)
+  assert np.isnan(float(model.loss))
+  with pytest.raises(RuntimeError, match='one-pass input stage'):
+    model.check_device_errors()
+  with pytest.raises(RuntimeError, match='one-pass input stage'):
+    model.endpoints()
 
 
 @pytest.mark.parametrize('N,K,H,W,C', [(2, 4, 16, 24, 3), (3, 16, 136, 136, 3), (2, 3, 16, 24, 4), (1, 1, 8, 8, 3), (4, 2, 40, 36, 4),

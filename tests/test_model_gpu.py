@@ -56,6 +56,8 @@ CASES = [
     ('geeco-f rgbd', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, img_channels=4, lambda_aux=0.5), True, 2, 136),
     ('e2e_vmc rgb', dict(window_size=3), False, 2, 144),
     ('geeco-f rgb 256', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16), True, 2, 256),
+    # BASELINE.json configs[0] (the reference's own CPU-runnable case, and bench.py's cpu_baseline workload): batch 4, seq_len 16
+    ('geeco-f rgb 256 N=4', dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=16, batch_size=4), True, 4, 256),
     # remaining goal_e2evmc branches (graph.py:362-385), velocity heads (:240-249, 430-450), L2 regulariser
     ('goal seq constant', dict(proc_obs='sequence', proc_tgt='constant', window_size=2), True, 2, 136),
     ('goal seq residual', dict(proc_obs='sequence', proc_tgt='residual', window_size=3), True, 2, 136),

@@ -237,3 +237,42 @@ def test_relu_tap_every_branch():
     torch.testing.assert_close(g, grads[k], rtol=1e-9, atol=1e-14, msg=k)
     torch.testing.assert_close(g2[k], grads[k], rtol=1e-9, atol=1e-14, msg=k)
   assert sorted(ep2['conv8']) == sorted(rec.calls) and all(v.shape == (2, 2, 2, 256) for v in ep2['conv8'].values())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The one vector in this tree that TensorFlow itself wrote: TF 1.15's own unit test
+# tensorflow/python/kernel_tests/rnn_cell_test.py::testBasicLSTMCell publishes, to 1e-2 (its assertAllClose tolerance there),
+# the result of two stacked cells of 2 units (state_is_tuple=False), every kernel entry 0.5, zero biases, x = [[1, 1]],
+# state = 0.1 * ones(1, 8):  output [[0.24024698, 0.24024698]] and new state
+# [[0.68967271, 0.68967271, 0.44848421, 0.44848421, 0.39897051, 0.39897051, 0.24024698, 0.24024698]] (layout c1 | h1 | c2 | h2).
+# What it pins: the cell formula c' = sigmoid(f + forget_bias) c + sigmoid(i) tanh(j), h' = sigmoid(o) tanh(c') with
+# forget_bias = 1 (0 would give c1 = 0.674...), a NON-zero incoming state, and the c-before-h layout of the non-tuple state.
+# What it does NOT pin: the gate order i, j, f, o -- all four pre-activations are equal when every kernel entry is 0.5.
+# (LSTMCell, which the reference uses at graph.py:217, and BasicLSTMCell share this formula when peepholes, clipping and
+# projection are off, as they are there.)  tests/test_kernels_gpu.py runs the same vector through the HIP entry points.
+# ----------------------------------------------------------------------------------------------------------------------
+TF_BASIC_LSTM_OUTPUT = [[0.24024698, 0.24024698]]
+TF_BASIC_LSTM_STATE = [[0.68967271, 0.68967271, 0.44848421, 0.44848421, 0.39897051, 0.39897051, 0.24024698, 0.24024698]]
+TF_BASIC_LSTM_TOL = 1e-2        # what the TF test itself asserts; the digits above are its literals
+
+
+def tf_basic_lstm_case(dtype=torch.float64):
+  x = torch.ones(1, 2, dtype=dtype)
+  state = torch.full((1, 8), 0.1, dtype=dtype)
+  kernel = torch.full((4, 8), 0.5, dtype=dtype)      # [x | h] (2 + 2) x 4 gates of 2 units
+  bias = torch.zeros(8, dtype=dtype)
+  return x, state, kernel, bias
+
+
+def test_lstm_cell_reproduces_the_vector_tf_publishes():
+  x, state, kernel, bias = tf_basic_lstm_case()
+  c1, h1 = O.lstm_cell(x, state[:, 0:2], state[:, 2:4], kernel, bias)
+  c2, h2 = O.lstm_cell(h1, state[:, 4:6], state[:, 6:8], kernel, bias)
+  new_state = torch.cat([c1, h1, c2, h2], 1)
+  np.testing.assert_allclose(h2.numpy(), TF_BASIC_LSTM_OUTPUT, atol=TF_BASIC_LSTM_TOL, rtol=0)
+  np.testing.assert_allclose(new_state.numpy(), TF_BASIC_LSTM_STATE, atol=TF_BASIC_LSTM_TOL, rtol=0)
+  # the literals carry eight digits of TF's float32 result: the fp64 restatement agrees with them to float32 rounding
+  np.testing.assert_allclose(new_state.numpy(), TF_BASIC_LSTM_STATE, atol=2e-7, rtol=0)
+  # forget_bias = 0 is NOT the published vector
+  c1_0, _ = O.lstm_cell(x, state[:, 0:2], state[:, 2:4], kernel, bias, forget_bias=0.0)
+  assert abs(float(c1_0[0, 0]) - TF_BASIC_LSTM_STATE[0][0]) > TF_BASIC_LSTM_TOL
