@@ -497,15 +497,17 @@ def timed_steps(model, steps, warmup, use_graph, world, dev, verbose=True, form=
 class Watchdog:
   """N > 1: the forms of the data-parallel step that capture RCCL's launches into a hipGraph have never run with more than one
   rank on hardware (no multi-GPU box was available to any round of this build).  A collective that HANGS inside a replayed
-  graph cannot be recovered in-process, and a process that touched the GPU is never restarted.  So: the always-safe form is
-  measured FIRST, in full (warm-up + the K timed steps), its line is kept as `provisional`, and this timer is armed around
-  everything that follows.  If that does not finish in time, rank 0 writes the provisional line -- a complete, valid
-  measurement of the safe form, marked as such -- and every rank leaves with os._exit (no atexit handlers, no destructors
-  that would wait for the stuck stream).  The run cannot end without a number."""
+  graph cannot be recovered in-process, a capture that FAILS leaves its streams in capture mode (runtime.TrainStepRunner._capture)
+  and a process that touched the GPU is never restarted.  So: the always-safe form is measured FIRST, in full (warm-up + the K
+  timed steps), its line is kept as `provisional`, and this timer is armed around everything that follows.  If that does not
+  finish in time -- or any rank raises the abort flag (``abort``: a counter in the rendezvous store, polled once a second, so
+  the peers of a rank whose capture failed do not sit in a collective until the deadline) -- rank 0 writes the provisional
+  line, a complete and valid measurement of the safe form marked as such, and every rank leaves with os._exit (no atexit
+  handlers, no destructors that would wait for a stuck stream).  The run cannot end without a number."""
 
-  def __init__(self, seconds, emit):
+  def __init__(self, seconds, emit, aborted=None):
     import threading
-    self.seconds, self.emit = float(seconds), emit
+    self.seconds, self.emit, self.aborted = float(seconds), emit, aborted
     self._stop = threading.Event()
     self._t = threading.Thread(target=self._run, name='bench-watchdog', daemon=True)
     self.provisional = None
@@ -517,21 +519,30 @@ class Watchdog:
   def disarm(self):
     self._stop.set()
 
-  def _run(self):
-    if self._stop.wait(self.seconds):
-      return
+  def fire(self, why):
+    """Leaves NOW with the provisional line (also called by the main thread when its own captured form raised)."""
     import faulthandler
-    log('WATCHDOG: the captured forms of the data-parallel step did not finish within %.0f s (phase: %s); leaving with the '
-        'measurement of the safe form' % (self.seconds, self.phase))
+    log('WATCHDOG: %s (phase: %s); leaving with the measurement of the safe form' % (why, self.phase))
     try:
       faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
     except Exception:
       pass
     try:
-      self.emit(self.provisional, self.phase)
+      self.emit(self.provisional, '%s; phase: %s' % (why, self.phase))
     finally:
       sys.stderr.flush()
       os._exit(0)
+
+  def _run(self):
+    t0 = time.monotonic()
+    while not self._stop.wait(1.0 if self.aborted else max(self.seconds, 0.01)):
+      if self.seconds > 0 and time.monotonic() - t0 >= self.seconds:
+        self.fire('what follows the safe form did not finish within %.0f s' % self.seconds)
+      try:
+        if self.aborted and self.aborted():
+          self.fire('another rank gave up on the captured forms')
+      except Exception:
+        pass
 
 
 def step_flop(channels, frames):
@@ -1043,39 +1054,50 @@ def main():
     log('N = %d, safe form (%s: exchange launched between three graphs): %.4f ms/step = %.1f frames/s (max over ranks, %d timed steps)'
         % (world, safe_form, ms, world * args.batch * args.seq_len * args.steps / r['dt'], args.steps))
 
-    def on_watchdog(provisional, phase):
+    def on_watchdog(provisional, why):
       if rank == 0 and provisional is not None:
-        provisional['comm'] = {'status': 'WATCHDOG: the forms behind the safe one did not finish (phase: %s); this line is the full '
-                                         'measurement of config.dp_form' % phase, 'forms_timed_in_full_ms': full, 'trial_ms': trial}
+        provisional['comm'] = {'status': 'WATCHDOG: %s; this line is the full measurement of config.dp_form' % why,
+                               'forms_timed_in_full_ms': full, 'trial_ms': trial}
         emit(provisional)
-    dog = Watchdog(args.dp_watchdog_s, on_watchdog)
+
+    def abort_flag(raise_it=False):
+      store = torch.distributed.distributed_c10d._get_default_store()
+      return int(store.add('bench_abort', 1 if raise_it else 0)) > 0
+    dog = Watchdog(args.dp_watchdog_s, on_watchdog, aborted=abort_flag)
     dog.provisional = headline(r, form)[0] if rank == 0 else None
     if args.dp_watchdog_s > 0:
       dog.arm()
-    if not (args.dp_fixed or args.dp_serial or args.no_graph):
-      dog.phase = 'trial of the one-graph forms'
-      cand, trial = pick_dp_runner(model, use_graph=True, log=log)
-      best = min(trial, key=trial.get)
-      log('one-graph forms, short trial: %s; fastest %s' % (json.dumps({k: round(v, 4) for k, v in trial.items()}), best))
-      if trial[best] < ms:
-        dog.phase = 'timed region of %s' % best
-        r2 = timed_region(model, cand, args.steps, args.warmup, world, dev)
-        r2['first_loss'] = first_loss
-        # (a form whose capture fell back -- gloo rehearsal -- is the three-graph form under another name: bucket_info says so)
-        full[best] = round(r2['dt'] / args.steps * 1e3, 4)
-        log('N = %d, form %s: %.4f ms/step in full' % (world, best, full[best]))
-        if r2['dt'] < r['dt']:
-          r, form = r2, best
-          if rank == 0:
-            dog.provisional = headline(r, form)[0]
-      del cand
+    try:
+      if not (args.dp_fixed or args.dp_serial or args.no_graph):
+        dog.phase = 'trial of the one-graph forms'
+        cand, trial = pick_dp_runner(model, use_graph=True, log=log)
+        best = min(trial, key=trial.get)
+        log('one-graph forms, short trial: %s; fastest %s' % (json.dumps({k: round(v, 4) for k, v in trial.items()}), best))
+        if trial[best] < ms:
+          dog.phase = 'timed region of %s' % best
+          r2 = timed_region(model, cand, args.steps, args.warmup, world, dev)
+          r2['first_loss'] = first_loss
+          # (a form on a backend that cannot capture -- gloo rehearsal -- is the three-graph form under another name: bucket_info says so)
+          full[best] = round(r2['dt'] / args.steps * 1e3, 4)
+          log('N = %d, form %s: %.4f ms/step in full' % (world, best, full[best]))
+          if r2['dt'] < r['dt']:
+            r, form = r2, best
+            if rank == 0:
+              dog.provisional = headline(r, form)[0]
+        del cand
+      if not args.skip_comm_report:
+        dog.phase = 'comm report'
+        comm = comm_report(args, model, r['runner'], dev, world, r['dt'] / args.steps * 1e3)
+    except Exception as e:      # a capture that failed (runtime.CaptureFailed) or anything else behind the safe form's measurement
+      log('%s: %s' % (type(e).__name__, str(e)[:500]))
+      try:
+        abort_flag(raise_it=True)      # the peers are (or will be) waiting in a collective this rank will not join
+      except Exception:
+        pass
+      dog.fire('%s on rank %d' % (type(e).__name__, rank))
+    dog.disarm()
   runner, dt, per_step = r['runner'], r['dt'], r['per_step']
   loss, total_steps = r['final_loss'], r['total_steps']
-  if world > 1 and not args.skip_comm_report:
-    dog.phase = 'comm report'
-    comm = comm_report(args, model, runner, dev, world, dt / args.steps * 1e3)
-  if dog is not None:
-    dog.disarm()
 
   rc = 0
   if rank == 0:

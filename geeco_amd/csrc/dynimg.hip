@@ -155,18 +155,19 @@ __global__ __launch_bounds__(256) void dynimg_wsum3_kernel(const DynParams p) {
 //     In-order start of workgroups is how the dispatcher of every CDNA part behaves, NOT a documented guarantee (CU masking, a
 //     partitioned device or a co-resident persistent kernel could starve a sample's last blocks).  So the wait is BOUNDED
 //     (g_wait_polls polls, seconds) and an expired wait is LOUD: the block counts itself into the sample's sticky `timeouts`
-//     word and normalises with NaN -- the images of that sample, the loss and every gradient behind them are NaN, and
-//     geeco_goal_dynimgs_timeouts() (which the host calls wherever it synchronises anyway) reports the count.  Nothing ever
-//     continues on stale min / max.  A workspace that has seen a timeout stays poisoned (its counters are no longer zero
+//     word and normalises with NaN, and geeco_goal_dynimgs_timeouts() (which the host calls wherever it synchronises anyway)
+//     reports the count.  The word is what makes it loud: the NaN images are visible as such (endpoints), but conv1's ReLU
+//     -- max(x, 0) returns 0 for a NaN -- would let a finite loss come out of them.  Nothing ever continues on stale min / max.  A workspace that has seen a timeout stays poisoned (its counters are no longer zero
 //     between calls) until the caller zero-fills it again;
 //   * ordering of the hand-off, at the hardware level (the C++ model has no word for "write-through store"): the slot stores
 //     and the counter add are agent-scope atomics = sc1 accesses that complete at the memory side, past the non-coherent
-//     per-XCD L2s; the producer drains its slot stores (s_waitcnt vmcnt(0)) BEFORE it issues the add, the consumer issues its
-//     slot loads AFTER the poll that saw the full count has returned (a workgroup-scope acquire fence: no cache maintenance,
-//     but neither the compiler nor the wave may move the slot loads above it), and every lane of the polling wave takes the
-//     count from lane 0 through readfirstlane, so "behind the poll" holds for all 64 lanes by data dependence, not by
-//     reconvergence.  Agent-scope release / acquire instead (buffer_wbl2 / buffer_inv sc1 per block) would write back and
-//     invalidate an XCD's whole L2 for four floats that never live in it;
+//     per-XCD L2s; the producer drains its slot stores (s_waitcnt vmcnt(0)) BEFORE it issues the add; on the consumer side
+//     every lane of the polling wave takes the final count from lane 0 through readfirstlane and the ADDRESS of its slot loads
+//     is computed from that count (+ count >> 31, i.e. + 0), so the slot loads are issued behind the poll that saw the full
+//     count by data dependence -- for all 64 lanes, for the compiler and for the wave -- not by reconvergence and without a
+//     fence (a workgroup-scope acquire fence here measured +2...3 us in the step: it drains the wave's prefetched frame loads
+//     of the NEXT sample, which the hand-off does not depend on).  Agent-scope release / acquire (buffer_wbl2 / buffer_inv
+//     sc1 per block) would write back and invalidate an XCD's whole L2 for four floats that never live in it;
 //   * the LAST block of a sample to leave zeroes the sample's two counters again: every call finds and leaves them zero (the
 //     slots need no reset: every block rewrites its own before it counts itself in).
 // The arithmetic per pixel is that of dynimg_wsum3_kernel + dynimg_norm_kernel (same sums in the same order, (D - min) / range
@@ -192,9 +193,7 @@ __device__ __forceinline__ unsigned dyn_wait_for_sample(DynCtl* c, unsigned got,
     }
     if (got < bps) __hip_atomic_fetch_add(&c->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  got = __builtin_amdgcn_readfirstlane(got);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  return got;
+  return __builtin_amdgcn_readfirstlane(got);
 }
 
 // a wave-uniform address as such (two SGPRs): loads from it + a 32-bit per-lane offset take the scalar-base form and need one VGPR
@@ -402,7 +401,9 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass_kernel(const DynP
       got = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     }
     // the other blocks of this sample run the same pass over the same number of frames: they are at most a few us behind
-    const bool expired = dyn_wait_for_sample(c, got, (unsigned)bps, polls, lane == 0) < (unsigned)bps;
+    got = dyn_wait_for_sample(c, got, (unsigned)bps, polls, lane == 0);
+    const bool expired = got < (unsigned)bps;
+    slots += got >> 31;      // + 0 (a count never has bit 31 set): the slot loads below carry an ADDRESS dependency on the final count
     f32x4 q = {INFINITY, -INFINITY, INFINITY, -INFINITY};
     for (int i = lane; i < bps; i += 64) {
       const float* sp = reinterpret_cast<const float*>(slots + i);
@@ -624,7 +625,9 @@ __global__ __launch_bounds__(THREADS) void dynimg_goal_onepass2_kernel(const Dyn
       const f32x4* slots = reinterpret_cast<const f32x4*>(ctl + p.N) + (long long)n * bps;
       unsigned got = 0;
       if (tid == 0) got = __hip_atomic_load(&c->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool expired = dyn_wait_for_sample(c, got, (unsigned)bps, polls, tid == 0) < (unsigned)bps;
+      got = dyn_wait_for_sample(c, got, (unsigned)bps, polls, tid == 0);
+      const bool expired = got < (unsigned)bps;
+      slots += got >> 31;      // + 0: address dependency of the slot loads on the final count (see dyn_wait_for_sample)
       f32x4 q = {INFINITY, -INFINITY, INFINITY, -INFINITY};
       for (int i = tid; i < bps; i += 64) {
         const float* sp = reinterpret_cast<const float*>(slots + i);

@@ -131,8 +131,8 @@ def check_input_stage(ws, N):
   if n:
     raise RuntimeError('geeco_amd: %d block(s) of the one-pass input stage gave up waiting for the other blocks of their sample '
                        '(the device did not start the blocks of a launch in index order: CU masking, a partitioned device, a '
-                       'co-resident persistent kernel?).  The images of those samples were written as NaN, and so were the loss '
-                       'and the gradients of those steps; zero-fill the workspace (ops.goal_dynimgs_ws) before using it again.' % n)
+                       'co-resident persistent kernel?).  The images of those samples were written as NaN (conv1\'s ReLU turns '
+                       'them into zeros: the losses of those steps are finite and WRONG); zero-fill the workspace (ops.goal_dynimgs_ws) before using it again.' % n)
 
 
 def dynimg(frames: torch.Tensor, Cpad=None) -> torch.Tensor:

@@ -61,6 +61,10 @@ def gradient_buckets(store):
   return early, [(lo, hi - lo) for lo, hi in late]
 
 
+class CaptureFailed(RuntimeError):
+  """A one-graph capture of the data-parallel step failed; the process cannot use the streams involved again (TrainStepRunner._capture)."""
+
+
 class TrainStepRunner:
   """``dp``: run the three-part data-parallel step (None = when the process group has more than one rank; True forces it
   with one rank, so that the exchange really goes through the backend -- tests).  ``overlap``: the early bucket goes out
@@ -74,7 +78,8 @@ class TrainStepRunner:
     hipGraph (RCCL's launches are stream work like any other; the fork to the communicator's stream and the joins become
     graph edges): one graph launch per step instead of three and no host-side stream joins (measured at one rank, bench.py
     ``dp_one_rank``: +18 us over the single-GPU step instead of +71).  ``overlap`` / ``skip_allreduce`` are then fixed at
-    capture time; if that capture fails on ANY rank every rank says so once and captures the three-graph form (``_capture``).
+    capture time; a backend whose collectives cannot be captured (anything but RCCL) gets the three-graph form, told once; a
+    capture that FAILS raises CaptureFailed and ends the run (``_capture`` says why there is no way back).
     None / False (default) = three graphs with the exchange launched eagerly between them: the form that is safe by
     construction (every collective is an ordinary RCCL launch, so a rank that replays and a rank that runs eagerly -- ragged
     end of an epoch, ``null_step`` -- issue the same kind of call on the communicator).  The one-graph form has only ever run
@@ -233,34 +238,34 @@ class TrainStepRunner:
             fn()
           graphs.append(g.replay)
       return graphs
-    if self.dp and self.capture_exchange:
-      # A capture records and executes nothing, so a failed one has moved no byte and advanced no counter; what it can leave
-      # behind is (a) the stream still in capture mode, (b) python-side flags set while recording (model._prepared: reset by
-      # the next forward(backward_too=True)), (c) on ONE rank only, a different form than its peers.  Hence: only the errors a
-      # capture-unsupported collective raises (RuntimeError: torch's HIP / c10d errors) are handled, the stream must be out of
-      # capture mode and idle afterwards, and the ranks AGREE on the form (MAX of "mine failed": itself a collective, which
-      # doubles as the check that the communicator still works) before anyone captures three graphs.  Anything else propagates
-      # and the process exits non-zero; a process that touched the GPU is never restarted.
-      err, graphs = None, None
-      try:
-        graphs = capture(self._parts())
-      except RuntimeError as e:
-        err = e
-      if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError('TrainStepRunner: the stream is still capturing after a failed one-graph capture') from err
-      torch.cuda.synchronize()
-      failed = gdist.max_over_ranks(0.0 if err is None else 1.0, self.model.store.params.device) > 0.0
-      if not failed:
-        self._graphs = graphs
-        return
+    if self.dp and self.capture_exchange and gdist.group_active() and gdist.backend() != 'nccl':
+      # Decided BEFORE anything is captured: only RCCL's launches are stream work a hipGraph can hold; any other backend's
+      # collective on a device tensor (gloo: copies through the host, stream synchronisation) cannot be captured, and an attempt
+      # cannot be undone (below).  Such a group gets the three-graph form, told once.
       import warnings
-      warnings.warn('TrainStepRunner: capturing the exchange into the step graph failed on %s (%s); every rank uses three '
-                    'graphs with the exchange between them' %
-                    ('this rank' if err is not None else 'another rank',
-                     'no error here' if err is None else '%s: %s' % (type(err).__name__, str(err)[:200])))
-      del graphs
+      warnings.warn("TrainStepRunner: capture_exchange asked for, but the '%s' backend's collectives cannot be captured into a "
+                    'hipGraph; using three graphs with the exchange between them' % gdist.backend())
       self.capture_exchange = False
-      self.model._prepared = False
+    if self.dp and self.capture_exchange:
+      # No in-process fallback from a FAILED attempt, by measurement (scripts/dev/ub/capture_abort.py, ROCm 7.2,
+      # profiles/r06/ub_capture_abort.txt): when a capture breaks with a forked stream not joined back -- the shape every failure
+      # inside a collective has, the communicator's stream being the fork -- hipStreamEndCapture returns an error and leaves the
+      # origin AND the forked stream in capture mode; neither a second EndCapture, nor joining the fork afterwards, nor
+      # BeginCapture on the same stream brings them back, and eager work on either stream then fails.  (First build of this
+      # round tried: capture_end raised `capturing stream has unjoined work`, the stream stayed in capture mode.)  So a failed
+      # one-graph capture ENDS the run: the current stream is put back (torch.cuda.graph leaves its side stream current when
+      # capture_end raises), and CaptureFailed goes up -- bench.py answers with the safe form's line it measured first, a
+      # training script exits non-zero and is restarted with --dp_form three_graphs.  Nothing was executed by the attempt.
+      orig = torch.cuda.current_stream()
+      try:
+        self._graphs = capture(self._parts())
+      except RuntimeError as e:
+        torch.cuda.set_stream(orig)
+        self.model._prepared = False
+        raise CaptureFailed('capturing the data-parallel step (with both all-reduces) into one hipGraph failed: %s: %s.  HIP '
+                            'leaves the streams of a failed capture in capture mode, so this process cannot capture or launch on '
+                            'them again: restart with dp_form=three_graphs (the default)' % (type(e).__name__, str(e)[:300])) from e
+      return
     self._graphs = capture(self._parts())
 
   def prepare(self):

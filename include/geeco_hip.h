@@ -77,8 +77,9 @@ int geeco_goal_dynimgs_fwd(const float* rgb, int64_t sample_stride, int64_t fram
                            const float* alpha_host, const float* alpha2_host, int N, int K, int64_t HW, float* cur_out,
                            float* buf_out, float* diff_out, void* ws, void* stream);
 /* The blocks of a sample wait for each other (bounded: seconds).  A wait that expires -- only if the device did not start the
- * blocks of a launch in index order, see csrc/dynimg.hip -- is never silent: that sample's two images are written as NaN (so is
- * everything computed from them) and the block counts itself into a sticky per-sample word in `ws`.  This entry sums those words
+ * blocks of a launch in index order, see csrc/dynimg.hip -- is never silent: that sample's two images are written as NaN (never
+ * with stale min / max; NB a ReLU turns NaN into 0, so the loss behind them can be finite) and the block counts itself into a
+ * sticky per-sample word in `ws`.  This entry sums those words
  * over the N samples into *count_host (0 = every image ever produced through this ws was normalised with its sample's true
  * min / max).  It copies N x 64 bytes to the host and SYNCHRONISES `stream`: call it where the host waits for the device
  * anyway (loss read-out, end of an epoch; the reference reads its loss in the same places, estimator.py:263-269).  A workspace

@@ -80,9 +80,9 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   assert 'three_graphs' in full and set(full) <= {'three_graphs', min(trial, key=trial.get)} and all(v > 0 for v in full.values())
   assert d['config']['dp_form'] in full and full[d['config']['dp_form']] == min(full.values())
   assert abs(d['ms_per_step'] - full[d['config']['dp_form']]) < 2e-3
-  # gloo's collectives cannot be captured: every one-graph form of this rehearsal fell back, in-process, to three graphs
-  # (TrainStepRunner._capture; RCCL one-graph forms: tests/test_dp_gpu.py)
-  assert 'capturing the exchange into the step graph failed' in out.stderr
+  # gloo's collectives cannot be captured: every one-graph form of this rehearsal is the three-graph form, decided before
+  # anything is captured (TrainStepRunner._capture; RCCL one-graph forms: tests/test_dp_gpu.py)
+  assert 'cannot be captured into a hipGraph' in out.stderr
   assert 'rccl' in c            # (gloo rehearsal: whatever RCCL logged, or the reason there is no log)
   assert set(c['graphs_per_step'].values()) == {3} and d['config']['graphs_per_step'] == 3
   assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c

@@ -81,10 +81,13 @@ def test_two_ranks_equal_single_process(dev):
 
 
 # ----------------------------------------------------------------------------------------------------
-# The fallback the one N > 1 run on real hardware relies on: a one-graph capture that FAILS must leave the process able to
-# capture the three-graph form and carry on.  gloo's all-reduce of a device tensor cannot be captured (it synchronises the
-# stream / copies through the host), so forcing capture_exchange=True over gloo provokes exactly that failure, in the same
-# process that then re-captures: the steps that follow must equal, bitwise, those of a runner that never tried.
+# capture_exchange=True on a backend whose collectives cannot be captured.  (a) The runner decides BEFORE it captures anything
+# (gloo's all-reduce of a device tensor goes through the host): told once, three graphs, and the steps equal, bitwise, those of
+# a runner that was never asked.  (b) Why it must decide before: a capture that FAILS cannot be undone on ROCm 7.2
+# (scripts/dev/ub/capture_abort.py, profiles/r06/ub_capture_abort.txt) -- the first build of this round let gloo's all-reduce into the
+# capture and tried to re-capture afterwards: `capturing stream has unjoined work`, stream stuck in capture mode.  The runner
+# therefore raises CaptureFailed (with the current stream put back), which bench.py answers with the line of the safe form it
+# measured first; provoked here by making the runner believe gloo is RCCL, in a process that is thrown away afterwards.
 # ----------------------------------------------------------------------------------------------------
 def _fallback_worker(rank, world, port, q):
   import warnings
@@ -110,8 +113,8 @@ def _fallback_worker(rank, world, port, q):
     for i in range(4):
       with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
-        runner.step()                     # step 1 eager; step 2 captures (forced: fails, agrees with the peer, re-captures) and replays
-      caught += [str(x.message) for x in w if 'capturing the exchange' in str(x.message)]
+        runner.step()                     # step 1 eager (forced: the one-pass form); step 2 captures three graphs and replays
+      caught += [str(x.message) for x in w if 'cannot be captured' in str(x.message)]
       torch.cuda.synchronize()
       losses.append(float(model.loss))
       assert not torch.cuda.is_current_stream_capturing()
@@ -122,7 +125,7 @@ def _fallback_worker(rank, world, port, q):
   torch.distributed.destroy_process_group()
 
 
-def test_failed_one_graph_capture_falls_back_in_process(dev):
+def test_one_graph_form_on_a_backend_that_cannot_capture(dev):
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   port = 34300 + os.getpid() % 1000
@@ -137,11 +140,54 @@ def test_failed_one_graph_capture_falls_back_in_process(dev):
     f, pl = out['forced'], out['plain']
     assert f['warned'] == 1 and pl['warned'] == 0, (rank, f['warned'], pl['warned'])       # said so once
     assert f['graphs'] == 3 and not f['capture_exchange'] and pl['graphs'] == 3
-    assert f['step'] == pl['step'] == 4 and not f['prepared']                              # the failed capture advanced nothing
+    assert f['step'] == pl['step'] == 4 and not f['prepared']
     assert f['losses'] == pl['losses'], (rank, f['losses'], pl['losses'])
     np.testing.assert_array_equal(f['params'], pl['params'])
     np.testing.assert_array_equal(f['m'], pl['m'])
   np.testing.assert_array_equal(res[0][1]['forced']['params'], res[1][1]['forced']['params'])   # replicas identical
+
+
+def _capture_failed_worker(port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from geeco_amd import dist as gdist
+  from geeco_amd import graph
+  from geeco_amd import runtime
+  from geeco_amd.params import create_e2evmc_config
+  torch.cuda.set_device(0)
+  assert gdist.init_from_env('gloo', single_rank_group=True) == 1 and gdist.group_active()
+  runtime.gdist.backend = lambda: 'nccl'          # the runner now believes the group's collectives can be captured
+  feats, labels = _batch(4)
+  model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, 'cuda:0', training=True)
+  model.store.initialize(seed=9)
+  model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
+  runner = runtime.TrainStepRunner(model, use_graph=True, warmup=1, dp=True, capture_exchange=True)
+  runner.step()                                   # eager
+  torch.cuda.synchronize()
+  step_before = int(model.store.global_step.item())
+  orig = torch.cuda.current_stream()
+  res = {'raised': None}
+  try:
+    runner.step()                                 # captures: gloo's all-reduce inside the capture fails
+  except runtime.CaptureFailed as e:
+    res.update(raised=str(e), stream_back=torch.cuda.current_stream() == orig, graphs=runner._graphs is None,
+               prepared=bool(getattr(model, '_prepared', False)))
+  q.put(res)
+  q.close()
+  q.join_thread()
+  os._exit(0)                                     # the streams of the failed capture are unusable: leave without teardown
+
+
+def test_failed_one_graph_capture_raises_capture_failed(dev):
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  p = ctx.Process(target=_capture_failed_worker, args=(35400 + os.getpid() % 1000, q))
+  p.start()
+  res = q.get(timeout=300)
+  p.join(timeout=60)
+  assert p.exitcode == 0
+  assert res['raised'] and 'one hipGraph failed' in res['raised'] and 'three_graphs' in res['raised'], res
+  assert res['stream_back'] and res['graphs'] and not res['prepared'], res
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -461,22 +461,30 @@ def test_bench_watchdog_leaves_with_the_provisional_line(tmp_path):
       "import sys, json, time, threading\n"
       "sys.path.insert(0, %r)\n"
       "import bench\n"
-      "def emit(p, phase):\n"
-      "  p['comm'] = {'status': 'WATCHDOG ' + phase}\n"
+      "def emit(p, why):\n"
+      "  p['comm'] = {'status': 'WATCHDOG ' + why}\n"
       "  print(json.dumps(p), flush=True)\n"
       "quiet = bench.Watchdog(0.2, emit); quiet.provisional = {'value': 0}; quiet.arm(); quiet.disarm()\n"
       "time.sleep(0.5)\n"
       "dog = bench.Watchdog(0.5, emit); dog.provisional = {'metric': 'm', 'value': 1.5}; dog.phase = 'trial'; dog.arm()\n"
       "threading.Event().wait(60)\n"             # the main thread 'hangs'
       "print('not reached')\n") % root
+  prog2 = prog.replace("dog = bench.Watchdog(0.5, emit)", "flag = []; threading.Timer(1.5, lambda: flag.append(1)).start(); "
+                       "dog = bench.Watchdog(45.0, emit, aborted=lambda: bool(flag))")
   t0 = __import__('time').time()
   out = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, timeout=50)
   assert out.returncode == 0 and __import__('time').time() - t0 < 30, out.stderr[-2000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1 and 'not reached' not in out.stdout
   d = json.loads(lines[0])
-  assert d['value'] == 1.5 and d['comm']['status'] == 'WATCHDOG trial'
+  assert d['value'] == 1.5 and d['comm']['status'].startswith('WATCHDOG what follows the safe form did not finish') and 'phase: trial' in d['comm']['status']
   assert 'WATCHDOG' in out.stderr and 'phase: trial' in out.stderr
+  # a peer's abort flag ends the wait long before the deadline
+  t0 = __import__('time').time()
+  out = subprocess.run([sys.executable, '-c', prog2], capture_output=True, text=True, timeout=50)
+  assert out.returncode == 0 and __import__('time').time() - t0 < 30, out.stderr[-2000:]
+  d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+  assert 'another rank gave up' in d['comm']['status'] and 'not reached' not in out.stdout
   from geeco_amd.runtime import DP_FORMS, DP_FORM_DEFAULT, dp_form_kwargs
   assert DP_FORM_DEFAULT == 'three_graphs' and dp_form_kwargs() == dict(overlap=True, capture_exchange=False)
   assert dp_form_kwargs('overlap_reserve16') == dict(overlap=True, capture_exchange=True, reserved_cus=16)
