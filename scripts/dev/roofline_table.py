@@ -8,6 +8,7 @@ The conv dispatches of a step come in a fixed order (forward conv1..conv8, then 
 conv2's dgrad is the fused conv2-dgrad + conv1-wgrad launch), which is how the two files are matched.
 """
 import json
+import os
 import sys
 
 PEAK = 157.3
@@ -39,6 +40,26 @@ def pmc_rows(path):
   return rows
 
 
+def envelope():
+  """(traffic TB/s, TFLOP/s) points of the newest committed MFMA x HBM envelope (scripts/dev/ub/mfma_envelope.hip), or None."""
+  root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'profiles')
+  for rnd in sorted(os.listdir(root), reverse=True):
+    path = os.path.join(root, rnd, 'ub_mfma_envelope.json')
+    if os.path.exists(path):
+      return json.load(open(path))['points'], 'profiles/%s/ub_mfma_envelope.json' % rnd
+  return None, None
+
+
+def attainable(points, tbs):
+  """Piecewise-linear in the traffic; flat beyond the last measured point (3.9 TB/s: nothing in the step moves more beside MFMAs)."""
+  if tbs <= points[0][0]:
+    return points[0][1]
+  for (x0, y0), (x1, y1) in zip(points, points[1:]):
+    if tbs <= x1:
+      return y0 + (y1 - y0) * (tbs - x0) / (x1 - x0)
+  return points[-1][1]
+
+
 def main(bench_path, pmc_path, tag):
   d = json.loads(open(bench_path).read().strip().splitlines()[-1])
   layers = {(r['layer'], r['op']): r for r in d['layers']}
@@ -51,15 +72,23 @@ def main(bench_path, pmc_path, tag):
         'share, HBM read / written MB per launch: `%s_pmc.txt` (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per '
         'MI355X_MICROARCH.md; PMC passes run 3-8 %% slower than unprofiled ones).\n'
         % (cfg['workload'], d['encoder_forward']['frames'], PEAK, tag, tag))
-  print('| launch | kernel | GFLOP | us alone | TFLOP/s | % of peak | us PMC | MFMA busy % | LDS conflict % | HBM read MB '
-        '| HBM written MB |')
-  print('|---|---|---|---|---|---|---|---|---|---|---|')
+  env, env_src = envelope()
+  if env:
+    print('`attainable`: what a loop of the product kernels\' SHAPE sustains beside this launch\'s HBM traffic ((read + written) MB / us '
+          'alone), interpolated from `%s` -- persistent block per CU, LDS-DMA loaders, resident B operands, one barrier per tile, no '
+          'index arithmetic; `of att.` = TFLOP/s / attainable.  It is the bound for the big persistent kernels (conv1-5); the launches '
+          'from conv6 up are latency-bound (too few tiles per CU for any steady state) and their `of att.` says how far.\n' % env_src)
+  print('| launch | kernel | GFLOP | us alone | TFLOP/s | % of peak | attainable TFLOP/s | of att. % | us PMC | MFMA busy % | LDS conflict % '
+        '| HBM read MB | HBM written MB |')
+  print('|---|---|---|---|---|---|---|---|---|---|---|---|---|')
   total = 0.0
   for key, p in zip(order, pmc):
     r = layers[key]
     total += r['us']
-    print('| %s %s | `%s` | %.2f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f |'
-          % (key[0], key[1], r['kernel'], r['flop'] / 1e9, r['us'], r['tflops'], 100 * r['frac'], p['us'], p['mfma'],
+    att = attainable(env, (p['rd'] + p['wr']) / r['us']) if env else None      # MB / us = TB/s
+    print('| %s %s | `%s` | %.2f | %.1f | %.1f | %.1f | %s | %s | %.1f | %.1f | %.1f | %.1f | %.1f |'
+          % (key[0], key[1], r['kernel'], r['flop'] / 1e9, r['us'], r['tflops'], 100 * r['frac'],
+             '%.1f' % att if att else '-', '%.1f' % (100 * r['tflops'] / att) if att else '-', p['us'], p['mfma'],
              p['ldsbc'], p['rd'], p['wr']))
   print('\nSum of the conv launches alone: %.0f us of a %.0f us step (%.1f k frames/s); the rest: input stage, decoder '
         'chain, slab reduces / split-K epilogues, Adam (`%s_step_trace.txt`).'
