@@ -22,6 +22,7 @@ the timed one).
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -276,18 +277,39 @@ def dominant_roofline(rows):
                      'share_of_conv_time': round(f['us'] / total, 4)}}
 
 
+def csrc_sha16():
+  """First 16 hex digits of the SHA-256 over the kernel sources (geeco_amd/csrc/*.hip, *.h, *.cpp, sorted by name): what a recorded
+  PMC figure is tied to (scripts/dev/pmc_roofline.py writes it beside the traffic)."""
+  import hashlib
+  h = hashlib.sha256()
+  d = os.path.join(ROOT, 'geeco_amd', 'csrc')
+  for fn in sorted(os.listdir(d)):
+    if fn.endswith(('.hip', '.h', '.cpp')):
+      h.update(fn.encode() + b'\0')
+      with open(os.path.join(d, fn), 'rb') as f:
+        h.update(f.read())
+  return h.hexdigest()[:16]
+
+
 def recorded_traffic(kname):
   """(HBM bytes per launch, where the figure comes from).  PMC counters cannot be read from inside this process, so
   this is the RECORDED measurement of the same kernel and shapes from the committed rocprofv3 PMC passes
   (profiles/rNN/pmc_roofline_kernel.json: FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide reads on gfx950,
-  + WRITE_SIZE; separate --pmc passes), newest round first, or (None, None) when there is none."""
-  for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+  + WRITE_SIZE; separate --pmc passes), newest round first, or (None, None) when there is none.  A record carries the hash of
+  the kernel sources its passes ran (``csrc_sha16``); when that is not the hash of THIS tree's sources the figure is
+  labelled STALE (it describes an earlier build of the kernels), as is a record from before the hash existed."""
+  rounds = sorted((d for d in os.listdir(os.path.join(ROOT, 'profiles')) if re.fullmatch(r'r\d+', d)), reverse=True)
+  for rnd in rounds:
     rel = os.path.join('profiles', rnd, 'pmc_roofline_kernel.json')
     try:
       with open(os.path.join(ROOT, rel)) as f:
         rec = json.load(f)
       if rec.get('kernel', '').replace(' ', '') == kname.replace(' ', ''):
-        return rec['traffic_bytes'], '%s (recorded rocprofv3 --pmc passes of this kernel at these shapes, not measured in this run)' % rel
+        have = rec.get('csrc_sha16')
+        fresh = have is not None and have == csrc_sha16()
+        return rec['traffic_bytes'], '%s (%s rocprofv3 --pmc passes of this kernel at these shapes, not measured in this run)' % (
+            rel, 'recorded' if fresh else 'STALE: recorded for %s, this run is %s;' %
+            ('kernel sources ' + have if have else 'a build from before the source hash was recorded', csrc_sha16()))
     except (OSError, ValueError, KeyError):
       pass
   return None, None

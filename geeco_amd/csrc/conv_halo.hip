@@ -1746,21 +1746,6 @@ struct FusedBottomParams {
   unsigned long long* stamps;   // -DGEECO_STAMPS builds only (scripts/dev/fused_stamps.py)
 };
 
-#ifndef FB_PRIO
-#define FB_PRIO 0     // dev: s_setprio experiments (1: upper half waves high, 2: alternating per step, 3: high while issuing MFMAs)
-#endif
-#ifndef FB_INTERLEAVE
-#define FB_INTERLEAVE 0   // 1: the filter-gradient work of a finished class rides inside the MFMA loop (measured: 484 vs 466 us); 0: after the loop
-#endif
-#ifndef FB_ABL
-#define FB_ABL 0      // dev ablations (wrong results): 1 = no LDS fragment reads, 2 = no global loads / halo stores
-#endif
-#ifndef FB_SKEW
-#define FB_SKEW 1     // dz2 halo planes of co-quad pair m start 2 m granules into their slot: staging stores 8-way -> 2-way bank conflicts
-#endif
-#ifndef FB_SCHED
-#define FB_SCHED 0    // dev: 0 = fenced groups (reads | MFMAs), 1 = compiler's own schedule, 2 = fenced steps, interleaved inside
-#endif
 constexpr int FB_WP = 14, FB_PLANE = 176, FB_XW = 67, FB_XPIECES = (10 * FB_XW + 63) / 64;
 constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 * FB_XPIECES * 64) * 16;
 
@@ -1779,7 +1764,6 @@ constexpr size_t FB_LDS_BYTES = (size_t)(9 * 32 * FB_WP + 2 * 12 * FB_PLANE + 2 
 // 805 MB per step: the kernel's largest read by far, and what its waves queue behind in the vector-memory pipe)
 template <int CREAL, bool BITS>
 __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const FusedBottomParams p) {
-  constexpr bool INTERLEAVE = FB_INTERLEAVE != 0;
   constexpr int CIN = 32, COUT = 48;
   constexpr int NT = 512;
   constexpr int COQ = COUT / 4;
@@ -1799,7 +1783,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
   // side only needs the planes of a quad PAIR (4 kb + {0, 1}, 4 kb + {2, 3}) at one phase mod 16, so pair m is skewed by
   // SKEW * m granules inside its 176-granule slot: the stores are 2-way (16 LDS cycles, under their 13-cycle issue cost)
   // and the fragment reads stay conflict free.
-  constexpr int SKEW = FB_SKEW ? 2 : 0;
+  constexpr int SKEW = 2;
   static_assert(PLANE >= PLANE_USED + SKEW * (COQ / 2 - 1) && PLANE % 16 == 0, "plane pitch");
   constexpr int HALO_USED = COQ * PLANE_USED;          // 1980 granules are loaded
   constexpr int HALO_F4 = COQ * PLANE;                 // 2112 granules per buffer
@@ -2061,45 +2045,21 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
     __builtin_amdgcn_sched_barrier(0);
     FSTAMP(tcount < 10 ? 6 * tcount + 1 : 64);
     frag(0, a_cur, b_cur);
-#if FB_PRIO == 1
-    if (half) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-#if FB_PRIO == 2
-      if (half) { if (it & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-      else      { if (it & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#elif FB_PRIO == 3
-      __builtin_amdgcn_s_setprio(0);
-#endif
-#if (FB_ABL & 1) == 0
       if (it + 1 < NIT) frag(it + 1, a_nxt, b_nxt);
-#else
-      a_nxt = a_cur; b_nxt[0] = b_cur[0]; b_nxt[1] = b_cur[1];
-#endif
-#if (FB_ABL & 2) == 0
       if (more && it >= NIT - NLOAD - 4 && it < NIT - 4) {
         const int j = it - (NIT - NLOAD - 4);
         hN[l_off[j]] = stage[j];
       }
       if (more && it < NLOAD) load_halo_i(it, n2, ty2, tx2);
       if (more && it == NLOAD) dma_x(n2, ty2, tx2, sX + (buf ^ 1) * SX_F4);
-#endif
       if constexpr (BITS) {
-#if (FB_ABL & 2) == 0
         if (more && it > NLOAD && it <= NLOAD + 4) {  // the NEXT tile's sign words: 4 x 16 B per lane
           const int m = it - NLOAD - 1;
           mbn[m >> 1][m & 1] = *reinterpret_cast<const u32x4*>(bits_row(m >> 1, n2, ty2, tx2) + 4 * (m & 1));
         }
-#endif
-        if constexpr (INTERLEAVE) {
-          if (it == 1 * KB - 1) class_x(3);           // one step before each class's filter-gradient work starts
-          if (it == 3 * KB - 1) class_x(2);
-          if (it == 5 * KB - 1) class_x(1);
-          if (it == NIT - 1) class_x(0);
-        } else if (it >= NIT - 4) {
-          class_x(it - (NIT - 4));
-        }
+        if (it >= NIT - 4) class_x(it - (NIT - 4));
       } else {
         if (it > NLOAD && it <= NLOAD + 16) {         // two mask dwords per step: (class, pixel k) of both channel tiles
           const int m = it - NLOAD - 1, c = m >> 2, k = m & 3;
@@ -2109,12 +2069,7 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
         }
         if (it >= NIT - 4) class_x(it - (NIT - 4));
       }
-#if FB_SCHED == 0
       __builtin_amdgcn_sched_barrier(0);
-#endif
-#if FB_PRIO == 3
-      __builtin_amdgcn_s_setprio(1);
-#endif
       {
         const int tap = ORDER[it / KB];
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -2126,40 +2081,15 @@ __global__ __launch_bounds__(512) void conv2_dgrad_conv1_wgrad_kernel(const Fuse
           for (int t = 0; t < 2; ++t)
             acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[t][s], acc[c][t], 0, 0, 0);
       }
-      if constexpr (BITS && INTERLEAVE) {
-        // classes 3 / 2 / 1 are complete after taps 1 / 3 / 5 of ORDER: their filter gradient rides on the next 4 steps
-        constexpr int S3 = 1 * KB, S2 = 3 * KB, S1 = 5 * KB;
-        if (it == S3) class_mask(3);
-        if (it >= S3 && it < S3 + 4) class_mfma(3, it - S3);
-        if (it == S2) class_mask(2);
-        if (it >= S2 && it < S2 + 4) class_mfma(2, it - S2);
-        if (it == S1) class_mask(1);
-        if (it >= S1 && it < S1 + 4) class_mfma(1, it - S1);
-      }
-#if FB_SCHED == 2
-      // one MFMA, then at most one LDS op, one global load and two VALU ops in its shadow
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      }
-#endif
-#if FB_SCHED != 1
       __builtin_amdgcn_sched_barrier(0);
-#endif
       a_cur = a_nxt;
       b_cur[0] = b_nxt[0];
       b_cur[1] = b_nxt[1];
     }
-#if FB_PRIO != 0
-    __builtin_amdgcn_s_setprio(0);
-#endif
     FSTAMP(tcount < 10 ? 6 * tcount + 2 : 64);
     // ---- the classes still open: ReluGrad, then conv1's filter gradient straight from the accumulators ----------
 #pragma unroll
-    for (int c = (BITS && INTERLEAVE ? 0 : 3); c >= 0; --c) {     // same class order (3, 2, 1, 0) everywhere: bitwise equal sums
+    for (int c = 3; c >= 0; --c) {     // class order 3, 2, 1, 0 (the filter-gradient work of a finished class INSIDE the MFMA loop measured 484 vs 466 us: profiles/NEGATIVE_RESULTS.md)
       class_mask(c);
 #pragma unroll
       for (int s = 0; s < 4; ++s) class_mfma(c, s);

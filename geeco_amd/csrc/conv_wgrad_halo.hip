@@ -34,9 +34,6 @@ static __device__ float g_zero_page[64];   // source of the DMA lanes that fall 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-#ifndef WL_ABL
-#define WL_ABL 0   // dev ablations (timing only, wrong results): 1 = no DMA inside the tile loop, 2 = no MFMAs
-#endif
 
 struct WgradHaloParams {
   const float* x;
@@ -216,9 +213,7 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
     // 0.4 % slower here.)
     if (more) {
       advance(n2, ty2, tx2);
-#if WL_ABL != 1
       if (NBUF == 2) dma_tile(buf ^ 1, n2, ty2, tx2);     // lands behind this tile's MFMAs
-#endif
     }
     if (cib == 0) {                                       // only the first ci block's slab carries the bias gradient (the others' sums
                                                           // were 8 VALU adds + 2 LDS reads per tile for nothing: -2...-3 us per step)
@@ -250,11 +245,7 @@ __global__ __launch_bounds__(64 * NCI * NCO, MINW) void conv_s2_wgrad_lds_kernel
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < COT; ++i)
-#if WL_ABL == 2
-          acc[t][i][0] += a[u & 1][i] * b[u & 1][t];
-#else
           acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u & 1][i], b[u & 1][t], acc[t][i], 0, 0, 0);
-#endif
     }
     if (NBUF == 2) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");

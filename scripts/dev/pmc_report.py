@@ -18,7 +18,7 @@ D = durations(1)
 ids = list(P[0].keys())
 adam = [i for i in ids if P[0][i]['name'].startswith('adam_kernel')]
 lo, hi = adam[-2], adam[-1]
-print('%-34s %8s %6s %6s %6s %6s %7s %8s %8s %6s %6s' % ('kernel', 'us', 'mfma%', 'wait%', 'winst%', 'valu%', 'ldsbc%', 'rdMB', 'wrMB', 'GB/s', 'clkGHz'))
+print('%-34s %8s %6s %6s %6s %6s %7s %8s %8s %6s %6s' % ('kernel', 'us', 'mfma%', 'wait%', 'winst%', 'valu%', 'ldsbc%', 'rdMB', 'wrMB', 'TB/s', 'clkGHz'))
 for i in ids:
   if not (lo < i <= hi): continue
   a = P[0][i]
@@ -32,7 +32,8 @@ for i in ids:
   gui = b.get('GRBM_GUI_ACTIVE', 0)
   # MFMA busy cycles are per-SIMD cycles summed; utilisation vs (busy cycles * 4 SIMD * CUs)? use ratio to wave cycles*4 as rough
   mf = a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0)
-  print('%-34s %8.1f %6.1f %6.1f %6.1f %6.1f %7.2f %8.1f %8.1f %6.0f %6.2f' % (
+  print('%-34s %8.1f %6.1f %6.1f %6.1f %6.1f %7.2f %8.1f %8.1f %6.2f %6.2f' % (
       a['name'][:34], us, 100 * mf / (us * 1e-6 * 2.4e9 * 1024) if us else 0, 100 * a.get('SQ_WAIT_ANY', 0) / wc, 100 * a.get('SQ_WAIT_INST_ANY', 0) / wc,
       100 * a.get('SQ_ACTIVE_INST_VALU', 0) / wc, 100 * a.get('SQ_LDS_BANK_CONFLICT', 0) / max(a.get('SQ_LDS_IDX_ACTIVE', 1), 1),
-      rd, wr, (rd + wr) / us * 1e-3 * 1e6 / 1e3 if us else 0, gui / 8 / (us * 1e3) if us else 0))
+      rd, wr, (rd + wr) / us if us else 0,      # MB / us = TB/s
+       gui / 8 / (us * 1e3) if us else 0))

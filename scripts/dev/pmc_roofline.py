@@ -2,7 +2,8 @@
 bench.py names in `roofline`, averaged over its launches in ONE step.  FETCH_SIZE is doubled (gfx950 reports half the
 bytes of wide coalesced reads: MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is; both in KiB units -> bytes.
 usage: pmc_roofline.py <pmc dir> "<kernel name>" <out.json>"""
-import csv, json, re, sys, collections
+import csv, json, os, re, sys, collections
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 d, kname, out = sys.argv[1], sys.argv[2], sys.argv[3]
 def load(i):
   o = collections.OrderedDict()
@@ -21,6 +22,7 @@ rd = [F[i].get('FETCH_SIZE', 0) * 1024 * 2 for i in sel]
 wr = [W.get(i, {}).get('WRITE_SIZE', 0) * 1024 for i in sel]
 rec = {'kernel': kname, 'launches_in_step': len(sel), 'fetch_bytes_x2': rd, 'write_bytes': wr,
        'traffic_bytes': int((sum(rd) + sum(wr)) / len(sel)),
+       'csrc_sha16': __import__('bench').csrc_sha16(),      # the kernel sources these passes ran: bench.py calls the figure stale for any other
        'method': 'rocprofv3 --pmc, separate passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE x 2 (gfx950 wide-read correction)'}
 json.dump(rec, open(out, 'w'), indent=1)
 print(rec)
