@@ -1,7 +1,8 @@
 #!/bin/bash
-# copies the set round_final.sh left under gpurun_out/r5final into profiles/r05/final_* (run here, after the gpurun call)
+# copies the set round_final.sh left under gpurun_out/<tag> into profiles/<round>/final_* (run here, after the gpurun call)
+#   usage: copy_final.sh [tag = r6final] [round = r06]
 set -e
-S=gpurun_out/r5final; D=profiles/r05
+S=gpurun_out/${1:-r6final}; D=profiles/${2:-r06}; mkdir -p $D
 cp $S/bench.json $D/final_bench.json
 cp $S/bench_driver_flags.json $D/final_bench_driver_flags.json
 cp $S/sprof/r1_kernel_stats.csv $D/final_kernel_stats.csv

@@ -28,7 +28,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 // IN: 1 KiB DMA pieces per tile and block; OUT: 1 KiB store pieces per tile and block (multiple of 4); RD: MFMAs per ds_read_b128;
 // STORE: 0 none, 1 by the K-half-0 compute waves (with the K-half reduction through LDS), 2 by the loader waves
-template <int IN, int OUT, int RD, int STORE, int LW, int GEOM = 0, int SLEEP = 0>
+template <int IN, int OUT, int RD, int STORE, int LW, int GEOM = 0, int SLEEP = 0, int NMF = 108>
 __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ big, long long big_f4, f32x4* __restrict__ outbuf, long long out_f4,
                                                      const float* __restrict__ wsrc, float* sink, unsigned long long* clk, int tiles, unsigned* fields) {
   constexpr int NBUF = 3;
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
   constexpr int NSLOT = (IN + LW - 1) / LW;                  // DMA pieces per loader wave and tile
   constexpr int OSLOT_L = (OUT + LW - 1) / LW;               // store pieces per loader wave and tile (STORE == 2)
   constexpr int OSLOT_C = OUT / 4;                           // store pieces per K-half-0 compute wave and tile (STORE == 1)
-  constexpr int NGRP = 108 / RD;                             // A-operand reads per wave and tile
-  static_assert(108 % RD == 0 && RD % 4 == 0, "RD divides 108 and is a multiple of the 4 k-steps of one read");
+  constexpr int NGRP = NMF / RD;                             // A-operand reads per wave and tile (NMF = 108: conv2's MFMA count; fewer: how much can a CU ingest?)
+  static_assert(NMF % RD == 0 && RD % 4 == 0, "RD divides 108 and is a multiple of the 4 k-steps of one read");
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
   f32x4* sH = lds;                                           // NBUF images
   f32x4* sR = lds + NBUF * IMG_F4;                           // 2 x (4 strips x 3 x 64) partial sums
@@ -222,13 +222,14 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
   sink[blockIdx.x * 512 + tid] = keep.x + keep.y + keep.z + keep.w;
 }
 
-template <int IN, int OUT, int RD, int STORE, int LW, int GEOM = 0, int SLEEP = 0>
+template <int IN, int OUT, int RD, int STORE, int LW, int GEOM = 0, int SLEEP = 0, int NMF = 108>
 void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, const float* wsrc, float* sink, unsigned long long* clk, int tiles) {
   static unsigned* fields = nullptr;
   if (!fields) hipMalloc(&fields, 128ll * 128 * 128 * 8);
   constexpr int IMG_F4 = (IN > 16 ? IN : 16) * 64;
   const size_t ldsb = (size_t)(3 * IMG_F4 + 2 * 768 + 4 * 16 * 13) * 16;
-  auto kern = env<IN, OUT, RD, STORE, LW, GEOM, SLEEP>;
+  auto kern = env<IN, OUT, RD, STORE, LW, GEOM, SLEEP, NMF>;
+  if (NMF != 108) printf("%d MFMAs per wave and tile: ", NMF);
   if (SLEEP) printf("loaders sleep %d x 64 cycles behind the barrier: ", SLEEP);
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -240,7 +241,7 @@ void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, co
   unsigned long long h[512]; hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
   double cyc = 0, real = 0;
   for (int i = 0; i < 256; ++i) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
-  const double tf = 108.0 * 2048.0 * 8 * 256 * tiles / (ms * 1e-3) / 1e12;
+  const double tf = (double)NMF * 2048.0 * 8 * 256 * tiles / (ms * 1e-3) / 1e12;
   const double rd = (double)IN * 1024 * 256 * tiles / (ms * 1e-3) / 1e12, wr = (STORE ? (double)OUT : 0.0) * 1024 * 256 * tiles / (ms * 1e-3) / 1e12;
   printf("%sin %2d KiB out %2d KiB per tile | 1 ds_read per %2d MFMAs | stores %-14s | %6.1f TFLOP/s = %4.1f %% | %5.2f + %4.2f = %5.2f TB/s | %.3f GHz | tile %5.0f cycles\n",
          GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
@@ -281,6 +282,12 @@ int main() {
     run<40, 12, 12, 1, 4, 3>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, 96);
     run<40, 12, 12, 1, 4, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 5>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    // how many bytes per clock can a CU take in through LDS-DMA when the MFMA stream is short?  (conv2's filter gradient needs 51 KiB per
+    // 6.9 k cycles of MFMA = 7.4 B/clk to be matrix-bound)
+    run<40, 12, 12, 0, 4, 0, 0, 72>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 0, 4, 0, 0, 36>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 0, 4, 0, 0, 12>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 0, 4, 1, 0, 12>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 2, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 2, 8>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 2, 16>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
