@@ -222,6 +222,63 @@ def test_lstm_cell_tf_published_vector(dev):
   np.testing.assert_allclose(new_state, TF_BASIC_LSTM_STATE, atol=2e-6, rtol=0)       # fp32 against the eight-digit literals
 
 
+def test_conv3x3_same_padding_tf_published_vectors(dev):
+  """TF 1.15's own conv_ops_test.py vectors for padding='SAME' with strides (tests/test_oracle_kat.py has the literals) through
+  geeco_conv3x3_fwd.  The entry point is 3 x 3 only, so TF's 2 x 2 filters sit inside a 3 x 3 kernel whose other taps are zero, at the
+  position where the 3 x 3 SAME window covers the pixels TF's 2 x 2 SAME window covers:
+    * stride 3 on 4 x 4 (testConv2DKernelSmallerThanStrideSame): 3 x 3 pads (1, 1), its window for output o starts at 3 o - 1; TF's
+      2 x 2 pads (0, 1), window starts at 3 o -> the filter goes to kernel rows / columns 1..2;
+    * stride 2 on 2 x 3 (testConv2D2x2FilterStride2Same): rows -- 3 x 3 pads (0, 1), 2 x 2 pads (0, 0): kernel rows 0..1; columns --
+      3 x 3 pads (1, 1), 2 x 2 pads (0, 1): kernel columns 1..2.
+  Channels are zero-padded to the entry point's multiples (Cin 4, Cout 16).  Exact: small integers in fp32."""
+  from geeco_amd import ops
+  from test_oracle_kat import TF_CONV_SAME_CASES, tf_running_numbers
+  for (in_sizes, f_sizes, stride, expected), (r0, c0) in ((TF_CONV_SAME_CASES[3], (1, 1)), (TF_CONV_SAME_CASES[0], (0, 1))):
+    _, H, W, C = in_sizes
+    kh, kw, _, Co = f_sizes
+    x = torch.zeros(1, H, W, 4)
+    x[..., :C] = tf_running_numbers(in_sizes, torch.float32)
+    w = torch.zeros(3, 3, 4, 16)
+    w[r0:r0 + kh, c0:c0 + kw, :C, :Co] = tf_running_numbers(f_sizes, torch.float32)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y = torch.full((1, Ho, Wo, 16), float('nan'), device=dev)
+    xd, wd, bd = x.to(dev), w.to(dev), torch.zeros(16, device=dev)
+    ws = ops._ws(ops.conv3x3_fwd_ws_bytes(1, 1, H, W, 4, 16, stride), dev)
+    ops.conv3x3_fwd_into(y, xd, wd, bd, 1, 0, 0, 0, 0, 1, H, W, 4, 16, stride, relu=False, ws=ws)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y[..., :Co].reshape(-1).cpu().numpy(), expected)
+    assert not y[..., Co:].any()
+
+
+def test_losses_tf_published_values(dev):
+  """tf.losses.mean_squared_error / softmax_cross_entropy values TF 1.15's own losses_test.py publishes (49.5; 10.0 to three places)
+  through the HIP decoder tail (geeco_heads_loss_fwd_bwd): fc1 = identity, head kernels = the first rows of the identity, zero biases,
+  so that the heads' predictions ARE the first entries of a non-negative h.  Pins "mean over all elements" (MSE) and "mean over the
+  batch" of one-hot cross entropy (labels = rint(cmd[:, 3]) + 1, estimator.py:208-210) in the HIP path itself."""
+  from geeco_amd import ops
+  from test_oracle_kat import (TF_MSE_LABELS, TF_MSE_LOSS, TF_MSE_PREDICTIONS, TF_XENT_LOGITS, TF_XENT_WRONG_CLASSES, TF_XENT_WRONG_LOSS)
+  H = F = 128
+  for kind, preds_in, target, expected, tol in (
+      (0, TF_MSE_PREDICTIONS, torch.tensor(TF_MSE_LABELS), TF_MSE_LOSS, 1e-5),
+      (1, TF_XENT_LOGITS, torch.tensor(TF_XENT_WRONG_CLASSES, dtype=torch.float32).reshape(-1, 1) - 1.0, TF_XENT_WRONG_LOSS, 5e-4)):
+    N = len(preds_in)
+    h = torch.zeros(N, H)
+    h[:, :3] = torch.tensor(preds_in)
+    w1, b1 = torch.eye(H, F), torch.zeros(F)
+    hw, hb = torch.zeros(F, 3), torch.zeros(3)
+    hw[:3, :3] = torch.eye(3)
+    d = lambda t: t.to(dev).contiguous()
+    preds, losses = torch.empty(N, 3, device=dev), torch.zeros(8, device=dev)
+    ws = torch.empty(ops.heads_ws_bytes(N, H, F) // 4 + 4, device=dev)
+    ops.heads_loss_into(preds, losses, d(h), d(w1), d(b1), [d(hw)], [d(hb)], [3], [kind], [1.0], [d(target)], [target.shape[1]], 1.0, N, H,
+                        F, ws)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(preds.cpu().numpy(), preds_in, rtol=0, atol=1e-6)
+    assert abs(float(losses[1]) - expected) <= tol and abs(float(losses[0]) - expected) <= tol, (kind, losses[:2].tolist())
+    if kind == 1:
+      assert abs(float(losses[1]) - 10.0000908) < 2e-5
+
+
 # fc1 + heads + losses (+ gradients): one workgroup per sample + a few blocks for the sums over the batch (H <= 128, Hfc 64 / 128);
 # other widths run the single-workgroup kernel; both against the oracle's decoder tail differentiated by autograd in fp64.
 @pytest.mark.parametrize('N,mode,H,F', [(1, 'cartesian', 128, 128), (7, 'cartesian', 128, 128), (32, 'cartesian', 128, 128),

@@ -276,3 +276,59 @@ def test_lstm_cell_reproduces_the_vector_tf_publishes():
   # forget_bias = 0 is NOT the published vector
   c1_0, _ = O.lstm_cell(x, state[:, 0:2], state[:, 2:4], kernel, bias, forget_bias=0.0)
   assert abs(float(c1_0[0, 0]) - TF_BASIC_LSTM_STATE[0][0]) > TF_BASIC_LSTM_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# More vectors TensorFlow itself wrote (literals of its own unit tests, TF 1.15; inputs there are "running numbers from 1" in
+# NHWC / HWIO order).  They pin exactly the conventions SURVEY 8c lists as "from source knowledge":
+#   * tensorflow/python/kernel_tests/conv_ops_test.py: testConv2D2x2FilterStride2Same, testConv2DKernelSmallerThanStrideSame
+#     (three cases), testConv2D1x1Filter -> padding='SAME' puts the odd pad element AFTER (bottom / right), out = ceil(in / s);
+#   * tensorflow/python/kernel_tests/losses_test.py: MeanSquaredErrorTest.testNonZeroLoss (49.5) -> mean over ALL elements;
+#     SoftmaxCrossEntropyLossTest.testAllWrong (10.0 to 3 places) / testAllCorrect (0) -> mean over the batch, one-hot labels.
+# The oracle's conv2d_same / same_pad take any kernel size, so TF's 1 x 1 and 2 x 2 cases go through it as published; the HIP
+# path (3 x 3 only) runs the stride-2 and stride-3 cases with the filter embedded in a 3 x 3 kernel (tests/test_kernels_gpu.py).
+# ----------------------------------------------------------------------------------------------------------------------
+TF_CONV_SAME_CASES = [      # (input sizes NHWC, filter sizes HWIO, stride, expected output flattened NHWC)
+    ([1, 2, 3, 3], [2, 2, 3, 3], 2, [2271.0, 2367.0, 2463.0, 1230.0, 1305.0, 1380.0]),      # testConv2D2x2FilterStride2Same
+    ([1, 3, 3, 1], [1, 1, 1, 1], 2, [1.0, 3.0, 7.0, 9.0]),                                    # testConv2DKernelSmallerThanStrideSame
+    ([1, 4, 4, 1], [1, 1, 1, 1], 2, [1.0, 3.0, 9.0, 11.0]),
+    ([1, 4, 4, 1], [2, 2, 1, 1], 3, [44.0, 28.0, 41.0, 16.0]),
+    ([1, 2, 3, 3], [1, 1, 3, 3], 1, [30.0, 36.0, 42.0, 66.0, 81.0, 96.0, 102.0, 126.0, 150.0, 138.0, 171.0, 204.0, 174.0, 216.0,
+                                      258.0, 210.0, 261.0, 312.0]),                          # testConv2D1x1Filter (SAME == VALID for 1 x 1)
+]
+TF_MSE_PREDICTIONS = [[4.0, 8.0, 12.0], [8.0, 1.0, 3.0]]       # MeanSquaredErrorTest
+TF_MSE_LABELS = [[1.0, 9.0, 2.0], [-5.0, -2.0, 6.0]]
+TF_MSE_LOSS = 49.5
+TF_XENT_LOGITS = [[10.0, 0.0, 0.0], [0.0, 10.0, 0.0], [0.0, 0.0, 10.0]]      # SoftmaxCrossEntropyLossTest
+TF_XENT_WRONG_CLASSES = [2, 0, 1]       # one-hot rows [0,0,1], [1,0,0], [0,1,0]
+TF_XENT_WRONG_LOSS = 10.0               # assertAlmostEqual(..., 10.0, 3): exact value ln(e^10 + 2) = 10.0000908
+
+
+def tf_running_numbers(sizes, dtype=torch.float64):
+  n = int(np.prod(sizes))
+  return torch.arange(1, n + 1, dtype=dtype).reshape(sizes)
+
+
+def test_conv_same_reproduces_the_vectors_tf_publishes():
+  for in_sizes, f_sizes, stride, expected in TF_CONV_SAME_CASES:
+    x, w = tf_running_numbers(in_sizes), tf_running_numbers(f_sizes)
+    y = O.conv2d_same(x, w, torch.zeros(f_sizes[3], dtype=torch.float64), stride, relu=False)
+    assert list(y.shape[1:3]) == [-(-in_sizes[1] // stride), -(-in_sizes[2] // stride)]
+    np.testing.assert_array_equal(y.reshape(-1).numpy(), expected)
+  # the convention the stride-2 layers of the encoder depend on, said out loud: even input, 3 x 3, stride 2 -> (0 before, 1 after);
+  # TF's 2 x 2 / stride 3 case on 4 pixels has the same (0, 1) split, its 2 x 2 / stride 2 case on 3 columns too
+  assert O.same_pad(4, 2, 3) == (2, 0, 1) and O.same_pad(3, 2, 2) == (2, 0, 1) and O.same_pad(256, 3, 2) == (128, 0, 1)
+  # the PyTorch convention (pad 1 before) gives a different answer on TF's stride-3 case
+  x, w = tf_running_numbers([1, 4, 4, 1]), tf_running_numbers([2, 2, 1, 1])
+  wrong = torch.nn.functional.conv2d(torch.nn.functional.pad(x.permute(0, 3, 1, 2), (1, 0, 1, 0)), w.permute(3, 2, 0, 1), stride=3)
+  assert wrong.reshape(-1).tolist() != [44.0, 28.0, 41.0, 16.0]
+
+
+def test_losses_reproduce_the_values_tf_publishes():
+  pred, lab = torch.tensor(TF_MSE_PREDICTIONS, dtype=torch.float64), torch.tensor(TF_MSE_LABELS, dtype=torch.float64)
+  assert float(O.mse(pred, lab)) == TF_MSE_LOSS                      # 297 / 6: a mean over the batch alone would give 148.5
+  logits = torch.tensor(TF_XENT_LOGITS, dtype=torch.float64)
+  wrong = float(O.softmax_xent(logits, torch.tensor(TF_XENT_WRONG_CLASSES), 3))
+  assert abs(wrong - TF_XENT_WRONG_LOSS) < 5e-4 and abs(wrong - math.log(math.exp(10.0) + 2.0)) < 1e-12      # a sum over the batch: 30
+  right = float(O.softmax_xent(10.0 * logits, torch.tensor([0, 1, 2]), 3))      # testAllCorrect: logits +-100 -> 0.0 to 3 places
+  assert abs(right) < 5e-4
