@@ -1067,12 +1067,16 @@ def main():
   safe_form = 'three_graphs_serial' if args.dp_serial else 'three_graphs'
   r = timed_steps(model, args.steps, args.warmup, not args.no_graph, world, dev, form=safe_form)
   first_loss = r['first_loss']
-  form, full, trial, dog, comm = safe_form, {}, {}, None, None
+  form, full, trial, dog, comm, identical = safe_form, {}, {}, None, None, {}
   log('timed region: %d steps in %.3f s' % (args.steps, r['dt']))
   if world > 1:
     from geeco_amd.runtime import pick_dp_runner
     ms = r['dt'] / args.steps * 1e3
     full[safe_form] = round(ms, 4)
+    # the replicas must be bitwise identical after any number of steps: the cheapest check there is that the exchange did its job
+    identical = {safe_form: gdist.replicas_identical(model.store)}
+    if not identical[safe_form]:
+      log('ERROR: the replicas differ after the safe form\'s steps: the gradient exchange is broken; the line below reports it')
     log('N = %d, safe form (%s: exchange launched between three graphs): %.4f ms/step = %.1f frames/s (max over ranks, %d timed steps)'
         % (world, safe_form, ms, world * args.batch * args.seq_len * args.steps / r['dt'], args.steps))
 
@@ -1102,7 +1106,10 @@ def main():
           # (a form on a backend that cannot capture -- gloo rehearsal -- is the three-graph form under another name: bucket_info says so)
           full[best] = round(r2['dt'] / args.steps * 1e3, 4)
           log('N = %d, form %s: %.4f ms/step in full' % (world, best, full[best]))
-          if r2['dt'] < r['dt']:
+          identical[best] = gdist.replicas_identical(model.store)
+          if not identical[best]:
+            log('ERROR: the replicas differ after the steps of form %s: its measurement is discarded, the safe form is reported' % best)
+          if r2['dt'] < r['dt'] and identical[best]:
             r, form = r2, best
             if rank == 0:
               dog.provisional = headline(r, form)[0]
@@ -1127,9 +1134,12 @@ def main():
     out, ok = headline(r, form)
     if not ok:
       rc = 4
+    if world > 1 and not all(identical.values()):
+      rc = 5
     if world > 1:
       comm = comm or {'status': 'skipped'}
       comm['timed_form'] = form
+      comm['replicas_bit_identical_after'] = identical
       comm['forms_timed_in_full_ms'] = full
       comm['trial_ms'] = {k: round(v, 4) for k, v in trial.items()} or None
       comm['order'] = ('safe form (%s) in full -> short trial of the one-graph forms -> the fastest of them in full if the trial '

@@ -128,6 +128,21 @@ def gather_floats(value: float, device):
   return [float(o.item()) for o in out]
 
 
+def replicas_identical(store) -> bool:
+  """True when parameters, Adam slots and step counter are BITWISE the same on every rank -- what data parallelism with a
+  summed gradient and a deterministic optimiser guarantees after any number of steps, and what a broken exchange (a bucket that
+  raced its producer, a rank that skipped a collective) destroys.  A 64-bit checksum per arena (sum of the raw words; order
+  independent, computed on the device), gathered over the ranks; one small collective."""
+  if world_size() == 1:
+    return True
+  sums = torch.stack([t.detach().view(torch.int32).sum(dtype=torch.int64) for t in (store.params, store.adam_m, store.adam_v)] +
+                     [store.global_step.detach().reshape(-1)[0].to(torch.int64)])
+  sums = sums.to(_coll_device(store.params.device))
+  out = [torch.zeros_like(sums) for _ in range(world_size())]
+  dist.all_gather(out, sums)
+  return all(torch.equal(o, out[0]) for o in out)
+
+
 def gather_strings(value: str, device, width=96):
   """Every rank's short string (a device identity), in rank order, on every rank."""
   if world_size() == 1:

@@ -470,6 +470,11 @@ class Estimator:
       torch.cuda.synchronize()
       for sp, _, _ in self._specs.values():      # a device-side error of any model that ran this epoch (input-stage timeout)
         sp.model.check_device_errors()
+    if nsteps and world > 1 and not gdist.replicas_identical(self._store):
+      # data parallel: summed gradients + a deterministic optimiser keep every replica bitwise equal; if they are not, the exchange
+      # lost or raced something and rank 0's checkpoint would be one replica's opinion
+      raise RuntimeError('geeco_amd: the replicas differ after %d data-parallel steps (rank %d): the gradient exchange is broken '
+                         '(dp_form=%s); nothing was saved' % (nsteps, rank, getattr(self.config, 'dp_form', None) or 'three_graphs'))
     # wall time of the input + step loop alone (the checkpoint written below is not part of the data path)
     self.last_train_stats = {'steps': nsteps, 'loop_seconds': time.time() - t0}
     if nsteps and rank == 0 and self.model_dir:

@@ -83,6 +83,7 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   # gloo's collectives cannot be captured: every one-graph form of this rehearsal is the three-graph form, decided before
   # anything is captured (TrainStepRunner._capture; RCCL one-graph forms: tests/test_dp_gpu.py)
   assert 'cannot be captured into a hipGraph' in out.stderr
+  assert c['replicas_bit_identical_after'] and all(c['replicas_bit_identical_after'].values()), c['replicas_bit_identical_after']
   assert 'rccl' in c            # (gloo rehearsal: whatever RCCL logged, or the reason there is no log)
   assert set(c['graphs_per_step'].values()) == {3} and d['config']['graphs_per_step'] == 3
   assert all(v > 0 for v in c['step_ms'].values()) and 'reserve_gain_ms' in c

@@ -337,6 +337,49 @@ def test_host_rendezvous_all_ranks_leave_together(world):
   assert min(a for _, a, _ in res) < last_arrival - 1.0            # (the others really did wait)
 
 
+# ----------------------------------------------------------------------------------------------------
+# bench.py's guard for the first N > 1 run: after any number of data-parallel steps the replicas are BITWISE identical
+# (dist.replicas_identical: a checksum per arena, gathered); one differing word on one rank must show.
+# ----------------------------------------------------------------------------------------------------
+def _replica_worker(rank, world, port, q):
+  sys.path.insert(0, ROOT)
+  os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  from geeco_amd import dist as gdist
+  from geeco_amd.variables import VariableStore
+  assert gdist.init_from_env('gloo') == world
+  st = VariableStore({'a/kernel': (3, 3, 4, 16), 'a/bias': (16,), 'b/kernel': (40, 8)}, 'cpu')
+  st.initialize(seed=3)
+  out = [gdist.replicas_identical(st)]
+  if rank == world - 1:
+    st.adam_v[17] = 1e-30                 # one word of one slot on one rank
+  out.append(gdist.replicas_identical(st))
+  if rank == world - 1:
+    st.adam_v[17] = 0.0
+    st.global_step += 1                   # a rank that took a step the others did not
+  out.append(gdist.replicas_identical(st))
+  if rank == world - 1:
+    st.global_step -= 1
+  out.append(gdist.replicas_identical(st))
+  dist.barrier()
+  dist.destroy_process_group()
+  q.put((rank, out))
+
+
+def test_replicas_identical_sees_one_differing_word():
+  world = 3
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 30150 + os.getpid() % 40
+  procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = sorted(q.get(timeout=120) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert all(out == [True, False, False, True] for _, out in res), res      # and every rank reaches the same verdict
+
+
 def test_host_rendezvous_without_a_group_returns():
   sys.path.insert(0, ROOT)
   from geeco_amd import dist as gdist
