@@ -23,6 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// in-kernel timeline (as conv_halo.hip's HSTAMP): [block][K half][64] s_memtime of lane 0 of waves 0 and 4, six stamps per tile for the first ten tiles
+__device__ unsigned long long g_stamps[256 * 2 * 64];
+#define ESTAMP(i) do { if (NMF == 107 + 1 && GEOM >= 2 && STORE != 2 && lane == 0 && (wid & 3) == 0 && (i) < 64) g_stamps[(blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -146,9 +150,14 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
   f32x4 keep = {0.f, 0.f, 0.f, 0.f};
   long long opos = 0;
   int cn = blockIdx.x, cty = 0, ctx = 0;
+  [[maybe_unused]] int pn = 0, pty = 0, ptx = 0;
+  [[maybe_unused]] f32x4 prev[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  [[maybe_unused]] unsigned dfield = 0;
   asm volatile("s_barrier" ::: "memory");
   int buf = 0;
   for (int t = 0; t < tiles; ++t) {
+    ESTAMP(t < 10 ? 6 * t + 0 : 64);
+    ESTAMP(t < 10 ? 6 * t + 1 : 64);
     f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const f32x4* hA = sH + buf * IMG_F4;
     // group g reads its A operand at a position that changes with group, strip and lane (conflict-free: consecutive lanes, consecutive
@@ -156,9 +165,38 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
     const f32x4* hW = hA + (strip * 2 + khalf) * 64 + lane;
     auto frag = [&](int g) { return hW[((g * 512) % (IMG_F4 - 511)) & ~63]; };
     f32x4 a_cur = frag(0), a_nxt = a_cur;
+    // STORE == 4: DEFERRED epilogue -- the K-half-0 wave keeps tile t - 1's accumulators (`prev`) and finishes that tile from INSIDE
+    // tile t's MFMA loop, a piece per group: both waves of a SIMD enter their MFMA loops right behind the barrier (the matrix pipe
+    // never waits for an epilogue), and a store that is held behind MFMAs (finding 13) holds nothing up
+    [[maybe_unused]] f32x4 dv[3];
+    [[maybe_unused]] f32x4* dso = sR + 2 * 768 + strip * 16 * 13;
+    [[maybe_unused]] const long long dpix = ((long long)(pn & 127) * 128 + pty * 4 + strip) * 128 + ptx * 16;
+    auto deferred = [&](int g) {
+      if (STORE != 4 || khalf != 0 || t == 0) return;
+      const int r = lane & 15, q = lane >> 4;
+      const f32x4* red = sR + ((t - 1) & 1) * 768;
+      if (g >= 1 && g <= 3) {                      // one output tile per group: partner's partial sums, bias, ReLU, into the staging
+        const int i = g - 1;
+        f32x4 v = prev[i] + red[(strip * 3 + i) * 64 + lane] + wreg[i][0];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        dso[r * 13 + 4 * i + q] = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dfield |= min(__float_as_uint(v[j]), 1u) << (4 * i + j);
+      }
+      if (g == 4) {
+        reinterpret_cast<unsigned short*>(fields)[(dpix + r) * 4 + q] = (unsigned short)dfield;
+        dfield = 0;
+      }
+      if (g >= 5 && g <= 7) {                      // one 1 KiB store per group
+        const int m = lane + 64 * (g - 5);
+        const int px = m / 12, c4 = m - px * 12;
+        __builtin_nontemporal_store(dso[px * 13 + c4], outbuf + dpix * 12 + m);
+      }
+    };
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
       if (g + 1 < NGRP) a_nxt = frag(g + 1);
+      deferred(g);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < RD; ++m) {
@@ -168,13 +206,66 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
       __builtin_amdgcn_sched_barrier(0);
       a_cur = a_nxt;
     }
-    if (STORE == 1) {
+    ESTAMP(t < 10 ? 6 * t + 2 : 64);
+    if (STORE == 4) {
+      f32x4* red = sR + (t & 1) * 768;
+      if (khalf == 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) red[(strip * 3 + i) * 64 + lane] = acc[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) prev[i] = acc[i];
+        pn = cn; pty = cty; ptx = ctx;
+      }
+      ESTAMP(t < 10 ? 6 * t + 3 : 64);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ESTAMP(t < 10 ? 6 * t + 4 : 64);
+    } else if (STORE == 3) {
+      // SPLIT EPILOGUE: both waves of a SIMD finish the tile together and each finalises HALF of the strip (pixels r < 8: the K-half-0
+      // wave, r >= 8: its partner): a lane sends its partial sums of the pixels it does not own through LDS and receives the partner's for
+      // the ones it owns; both waves then run bias / ReLU / sign words / transposition / stores at the same time -- no store of one wave
+      // sits behind the other wave's MFMA stream (finding 13), and the two MFMA loops that follow run INTERLEAVED on the SIMD
+      f32x4* red = sR + (t & 1) * 768;
+      const int r = lane & 15, q = lane >> 4;
+      const bool mine = (r < 8) == (khalf == 0);
+      if (!mine) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) red[(strip * 3 + i) * 64 + lane] = acc[i];
+      }
+      ESTAMP(t < 10 ? 6 * t + 3 : 64);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ESTAMP(t < 10 ? 6 * t + 4 : 64);
+      f32x4* so = sR + 2 * 768 + (strip * 2 + khalf) * 8 * 13;
+      const long long pix = ((long long)(cn & 127) * 128 + cty * 4 + strip) * 128 + ctx * 16 + 8 * khalf;
+      if (mine) {
+        unsigned field = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          f32x4 v = acc[i] + red[(strip * 3 + i) * 64 + lane] + wreg[i][0];
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          so[(r & 7) * 13 + 4 * i + q] = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) field |= min(__float_as_uint(v[j]), 1u) << (4 * i + j);
+        }
+        reinterpret_cast<unsigned short*>(fields)[(pix + (r & 7)) * 4 + q] = (unsigned short)field;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {          // the wave's 8 pixels x 192 bytes = 1.5 KiB of consecutive bytes
+        const int m = lane + 64 * jj;
+        if (m < 96) {
+          const int px = m / 12, c4 = m - px * 12;
+          __builtin_nontemporal_store(so[px * 13 + c4], outbuf + pix * 12 + m);
+        }
+      }
+    } else if (STORE == 1) {
       f32x4* red = sR + (t & 1) * 768;
       if (khalf == 1) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) red[(strip * 3 + i) * 64 + lane] = acc[i];
       }
+      ESTAMP(t < 10 ? 6 * t + 3 : 64);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      ESTAMP(t < 10 ? 6 * t + 4 : 64);
       if (khalf == 0 && GEOM >= 2) {
         // the product's epilogue, instruction for instruction (conv_s2_halo_fwd_ws_kernel): bias, ReLU, the 16-bit sign word of the
         // lane's 12 outputs (stored as a short), the strip transposed through LDS so that every store writes 1 KiB of consecutive bytes
@@ -215,6 +306,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
       keep += acc[0] + acc[1] + acc[2];
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    ESTAMP(t < 10 ? 6 * t + 5 : 64);
     if (GEOM == 5) { if (++ctx == 4) { ctx = 0; if (++cty == 64) { cty = 0; ++cn; } } }
     else if (++ctx == 8) { ctx = 0; if (++cty == 32) { cty = 0; ++cn; } }
     buf = buf + 1 == NBUF ? 0 : buf + 1;
@@ -243,8 +335,25 @@ void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, co
   for (int i = 0; i < 256; ++i) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
   const double tf = (double)NMF * 2048.0 * 8 * 256 * tiles / (ms * 1e-3) / 1e12;
   const double rd = (double)IN * 1024 * 256 * tiles / (ms * 1e-3) / 1e12, wr = (STORE ? (double)OUT : 0.0) * 1024 * 256 * tiles / (ms * 1e-3) / 1e12;
+  if (GEOM == 2 && tiles == 96) {
+    printf("  (stores: %s)\n", STORE == 3 ? "both K halves" : STORE == 4 ? "K half 0, deferred into the next tile's MFMA loop" : "K half 0");
+    static unsigned long long hs[256 * 2 * 64];
+    hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+    const char* names[5] = {"(advance)", "MFMA loop (9 steps)", "partial sums -> LDS", "barrier", "epilogue"};
+    for (int kh = 0; kh < 2; ++kh) {
+      printf("  timeline, K half %d (wave %d), tiles 2..8 of every block, cycles:", kh, 4 * kh);
+      for (int i = 0; i < 5; ++i) {
+        double sum = 0; int n = 0;
+        for (int b = 0; b < 256; ++b) for (int t = 2; t < 9; ++t) { sum += (double)(hs[(b * 2 + kh) * 64 + 6 * t + i + 1] - hs[(b * 2 + kh) * 64 + 6 * t + i]); ++n; }
+        printf("  %s %.0f", names[i], sum / n);
+      }
+      double per = 0; int n = 0;
+      for (int b = 0; b < 256; ++b) for (int t = 2; t < 8; ++t) { per += (double)(hs[(b * 2 + kh) * 64 + 6 * (t + 1)] - hs[(b * 2 + kh) * 64 + 6 * t]); ++n; }
+      printf("  | tile period %.0f\n", per / n);
+    }
+  }
   printf("%sin %2d KiB out %2d KiB per tile | 1 ds_read per %2d MFMAs | stores %-14s | %6.1f TFLOP/s = %4.1f %% | %5.2f + %4.2f = %5.2f TB/s | %.3f GHz | tile %5.0f cycles\n",
-         GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
+         GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : STORE == 3 ? "both K halves" : STORE == 4 ? "deferred" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
          cyc / real * 0.1, cyc / 256 / tiles);
   fflush(stdout);
 }
@@ -280,6 +389,12 @@ int main() {
     run<40, 12, 12, 1, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, 96);
     run<40, 12, 12, 1, 4, 3>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 3>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, 96);
+    // the split epilogue (both waves of a SIMD finish together, each stores half of the strip)
+    run<40, 12, 12, 3, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 3, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, 96);
+    // the deferred epilogue (the K-half-0 wave finishes tile t - 1 from inside tile t's MFMA loop)
+    run<40, 12, 12, 4, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 4, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, 96);
     run<40, 12, 12, 1, 4, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 5>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     // how many bytes per clock can a CU take in through LDS-DMA when the MFMA stream is short?  (conv2's filter gradient needs 51 KiB per
