@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // in-kernel timeline (as conv_halo.hip's HSTAMP): [block][K half][64] s_memtime of lane 0 of waves 0 and 4, six stamps per tile for the first ten tiles
 __device__ unsigned long long g_stamps[256 * 2 * 64];
-#define ESTAMP(i) do { if (NMF == 107 + 1 && GEOM >= 2 && STORE != 2 && lane == 0 && (wid & 3) == 0 && (i) < 64) g_stamps[(blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ESTAMP(i) do { if (NMF == 107 + 1 && GEOM >= 2 && STORE != 2 && STORE != 5 && lane == 0 && (wid & 3) == 0 && (i) < 64) g_stamps[(blockIdx.x * 2 + (wid >> 2)) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
     for (int t = 0; t < tiles; ++t) {
       // SLEEP: the loaders hold their DMA back by SLEEP x 64 cycles behind the tile barrier (the image they fetch is needed two tiles
       // from now; the K-half-0 waves' stores of the tile just finished enter the CU's vector-memory queue first)
-      if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+      if (SLEEP > 0 && STORE != 5) __builtin_amdgcn_s_sleep(SLEEP);
       if (IN > 0) { dma(slot); slot = slot + 1 == NBUF ? 0 : slot + 1; }
       if (STORE == 2) {
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
           __builtin_nontemporal_store(so[px * 13 + c4], outbuf + pix * 12 + m);
         }
       }
-    } else if (STORE == 1) {
+    } else if (STORE == 1 || STORE == 5) {
       f32x4* red = sR + (t & 1) * 768;
       if (khalf == 1) {
 #pragma unroll
@@ -266,6 +266,8 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
       ESTAMP(t < 10 ? 6 * t + 3 : 64);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       ESTAMP(t < 10 ? 6 * t + 4 : 64);
+      // STORE == 5: the K-half-1 wave gives its partner's stores an MFMA-free window before it starts the next tile's loop
+      if (STORE == 5 && khalf == 1 && SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
       if (khalf == 0 && GEOM >= 2) {
         // the product's epilogue, instruction for instruction (conv_s2_halo_fwd_ws_kernel): bias, ReLU, the 16-bit sign word of the
         // lane's 12 outputs (stored as a short), the strip transposed through LDS so that every store writes 1 KiB of consecutive bytes
@@ -322,7 +324,7 @@ void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, co
   const size_t ldsb = (size_t)(3 * IMG_F4 + 2 * 768 + 4 * 16 * 13) * 16;
   auto kern = env<IN, OUT, RD, STORE, LW, GEOM, SLEEP, NMF>;
   if (NMF != 108) printf("%d MFMAs per wave and tile: ", NMF);
-  if (SLEEP) printf("loaders sleep %d x 64 cycles behind the barrier: ", SLEEP);
+  if (SLEEP) printf("%s sleep %d x 64 cycles behind the barrier: ", STORE == 5 ? "K-half-1 waves" : "loaders", SLEEP);
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(kern, dim3(256), dim3(512 + 64 * LW), ldsb, 0, big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles, fields);
@@ -353,7 +355,7 @@ void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, co
     }
   }
   printf("%sin %2d KiB out %2d KiB per tile | 1 ds_read per %2d MFMAs | stores %-14s | %6.1f TFLOP/s = %4.1f %% | %5.2f + %4.2f = %5.2f TB/s | %.3f GHz | tile %5.0f cycles\n",
-         GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : STORE == 3 ? "both K halves" : STORE == 4 ? "deferred" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
+         GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : STORE == 3 ? "both K halves" : STORE == 4 ? "deferred" : STORE == 5 ? "K half 0, partner sleeps" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
          cyc / real * 0.1, cyc / 256 / tiles);
   fflush(stdout);
 }
@@ -395,6 +397,12 @@ int main() {
     // the deferred epilogue (the K-half-0 wave finishes tile t - 1 from inside tile t's MFMA loop)
     run<40, 12, 12, 4, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 4, 4, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, 96);
+    // the partner wave holds its MFMA loop back so that the K-half-0 wave's stores go out at once
+    run<40, 12, 12, 5, 4, 2, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 5, 4, 2, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 5, 4, 2, 6>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 5, 4, 2, 8>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 5, 4, 2, 12>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 5>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     // how many bytes per clock can a CU take in through LDS-DMA when the MFMA stream is short?  (conv2's filter gradient needs 51 KiB per
