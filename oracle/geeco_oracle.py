@@ -10,7 +10,12 @@ here (``import tensorflow`` -> ModuleNotFoundError).  This file therefore restat
 reference's graph from its source text plus the published TF-1.15 op semantics listed in
 SURVEY.md par. 8c, and is pinned only by the analytic known-answer tests in
 ``tests/test_oracle_kat.py`` (alpha tables, SAME/stride-2 alignment probe, zero-weight LSTM,
-ln 3 cross-entropy, Adam step 1, parameter counts).
+ln 3 cross-entropy, Adam step 1, parameter counts) and -- round 6 -- by literals of TensorFlow 1.15's OWN
+unit tests reproduced from memory and confirmed by exact agreement with this file (rnn_cell_test.py
+testBasicLSTMCell; conv_ops_test.py testConv2D2x2FilterStride2Same / testConv2DKernelSmallerThanStrideSame /
+testConv2D1x1Filter; losses_test.py MeanSquaredErrorTest.testNonZeroLoss, SoftmaxCrossEntropyLossTest): the
+LSTM cell formula, padding='SAME' with strides, the two loss reductions.  Still unpinned by any TF-written
+number: Adam's epsilon placement, the LSTM gate order, rint.
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
 The restatement is written with torch CPU tensors (fp32 or fp64 selectable) so gradients come
