@@ -15,9 +15,13 @@ samples of 5 launches each: FLOP, us, TFLOP/s, fraction of the fp32 MFMA peak), 
 share of the step, taken from that table, plus the same by kernel family), ``hbm`` (dynimg calls and Adam against the
 HBM peak), ``encoder_forward``, ``other_configs`` (config 4 and the per-GPU shape of config 5, a few steps each, with
 their own oracle-pinned loss check) and ``cpu_baseline`` (the CPU restatement in oracle/, timed on the host cores).
-N > 1 adds ``ranks`` (per-rank ms/step, device identities: the run refuses ranks that share a GPU) and ``comm`` (the
-all-reduce alone and the step with the exchange overlapped / serial / skipped; ``--dp-serial`` makes the serial order
-the timed one).
+N > 1 adds ``ranks`` (per-rank ms/step, device identities: the run refuses ranks that share a GPU) and ``comm``.  Order of an
+N > 1 run: the ALWAYS-SAFE form of the data-parallel step first, in full (three replayed graphs, both all-reduces
+ordinary RCCL launches between them): its figure goes to stderr at once and its JSON line is kept behind a watchdog; then a short
+trial of the one-graph forms (RCCL captured into the step graph), the fastest of them in full if it beat the safe form; ``value`` =
+the faster full measurement (``config.dp_form``), with the replicas checked bitwise identical after each; then the comm report
+(every form once more, the exchange alone).  A capture that fails, a form that hangs or replicas that differ cannot take the
+number away: rank 0 prints the safe form's line and every rank leaves.
 """
 import argparse
 import json
