@@ -26,8 +26,8 @@ every activation the device wrote) on the device's conv1 inputs, and
   (c) (round 4, mask-INDEPENDENT backstops) the device's conv8 features of EVERY frame equal the plain oracle's (2e-4 of
       the maximum: a forward error that changes magnitudes but not signs cannot hide in the frames between the first and
       the last); the decisions are copied out of the activation buffers BEFORE the device's backward runs (no buffer the
-      backward reuses can alias them); config 2 (the bench shape; round 4 also config 5, dropped there for the suite's wall
-      time): every gradient also within PLAIN_TOL = 5e-3 of max |g| of the fp64 oracle under its OWN decisions (loose by
+      backward reuses can alias them); EVERY config (round 6; rounds 4-5: config 2 only, for the suite's wall time -- measured now:
+      + 9 s for config 5, + 25 s for config 4): every gradient also within PLAIN_TOL = 5e-3 of max |g| of the oracle under its OWN decisions (loose by
       necessity: a handful of rounding-level flips move a filter gradient by up to 1e-3, the measured worst being 5.8e-4,
       tests/golden/full_size_plain_oracle_r03.json); configs 4 (oracle encoder in fp32 for time) and 5: the first, the two
       middle and the last frame of encoder 0 (config 4: 0, 511, 512, 1023 -- around the 2^31-element boundary) additionally
@@ -113,7 +113,8 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
     with open(os.path.join(out_dir, 'full_size_progress.log'), 'a') as f:
       f.write('%s %6.1f s %s\n' % (name.split()[0], time.time() - t0, text))
 
-  plain_backstop = name.startswith('config2')      # the second full backward (own decisions) once, on the bench shape
+  plain_backstop = True       # the second full backward, under the oracle's OWN decisions (round 6: every config; rounds 4-5: config 2 only)
+  fp64_frames = not name.startswith('config2')      # configs 4 and 5 additionally: single frames through the fp64 encoder
   tr = O.OracleTrainer(ocfg, goal, P, dtype=torch.float64)
   loss_ref, parts_ref, grads_ref, pred_ref, ep_ref = O.loss_and_grads_chunked(
       tr, feats, labels, chunk=32, enc_dtype=enc_dtype, encoder_inputs=enc_inputs, masks_fn=masks_fn, plain_grads=plain_backstop,
@@ -128,7 +129,7 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
     err = np.abs(f8[g] - ref8).reshape(ref8.shape[0], -1).max(axis=1)
     assert err.max() <= 2e-4 * scale, (scope, 'frame %d' % int(err.argmax()), float(err.max()), scale)
   fp64_subset = None
-  if not plain_backstop:   # configs 4 and 5: the frames at the ends and around the 2^31-element boundary through the fp64 encoder
+  if fp64_frames:          # configs 4 and 5: the frames at the ends and around the 2^31-element boundary through the fp64 encoder
     Pe = {k: v for k, v in tr.P.items() if '/conv' in k}
     fp64_subset = {}
     for fr in sorted({0, enc.Nf // 2 - 1, enc.Nf // 2, enc.Nf - 1}):
@@ -186,8 +187,9 @@ def test_full_size_forward_backward(dev, name, cfg_kw, goal, N, enc_dtype):
   with open(os.path.join(out_dir, 'full_size_achieved_%s.json' % name.split()[0]), 'w') as f:
     json.dump({'case': name, 'bound': '%g of max|g| and %g relative L2, against the fp64 oracle under the device\'s ReLU decisions' % (GRAD_TOL, GRAD_TOL),
                'oracle_encoder_dtype': str(enc_dtype).replace('torch.', ''),
-               'backstop': ('plain fp64 oracle (own decisions), %g of max|g|: worst %.3g at %s' % (PLAIN_TOL, worst_plain[1], worst_plain[0])
-                            if plain_backstop else 'fp64 encoder of frames %s' % sorted(fp64_subset)),
+               'backstop': 'plain oracle (own decisions; encoder in %s), %g of max|g|: worst %.3g at %s' %
+                           (str(enc_dtype).replace('torch.', ''), PLAIN_TOL, worst_plain[1], worst_plain[0]) +
+                           ('; fp64 encoder of frames %s' % sorted(fp64_subset) if fp64_subset else ''),
                'fp64_frame_subset': fp64_subset,
                'relu_decisions': {'differing': n_dis, 'total': n_tot, 'max_abs_preactivation_where_differing': float('%.3g' % worst_z),
                                   'per_layer': {s: [[n, float('%.3g' % z), t] for n, z, t in st] for s, st in dis.items()}},
