@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
               off = off < lim ? off : lim;
             }
             __builtin_amdgcn_global_load_lds((gptr_t)(xg + off), (lptr_t)(sH + buf * IMG_F4 + (lw + LW * i) * 64), 16, 0, 0);
+            if (GEOM == 6 && SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);      // PACED issue: SLEEP x 64 cycles between a loader's DMA pieces
           }
         if (GEOM == 5) { if (++gtx == 4) { gtx = 0; if (++gty == 64) { gty = 0; gn = (gn + 1) & 255; } } return; }
         if (++gtx == 8) { gtx = 0; if (++gty == 32) { gty = 0; gn = (gn + 1) & 255; } }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void env(const f32x4* __restrict__ b
     for (int t = 0; t < tiles; ++t) {
       // SLEEP: the loaders hold their DMA back by SLEEP x 64 cycles behind the tile barrier (the image they fetch is needed two tiles
       // from now; the K-half-0 waves' stores of the tile just finished enter the CU's vector-memory queue first)
-      if (SLEEP > 0 && STORE != 5) __builtin_amdgcn_s_sleep(SLEEP);
+      if (SLEEP > 0 && STORE != 5 && GEOM != 6) __builtin_amdgcn_s_sleep(SLEEP);
       if (IN > 0) { dma(slot); slot = slot + 1 == NBUF ? 0 : slot + 1; }
       if (STORE == 2) {
 #pragma unroll
@@ -324,7 +325,8 @@ void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, co
   const size_t ldsb = (size_t)(3 * IMG_F4 + 2 * 768 + 4 * 16 * 13) * 16;
   auto kern = env<IN, OUT, RD, STORE, LW, GEOM, SLEEP, NMF>;
   if (NMF != 108) printf("%d MFMAs per wave and tile: ", NMF);
-  if (SLEEP) printf("%s sleep %d x 64 cycles behind the barrier: ", STORE == 5 ? "K-half-1 waves" : "loaders", SLEEP);
+  if (SLEEP && GEOM == 6) printf("%d x 64 cycles between a loader's DMA pieces: ", SLEEP);
+  else if (SLEEP) printf("%s sleep %d x 64 cycles behind the barrier: ", STORE == 5 ? "K-half-1 waves" : "loaders", SLEEP);
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(kern, dim3(256), dim3(512 + 64 * LW), ldsb, 0, big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles, fields);
@@ -354,8 +356,9 @@ void run(const f32x4* big, long long big_f4, f32x4* outbuf, long long out_f4, co
       printf("  | tile period %.0f\n", per / n);
     }
   }
+  if (LW != 4) printf("%d loader waves: ", LW);
   printf("%sin %2d KiB out %2d KiB per tile | 1 ds_read per %2d MFMAs | stores %-14s | %6.1f TFLOP/s = %4.1f %% | %5.2f + %4.2f = %5.2f TB/s | %.3f GHz | tile %5.0f cycles\n",
-         GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : STORE == 3 ? "both K halves" : STORE == 4 ? "deferred" : STORE == 5 ? "K half 0, partner sleeps" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
+         GEOM == 6 ? "conv2 geometry + its epilogue, DMA pieces paced: " : GEOM == 5 ? "conv2 as 2 x 32 tiles (5 runs of 8 KiB) + its epilogue: " : GEOM == 4 ? "conv2 geometry + its epilogue, loaders without the edge clamp: " : GEOM == 3 ? "conv2 geometry + its epilogue + pair-swizzled DMA: " : GEOM == 2 ? "conv2 geometry + its epilogue: " : GEOM ? "conv2 geometry: " : "", IN, STORE ? OUT : 0, RD, STORE == 0 ? "none" : STORE == 1 ? "compute waves" : STORE == 3 ? "both K halves" : STORE == 4 ? "deferred" : STORE == 5 ? "K half 0, partner sleeps" : "loader waves", tf, tf / 157.3 * 100, rd, wr, rd + wr,
          cyc / real * 0.1, cyc / 256 / tiles);
   fflush(stdout);
 }
@@ -403,6 +406,14 @@ int main() {
     run<40, 12, 12, 5, 4, 2, 6>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 5, 4, 2, 8>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 5, 4, 2, 12>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    // more / fewer loader waves for the same 40 pieces
+    run<40, 12, 12, 1, 8, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 1, 2, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    // paced DMA issue
+    run<40, 12, 12, 1, 4, 6, 1>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 1, 4, 6, 2>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 1, 4, 6, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
+    run<40, 12, 12, 1, 4, 6, 8>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 4>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     run<40, 12, 12, 1, 4, 5>(big, big_f4, outbuf, out_f4, wsrc, sink, clk, tiles);
     // how many bytes per clock can a CU take in through LDS-DMA when the MFMA stream is short?  (conv2's filter gradient needs 51 KiB per
