@@ -67,6 +67,30 @@ def test_estimator_errors(dev, tmp_path):
         input_fn=synthetic_batches(2, 4, 1, (136, 136), 3, False))
 
 
+def test_estimator_raises_on_an_expired_input_stage_wait(dev, tmp_path):
+  """A device-side error of the one-pass input stage reaches the caller of Estimator.train / evaluate (the places where the host reads
+  results anyway: loss read-outs, epoch ends) as a RuntimeError, and nothing is saved for that epoch.  Provoked with a wait bound of zero
+  polls (tests/test_kernels_gpu.py::test_goal_dynimgs_expired_wait_is_loud); a healthy epoch before it passes."""
+  from geeco_amd import estimator as est
+  from geeco_amd._native import load as lib
+  from geeco_amd.input_fn import synthetic_batches
+  params = _params()
+  params['log_steps'] = 1000               # (no loss read-out inside the epoch: the check at the epoch's end must catch it)
+  e = est.Estimator(est.goal_e2evmc_model_fn, str(tmp_path), est.RunConfig(use_hipgraph=False), params)
+  e.train(input_fn=synthetic_batches(4, 3, 2, (136, 136), 3, True, seed=5))
+  assert os.path.basename(est.latest_checkpoint(str(tmp_path))) == 'model.ckpt-2'
+  old = lib().geeco_goal_dynimgs_set_wait_polls(0)
+  try:
+    with pytest.raises(RuntimeError, match='one-pass input stage'):
+      e.train(input_fn=synthetic_batches(4, 3, 2, (136, 136), 3, True, seed=6))
+  finally:
+    lib().geeco_goal_dynimgs_set_wait_polls(old)
+  assert os.path.basename(est.latest_checkpoint(str(tmp_path))) == 'model.ckpt-2'      # the poisoned epoch wrote no checkpoint
+  # evaluation through the same (poisoned) workspace reports it too: the word is sticky until the workspace is zero-filled again
+  with pytest.raises(RuntimeError, match='one-pass input stage'):
+    e.evaluate(input_fn=synthetic_batches(4, 3, 1, (136, 136), 3, True, seed=7))
+
+
 def test_train_script_synthetic(dev, tmp_path):
   md = str(tmp_path / 'run')
   cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'train_e2evmc.py'), '--dataset_dir', 'synthetic:4:136x136',
