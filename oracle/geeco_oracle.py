@@ -468,7 +468,11 @@ def model_loss(pred, targets, P, cfg: Config):
 
 def adam_step_tf(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
   """tf.train.AdamOptimizer [TF1.15]: lr_t = lr sqrt(1-b2^t)/(1-b1^t); theta -= lr_t m/(sqrt(v)+eps).
-  ``step`` is the 1-based update count. In-place on numpy/torch arrays; returns lr_t."""
+  ``step`` is the 1-based update count. In-place on numpy/torch arrays; returns lr_t.
+  Where epsilon sits is published twice by TF 1.15 itself: the class docstring ("... uses the formulation just before Section 2.1
+  of the Kingma and Ba paper rather than the formulation in Algorithm 1, the 'epsilon' referred to here is 'epsilon hat'") and the
+  numpy reference its own unit test compares every step against (tensorflow/python/training/adam_test.py, adam_update_numpy:
+  ``param - alpha_t * m_t / (np.sqrt(v_t) + epsilon)``); tests/test_oracle_kat.py runs that test's protocol."""
   lr_t = lr * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
   m *= b1; m += (1.0 - b1) * g
   v *= b2; v += (1.0 - b2) * g * g

@@ -250,6 +250,31 @@ def test_conv3x3_same_padding_tf_published_vectors(dev):
     assert not y[..., Co:].any()
 
 
+def test_adam_follows_the_protocol_of_tfs_own_test(dev):
+  """geeco_adam_prepare + geeco_adam_tf through TF 1.15's adam_test.py::testBasic protocol (var [1, 2] / [3, 4], constant gradients 0.1 /
+  0.01, three steps, lr 0.001) against the numpy reference that test carries (tests/test_oracle_kat.py: tf_adam_update_numpy): epsilon
+  beside sqrt(v) ("epsilon hat"), lr_t from the step counter kept in device memory."""
+  from geeco_amd import ops
+  from test_oracle_kat import TF_ADAM_GRADS, TF_ADAM_VARS, tf_adam_update_numpy
+  p = torch.tensor(TF_ADAM_VARS[0] + TF_ADAM_VARS[1], device=dev)
+  g = torch.tensor(TF_ADAM_GRADS[0] + TF_ADAM_GRADS[1], device=dev)
+  m, v = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+  step = torch.zeros(1, dtype=torch.int64, device=dev)
+  scal = torch.zeros(2, device=dev)
+  ref, rm, rv = np.array(TF_ADAM_VARS[0] + TF_ADAM_VARS[1]), np.zeros(4), np.zeros(4)
+  gn = np.array(TF_ADAM_GRADS[0] + TF_ADAM_GRADS[1])
+  for t in (1, 2, 3):
+    ops.adam_prepare(step, 0.001, scal)
+    ops.adam_tf(p, g, m, v, 4, scal)
+    torch.cuda.synchronize()
+    ref, rm, rv = tf_adam_update_numpy(ref, gn, t, rm, rv)
+    assert int(step.item()) == t
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=3e-7, atol=0)      # (TF's test itself asserts 1e-6 on float32 variables)
+    # the slots carry float32(0.9) / float32(0.999), as TF's float32 kernel does: 1 - float32(0.999) differs from 0.001 by 1.3e-5 relative
+    np.testing.assert_allclose(m.cpu().numpy(), rm, rtol=1e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), rv, rtol=2e-5)
+
+
 def test_losses_tf_published_values(dev):
   """tf.losses.mean_squared_error / softmax_cross_entropy values TF 1.15's own losses_test.py publishes (49.5; 10.0 to three places)
   through the HIP decoder tail (geeco_heads_loss_fwd_bwd): fc1 = identity, head kernels = the first rows of the identity, zero biases,

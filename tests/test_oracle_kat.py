@@ -332,3 +332,39 @@ def test_losses_reproduce_the_values_tf_publishes():
   assert abs(wrong - TF_XENT_WRONG_LOSS) < 5e-4 and abs(wrong - math.log(math.exp(10.0) + 2.0)) < 1e-12      # a sum over the batch: 30
   right = float(O.softmax_xent(10.0 * logits, torch.tensor([0, 1, 2]), 3))      # testAllCorrect: logits +-100 -> 0.0 to 3 places
   assert abs(right) < 5e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# tf.train.AdamOptimizer: TF 1.15's own unit test (tensorflow/python/training/adam_test.py, testBasic) runs var0 = [1, 2],
+# var1 = [3, 4] with the constant gradients [0.1, 0.1] / [0.01, 0.01] for three steps at the default lr = 0.001 and compares
+# every step against a numpy reference it carries (adam_update_numpy: alpha_t = alpha sqrt(1 - beta2^t) / (1 - beta1^t);
+# param - alpha_t m_t / (sqrt(v_t) + epsilon)).  It publishes no literals, so this pins the PROTOCOL and the formula TF
+# holds itself to (epsilon beside sqrt(v), "epsilon hat" of its docstring), not numbers; the literal values below follow from
+# that formula in closed form for a constant gradient: m_t / (1 - beta1^t) = g and v_t / (1 - beta2^t) = g^2, so every step moves
+# the parameter by lr g / (|g| + eps / sqrt(1 - beta2^t)) -- 3 x 0.001 up to the epsilon term.
+# ----------------------------------------------------------------------------------------------------------------------
+TF_ADAM_VARS = [[1.0, 2.0], [3.0, 4.0]]
+TF_ADAM_GRADS = [[0.1, 0.1], [0.01, 0.01]]
+
+
+def tf_adam_update_numpy(param, g_t, t, m, v, alpha=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+  """The reference TF's adam_test.py compares against, restated."""
+  alpha_t = alpha * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+  m_t = beta1 * m + (1 - beta1) * g_t
+  v_t = beta2 * v + (1 - beta2) * g_t * g_t
+  return param - alpha_t * m_t / (np.sqrt(v_t) + epsilon), m_t, v_t
+
+
+def test_adam_follows_the_protocol_of_tfs_own_test():
+  for var0, g0 in zip(TF_ADAM_VARS, TF_ADAM_GRADS):
+    ref, rm, rv = np.array(var0), np.zeros(2), np.zeros(2)
+    p, m, v = np.array(var0), np.zeros(2), np.zeros(2)
+    g = np.array(g0)
+    for t in (1, 2, 3):
+      ref, rm, rv = tf_adam_update_numpy(ref, g, t, rm, rv)
+      O.adam_step_tf(p, g, m, v, t, 0.001)
+      np.testing.assert_allclose(p, ref, rtol=1e-14, atol=0)
+      np.testing.assert_allclose(m, rm, rtol=1e-14); np.testing.assert_allclose(v, rv, rtol=1e-14)
+      closed = np.array(var0) - sum(0.001 * g / (np.abs(g) + 1e-8 / math.sqrt(1 - 0.999 ** k)) for k in range(1, t + 1))
+      np.testing.assert_allclose(p, closed, rtol=1e-12)
+    assert np.all(np.abs((np.array(var0) - p) - 0.003) < 1e-7)
