@@ -14,6 +14,14 @@
 //     K-half-1 partner's partial sums went through LDS (STORE = 1: the product's arrangement), or by the loader waves
 //     (STORE = 2: the compute waves never touch the vector-memory pipe -- the most favourable arrangement there is), or not at
 //     all (STORE = 0).
+// Further switches (template parameters; what each measured: profiles/r06/ub_mfma_envelope.txt, findings 29-30, 35-36):
+//   GEOM  1 conv2 forward's addresses (9 runs of 4.1 KiB per tile, 32 KiB apart; 4 x 3 KiB out), 2 + its epilogue instruction for instruction,
+//         3 + pair-swizzled DMA order, 4 loaders without the edge clamp, 5 a 2 x 32 tile instead of 4 x 16, 6 paced DMA issue (SLEEP);
+//   STORE 3 split epilogue (both waves of a SIMD finalise half of the strip), 4 deferred epilogue (tile t - 1 finished inside tile t's MFMA
+//         loop), 5 the partner wave sleeps behind the barrier (SLEEP);
+//   SLEEP loaders (or, STORE 5, the K-half-1 waves) sleep SLEEP x 64 cycles behind the tile barrier;  NMF MFMAs per wave and tile (108 = conv2;
+//         fewer: how much a CU ingests);  LW loader waves;  `tiles` 6 000 (steady state) or 96 (the product's launch length, with in-kernel
+//         timelines of the K-half-0 / K-half-1 waves as scripts/dev/halo_stamps.py prints them for the product).
 // Prints TFLOP/s (algorithmic = executed here), the HBM traffic it ran beside (reads + writes) and the mean shader clock.
 //   build: hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -o mfma_envelope mfma_envelope.hip
 #include <hip/hip_runtime.h>
