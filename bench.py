@@ -535,6 +535,7 @@ class Watchdog:
     import threading
     self.seconds, self.emit, self.aborted = float(seconds), emit, aborted
     self._stop = threading.Event()
+    self._once = threading.Lock()      # fire() may be reached by the timer thread and by the main thread's exception path at once
     self._t = threading.Thread(target=self._run, name='bench-watchdog', daemon=True)
     self.provisional = None
     self.phase = 'start'
@@ -548,6 +549,8 @@ class Watchdog:
   def fire(self, why):
     """Leaves NOW with the provisional line (also called by the main thread when its own captured form raised)."""
     import faulthandler
+    if not self._once.acquire(blocking=False):
+      time.sleep(3600)                 # the other caller is writing the line and will end the process
     log('WATCHDOG: %s (phase: %s); leaving with the measurement of the safe form' % (why, self.phase))
     try:
       faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
