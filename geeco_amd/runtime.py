@@ -71,9 +71,11 @@ class TrainStepRunner:
   beside part 2 (default); False = both buckets after part 2 (``bench.py --dp-serial``: the difference between the two
   is what the overlap buys on a given node)."""
 
-  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True, reserved_cus=0, capture_exchange=None):
+  def __init__(self, model, use_graph=True, warmup=2, dp=None, overlap=True, reserved_cus=0, capture_exchange=None, eager_adam=False):
     """``reserved_cus``: CUs the two persistent kernels of part 2 leave to the collective that runs beside them (0 = none;
-    a launch argument of those kernels, applied around THIS runner's part 2 only).  ``capture_exchange``: capture the
+    a launch argument of those kernels, applied around THIS runner's part 2 only).  ``eager_adam`` (three-graph form only): part 3 is
+    not a graph but the optimiser's two pieces launched eagerly, the early one as soon as the early bucket has arrived, beside the late
+    bucket's all-reduce (two graph launches per step).  ``capture_exchange``: capture the
     whole data-parallel step -- the three parts AND both all-reduces, the early one as a branch beside part 2 -- into ONE
     hipGraph (RCCL's launches are stream work like any other; the fork to the communicator's stream and the joins become
     graph edges): one graph launch per step instead of three and no host-side stream joins (measured at one rank, bench.py
@@ -87,6 +89,7 @@ class TrainStepRunner:
     ``--dp_form`` of scripts/train_e2evmc.py, and bench.py, which times the safe form first and the captured forms behind it."""
     self.model = model
     self.capture_exchange = bool(capture_exchange)
+    self.eager_adam = bool(eager_adam)
     self.reserved_cus = int(reserved_cus)
     self.world = gdist.world_size()
     model.world = self.world
@@ -120,7 +123,8 @@ class TrainStepRunner:
         redirect(None, None)
     # The optimiser step in two pieces (whole data-parallel step in one pass over the stream: eager, or captured as ONE graph):
     # everything that came with the early bucket is updated while the late bucket is on the wire, the late bucket's variables
-    # follow with their gradients read straight from the staging buffer (no unpack copies).  Three replayed graphs keep part 3 whole.
+    # follow with their gradients read straight from the staging buffer (no unpack copies).  The three-graph form runs the same two
+    # pieces back to back as its part 3 (round 6; it kept the unpack copies + one whole Adam launch before).
     self.split_adam = (self.dp and self.staging is not None and hasattr(model, 'apply_gradients_of')
                        and 1 <= len(self.early) <= 8 and 1 <= len(self.late) <= 8 and _dev.env('GEECO_NO_SPLIT_ADAM') is None)
     if self.redirected and self.early:
@@ -131,7 +135,7 @@ class TrainStepRunner:
       self.early_calls = list(self.early)
 
   def bucket_info(self):
-    return {'graphs_per_step': (1 if (self.capture_exchange or not self.dp) else 3) if self.use_graph else 0,
+    return {'graphs_per_step': (1 if (self.capture_exchange or not self.dp) else 2 if (self.eager_adam and self.split_adam) else 3) if self.use_graph else 0,
             'early_bytes': 4 * sum(n for _, n in self.early), 'early_ranges': len(self.early),
             'early_allreduce_calls': len(self.early_calls), 'early_bytes_on_the_wire': 4 * sum(n for _, n in self.early_calls),
             'late_bytes': 4 * sum(n for _, n in self.late), 'late_ranges': len(self.late),
@@ -217,14 +221,35 @@ class TrainStepRunner:
         w.wait()
       self._part3_late()
       return
+    if len(run) == 2:                      # two graphs + the optimiser's pieces launched eagerly (eager_adam)
+      # part 2's graph carries the optimiser's per-step scalars (adam_prepare rides in its last slab-sum launch); a REPLAY runs no
+      # python, so the flag that tells apply_gradients_of not to prepare again is set here
+      self.model._prepared = True
+      for w in works:
+        w.wait()
+      self._part3_early()                  # beside the late bucket's all-reduce
+      for w in late:
+        w.wait()
+      self._part3_late()
+      return
     for w in works + late:
       w.wait()
     run[2]()
 
+  def _part3_pieces(self):
+    """Part 3 of the three-graph form: the optimiser step as the same two pieces the one-pass forms use, back to back (both buckets have
+    arrived by then) -- conv1 / conv2 are updated from the staging buffer, so the three unpack copies of ``_part3`` are not launched."""
+    self._part3_early()
+    self._part3_late()
+
   def _parts(self):
     if not self.dp:
       return [self._whole_step]
-    return [self._dp_step] if self.capture_exchange else [self._part1, self._part2, self._part3]
+    if self.capture_exchange:
+      return [self._dp_step]
+    if self.eager_adam and self.split_adam:
+      return [self._part1, self._part2]
+    return [self._part1, self._part2, self._part3_pieces if self.split_adam else self._part3]
 
   def _capture(self):
     # the warm-up steps before this call already ran eagerly
@@ -306,13 +331,16 @@ class TrainStepRunner:
 DP_FORMS = {
     'three_graphs': dict(overlap=True, capture_exchange=False),          # DEFAULT: exchange launched eagerly between three graphs
     'three_graphs_serial': dict(overlap=False, capture_exchange=False),  # ... both buckets behind part 2
+    'two_graphs': dict(overlap=True, capture_exchange=False, eager_adam=True),   # parts 1 and 2 as graphs, the optimiser's two pieces launched
+                                                                                 # eagerly: the early one beside the late bucket's all-reduce (as safe as
+                                                                                 # three_graphs: every collective an ordinary launch; -8 us at one rank)
     'overlap': dict(overlap=True, capture_exchange=True),                # ONE graph, early bucket beside part 2, every CU to compute
     'overlap_reserve16': dict(overlap=True, capture_exchange=True, reserved_cus=16),   # ... part 2's persistent kernels leave 16 CUs to RCCL
     'overlap_reserve32': dict(overlap=True, capture_exchange=True, reserved_cus=32),   # ... or 32 (RCCL's channel count decides)
     'serial': dict(overlap=False, capture_exchange=True),                # ONE graph, both buckets behind part 2
 }
 DP_FORM_DEFAULT = 'three_graphs'
-DP_CANDIDATES = tuple((k, DP_FORMS[k]) for k in ('overlap', 'overlap_reserve16', 'overlap_reserve32', 'serial'))   # bench.py's trial
+DP_CANDIDATES = tuple((k, DP_FORMS[k]) for k in ('two_graphs', 'overlap', 'overlap_reserve16', 'overlap_reserve32', 'serial'))   # bench.py's trial
 
 
 def dp_form_kwargs(name=None):

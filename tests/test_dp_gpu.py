@@ -202,7 +202,7 @@ def _global_batches():
   return [full[0], cut(full[1], 3), cut(full[2], 1)]
 
 
-def _est_worker(rank, world, port, q):
+def _est_worker(rank, world, port, q, dp_form=None):
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   from geeco_amd import dist as gdist
@@ -211,20 +211,21 @@ def _est_worker(rank, world, port, q):
   torch.cuda.set_device(0)
   gdist.init_from_env('gloo')
   params = {'e2evmc_config': create_e2evmc_config(KW), 'log_steps': 100, 'debug': False}
-  e = est.Estimator(est.goal_e2evmc_model_fn, None, est.RunConfig(init_seed=4), params)
+  e = est.Estimator(est.goal_e2evmc_model_fn, None, est.RunConfig(init_seed=4, dp_form=dp_form), params)
   e.train(input_fn=lambda: iter(_global_batches()))
   torch.cuda.synchronize()
   q.put((rank, e._store.params.detach().cpu().numpy(), int(e._store.global_step.item())))
   torch.distributed.destroy_process_group()
 
 
-def test_estimator_ragged_batches_two_ranks(dev):
+@pytest.mark.parametrize('dp_form', [None, 'two_graphs'], ids=['default form', 'two_graphs'])
+def test_estimator_ragged_batches_two_ranks(dev, dp_form):
   from geeco_amd import estimator as est
   from geeco_amd.params import create_e2evmc_config
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 30700 + os.getpid() % 1000
-  procs = [ctx.Process(target=_est_worker, args=(r, 2, port, q)) for r in range(2)]
+  port = 30700 + os.getpid() % 1000 + (7 if dp_form else 0)
+  procs = [ctx.Process(target=_est_worker, args=(r, 2, port, q, dp_form)) for r in range(2)]
   for p in procs:
     p.start()
   res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -364,7 +365,10 @@ def _rccl_worker(port, overlap, one_graph, q):
   gdist.broadcast_variables(model.store)
   model.load_batch({k: torch.from_numpy(v) for k, v in feats.items()}, {k: torch.from_numpy(v) for k, v in labels.items()})
   # True = the exchange captured into the step graph (opt-in: dp_form 'overlap' / 'serial'); default = three graphs
-  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap, **({'capture_exchange': True} if one_graph else {}))
+  two_graphs = one_graph == 'two'          # parts 1 and 2 as graphs, the optimiser's two pieces launched eagerly (runtime.DP_FORMS['two_graphs'])
+  one_graph = one_graph is True
+  runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap,
+                           **({'capture_exchange': True} if one_graph else {'eager_adam': True} if two_graphs else {}))
   assert runner.capture_exchange == one_graph
   info = runner.bucket_info()
   losses = []
@@ -385,25 +389,27 @@ def _rccl_worker(port, overlap, one_graph, q):
     assert model.enc.late is None and model.enc.reserved_cus == 0 and np.isfinite(float(model.loss))
     assert not torch.equal(before, model.store.params)
     model.store.params.copy_(before)      # (the comparison below is about the first runner's five steps)
-  q.put((model.store.params.detach().cpu().numpy(), losses, info, runner._graphs is not None and len(runner._graphs) == (1 if one_graph else 3)
-         and runner.capture_exchange == one_graph))
+  q.put((model.store.params.detach().cpu().numpy(), losses, info, runner._graphs is not None
+         and len(runner._graphs) == (1 if one_graph else 2 if two_graphs else 3) and runner.capture_exchange == one_graph))
   torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap,one_graph', [(True, True), (False, True), (True, False), (False, False)],
-                         ids=['one graph overlap', 'one graph serial', 'three graphs overlap', 'three graphs serial'])
+@pytest.mark.parametrize('overlap,one_graph', [(True, True), (False, True), (True, False), (False, False), (True, 'two')],
+                         ids=['one graph overlap', 'one graph serial', 'three graphs overlap', 'three graphs serial', 'two graphs'])
 def test_dp_step_over_rccl_one_rank(dev, overlap, one_graph):
   from geeco_amd import graph
   from geeco_amd.params import create_e2evmc_config
   from geeco_amd.runtime import TrainStepRunner
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  p = ctx.Process(target=_rccl_worker, args=(32800 + os.getpid() % 1000 + 2 * int(one_graph) + int(overlap), overlap, one_graph, q))
+  p = ctx.Process(target=_rccl_worker, args=(32800 + os.getpid() % 1000 + 2 * int(one_graph is True) + int(overlap) + 4 * int(one_graph == 'two'),
+                                             overlap, one_graph, q))
   p.start()
   params, losses, info, three = q.get(timeout=600)
   p.join(timeout=120)
   assert p.exitcode == 0
-  assert three and info['graphs_per_step'] == (1 if one_graph else 3) and info['early_allreduce_calls'] == 1 and info['late_written_in_place'] and info['late_ranges'] == 3
+  assert three and info['graphs_per_step'] == (1 if one_graph is True else 2 if one_graph == 'two' else 3)
+  assert info['early_allreduce_calls'] == 1 and info['late_written_in_place'] and info['late_ranges'] == 3
   assert info['mode'] == ('overlap' if overlap else 'serial')
   feats, labels = _batch(4)
   model = graph.GoalE2EVMC(create_e2evmc_config(KW), 4, dev, training=True)
