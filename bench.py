@@ -18,8 +18,9 @@ their own oracle-pinned loss check) and ``cpu_baseline`` (the CPU restatement in
 N > 1 adds ``ranks`` (per-rank ms/step, device identities: the run refuses ranks that share a GPU) and ``comm``.  Order of an
 N > 1 run: the ALWAYS-SAFE form of the data-parallel step first, in full (three replayed graphs, both all-reduces
 ordinary RCCL launches between them): its figure goes to stderr at once and its JSON line is kept behind a watchdog; then a short
-trial of the one-graph forms (RCCL captured into the step graph), the fastest of them in full if it beat the safe form; ``value`` =
-the faster full measurement (``config.dp_form``), with the replicas checked bitwise identical after each; then the comm report
+trial of the other safe forms (early bucket beside part 2 with / without CUs left to RCCL, or behind it), the fastest in full if it beats
+the form on record; then the same for the one-graph forms (RCCL captured into the step graph); ``value`` =
+the fastest full measurement (``config.dp_form``), with the replicas checked bitwise identical after each; then the comm report
 (every form once more, the exchange alone).  A capture that fails, a form that hangs or replicas that differ cannot take the
 number away: rank 0 prints the safe form's line and every rank leaves.
 """
@@ -840,6 +841,8 @@ DP_MODES = (   # name, TrainStepRunner arguments, skip the exchange.  The three-
     ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # = runtime.DP_FORMS['three_graphs'], the default
     ('three_graphs_serial', dict(overlap=False, capture_exchange=False), False),
     ('two_graphs', dict(overlap=True, capture_exchange=False, eager_adam=True), False),      # = runtime.DP_FORMS['two_graphs']
+    ('two_graphs_reserve16', dict(overlap=True, capture_exchange=False, eager_adam=True, reserved_cus=16), False),
+    ('two_graphs_serial', dict(overlap=False, capture_exchange=False, eager_adam=True), False),
     ('overlap', dict(overlap=True, capture_exchange=True), False),                 # ONE graph, exchange captured
     ('serial', dict(overlap=False, capture_exchange=True), False),
     ('overlap_reserve%d' % DP_RESERVE_PROBE, dict(overlap=True, capture_exchange=True, reserved_cus=DP_RESERVE_PROBE), False),
@@ -1078,7 +1081,7 @@ def main():
   form, full, trial, dog, comm, identical = safe_form, {}, {}, None, None, {}
   log('timed region: %d steps in %.3f s' % (args.steps, r['dt']))
   if world > 1:
-    from geeco_amd.runtime import pick_dp_runner
+    from geeco_amd.runtime import DP_CANDIDATES_CAPTURED, DP_CANDIDATES_SAFE, pick_dp_runner
     ms = r['dt'] / args.steps * 1e3
     full[safe_form] = round(ms, 4)
     # the replicas must be bitwise identical after any number of steps: the cheapest check there is that the exchange did its job
@@ -1103,25 +1106,32 @@ def main():
       dog.arm()
     try:
       if not (args.dp_fixed or args.dp_serial or args.no_graph):
-        dog.phase = 'trial of the other forms'
-        cand, trial = pick_dp_runner(model, use_graph=True, log=log)
-        best = min(trial, key=trial.get)
-        log('other forms (two_graphs: eager optimiser pieces; the rest: RCCL captured into ONE graph), short trial: %s; fastest %s' % (json.dumps({k: round(v, 4) for k, v in trial.items()}), best))
-        if trial[best] < ms:
-          dog.phase = 'timed region of %s' % best
-          r2 = timed_region(model, cand, args.steps, args.warmup, world, dev)
-          r2['first_loss'] = first_loss
-          # (a form on a backend that cannot capture -- gloo rehearsal -- is the three-graph form under another name: bucket_info says so)
-          full[best] = round(r2['dt'] / args.steps * 1e3, 4)
-          log('N = %d, form %s: %.4f ms/step in full' % (world, best, full[best]))
-          identical[best] = gdist.replicas_identical(model.store)
-          if not identical[best]:
-            log('ERROR: the replicas differ after the steps of form %s: its measurement is discarded, the safe form is reported' % best)
-          if r2['dt'] < r['dt'] and identical[best]:
-            r, form = r2, best
-            if rank == 0:
-              dog.provisional = headline(r, form)[0]
-        del cand
+        # two trials, the second only behind the first: (1) the other forms in which every collective is an ordinary launch (early
+        # bucket beside part 2 with and without CUs left to RCCL, or behind it; the optimiser's pieces eager): the best of them in full,
+        # so that the best SAFE number is on record before (2) anything captures RCCL into a graph
+        for label, cands in (('safe forms', DP_CANDIDATES_SAFE), ('one-graph forms', DP_CANDIDATES_CAPTURED)):
+          dog.phase = 'trial of the %s' % label
+          cand, t_ = pick_dp_runner(model, use_graph=True, candidates=cands, log=log)
+          trial.update(t_)
+          best = min(t_, key=t_.get)
+          cur_ms = r['dt'] / args.steps * 1e3
+          log('%s, short trial: %s; fastest %s (the form on record: %s, %.4f ms)' %
+              (label, json.dumps({k: round(v, 4) for k, v in t_.items()}), best, form, cur_ms))
+          if t_[best] < cur_ms:
+            dog.phase = 'timed region of %s' % best
+            r2 = timed_region(model, cand, args.steps, args.warmup, world, dev)
+            r2['first_loss'] = first_loss
+            # (a form on a backend that cannot capture -- gloo rehearsal -- is the three-graph form under another name: bucket_info says so)
+            full[best] = round(r2['dt'] / args.steps * 1e3, 4)
+            log('N = %d, form %s: %.4f ms/step in full' % (world, best, full[best]))
+            identical[best] = gdist.replicas_identical(model.store)
+            if not identical[best]:
+              log('ERROR: the replicas differ after the steps of form %s: its measurement is discarded' % best)
+            if r2['dt'] < r['dt'] and identical[best]:
+              r, form = r2, best
+              if rank == 0:
+                dog.provisional = headline(r, form)[0]
+          del cand
       if not args.skip_comm_report:
         dog.phase = 'comm report'
         comm = comm_report(args, model, r['runner'], dev, world, r['dt'] / args.steps * 1e3)
@@ -1150,8 +1160,8 @@ def main():
       comm['replicas_bit_identical_after'] = identical
       comm['forms_timed_in_full_ms'] = full
       comm['trial_ms'] = {k: round(v, 4) for k, v in trial.items()} or None
-      comm['order'] = ('safe form (%s) in full -> short trial of the one-graph forms -> the fastest of them in full if the trial '
-                       'beats the safe form -> value = the faster full measurement -> comm report' % safe_form)
+      comm['order'] = ('safe form (%s) in full -> short trial of the other safe forms, the fastest in full if it beats the form on record -> the '
+                       'same for the one-graph forms -> value = the fastest full measurement -> comm report' % safe_form)
       comm['rccl'] = rccl_info(rccl_log)
       out['comm'] = comm
     if not args.skip_layers:      # rank 0's GPU alone, after the timed region (any N: the per-GPU work is the same)

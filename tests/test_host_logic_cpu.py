@@ -490,6 +490,8 @@ def test_bench_watchdog_leaves_with_the_provisional_line(tmp_path):
   assert dp_form_kwargs('overlap_reserve16') == dict(overlap=True, capture_exchange=True, reserved_cus=16)
   assert all(set(kw) <= {'overlap', 'capture_exchange', 'reserved_cus', 'eager_adam'} for kw in DP_FORMS.values())
   assert dp_form_kwargs('two_graphs') == dict(overlap=True, capture_exchange=False, eager_adam=True)
+  from geeco_amd.runtime import DP_CANDIDATES_CAPTURED, DP_CANDIDATES_SAFE
+  assert all(not kw['capture_exchange'] for _, kw in DP_CANDIDATES_SAFE) and all(kw['capture_exchange'] for _, kw in DP_CANDIDATES_CAPTURED)
   with pytest.raises(ValueError):
     dp_form_kwargs('fastest')
 
