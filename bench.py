@@ -815,7 +815,8 @@ def rccl_info(path):
       os.unlink(path)
     except OSError:
       pass
-  out = {'status': 'ok', 'log_lines': len(lines)}
+  out = {'status': 'ok', 'log_lines': len(lines), 'max_nchannels': os.environ.get('NCCL_MAX_NCHANNELS'),
+         'graph_register': os.environ.get('NCCL_GRAPH_REGISTER')}
   for l in [l for l in lines if ' WARN ' in l][:10]:
     log('RCCL: ' + l[:300])
   text = '\n'.join(lines)

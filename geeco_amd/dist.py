@@ -18,6 +18,15 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 # eagerly (ragged end of an epoch: a new-batch-size runner in its warm-up steps, null_step) would hand the communicator
 # differently registered buffers for one collective.  Read by RCCL when the communicator is created; the caller's own value wins.
 os.environ.setdefault('NCCL_GRAPH_REGISTER', '0')
+# RCCL's collective kernels on gfx950 (ncclDevKernel_Generic_*: read out of librccl's code object, ROCm 7.2) take 248-256 VGPRs per
+# wave and 37.7 KB of LDS per 256-thread workgroup, one workgroup per channel.  The kernels the early gradient bucket runs beside
+# (conv3's input gradient 244 VGPRs, conv2's filter gradient 256, the fused bottom 209: two waves per SIMD, one block per CU) leave
+# no SIMD with 256 free registers, so an RCCL workgroup can NEVER share a CU with one of their blocks: every channel RCCL opens for
+# that all-reduce takes a whole CU away from them (or waits for one).  30 MB in the ~1 ms of part 2 needs nowhere near RCCL's default
+# channel count; 16 channels are 16 CUs -- what the `*_reserve16` forms of runtime.DP_FORMS leave free (6.5 % of part 2) -- and at
+# >= 5 GB/s per channel still finish inside part 2.  Reasoned, NOT measured (no multi-GPU box was available to this build): read by
+# RCCL when the communicator is created; the caller's own value wins; bench.py reports the value in force (comm.rccl.max_nchannels).
+os.environ.setdefault('NCCL_MAX_NCHANNELS', '16')
 
 import torch
 import torch.distributed as dist

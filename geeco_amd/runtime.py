@@ -335,6 +335,7 @@ DP_FORMS = {
                                                                                  # eagerly: the early one beside the late bucket's all-reduce (as safe as
                                                                                  # three_graphs: every collective an ordinary launch; -8 us at one rank)
     'two_graphs_reserve16': dict(overlap=True, capture_exchange=False, eager_adam=True, reserved_cus=16),   # ... part 2 leaves 16 CUs to RCCL
+    'two_graphs_reserve32': dict(overlap=True, capture_exchange=False, eager_adam=True, reserved_cus=32),   # ... or 32 (should RCCL open more channels)
     'two_graphs_serial': dict(overlap=False, capture_exchange=False, eager_adam=True),                      # ... both buckets behind part 2
     'overlap': dict(overlap=True, capture_exchange=True),                # ONE graph, early bucket beside part 2, every CU to compute
     'overlap_reserve16': dict(overlap=True, capture_exchange=True, reserved_cus=16),   # ... part 2's persistent kernels leave 16 CUs to RCCL
@@ -344,7 +345,7 @@ DP_FORMS = {
 DP_FORM_DEFAULT = 'three_graphs'
 # bench.py's trials: first the forms in which every collective is an ordinary launch (whether the early bucket should run beside part 2 at
 # all -- part 2's kernels fill every CU's registers -- with CUs left to RCCL, or behind it, is a property of the node), then the captured ones
-DP_CANDIDATES_SAFE = tuple((k, DP_FORMS[k]) for k in ('two_graphs', 'two_graphs_reserve16', 'two_graphs_serial', 'three_graphs_serial'))
+DP_CANDIDATES_SAFE = tuple((k, DP_FORMS[k]) for k in ('two_graphs', 'two_graphs_reserve16', 'two_graphs_reserve32', 'two_graphs_serial', 'three_graphs_serial'))
 DP_CANDIDATES_CAPTURED = tuple((k, DP_FORMS[k]) for k in ('overlap', 'overlap_reserve16', 'overlap_reserve32', 'serial'))
 DP_CANDIDATES = DP_CANDIDATES_SAFE + DP_CANDIDATES_CAPTURED
 

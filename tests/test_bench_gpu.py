@@ -75,7 +75,7 @@ def test_bench_two_ranks_rehearsal_and_shared_gpu_refusal(tmp_path):
   # of the one-graph forms, the fastest of those in full if the trial beat the safe form, the comm report
   assert 'safe form (three_graphs' in out.stderr and out.stderr.index('safe form (three_graphs') < out.stderr.index('dp form overlap')
   trial = c['trial_ms']
-  assert set(trial) == {'two_graphs', 'two_graphs_reserve16', 'two_graphs_serial', 'three_graphs_serial', 'overlap', 'overlap_reserve16',
+  assert set(trial) == {'two_graphs', 'two_graphs_reserve16', 'two_graphs_reserve32', 'two_graphs_serial', 'three_graphs_serial', 'overlap', 'overlap_reserve16',
                         'overlap_reserve32', 'serial'} and all(v > 0 for v in trial.values())
   full = c['forms_timed_in_full_ms']
   assert 'three_graphs' in full and set(full) <= set(trial) | {'three_graphs'} and 1 <= len(full) <= 3 and all(v > 0 for v in full.values())
