@@ -64,6 +64,9 @@ def parse_args():
   ap.add_argument('--dp-watchdog-s', type=float, default=240.0,
                   help='N > 1: seconds the captured forms (trial, second timed region, comm report) may take after the safe form '
                        'has been measured; beyond that rank 0 prints the safe form\'s line and every rank exits (0 = no watchdog)')
+  ap.add_argument('--extras-watchdog-s', type=float, default=300.0,
+                  help='N = 1: seconds the legs after the headline, roofline and CPU baseline (dp_one_rank, other configs, input pipeline, '
+                       'inference) may take together; beyond that the line as it stood is printed and the process exits (0 = no watchdog)')
   ap.add_argument('--skip-comm-report', action='store_true', help='N > 1: skip the comm report (every form of the step, exchange alone)')
   ap.add_argument('--skip-other-configs', action='store_true', help='skip the other_configs leg (config 4 / config 5 shapes)')
   ap.add_argument('--skip-input-pipeline', action='store_true', help='skip the input_pipeline leg (on-disk dataset -> Estimator.train)')
@@ -530,11 +533,16 @@ class Watchdog:
   finish in time -- or any rank raises the abort flag (``abort``: a counter in the rendezvous store, polled once a second, so
   the peers of a rank whose capture failed do not sit in a collective until the deadline) -- rank 0 writes the provisional
   line, a complete and valid measurement of the safe form marked as such, and every rank leaves with os._exit (no atexit
-  handlers, no destructors that would wait for a stuck stream).  The run cannot end without a number."""
+  handlers, no destructors that would wait for a stuck stream).  The run cannot end without a number.
 
-  def __init__(self, seconds, emit, aborted=None):
+  N = 1: the same timer around the legs that FOLLOW the headline, its roofline and the CPU baseline (dp_one_rank -- which replays
+  graphs with RCCL's one-rank launches captured --, the other configurations, input pipeline, inference): one GPU-suite run of
+  round 6 sat in exactly such a replay for seven minutes (profiles/r06/asked_and_answered.md), so the line the driver needs is
+  complete BEFORE those legs start and is what the run leaves with if one of them stalls (``extras``: which, and why)."""
+
+  def __init__(self, seconds, emit, aborted=None, keeps='the measurement of the safe form', after='what follows the safe form'):
     import threading
-    self.seconds, self.emit, self.aborted = float(seconds), emit, aborted
+    self.seconds, self.emit, self.aborted, self.keeps, self.after = float(seconds), emit, aborted, keeps, after
     self._stop = threading.Event()
     self._once = threading.Lock()      # fire() may be reached by the timer thread and by the main thread's exception path at once
     self._t = threading.Thread(target=self._run, name='bench-watchdog', daemon=True)
@@ -552,7 +560,7 @@ class Watchdog:
     import faulthandler
     if not self._once.acquire(blocking=False):
       time.sleep(3600)                 # the other caller is writing the line and will end the process
-    log('WATCHDOG: %s (phase: %s); leaving with the measurement of the safe form' % (why, self.phase))
+    log('WATCHDOG: %s (phase: %s); leaving with %s' % (why, self.phase, self.keeps))
     try:
       faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
     except Exception:
@@ -567,7 +575,7 @@ class Watchdog:
     t0 = time.monotonic()
     while not self._stop.wait(1.0 if self.aborted else max(self.seconds, 0.01)):
       if self.seconds > 0 and time.monotonic() - t0 >= self.seconds:
-        self.fire('what follows the safe form did not finish within %.0f s' % self.seconds)
+        self.fire('%s did not finish within %.0f s' % (self.after, self.seconds))
       try:
         if self.aborted and self.aborted():
           self.fire('another rank gave up on the captured forms')
@@ -839,7 +847,8 @@ def rccl_info(path):
 
 DP_MODES = (   # name, TrainStepRunner arguments, skip the exchange.  The three-graph forms FIRST (nothing captures RCCL), then the
     # one-graph forms, then the probe that leaves the replicas diverged (comm_report puts them back in step behind it)
-    ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # = runtime.DP_FORMS['three_graphs'], the default
+    ('three_graphs_reserve16', dict(overlap=True, capture_exchange=False, reserved_cus=16), False),   # = runtime.DP_FORM_DEFAULT
+    ('three_graphs_overlap', dict(overlap=True, capture_exchange=False), False),   # = runtime.DP_FORMS['three_graphs']
     ('three_graphs_serial', dict(overlap=False, capture_exchange=False), False),
     ('two_graphs', dict(overlap=True, capture_exchange=False, eager_adam=True), False),      # = runtime.DP_FORMS['two_graphs']
     ('two_graphs_reserve16', dict(overlap=True, capture_exchange=False, eager_adam=True, reserved_cus=16), False),
@@ -1076,7 +1085,7 @@ def main():
   # ---- the timed region -----------------------------------------------------------------------------------------------------
   # N > 1: the ALWAYS-SAFE form first, in full -- three replayed graphs with both all-reduces as ordinary RCCL launches between
   # them -- and its figure on stderr at once; only then anything that captures RCCL into a graph (see Watchdog).
-  safe_form = 'three_graphs_serial' if args.dp_serial else 'three_graphs'
+  safe_form = 'three_graphs_serial' if args.dp_serial else 'three_graphs_reserve16'      # = runtime.DP_FORM_DEFAULT, what Estimator.train runs
   r = timed_steps(model, args.steps, args.warmup, not args.no_graph, world, dev, form=safe_form)
   first_loss = r['first_loss']
   form, full, trial, dog, comm, identical = safe_form, {}, {}, None, None, {}
@@ -1178,14 +1187,31 @@ def main():
                                 'ms': round(ms_enc, 3), 'frames': model.enc.G * model.enc.Nf}
       out['step_frac_of_f32_mfma_peak'] = round(step_flop(args.channels, model.enc.G * model.enc.Nf) / (ms_step * 1e-3) / 1e12
                                                 / PEAK_F32_MFMA_TFLOPS, 4)
+    xdog = None
+    if world == 1:
+      # everything the contract asks of the line is in `out` from here on; the legs below only add to it
+      if not args.skip_cpu:
+        out['cpu_baseline'] = cpu_baseline(args)
+
+      def on_extras(provisional, why):
+        provisional['extras'] = 'WATCHDOG: %s; the legs after it are missing from this line' % why
+        emit(provisional)
+      xdog = Watchdog(args.extras_watchdog_s, on_extras, keeps='the line as it stood before that leg', after='the legs after the headline')
+      xdog.provisional = dict(out)
+      if args.extras_watchdog_s > 0:
+        xdog.arm()
     if world == 1 and not args.skip_dp_one_rank:
+      xdog.phase = 'dp_one_rank'
       out['dp_one_rank'] = dp_one_rank_report(args, model, runner, dev)
+      xdog.provisional = dict(out)
       log('dp_one_rank: %s' % json.dumps({k: out['dp_one_rank'].get(k) for k in ('status', 'single_graph_ms', 'ms_per_step', 'delta_vs_single_graph_us', 'allreduce_us_one_rank')}))
     if world == 1 and not args.skip_other_configs:
       del runner, r
+      xdog.phase = 'other_configs'
       out['other_configs'], ok2 = other_configs(args, dev)
       if not ok2:
         rc = 4
+      xdog.provisional = dict(out)
     if world == 1 and not (args.skip_input_pipeline and args.skip_inference) and args.model == 'geeco-f' and args.channels == 3:
       import shutil
       import tempfile
@@ -1195,13 +1221,16 @@ def main():
       try:
         e = root = kw = None
         if not args.skip_input_pipeline:
+          xdog.phase = 'input_pipeline'
           out['input_pipeline'], e, root, kw = input_pipeline_report(args, dev, ms_step, workdir)
+          xdog.provisional = dict(out)
         if not args.skip_inference:
+          xdog.phase = 'inference'
           out['inference'] = inference_report(args, dev, e, root, kw, workdir)
       finally:
         shutil.rmtree(workdir, ignore_errors=True)
-    if world == 1 and not args.skip_cpu:
-      out['cpu_baseline'] = cpu_baseline(args)
+    if xdog is not None:
+      xdog.disarm()
     emit(out)
   # N > 1: ranks 1..N-1 have nothing to do after the timed region and the comm report; they wait here ON THE HOST (no
   # collective pending, GPUs idle) until rank 0 has finished its tables and printed the line, then all ranks leave together

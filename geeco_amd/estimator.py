@@ -64,8 +64,9 @@ class RunConfig:
     # reference's variable names, Adam slots and global_step): what tf.train.Saver consumers such as the reference's
     # predictor (predictor.py:85-95) and _export_snapshot (train_e2evmc.py:160-181) expect to find
     self.save_tf_bundle = save_tf_bundle
-    # data parallel only: the form of the step (runtime.DP_FORMS).  None = 'three_graphs' -- every
-    # collective an ordinary RCCL launch between three replayed graphs, safe with ragged epochs by construction.  'overlap'
+    # data parallel only: the form of the step (runtime.DP_FORMS).  None = 'three_graphs_reserve16' -- every
+    # collective an ordinary RCCL launch between three replayed graphs (safe with ragged epochs by construction), part 2's persistent
+    # kernels leaving 16 CUs to RCCL's workgroups, which cannot share a CU with them (profiles/HARDWARE_FINDINGS.md 37).  'overlap'
     # (the whole step incl. both all-reduces as ONE hipGraph), 'overlap_reserve16/32', 'serial', 'three_graphs_serial' are
     # opt-in: take the one bench.py reports as fastest on the node at hand (comm.step_ms / comm.timed_form of an N > 1 run)
     self.dp_form = dp_form
@@ -474,7 +475,7 @@ class Estimator:
       # data parallel: summed gradients + a deterministic optimiser keep every replica bitwise equal; if they are not, the exchange
       # lost or raced something and rank 0's checkpoint would be one replica's opinion
       raise RuntimeError('geeco_amd: the replicas differ after %d data-parallel steps (rank %d): the gradient exchange is broken '
-                         '(dp_form=%s); nothing was saved' % (nsteps, rank, getattr(self.config, 'dp_form', None) or 'three_graphs'))
+                         '(dp_form=%s); nothing was saved' % (nsteps, rank, getattr(self.config, 'dp_form', None) or 'three_graphs_reserve16'))
     # wall time of the input + step loop alone (the checkpoint written below is not part of the data path)
     self.last_train_stats = {'steps': nsteps, 'loop_seconds': time.time() - t0}
     if nsteps and rank == 0 and self.model_dir:

@@ -329,7 +329,9 @@ class TrainStepRunner:
 
 # Every form of the data-parallel step by name (RunConfig.dp_form, --dp_form, bench.py's comm.step_ms keys).
 DP_FORMS = {
-    'three_graphs': dict(overlap=True, capture_exchange=False),          # DEFAULT: exchange launched eagerly between three graphs
+    'three_graphs_reserve16': dict(overlap=True, capture_exchange=False, reserved_cus=16),   # DEFAULT: exchange launched eagerly between three
+                                                                         # graphs; part 2's persistent kernels leave 16 CUs to RCCL (finding 37)
+    'three_graphs': dict(overlap=True, capture_exchange=False),          # ... every CU to part 2 (RCCL's workgroups then wait for CUs or take them)
     'three_graphs_serial': dict(overlap=False, capture_exchange=False),  # ... both buckets behind part 2
     'two_graphs': dict(overlap=True, capture_exchange=False, eager_adam=True),   # parts 1 and 2 as graphs, the optimiser's two pieces launched
                                                                                  # eagerly: the early one beside the late bucket's all-reduce (as safe as
@@ -342,10 +344,11 @@ DP_FORMS = {
     'overlap_reserve32': dict(overlap=True, capture_exchange=True, reserved_cus=32),   # ... or 32 (RCCL's channel count decides)
     'serial': dict(overlap=False, capture_exchange=True),                # ONE graph, both buckets behind part 2
 }
-DP_FORM_DEFAULT = 'three_graphs'
+DP_FORM_DEFAULT = 'three_graphs_reserve16'
 # bench.py's trials: first the forms in which every collective is an ordinary launch (whether the early bucket should run beside part 2 at
 # all -- part 2's kernels fill every CU's registers -- with CUs left to RCCL, or behind it, is a property of the node), then the captured ones
-DP_CANDIDATES_SAFE = tuple((k, DP_FORMS[k]) for k in ('two_graphs', 'two_graphs_reserve16', 'two_graphs_reserve32', 'two_graphs_serial', 'three_graphs_serial'))
+DP_CANDIDATES_SAFE = tuple((k, DP_FORMS[k]) for k in ('three_graphs', 'two_graphs', 'two_graphs_reserve16', 'two_graphs_reserve32', 'two_graphs_serial',
+                                                      'three_graphs_serial'))
 DP_CANDIDATES_CAPTURED = tuple((k, DP_FORMS[k]) for k in ('overlap', 'overlap_reserve16', 'overlap_reserve32', 'serial'))
 DP_CANDIDATES = DP_CANDIDATES_SAFE + DP_CANDIDATES_CAPTURED
 

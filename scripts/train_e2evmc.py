@@ -78,8 +78,8 @@ ARGPARSER.add_argument('--initial_eval', default=False, action='store_true',
                        help='Runs an evaluation before the first training iteration.')
 # the one flag the reference does not have (it has no data parallelism, train_e2evmc.py:221-224, 260-264)
 ARGPARSER.add_argument('--dp_form', type=str, default=None,
-                       help='Data parallel only: form of the step, one of three_graphs (default: exchange launched between three '
-                            'replayed hipGraphs) | three_graphs_serial | two_graphs (the optimiser launched eagerly behind two graphs; also two_graphs_reserve16, two_graphs_serial) | overlap (whole step '
+                       help='Data parallel only: form of the step, one of three_graphs_reserve16 (default: exchange launched between three '
+                            'replayed hipGraphs, 16 CUs left to RCCL) | three_graphs | three_graphs_serial | two_graphs (the optimiser launched eagerly behind two graphs; also two_graphs_reserve16, two_graphs_serial) | overlap (whole step '
                             'incl. both all-reduces as ONE hipGraph) '
                             '| overlap_reserve16 | overlap_reserve32 | serial.  bench.py --gpus N reports which is fastest on a node.')
 

@@ -60,7 +60,7 @@ def test_dp_gradients_equal_global_batch(tmp_path, world):
   from geeco_amd.params import create_e2evmc_config
   from geeco_amd.variables import VariableStore
   from oracle import geeco_oracle as O
-  port = 29500 + (os.getpid() % 2000) + world
+  port = 20000 + (os.getpid() % 2000) + world
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
@@ -188,7 +188,7 @@ def _bucket_worker(rank, world, port, q, can_redirect=False, overlap=True, split
                               'world8-late-in-place', 'adam-in-two-pieces', 'adam-in-two-pieces-packed-serial', 'world4-adam-in-two-pieces-serial'])
 def test_bucketed_exchange_covers_the_arena(world, can_redirect, overlap, split):
   sys.path.insert(0, ROOT)
-  port = 31500 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap) + 10 * world + 100 * int(split)
+  port = 22100 + (os.getpid() % 2000) + 3 * int(can_redirect) + int(overlap) + 10 * world + 100 * int(split)
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q, can_redirect, overlap, split)) for r in range(world)]
@@ -279,7 +279,7 @@ def test_ragged_schedule_null_steps_world4():
   over the GLOBAL batch on every rank, and the mixed ``step`` / ``null_step`` calls must pair up in the exchange (a
   mismatch hangs: the queue read below times out)."""
   sys.path.insert(0, ROOT)
-  world, port = 4, 33500 + (os.getpid() % 2000)
+  world, port = 4, 24300 + (os.getpid() % 2000)
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
   procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
@@ -324,7 +324,7 @@ def _rendezvous_worker(rank, world, port, q):
 def test_host_rendezvous_all_ranks_leave_together(world):
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 29950 + os.getpid() % 40 + world
+  port = 26400 + os.getpid() % 40 + world
   procs = [ctx.Process(target=_rendezvous_worker, args=(r, world, port, q)) for r in range(world)]
   for p in procs:
     p.start()
@@ -369,7 +369,7 @@ def test_replicas_identical_sees_one_differing_word():
   world = 3
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 30150 + os.getpid() % 40
+  port = 26500 + os.getpid() % 40
   procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
   for p in procs:
     p.start()

@@ -21,7 +21,36 @@ def _batch(n):
   return O.synthetic_batch(O.make_config(**KW), True, n, seed=31, H=136, W=136)
 
 
+def _child_watchdog(seconds=240):
+  """In a spawned worker: a child that is stuck (a collective that never returns, a graph replay that never ends) writes every
+  thread's Python stack to stderr and exits non-zero instead of sitting there until the parent's limit."""
+  import faulthandler
+  faulthandler.dump_traceback_later(seconds, exit=True)
+
+
+def _results(procs, q, n, limit=300):
+  """n results from the workers' queue; a worker that died (or the limit) fails the test AT ONCE with the exit codes, not after
+  a silent q.get(timeout=...) -- ten silent minutes look like a hung GPU box from outside."""
+  import queue
+  import time
+  out, t0 = [], time.time()
+  while len(out) < n:
+    try:
+      out.append(q.get(timeout=2))
+      continue
+    except queue.Empty:
+      pass
+    dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+    if dead or time.time() - t0 > limit:
+      for p in procs:
+        if p.is_alive():
+          p.kill()
+      raise AssertionError('worker exit codes %s after %.0f s, %d of %d results (worker stderr above)' % ([p.exitcode for p in procs], time.time() - t0, len(out), n))
+  return out
+
+
 def _worker(rank, world, port, q):
+  _child_watchdog()
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   from geeco_amd import dist as gdist
@@ -52,11 +81,11 @@ def test_two_ranks_equal_single_process(dev):
   from geeco_amd.params import create_e2evmc_config
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 29600 + os.getpid() % 1000
+  port = 26600 + os.getpid() % 1000
   procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
   for p in procs:
     p.start()
-  res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  res = sorted(_results(procs, q, 2), key=lambda t: t[0])
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
@@ -90,6 +119,7 @@ def test_two_ranks_equal_single_process(dev):
 # measured first; provoked here by making the runner believe gloo is RCCL, in a process that is thrown away afterwards.
 # ----------------------------------------------------------------------------------------------------
 def _fallback_worker(rank, world, port, q):
+  _child_watchdog()
   import warnings
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -128,11 +158,11 @@ def _fallback_worker(rank, world, port, q):
 def test_one_graph_form_on_a_backend_that_cannot_capture(dev):
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 34300 + os.getpid() % 1000
+  port = 27600 + os.getpid() % 1000
   procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
   for p in procs:
     p.start()
-  res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  res = sorted(_results(procs, q, 2), key=lambda t: t[0])
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
@@ -148,6 +178,7 @@ def test_one_graph_form_on_a_backend_that_cannot_capture(dev):
 
 
 def _capture_failed_worker(port, q):
+  _child_watchdog()
   sys.path.insert(0, ROOT)
   os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   from geeco_amd import dist as gdist
@@ -181,9 +212,9 @@ def _capture_failed_worker(port, q):
 def test_failed_one_graph_capture_raises_capture_failed(dev):
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  p = ctx.Process(target=_capture_failed_worker, args=(35400 + os.getpid() % 1000, q))
+  p = ctx.Process(target=_capture_failed_worker, args=(28600 + os.getpid() % 1000, q))
   p.start()
-  res = q.get(timeout=300)
+  res = _results([p], q, 1)[0]
   p.join(timeout=60)
   assert p.exitcode == 0
   assert res['raised'] and 'one hipGraph failed' in res['raised'] and 'three_graphs' in res['raised'], res
@@ -203,6 +234,7 @@ def _global_batches():
 
 
 def _est_worker(rank, world, port, q, dp_form=None):
+  _child_watchdog()
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   from geeco_amd import dist as gdist
@@ -224,11 +256,11 @@ def test_estimator_ragged_batches_two_ranks(dev, dp_form):
   from geeco_amd.params import create_e2evmc_config
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 30700 + os.getpid() % 1000 + (7 if dp_form else 0)
+  port = 29600 + os.getpid() % 1000 + (7 if dp_form else 0)
   procs = [ctx.Process(target=_est_worker, args=(r, 2, port, q, dp_form)) for r in range(2)]
   for p in procs:
     p.start()
-  res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+  res = sorted(_results(procs, q, 2), key=lambda t: t[0])
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
@@ -249,6 +281,7 @@ def test_estimator_ragged_batches_two_ranks(dev, dp_form):
 # the one-GPU test box; the first multi-GPU box that runs the suite runs it.
 # ----------------------------------------------------------------------------------------------------
 def _est_worker_rccl(rank, world, port, dp_form, q):
+  _child_watchdog()
   sys.path.insert(0, ROOT)
   os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                     HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -267,7 +300,7 @@ def _est_worker_rccl(rank, world, port, dp_form, q):
 
 # (the one-graph forms have never run with two ranks: they are tried only when asked for, so that an unattended suite on a
 # multi-GPU box cannot hang in a captured collective; GEECO_TEST_ONE_GRAPH_DP=1 adds them)
-_RCCL_FORMS = ['three_graphs'] + (['overlap', 'serial', 'overlap_reserve16'] if os.environ.get('GEECO_TEST_ONE_GRAPH_DP') == '1' else [])
+_RCCL_FORMS = ['three_graphs_reserve16', 'three_graphs'] + (['overlap', 'serial', 'overlap_reserve16'] if os.environ.get('GEECO_TEST_ONE_GRAPH_DP') == '1' else [])
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL refuses two ranks on one device)')
@@ -277,12 +310,12 @@ def test_estimator_ragged_batches_two_gpus_over_rccl(dev, dp_form):
   from geeco_amd.params import create_e2evmc_config
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 36100 + os.getpid() % 1000
+  port = 30610 + os.getpid() % 1000
   procs = [ctx.Process(target=_est_worker_rccl, args=(r, 2, port, dp_form, q)) for r in range(2)]
   for p in procs:
     p.start()
   try:
-    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    res = sorted(_results(procs, q, 2), key=lambda t: t[0])
     for p in procs:
       p.join(timeout=120)
       assert p.exitcode == 0
@@ -322,7 +355,7 @@ def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
   for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
     env.pop(k, None)
-  port = 31900 + os.getpid() % 1000
+  port = 31620 + os.getpid() % 1000
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', str(port), os.path.join(ROOT, 'tests', '_dp_launch.py'), os.path.join(ROOT, 'scripts', 'train_e2evmc.py'),
          '--dataset_dir', root, '--model_dir', md,
@@ -350,6 +383,7 @@ def test_train_script_two_ranks_on_disk_dataset(dev, tmp_path):
 # with the plain one-graph step.
 # ----------------------------------------------------------------------------------------------------
 def _rccl_worker(port, overlap, one_graph, q):
+  _child_watchdog()
   sys.path.insert(0, ROOT)
   os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                     HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -402,10 +436,10 @@ def test_dp_step_over_rccl_one_rank(dev, overlap, one_graph):
   from geeco_amd.runtime import TrainStepRunner
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  p = ctx.Process(target=_rccl_worker, args=(32800 + os.getpid() % 1000 + 2 * int(one_graph is True) + int(overlap) + 4 * int(one_graph == 'two'),
+  p = ctx.Process(target=_rccl_worker, args=(18900 + os.getpid() % 1000 + 2 * int(one_graph is True) + int(overlap) + 4 * int(one_graph == 'two'),
                                              overlap, one_graph, q))
   p.start()
-  params, losses, info, three = q.get(timeout=600)
+  params, losses, info, three = _results([p], q, 1)[0]
   p.join(timeout=120)
   assert p.exitcode == 0
   assert three and info['graphs_per_step'] == (1 if one_graph is True else 2 if one_graph == 'two' else 3)

@@ -486,7 +486,8 @@ def test_bench_watchdog_leaves_with_the_provisional_line(tmp_path):
   d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
   assert 'another rank gave up' in d['comm']['status'] and 'not reached' not in out.stdout
   from geeco_amd.runtime import DP_FORMS, DP_FORM_DEFAULT, dp_form_kwargs
-  assert DP_FORM_DEFAULT == 'three_graphs' and dp_form_kwargs() == dict(overlap=True, capture_exchange=False)
+  assert DP_FORM_DEFAULT == 'three_graphs_reserve16' and dp_form_kwargs() == dict(overlap=True, capture_exchange=False, reserved_cus=16)
+  assert dp_form_kwargs('three_graphs') == dict(overlap=True, capture_exchange=False)
   assert dp_form_kwargs('overlap_reserve16') == dict(overlap=True, capture_exchange=True, reserved_cus=16)
   assert all(set(kw) <= {'overlap', 'capture_exchange', 'reserved_cus', 'eager_adam'} for kw in DP_FORMS.values())
   assert dp_form_kwargs('two_graphs') == dict(overlap=True, capture_exchange=False, eager_adam=True)
