@@ -289,7 +289,7 @@ class TrainStepRunner:
         self.model._prepared = False
         raise CaptureFailed('capturing the data-parallel step (with both all-reduces) into one hipGraph failed: %s: %s.  HIP '
                             'leaves the streams of a failed capture in capture mode, so this process cannot capture or launch on '
-                            'them again: restart with dp_form=three_graphs (the default)' % (type(e).__name__, str(e)[:300])) from e
+                            'them again: restart with a three_graphs* form (three_graphs_reserve16 is the default)' % (type(e).__name__, str(e)[:300])) from e
       return
     self._graphs = capture(self._parts())
 

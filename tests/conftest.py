@@ -12,6 +12,15 @@ def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+  """The tests whose workers form an RCCL communicator run LAST: one GPU-suite run of round 6 sat silent in the first of them
+  (cause unknown, profiles/r06/asked_and_answered.md); under ``-x`` whatever comes behind a stalled test is lost, so nothing
+  should come behind them.  The order among all other tests is untouched."""
+  last = [it for it in items if 'over_rccl' in it.nodeid]
+  if last:
+    items[:] = [it for it in items if 'over_rccl' not in it.nodeid] + last
+
+
 @pytest.fixture(scope='session')
 def dev():
   import torch
