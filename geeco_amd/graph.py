@@ -417,12 +417,16 @@ class ConvEncoderStack:
     self.launch_fwd(top)
     return False
 
-  def backward(self, hi=7, lo=0, prepare=None, defer_dgrad=False, lead_dgrad=None):
+  def backward(self, hi=7, lo=0, prepare=None, defer_dgrad=False, lead_dgrad=None, defer_sums=None, before_bottom=None):
     """Expects ``self.dz[7]`` = d(loss)/d(pre-activation of conv8) (ReluGrad already applied).  Runs layers
     hi..lo (the data-parallel runner splits the chain at conv3 / conv2 to start the gradient exchange early).
     ``prepare`` = (global_step, lr, scal): the optimiser's per-step scalars ride in this part's slab-sum launch.
     ``defer_dgrad``: layer lo's INPUT gradient is left to the next part, which opens with it (``lead_dgrad=lo``): every
-    gradient of the early bucket exists once layer lo's filter gradient does, so the bucket leaves a launch earlier."""
+    gradient of the early bucket exists once layer lo's filter gradient does, so the bucket leaves a launch earlier.
+    ``defer_sums`` (a list): this part's pending slab sums are handed to the caller instead of launched (``prepare`` must be None).
+    ``before_bottom``: called right before the LAST launch of the chain, conv2's input gradient (+ conv1's filter gradient when
+    the bottom is fused) -- _ModelBase.backward_and_apply releases the optimiser's early piece onto a second stream there."""
+    assert defer_sums is None or prepare is None
     main = torch.cuda.current_stream()
     sides = self.sides if self.two_streams else []
     pending = [] if self.batch_reduce else None   # slab sums of all layers of this part: one launch at the end
@@ -461,11 +465,16 @@ class ConvEncoderStack:
         self.launch_wgrad(l, pending)
       if l == 0 or (l == lo and defer_dgrad):
         break   # conv1's input is data: no dgrad / the next part opens with this layer's
+      if l == 1 and before_bottom is not None:
+        before_bottom()
       self.launch_dgrad(l, pending)
       if l == 1 and self.fused_bottom:
         break
     for side in sides:
       main.wait_stream(side)
+    if defer_sums is not None and pending is not None:
+      defer_sums.extend(pending)
+      return
     if pending or (prepare is not None and pending is not None):
       ops.slab_reduce_batch(pending, prepare)
     elif prepare is not None:
@@ -756,6 +765,63 @@ class _ModelBase:
                 l2=float(cfg.l2_regularizer))
     self._refresh_after_update()
 
+  def can_apply_beside_bottom(self):
+    """backward_and_apply needs the slab sums batched per part (the default) and a CUDA device."""
+    return bool(self.enc.training and self.enc.batch_reduce and not self.enc.two_streams and self.store.params.is_cuda)
+
+  def backward_and_apply(self, early, late):
+    """Backward + optimiser step of a single-GPU training step with the optimiser's HBM-streaming work hidden beside the fused
+    encoder-bottom backward (round 6, profiles/HARDWARE_FINDINGS.md 38).  ``early`` / ``late`` = runtime.gradient_buckets(store):
+    late = conv1 / conv2 of the encoders, whose gradients the last launch of the backward produces; early = everything else
+    (99.4 % of the arena), complete once conv3's filter gradient exists.
+
+      main:  ... conv3 wgrad | conv3 dgrad | conv2 wgrad | * | conv2 dgrad + conv1 wgrad (454 us, MFMA-bound) | late slab sums | join | Adam(late)
+      side:                                                * -> slab sums of conv3..conv8 (+ lr_t) -> Adam(early)
+
+    The fused bottom holds two 209-VGPR waves per SIMD and 151 KB of LDS: 80 registers per lane and 9 KB of LDS stay free on every
+    CU, room for one block of the slab sums (55 VGPRs, 4 KB) or of Adam (51 VGPRs) at a time, and the bottom moves 1.1 TB/s of the
+    8 the HBM has.  Beside it the 35 + 33 us of streaming work take 190 + 155 us and end long before its 455 us are over, which
+    stay 455.  Order matters twice: released any earlier the side work could not co-reside (conv2's filter gradient and conv3's
+    input gradient fill the register file) but would start first and delay them -- and `*` is behind conv3's input gradient, the
+    last reader of a variable of the early piece (conv3's kernel); and the side launches are issued BEHIND the bottom's (see
+    below).  Element by element the arithmetic of backward(adam_prepare=True) + apply_gradients(): bitwise the same parameters,
+    slots and gradients (tests/test_model_gpu.py)."""
+    side = getattr(self, '_opt_stream', None)
+    if side is None:
+      side = self._opt_stream = torch.cuda.Stream(device=self.store.params.device)
+    main = torch.cuda.current_stream()
+    what = _dev.env('GEECO_BESIDE', 'both')      # development A/B: which of the two pieces goes beside the bottom
+    sums = []
+    self.backward(part='upper', defer_sums=sums)
+    prepare = self._prepare_args(True)
+    if what == 'adam':
+      ops.slab_reduce_batch(sums, prepare)
+      prepare = None
+    g = self.store.grads
+    ev = torch.cuda.Event()
+    marked = []
+
+    def mark():      # conv2's filter gradient has been launched: everything before it (conv3's input gradient too) precedes `ev`
+      ev.record(main)
+      marked.append(True)
+    self.backward(part='bottom', before_bottom=mark)
+    if not marked:       # (an encoder whose chain has no conv2 input gradient: nothing to hide behind)
+      mark()
+    # The side work is launched BEHIND the fused bottom (and waits for `ev`, recorded in front of it): the bottom's packet is the
+    # older one, its 256 persistent blocks take their CUs first, and the streaming blocks then fill what those leave, one per CU
+    # at a time.  Issued in front of it (hipGraph replays nodes in creation order) the streaming blocks take the wave slots first,
+    # the bottom's block cannot become resident on a CU until they have drained, and the bottom ends 35-45 us late (measured).
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+      if sums or prepare is not None:
+        ops.slab_reduce_batch(sums, prepare)
+      if what != 'reduce':
+        self.apply_gradients_of([(g[off:off + n], off, n) for off, n in early], last=False)
+    main.wait_stream(side)
+    if what == 'reduce':
+      self.apply_gradients_of([(g[off:off + n], off, n) for off, n in early], last=False)
+    self.apply_gradients_of([(g[off:off + n], off, n) for off, n in late], last=True)
+
   def _refresh_after_update(self):
     s = self.store
     # weights changed: re-derive the padded / transposed copies now (the version stamp is unchanged, so
@@ -933,12 +999,14 @@ class GoalE2EVMC(_ModelBase):
     d.forward(backward_too)
     self._finish_forward()
 
-  def backward(self, part=None, adam_prepare=False):
+  def backward(self, part=None, adam_prepare=False, defer_sums=None, before_bottom=None):
     """part None = whole backward; 'upper' / 'bottom' = the two halves the data-parallel runner captures
     separately (runtime.py): everything down to conv3, then the encoder bottom (conv2 / conv1).  ``adam_prepare``: see
-    _prepare_args (ignored for part 'upper': the optimiser's scalars ride in the LAST slab-sum launch of the step)."""
+    _prepare_args (ignored for part 'upper': the optimiser's scalars ride in the LAST slab-sum launch of the step).
+    ``defer_sums`` (part 'upper') / ``before_bottom`` (part 'bottom'): ConvEncoderStack.backward, used by backward_and_apply."""
     if part == 'bottom':
-      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None)
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None,
+                        before_bottom=before_bottom)
       return
     N, K, jn = self.N, self.K, self.cfg.dim_jnt_state
     d = self.decoder
@@ -969,7 +1037,8 @@ class GoalE2EVMC(_ModelBase):
       for t in range(K):
         ops.state_concat_bwd_into([df[0][t], df[1][t]], d.dstates[t], d.D, [f[0][t], f[1][t]], self.feat_ch, 1, jn, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
-                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD)
+                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD,
+                      defer_sums=defer_sums if part == 'upper' else None)
 
   def endpoints(self):
     """dynbuff / dyndiff debug endpoints (graph.py:377,393,401): the LAST computed images."""
@@ -1014,9 +1083,10 @@ class E2EVMC(_ModelBase):
     d.forward(backward_too)
     self._finish_forward()
 
-  def backward(self, part=None, adam_prepare=False):
+  def backward(self, part=None, adam_prepare=False, defer_sums=None, before_bottom=None):
     if part == 'bottom':
-      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None)
+      self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None,
+                        before_bottom=before_bottom)
       return
     N, K = self.N, self.K
     d = self.decoder
@@ -1026,7 +1096,8 @@ class E2EVMC(_ModelBase):
     for t in range(K):
       ops.state_concat_bwd_into([dfe[t]], d.dstates[t], d.D, [feats[t]], [256], 1, self.cfg.dim_jnt_state, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
-                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD)
+                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD,
+                      defer_sums=defer_sums if part == 'upper' else None)
 
   def endpoints(self):
     return {'conv8': self.enc.features}

@@ -127,6 +127,10 @@ class TrainStepRunner:
     # pieces back to back as its part 3 (round 6; it kept the unpack copies + one whole Adam launch before).
     self.split_adam = (self.dp and self.staging is not None and hasattr(model, 'apply_gradients_of')
                        and 1 <= len(self.early) <= 8 and 1 <= len(self.late) <= 8 and _dev.env('GEECO_NO_SPLIT_ADAM') is None)
+    # Single GPU: the optimiser's streaming work (slab sums of conv3..conv8, Adam over 99 % of the arena) runs on a second stream
+    # beside the fused encoder-bottom backward instead of behind it (graph._ModelBase.backward_and_apply; bitwise the plain step)
+    self.beside_bottom = (not self.dp and hasattr(model, 'backward_and_apply') and model.can_apply_beside_bottom()
+                          and 1 <= len(self.early) <= 8 and 1 <= len(self.late) <= 8 and _dev.env('GEECO_NO_ADAM_BESIDE_BOTTOM') is None)
     if self.redirected and self.early:
       lo = min(off for off, _ in self.early)
       hi = max(off + n for off, n in self.early)
@@ -189,6 +193,10 @@ class TrainStepRunner:
     self.model.apply_gradients()
 
   def _whole_step(self):
+    if self.beside_bottom:
+      self.model.forward(backward_too=True)
+      self.model.backward_and_apply(self.early, self.late)
+      return
     self._part1()
     self._part3()
 

@@ -1,10 +1,17 @@
-"""Print the kernels of one training step (between two adam_kernel dispatches) from a rocprofv3 kernel trace."""
+"""Print the kernels of one training step (between two adam_kernel dispatches, or two input-stage dispatches) from a rocprofv3 kernel trace."""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adam_kernel')]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
-a, b = idx[which - 1] + 1, idx[which] + 1
+if len(idx) >= 2:
+  a, b = idx[which - 1] + 1, idx[which] + 1
+else:
+  # the single-GPU step of round 6 ends with adam_segments_kernel (twice per step): a step = from one input-stage dispatch to the next
+  first = next(r['Kernel_Name'] for r in rows if 'dynimg' in r['Kernel_Name'] or 'window' in r['Kernel_Name'])
+  idx = [i for i, r in enumerate(rows) if r['Kernel_Name'] == first]
+  which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
+  a, b = idx[which - 1], idx[which]
 tot = 0
 t0 = int(rows[a]['Start_Timestamp'])
 agg = {}

@@ -223,3 +223,40 @@ def test_optimiser_scalars_ride_in_the_last_slab_sum(dev, goal):
   b.backward()                        # no update follows: nothing may have advanced
   torch.cuda.synchronize()
   assert int(b.store.global_step.item()) == 3
+
+
+@pytest.mark.parametrize('use_graph', [False, True], ids=['eager', 'hipGraph'])
+@pytest.mark.parametrize('goal', [True, False], ids=['geeco-f', 'e2e_vmc'])
+def test_optimiser_beside_the_encoder_bottom_is_bitwise_the_plain_step(dev, goal, use_graph):
+  """The single-GPU step of runtime.TrainStepRunner runs the slab sums of conv3..conv8 and Adam's early piece (99 % of the
+  arena) on a second stream beside the fused encoder-bottom backward and Adam's late piece (conv1 / conv2) behind it
+  (graph._ModelBase.backward_and_apply).  Parameters, both Adam slots, the gradient arena, the step counter and every
+  step's loss are bitwise those of train_step() (one slab-sum launch at the end + one Adam pass), eagerly and replayed."""
+  from geeco_amd.runtime import TrainStepRunner
+  cfg_kw = dict(proc_obs='dynimg', proc_tgt='dyndiff', window_size=3, lr=1e-3) if goal else dict(window_size=3, lr=1e-3)
+  ocfg, P, feats, labels = _mk(cfg_kw, goal, 2, 136)
+  a = _build(ocfg, goal, P, feats, labels, dev)
+  b = _build(ocfg, goal, P, feats, labels, dev)
+  r = TrainStepRunner(a, use_graph=use_graph, warmup=2)
+  assert r.beside_bottom and a.can_apply_beside_bottom() and len(r.early) >= 1 and len(r.late) >= 1
+  la, lb = [], []
+  for _ in range(6):          # (warm-up steps run eagerly, the rest replayed when use_graph)
+    r.step()
+    b.train_step()
+    torch.cuda.synchronize()
+    la.append(float(a.loss))
+    lb.append(float(b.loss))
+  assert (r._graphs is not None) == use_graph
+  assert la == lb
+  assert int(a.store.global_step.item()) == int(b.store.global_step.item()) == 6
+  for name in ('params', 'adam_m', 'adam_v', 'grads'):
+    assert torch.equal(getattr(a.store, name), getattr(b.store, name)), name
+  assert float(a.scal[0]) == float(b.scal[0])
+  # the plain path through the same runner (what a model without batched slab sums gets): the same bits again
+  c = _build(ocfg, goal, P, feats, labels, dev)
+  rc = TrainStepRunner(c, use_graph=use_graph, warmup=2)
+  rc.beside_bottom = False
+  for _ in range(6):
+    rc.step()
+  torch.cuda.synchronize()
+  assert torch.equal(a.store.params, c.store.params) and torch.equal(a.store.adam_v, c.store.adam_v)
