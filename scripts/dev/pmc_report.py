@@ -17,7 +17,13 @@ D = durations(1)
 # dispatch ids should align between passes (same program); take last step: after the second-to-last adam
 ids = list(P[0].keys())
 adam = [i for i in ids if P[0][i]['name'].startswith('adam_kernel')]
-lo, hi = adam[-2], adam[-1]
+if len(adam) >= 2:
+  lo, hi = adam[-2], adam[-1]
+else:      # round 6: the single-GPU step ends with adam_segments_kernel (twice per step): a step = from one input-stage dispatch to the next
+  starts = [i for i in ids if 'dynimg' in P[0][i]['name'] or 'window' in P[0][i]['name']]
+  first = P[0][starts[0]]['name']
+  starts = [i for i in starts if P[0][i]['name'] == first]
+  lo, hi = starts[-2] - 1, starts[-1] - 1
 print('%-34s %8s %6s %6s %6s %6s %7s %8s %8s %6s %6s' % ('kernel', 'us', 'mfma%', 'wait%', 'winst%', 'valu%', 'ldsbc%', 'rdMB', 'wrMB', 'TB/s', 'clkGHz'))
 for i in ids:
   if not (lo < i <= hi): continue

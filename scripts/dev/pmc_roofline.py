@@ -14,7 +14,13 @@ def load(i):
 F, W = load(2), load(3)
 ids = list(F.keys())
 adam = [i for i in ids if F[i]['name'].startswith('adam_kernel')]
-lo, hi = adam[-2], adam[-1]
+if len(adam) >= 2:
+  lo, hi = adam[-2], adam[-1]
+else:      # round 6: the single-GPU step ends with adam_segments_kernel (twice per step): a step = from one input-stage dispatch to the next
+  starts = [i for i in ids if 'dynimg' in F[i]['name'] or 'window' in F[i]['name']]
+  first = F[starts[0]]['name']
+  starts = [i for i in starts if F[i]['name'] == first]
+  lo, hi = starts[-2] - 1, starts[-1] - 1
 norm = lambda s: s.replace(' ', '')
 sel = [i for i in ids if lo < i <= hi and norm(F[i]['name']) == norm(kname)]
 assert sel, 'kernel %r not found in the last step' % kname
