@@ -769,6 +769,15 @@ class _ModelBase:
     """backward_and_apply needs the slab sums batched per part (the default) and a CUDA device."""
     return bool(self.enc.training and self.enc.batch_reduce and not self.enc.two_streams and self.store.params.is_cuda)
 
+  def optimizer_stream(self):
+    """The second stream of backward_and_apply: one of the encoder's filter-gradient side streams, idle from conv2's filter gradient
+    on (a process gets 4 hardware queues by default; a stream more would share one with another stream -- RCCL's, perhaps)."""
+    side = getattr(self, '_opt_stream', None)
+    if side is None:
+      sides = getattr(self.enc, 'sides', None)
+      side = self._opt_stream = sides[0] if sides else torch.cuda.Stream(device=self.store.params.device)
+    return side
+
   def backward_and_apply(self, early, late):
     """Backward + optimiser step of a single-GPU training step with the optimiser's HBM-streaming work hidden beside the fused
     encoder-bottom backward (round 6, profiles/HARDWARE_FINDINGS.md 38).  ``early`` / ``late`` = runtime.gradient_buckets(store):
@@ -786,9 +795,7 @@ class _ModelBase:
     last reader of a variable of the early piece (conv3's kernel); and the side launches are issued BEHIND the bottom's (see
     below).  Element by element the arithmetic of backward(adam_prepare=True) + apply_gradients(): bitwise the same parameters,
     slots and gradients (tests/test_model_gpu.py)."""
-    side = getattr(self, '_opt_stream', None)
-    if side is None:
-      side = self._opt_stream = torch.cuda.Stream(device=self.store.params.device)
+    side = self.optimizer_stream()
     main = torch.cuda.current_stream()
     what = _dev.env('GEECO_BESIDE', 'both')      # development A/B: which of the two pieces goes beside the bottom
     sums = []
@@ -1002,7 +1009,7 @@ class GoalE2EVMC(_ModelBase):
   def backward(self, part=None, adam_prepare=False, defer_sums=None, before_bottom=None):
     """part None = whole backward; 'upper' / 'bottom' = the two halves the data-parallel runner captures
     separately (runtime.py): everything down to conv3, then the encoder bottom (conv2 / conv1).  ``adam_prepare``: see
-    _prepare_args (ignored for part 'upper': the optimiser's scalars ride in the LAST slab-sum launch of the step).
+    _prepare_args (the optimiser's scalars ride in the slab-sum launch of the part it is passed to -- once per step).
     ``defer_sums`` (part 'upper') / ``before_bottom`` (part 'bottom'): ConvEncoderStack.backward, used by backward_and_apply."""
     if part == 'bottom':
       self.enc.backward(hi=ConvEncoderStack.SPLIT - 1, lo=0, prepare=self._prepare_args(adam_prepare), lead_dgrad=ConvEncoderStack.SPLIT if ConvEncoderStack.DEFER_SPLIT_DGRAD else None,
@@ -1037,7 +1044,7 @@ class GoalE2EVMC(_ModelBase):
       for t in range(K):
         ops.state_concat_bwd_into([df[0][t], df[1][t]], d.dstates[t], d.D, [f[0][t], f[1][t]], self.feat_ch, 1, jn, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
-                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD,
+                      prepare=self._prepare_args(adam_prepare and defer_sums is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD,
                       defer_sums=defer_sums if part == 'upper' else None)
 
   def endpoints(self):
@@ -1096,7 +1103,7 @@ class E2EVMC(_ModelBase):
     for t in range(K):
       ops.state_concat_bwd_into([dfe[t]], d.dstates[t], d.D, [feats[t]], [256], 1, self.cfg.dim_jnt_state, N, _CELLS)
     self.enc.backward(hi=7, lo=ConvEncoderStack.SPLIT if part == 'upper' else 0,
-                      prepare=self._prepare_args(adam_prepare and part is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD,
+                      prepare=self._prepare_args(adam_prepare and defer_sums is None), defer_dgrad=part == 'upper' and ConvEncoderStack.DEFER_SPLIT_DGRAD,
                       defer_sums=defer_sums if part == 'upper' else None)
 
   def endpoints(self):

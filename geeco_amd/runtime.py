@@ -131,6 +131,12 @@ class TrainStepRunner:
     # beside the fused encoder-bottom backward instead of behind it (graph._ModelBase.backward_and_apply; bitwise the plain step)
     self.beside_bottom = (not self.dp and hasattr(model, 'backward_and_apply') and model.can_apply_beside_bottom()
                           and 1 <= len(self.early) <= 8 and 1 <= len(self.late) <= 8 and _dev.env('GEECO_NO_ADAM_BESIDE_BOTTOM') is None)
+    # ... and the ONE-GRAPH forms of the data-parallel step (and their eager warm-up steps) do the same with Adam's early piece.  RCCL only:
+    # with gloo the form is three graphs anyway, and two gloo ranks that share one GPU (the rehearsals of tests/) run 10 x slower once
+    # every process drives one more hardware queue -- the side stream is otherwise only ever used inside captures.
+    self.dp_beside_bottom = (self.dp and self.overlap and self.capture_exchange and self.split_adam and self.redirected
+                             and hasattr(model, 'can_apply_beside_bottom') and model.can_apply_beside_bottom() and gdist.backend() == 'nccl'
+                             and _dev.env('GEECO_NO_DP_ADAM_BESIDE') is None)
     if self.redirected and self.early:
       lo = min(off for off, _ in self.early)
       hi = max(off + n for off, n in self.early)
@@ -153,14 +159,17 @@ class TrainStepRunner:
     else:
       self.model.backward(adam_prepare=True)      # (the optimiser's scalars ride in the backward's last slab-sum launch)
 
-  def _part2(self):
+  def _part2(self, prepare=True, before_bottom=None):
     enc = getattr(self.model, 'enc', None)
     if self.redirected:
       self.model.redirect_late_gradients(self.staging, self.late)
     if enc is not None and self.reserved_cus:
       enc.reserved_cus = self.reserved_cus
     try:
-      self.model.backward(part='bottom', adam_prepare=True)
+      if before_bottom is None:
+        self.model.backward(part='bottom', adam_prepare=prepare)
+      else:
+        self.model.backward(part='bottom', adam_prepare=prepare, before_bottom=before_bottom)
     finally:
       if enc is not None:
         enc.reserved_cus = 0
@@ -211,9 +220,44 @@ class TrainStepRunner:
       return []
     return [gdist.allreduce_async(self.staging)]
 
+  def _dp_step_beside(self):
+    """The one-pass data-parallel step (eager, or under ONE capture) with the early piece of the optimiser step on a second stream
+    beside the fused encoder-bottom backward, as the single-GPU step has it (graph._ModelBase.backward_and_apply, finding 38):
+    the early bucket's all-reduce runs beside conv3's input gradient and conv2's filter gradient and has normally arrived when
+    the fused bottom starts; Adam's pass over it then streams beside the bottom instead of behind the late bucket's launch.  The
+    optimiser's scalars ride in the slab-sum launch of part 1 (they must exist before the early piece).  If the bucket is late the
+    early piece simply runs when it arrives -- behind the bottom at worst, where it used to be."""
+    m = self.model
+    main = torch.cuda.current_stream()
+    side = m.optimizer_stream()
+    m.forward(backward_too=True)
+    m.backward(part='upper', adam_prepare=True)
+    works = self._exchange_early()
+    ev = torch.cuda.Event()
+    marked = []
+
+    def mark():
+      ev.record(main)
+      marked.append(True)
+    self._part2(prepare=False, before_bottom=mark)
+    if not marked:
+      mark()
+    late = self._exchange_late()           # (issued before the side work: its launch is on the critical path, the early piece is not)
+    side.wait_event(ev)                    # behind conv3's input gradient (reads conv3's kernel) and behind the bottom's launch packet
+    with torch.cuda.stream(side):
+      for w in works:
+        w.wait()
+      self._part3_early()
+    for w in late:
+      w.wait()
+    main.wait_stream(side)
+    self._part3_late()
+
   def _dp_step(self, run=None):
     """The data-parallel step: ``run`` = the three parts as callables (captured graphs' replays or the eager functions)."""
     whole = run is None                    # not three replayed graphs: the parts run right here (eagerly, or under ONE capture)
+    if whole and self.dp_beside_bottom:
+      return self._dp_step_beside()
     run = run or [self._part1, self._part2, self._part3]
     run[0]()
     works = self._exchange_early() if self.overlap else []   # on the communicator's stream, behind part 1, beside part 2

@@ -404,6 +404,9 @@ def _rccl_worker(port, overlap, one_graph, q):
   runner = TrainStepRunner(model, use_graph=True, warmup=1, dp=True, overlap=overlap,
                            **({'capture_exchange': True} if one_graph else {'eager_adam': True} if two_graphs else {}))
   assert runner.capture_exchange == one_graph
+  # one graph + early bucket beside part 2 over RCCL: Adam's early piece runs on a second stream beside the fused encoder bottom
+  # (runtime.TrainStepRunner._dp_step_beside); the bitwise comparison with the single-GPU step below covers it
+  assert runner.dp_beside_bottom == (one_graph and overlap) and not runner.beside_bottom
   info = runner.bucket_info()
   losses = []
   for i in range(5):
