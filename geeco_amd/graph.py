@@ -466,7 +466,7 @@ class ConvEncoderStack:
       if l == 0 or (l == lo and defer_dgrad):
         break   # conv1's input is data: no dgrad / the next part opens with this layer's
       if l == 1 and before_bottom is not None:
-        before_bottom()
+        before_bottom(pending)
       self.launch_dgrad(l, pending)
       if l == 1 and self.fused_bottom:
         break
@@ -784,8 +784,8 @@ class _ModelBase:
     late = conv1 / conv2 of the encoders, whose gradients the last launch of the backward produces; early = everything else
     (99.4 % of the arena), complete once conv3's filter gradient exists.
 
-      main:  ... conv3 wgrad | conv3 dgrad | conv2 wgrad | * | conv2 dgrad + conv1 wgrad (454 us, MFMA-bound) | late slab sums | join | Adam(late)
-      side:                                                * -> slab sums of conv3..conv8 (+ lr_t) -> Adam(early)
+      main:  ... conv3 wgrad | conv3 dgrad | conv2 wgrad | * | conv2 dgrad + conv1 wgrad (454 us, MFMA-bound) | conv1's slab sum | join | Adam(late)
+      side:                                                * -> slab sums of conv2..conv8 (+ lr_t) -> Adam(early)
 
     The fused bottom holds two 209-VGPR waves per SIMD and 151 KB of LDS: 80 registers per lane and 9 KB of LDS stay free on every
     CU, room for one block of the slab sums (55 VGPRs, 4 KB) or of Adam (51 VGPRs) at a time, and the bottom moves 1.1 TB/s of the
@@ -808,8 +808,11 @@ class _ModelBase:
     ev = torch.cuda.Event()
     marked = []
 
-    def mark():      # conv2's filter gradient has been launched: everything before it (conv3's input gradient too) precedes `ev`
+    def mark(pending=None):      # conv2's filter gradient has been launched: everything before it (conv3's input gradient too) precedes `ev`
       ev.record(main)
+      if pending:                # ... and its slab sum joins the ones that run beside the bottom: only conv1's stays behind it
+        sums.extend(pending)
+        del pending[:]
       marked.append(True)
     self.backward(part='bottom', before_bottom=mark)
     if not marked:       # (an encoder whose chain has no conv2 input gradient: nothing to hide behind)

@@ -236,7 +236,7 @@ class TrainStepRunner:
     ev = torch.cuda.Event()
     marked = []
 
-    def mark():
+    def mark(pending=None):
       ev.record(main)
       marked.append(True)
     self._part2(prepare=False, before_bottom=mark)
